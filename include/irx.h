@@ -1,0 +1,218 @@
+/*
+ * irx.h — C-ABI of libirx.so: the MI355X (gfx950 / CDNA4) native operator library behind
+ * InstanceRefer's data-parallel hot path (sparse-voxel 3D conv backbone, per-instance
+ * extractors, language-instance matching).
+ *
+ * What this boundary replaces (reference = CurryYuan/InstanceRefer, paths relative to its root):
+ * the reference owns no native code; its hot path calls pybind11 back-ends of un-vendored
+ * third-party packages:
+ *   torchsparse  (hash / hash-query / neighbour-map / gather-GEMM-scatter conv / voxelise)
+ *       call sites  models/basic_blocks.py:14-21,32-44,182   models/attribute_module.py:20,65-70,101,105
+ *                   models/scene_module.py:20                lib/dataset.py:229-234,256-261,458
+ *   torch_cluster.knn + torch_scatter max  (through torch_geometric)
+ *       call sites  models/basic_blocks.py:100,120,125
+ * Every entry point below names the call site(s) it stands in for.
+ *
+ * Conventions (all functions):
+ *   - `extern "C"`, plain pointers + sizes; no torch / STL types cross the boundary.
+ *   - Every pointer is a DEVICE pointer unless the parameter name ends in `_host`.
+ *   - The CALLER owns every buffer, including workspaces (sizes from the `*_workspace_bytes`
+ *     queries, which are pure host arithmetic). Functions never allocate device memory,
+ *     never synchronise the device and never throw.
+ *   - Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *   - Return 0 on success, a negative irx_status otherwise; `irx_last_error()` returns a
+ *     thread-local, human-readable message for the last failure on the calling thread.
+ *   - Re-entrant across streams; safe to call from PyTorch's autograd worker thread.
+ *
+ * Data layout in HBM:
+ *   coords   int32  [N][4]   (x, y, z, batch) — torchsparse's `C` layout, batch LAST
+ *                            (models/basic_blocks.py:176,233 index columns 0..2 / 3).
+ *                            x,y,z are in ORIGINAL-resolution voxel units (multiples of the
+ *                            tensor stride), each within [-32768, 32767]; batch in [0, 32767].
+ *   feats    float  [N][C]   row-major, C contiguous (torchsparse's `F`).
+ *   keys     uint64 [N]      (batch << 48) | morton3(x+32768, y+32768, z+32768): the library's
+ *                            canonical order is ascending key (Z-order inside each batch item).
+ *   nbr      int32  [K][ld]  output-stationary neighbour table: nbr[k][q] = row index of the
+ *                            INPUT voxel at coord(q) + offset_k, or -1.  (k-major, ld >= n_out.)
+ *   weights  float  [K][Cin][Cout]   torchsparse `Conv3d.kernel` layout (state-dict compatible).
+ *   Kernel-offset enumeration follows torchsparse: odd kernel sizes
+ *   enumerate x fastest ({-1,0,1}*stride), even sizes enumerate z fastest ({0,1}*stride).
+ */
+#ifndef IRX_H_
+#define IRX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRX_VERSION_MAJOR 0
+#define IRX_VERSION_MINOR 1
+
+typedef enum irx_status {
+  IRX_OK = 0,
+  IRX_ERR_INVALID_ARG = -1,   /* bad size / null pointer / unsupported channel count      */
+  IRX_ERR_LAUNCH = -2,        /* hipLaunchKernel or hipMemsetAsync reported an error       */
+  IRX_ERR_WORKSPACE = -3,     /* workspace too small                                       */
+  IRX_ERR_NO_DEVICE = -4      /* no HIP device visible                                     */
+} irx_status;
+
+/* ---- library ------------------------------------------------------------------------- */
+int irx_version(void);                       /* major*1000 + minor                          */
+const char* irx_last_error(void);            /* thread-local message of the last failure    */
+/* Fills up to 8 ints: {CU count, wavefront size, LDS bytes/CU, L2 bytes, clock kHz,
+ * gcn arch number (950), total HBM MiB, 0}. Host call; returns IRX_ERR_NO_DEVICE w/o GPU.  */
+int irx_device_props(int device, int* out8_host);
+
+/* ---- coordinates, hashing, voxelisation --------------------------------------------- */
+
+/* keys[i] = (b<<48)|morton(x,y,z) for coords[i]. */
+int irx_coords_to_keys(const int32_t* coords, int n, uint64_t* keys, void* stream);
+
+/* Quantise points to voxel coordinates exactly as torchsparse.utils.sparse_quantize does
+ * before hashing: coord = floor(xyz / voxel) evaluated in float64 (no min-shift; negatives
+ * kept) — replaces the `np.floor(coords / quantization_size)` step reached from
+ * models/attribute_module.py:65-69 and lib/dataset.py:229-233,256-260.
+ * xyz: [n][3] (float64 when xyz_is_f64 else float32), batch: int32 [n] or NULL (=0).
+ * Writes coords int32 [n][4] and keys uint64 [n]. */
+int irx_quantize(const void* xyz, int xyz_is_f64, const int32_t* batch, int n,
+                 double voxel_x, double voxel_y, double voxel_z,
+                 int32_t* coords, uint64_t* keys, void* stream);
+
+/* Capacity (number of slots, a power of two >= 2n) of the open-addressing table for n keys. */
+size_t irx_hash_capacity(int n);
+
+/* Voxel de-duplication with torchsparse's FIRST-OCCURRENCE rule (np.unique(return_index=True)
+ * keeps the smallest original index of each voxel): inserts every key with
+ * atomicMin(point index); on return table_vals[slot] = smallest point index of that voxel.
+ * table_keys/table_vals: [capacity]; the function clears them itself. */
+int irx_voxel_insert(const uint64_t* keys, int n, uint64_t* table_keys, int32_t* table_vals,
+                     size_t capacity, void* stream);
+
+/* Wave-ballot + prefix-sum compaction of the winners of irx_voxel_insert: writes the point
+ * indices whose voxel they represent to winners[0 .. *count) (unordered; the caller sorts
+ * by key) and the number of voxels to count[0] (device int32, cleared by the function). */
+int irx_voxel_select(const uint64_t* keys, int n, const uint64_t* table_keys,
+                     const int32_t* table_vals, size_t capacity, int32_t* winners,
+                     int32_t* count, void* stream);
+
+/* Build key -> row index table for n UNIQUE keys (torchsparse `sphash` + hashmap insert). */
+int irx_hash_build(const uint64_t* keys, int n, uint64_t* table_keys, int32_t* table_vals,
+                   size_t capacity, void* stream);
+
+/* Neighbour table for a stride-preserving convolution (torchsparse `sphash(coords, offsets)`
+ * + `sphashquery`, reached from spnn.Conv3d at models/basic_blocks.py:14,32,39).
+ * kernel_size must be 3 (K = 27). tensor_stride = current stride s; offsets {-s,0,s}^3,
+ * x fastest.  nbr: int32 [27][ld]. */
+int irx_kmap_build_s1(const int32_t* coords, int n, int tensor_stride,
+                      const uint64_t* table_keys, const int32_t* table_vals, size_t capacity,
+                      int32_t* nbr, int ld, void* stream);
+
+/* Strided (kernel 2, stride 2) down-sampling of a key-sorted coordinate set
+ * (torchsparse `spdownsample` + kernel map, reached from BasicConvolutionBlock(ks=2,
+ * stride=2) at models/basic_blocks.py:68,73,78,83): out coords = unique(floor(c/(2s))*2s, b).
+ * Because rows are in ascending Morton-key order, parents are a segmented scan:
+ *   parent[i]   int32 [n]      row of the output voxel that input row i falls into
+ *   koff[i]     uint8 [n]      kernel-offset index of input i inside its parent (z fastest)
+ *   out_coords  int32 [cap][4], out_keys uint64 [cap]   (cap >= n is always enough)
+ *   child       int32 [8][ld]  child[k][p] = input row at parent p + offset_k, or -1
+ *                              (the function fills it with -1 first; ld >= cap)
+ *   n_out       int32 [1]      device counter
+ * workspace: irx_downsample_workspace_bytes(n). */
+size_t irx_downsample_workspace_bytes(int n);
+int irx_downsample(const uint64_t* keys, const int32_t* coords, int n, int tensor_stride,
+                   int32_t* parent, uint8_t* koff, int32_t* out_coords, uint64_t* out_keys,
+                   int32_t* child, int ld, int32_t* n_out, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* Transposed table of a down-sampling map for its data-gradient: tbl[k][i] = parent[i] if
+ * koff[i]==k else -1  (int32 [8][ld], ld >= n). */
+int irx_kmap_down_transpose(const int32_t* parent, const uint8_t* koff, int n, int32_t* tbl,
+                            int ld, void* stream);
+
+/* Table for SparseCrop + ToDenseBEVConvolution (models/basic_blocks.py:174-243,
+ * models/scene_module.py:22-27): dense cell c = (b, ix, iy), ix < nx, iy < ny; for each
+ * z-bin k < nz looks up voxel (ix*s, iy*s, k*s, b) -> tbl[k][c] (int32 [nz][ld]); also the
+ * transposed form for the data-gradient: cell_of_row int32 [n] (-1 when outside the crop
+ * window) and zbin_of_row uint8 [n]. */
+int irx_bev_table(const int32_t* coords, int n, int tensor_stride, int batch_size, int nx,
+                  int ny, int nz, const uint64_t* table_keys, const int32_t* table_vals,
+                  size_t capacity, int32_t* tbl, int ld, int32_t* cell_of_row,
+                  uint8_t* zbin_of_row, void* stream);
+
+/* ---- sparse convolution (spnn.Conv3d fwd + bwd; models/basic_blocks.py:14-19,32-43) --- */
+
+/* y[q][:] = sum_k x[nbr[k'][q]][:] * W[k]    (k' = K-1-k when flip_k, else k)
+ * with W[k] = w[k][cin][cout]               when !trans_w   (forward)
+ *      W[k] = transpose(w[k][cout'][cin'])  when  trans_w   (data-gradient: pass x = dy,
+ *             cin = conv's Cout, cout = conv's Cin, w = the forward weight unchanged)
+ * Output-stationary: every output row is written exactly once (no atomics; deterministic).
+ * fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+ * Requirements: cout % 16 == 0 (cin arbitrary). y: [n_out][cout]. */
+int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr, int ld, int n_out,
+                   int K, int cin, int cout, int flip_k, int trans_w, float* y, void* stream);
+
+/* dw[k][ci][co] = sum_q x[nbr[k][q]][ci] * dy[q][co].  Deterministic two-stage reduction
+ * through `workspace` (irx_spconv_wgrad_workspace_bytes). */
+size_t irx_spconv_wgrad_workspace_bytes(int n_out, int K, int cin, int cout);
+int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out,
+                     int K, int cin, int cout, float* dw, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ---- BatchNorm(+residual)(+ReLU) over voxel rows (spnn.BatchNorm / spnn.ReLU and the
+ *      residual add at models/basic_blocks.py:20-21,37-38,44,52,55) ----------------------- */
+
+/* Train-mode statistics of x [n][c]: mean, biased var -> invstd = rsqrt(var+eps); updates
+ * running_mean/var with `momentum` (unbiased var) when running_mean != NULL — nn.BatchNorm1d
+ * semantics. workspace: irx_bn_workspace_bytes(n, c). */
+size_t irx_bn_workspace_bytes(int n, int c);
+int irx_bn_stats(const float* x, int n, int c, float eps, float momentum, float* mean,
+                 float* invstd, float* running_mean, float* running_var, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* y = act( (x - mean) * invstd * gamma + beta (+ residual) ), act = ReLU when relu != 0. */
+int irx_bn_apply(const float* x, int n, int c, const float* mean, const float* invstd,
+                 const float* gamma, const float* beta, const float* residual, int relu,
+                 float* y, void* stream);
+
+/* Backward of irx_bn_apply∘irx_bn_stats (train mode). g = dy * (y > 0) when relu.
+ * Outputs: dx [n][c]; dgamma, dbeta [c]; dresidual [n][c] (= g) when dresidual != NULL. */
+int irx_bn_backward(const float* x, const float* y, const float* dy, int n, int c,
+                    const float* mean, const float* invstd, const float* gamma, int relu,
+                    float* dx, float* dgamma, float* dbeta, float* dresidual, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ---- segmented reductions ------------------------------------------------------------- */
+
+/* spnn.GlobalMaxPooling (models/attribute_module.py:20,105) and the `aggr='max'` of
+ * MessagePassing (models/basic_blocks.py:100,125): rows of segment s are
+ * [offsets[s], offsets[s+1]).  y [nseg][c]; argmax int32 [nseg][c] (row index, -1 and y=0
+ * for an empty segment — torch_scatter's fill). */
+int irx_segment_max(const float* x, const int32_t* offsets, int nseg, int c, float* y,
+                    int32_t* argmax, void* stream);
+/* dx must be zero-filled by the caller: dx[argmax[s][j]][j] = dy[s][j]. */
+int irx_segment_max_backward(const float* dy, const int32_t* argmax, int nseg, int c,
+                             float* dx, void* stream);
+/* Mean over equal-length segments (per-instance mean of the (1024, C0) instance points,
+ * models/relation_module.py:67-68): x [nseg][len][c] -> y [nseg][c], fp32 in, fp64 accumulate. */
+int irx_segment_mean(const float* x, int nseg, int len, int c, float* y, void* stream);
+
+/* offsets[b] = first row whose batch index >= b, for b in [0, nseg]  (rows sorted by batch). */
+int irx_batch_offsets(const int32_t* coords, int n, int nseg, int32_t* offsets, void* stream);
+
+/* ---- instance graph ------------------------------------------------------------------- */
+
+/* torch_cluster.knn(x=support, y=query, k, batch_x, batch_y) (models/basic_blocks.py:120):
+ * for every query the k nearest support rows with the same batch id (Euclidean, fp32; ties
+ * -> lower support index). support rows of one batch id are contiguous:
+ * sup_offsets int32 [nbatch+1]. nbr_idx int32 [nq][k] (-1 padded when a batch item has < k
+ * support rows), ascending distance. */
+int irx_knn_batched(const float* sup_xyz, const int32_t* sup_offsets, const float* qry_xyz,
+                    const int32_t* qry_batch, int nq, int k, int32_t* nbr_idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRX_H_ */

@@ -1,0 +1,110 @@
+"""ctypes binding of libirx.so (include/irx.h). Thin: argument marshalling + status -> RuntimeError.
+
+There is deliberately NO CPU or pure-PyTorch fallback here: if the HIP library is missing or the
+tensors are not on a HIP device the call raises. The CPU restatement lives in /oracle and is test
+infrastructure only.
+"""
+import ctypes
+import os
+
+import torch
+
+from ._build import LIB_PATH
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_Z = _c.c_size_t
+_F = _c.c_float
+_D = _c.c_double
+
+# name -> (restype, argtypes) : mirrors include/irx.h one to one
+_SIGNATURES = {
+    "irx_version": (_I, []),
+    "irx_last_error": (_c.c_char_p, []),
+    "irx_device_props": (_I, [_I, _P]),
+    "irx_coords_to_keys": (_I, [_P, _I, _P, _P]),
+    "irx_quantize": (_I, [_P, _I, _P, _I, _D, _D, _D, _P, _P, _P]),
+    "irx_hash_capacity": (_Z, [_I]),
+    "irx_voxel_insert": (_I, [_P, _I, _P, _P, _Z, _P]),
+    "irx_voxel_select": (_I, [_P, _I, _P, _P, _Z, _P, _P, _P]),
+    "irx_hash_build": (_I, [_P, _I, _P, _P, _Z, _P]),
+    "irx_kmap_build_s1": (_I, [_P, _I, _I, _P, _P, _Z, _P, _I, _P]),
+    "irx_downsample_workspace_bytes": (_Z, [_I]),
+    "irx_downsample": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
+    "irx_kmap_down_transpose": (_I, [_P, _P, _I, _P, _I, _P]),
+    "irx_bev_table": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _I, _P, _P, _P]),
+    "irx_spconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "irx_spconv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "irx_spconv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    "irx_bn_workspace_bytes": (_Z, [_I, _I]),
+    "irx_bn_stats": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
+    "irx_bn_apply": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "irx_bn_backward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "irx_segment_max": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "irx_segment_max_backward": (_I, [_P, _P, _I, _I, _P, _P]),
+    "irx_segment_mean": (_I, [_P, _I, _I, _I, _P, _P]),
+    "irx_batch_offsets": (_I, [_P, _I, _I, _P, _P]),
+    "irx_knn_batched": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load libirx.so (once). Raises with a build hint when it is missing — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libirx.so not found at %s — build it with `python -m instancerefer_amd._build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the irx operators." % LIB_PATH)
+    # torch has already mapped its bundled libamdhip64.so (SONAME libamdhip64.so.7); the loader
+    # resolves libirx's NEEDED entry against that copy, so both share one HIP runtime / streams.
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().irx_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError("%s failed (status %d): %s" % (what, rc, last_error()))
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). The tensor must be contiguous and on a HIP device."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("irx operators need tensors on a HIP device (got %s); the CPU path exists "
+                           "only as the test oracle under /oracle" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("irx operators need contiguous tensors")
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (status %d): %s" % (name, rc, last_error()))
+
+
+def hash_capacity(n: int) -> int:
+    return int(load().irx_hash_capacity(int(n)))

@@ -1,0 +1,84 @@
+// irx_common.h — shared device/host helpers for libirx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/irx.h"
+
+#define IRX_WAVE 64
+#define IRX_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define IRX_COORD_BIAS 32768
+
+// ---- error plumbing (thread-local message; functions never throw) -----------------------
+void irx_set_error(const char* fmt, ...);
+
+#define IRX_REQUIRE(cond, ...)                 \
+  do {                                         \
+    if (!(cond)) {                             \
+      irx_set_error(__VA_ARGS__);              \
+      return IRX_ERR_INVALID_ARG;              \
+    }                                          \
+  } while (0)
+
+#define IRX_CHECK_LAUNCH(name)                                                  \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      irx_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+      return IRX_ERR_LAUNCH;                                                    \
+    }                                                                           \
+  } while (0)
+
+#define IRX_CHECK_HIP(expr, name)                                               \
+  do {                                                                          \
+    hipError_t e__ = (expr);                                                    \
+    if (e__ != hipSuccess) {                                                    \
+      irx_set_error("%s: %s", name, hipGetErrorString(e__));                    \
+      return IRX_ERR_LAUNCH;                                                    \
+    }                                                                           \
+  } while (0)
+
+static inline int irx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- Morton (Z-order) keys ---------------------------------------------------------------
+// 16-bit coordinate -> bits spread to every third position (48-bit interleave).
+__host__ __device__ static inline uint64_t irx_spread3(uint32_t v) {
+  uint64_t x = v & 0xFFFFu;
+  x = (x | (x << 32)) & 0x00FF00000000FFFFull;  // not needed for 16 bits but keeps pattern
+  x = (x | (x << 16)) & 0x00FF0000FF0000FFull;
+  x = (x | (x << 8)) & 0xF00F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x30C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x9249249249249249ull;
+  return x;
+}
+
+// key = batch<<48 | interleave(x,y,z) with x in bit 0 (x fastest), biased to unsigned.
+__host__ __device__ static inline uint64_t irx_make_key(int x, int y, int z, int b) {
+  uint32_t ux = (uint32_t)(x + IRX_COORD_BIAS), uy = (uint32_t)(y + IRX_COORD_BIAS),
+           uz = (uint32_t)(z + IRX_COORD_BIAS);
+  uint64_t m = irx_spread3(ux) | (irx_spread3(uy) << 1) | (irx_spread3(uz) << 2);
+  return ((uint64_t)(uint32_t)b << 48) | (m & 0xFFFFFFFFFFFFull);
+}
+
+// ---- open-addressing hash (linear probing, 64-bit keys) ---------------------------------
+__host__ __device__ static inline uint64_t irx_mix64(uint64_t k) {
+  // murmur3 finaliser
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return k;
+}
+
+__device__ static inline int irx_hash_lookup(const uint64_t* __restrict__ tk,
+                                             const int32_t* __restrict__ tv, uint64_t mask,
+                                             uint64_t key) {
+  uint64_t slot = irx_mix64(key) & mask;
+  while (true) {
+    uint64_t cur = tk[slot];
+    if (cur == key) return tv[slot];
+    if (cur == IRX_EMPTY_KEY) return -1;
+    slot = (slot + 1) & mask;
+  }
+}

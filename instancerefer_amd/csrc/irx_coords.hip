@@ -1,0 +1,476 @@
+// irx_coords.hip — coordinate keys, hash-based voxelisation, neighbour-table ("rule") generation.
+// All kernels are HBM/L2-latency bound integer work: coalesced 16-byte coordinate loads, one
+// thread per (voxel[, offset]) probe, wave-wide ballot + mbcnt prefix for compaction.
+#include <stdarg.h>
+#include "irx_common.h"
+
+// ---------------------------------------------------------------- error plumbing (host) ----
+static thread_local char g_irx_err[512] = "";
+void irx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_irx_err, sizeof(g_irx_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* irx_last_error(void) { return g_irx_err; }
+extern "C" int irx_version(void) { return IRX_VERSION_MAJOR * 1000 + IRX_VERSION_MINOR; }
+
+extern "C" int irx_device_props(int device, int* out8) {
+  IRX_REQUIRE(out8 != nullptr, "irx_device_props: null output");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
+    irx_set_error("irx_device_props: no HIP device %d (count %d)", device, ndev);
+    return IRX_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t p;
+  IRX_CHECK_HIP(hipGetDeviceProperties(&p, device), "hipGetDeviceProperties");
+  out8[0] = p.multiProcessorCount;
+  out8[1] = p.warpSize;
+  out8[2] = (int)p.maxSharedMemoryPerMultiProcessor;
+  out8[3] = p.l2CacheSize;
+  out8[4] = p.clockRate;
+  int arch = 0;
+  for (const char* c = p.gcnArchName; *c && *c != ':'; ++c)
+    if (*c >= '0' && *c <= '9') arch = arch * 10 + (*c - '0');
+  out8[5] = arch;
+  out8[6] = (int)(p.totalGlobalMem >> 20);
+  out8[7] = 0;
+  return IRX_OK;
+}
+
+extern "C" size_t irx_hash_capacity(int n) {
+  size_t cap = 64;
+  while (cap < (size_t)2 * (size_t)(n > 0 ? n : 1)) cap <<= 1;
+  return cap;
+}
+
+// --------------------------------------------------------------------------- kernels ------
+__global__ void k_coords_to_keys(const int4* __restrict__ coords, int n, uint64_t* __restrict__ keys) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  keys[i] = irx_make_key(c.x, c.y, c.z, c.w);
+}
+
+template <typename T>
+__global__ void k_quantize(const T* __restrict__ xyz, const int32_t* __restrict__ batch, int n,
+                           double vx, double vy, double vz, int4* __restrict__ coords,
+                           uint64_t* __restrict__ keys) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // float64 division then floor — bit-identical to numpy's `np.floor(coords / voxel)`.
+  double x = (double)xyz[3 * (size_t)i + 0], y = (double)xyz[3 * (size_t)i + 1],
+         z = (double)xyz[3 * (size_t)i + 2];
+  int cx = (int)floor(x / vx), cy = (int)floor(y / vy), cz = (int)floor(z / vz);
+  int b = batch ? batch[i] : 0;
+  coords[i] = make_int4(cx, cy, cz, b);
+  keys[i] = irx_make_key(cx, cy, cz, b);
+}
+
+__global__ void k_fill_table(uint64_t* __restrict__ tk, int32_t* __restrict__ tv, size_t cap) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < cap; i += stride) {
+    tk[i] = IRX_EMPTY_KEY;
+    tv[i] = 0x7FFFFFFF;
+  }
+}
+
+// insert with first-occurrence rule: value = min(point index) over points of that voxel.
+__global__ void k_voxel_insert(const uint64_t* __restrict__ keys, int n, uint64_t* tk, int32_t* tv,
+                               uint64_t mask) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key = keys[i];
+  uint64_t slot = irx_mix64(key) & mask;
+  while (true) {
+    unsigned long long prev =
+        atomicCAS((unsigned long long*)&tk[slot], (unsigned long long)IRX_EMPTY_KEY,
+                  (unsigned long long)key);
+    if (prev == IRX_EMPTY_KEY || prev == key) {
+      atomicMin(&tv[slot], i);
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+// A point wins when it is the first occurrence of its voxel. Wave-aggregated append:
+// ballot -> one atomicAdd per wave -> lane offset by mbcnt (prefix popcount of lower lanes).
+__global__ void k_voxel_select(const uint64_t* __restrict__ keys, int n,
+                               const uint64_t* __restrict__ tk, const int32_t* __restrict__ tv,
+                               uint64_t mask, int32_t* __restrict__ winners, int32_t* count) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool win = false;
+  if (i < n) win = (irx_hash_lookup(tk, tv, mask, keys[i]) == i);
+  unsigned long long ballot = __ballot(win);
+  if (ballot == 0ull) return;
+  int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == (__ffsll((long long)ballot) - 1)) base = atomicAdd(count, __popcll(ballot));
+  base = __shfl(base, __ffsll((long long)ballot) - 1);
+  if (win) {
+    unsigned long long lower = ballot & ((1ull << lane) - 1ull);
+    winners[base + __popcll(lower)] = i;
+  }
+}
+
+// one thread per (offset k, voxel q): consecutive threads -> consecutive q (coalesced stores).
+__global__ void k_kmap_s1(const int4* __restrict__ coords, int n, int s,
+                          const uint64_t* __restrict__ tk, const int32_t* __restrict__ tv,
+                          uint64_t mask, int32_t* __restrict__ nbr, int ld) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (q >= n) return;
+  int4 c = coords[q];
+  int dx = (k % 3) - 1, dy = ((k / 3) % 3) - 1, dz = (k / 9) - 1;  // x fastest (odd kernel)
+  int r;
+  if (k == 13) {
+    r = q;
+  } else {
+    int x = c.x + dx * s, y = c.y + dy * s, z = c.z + dz * s;
+    if (x < -IRX_COORD_BIAS || x >= IRX_COORD_BIAS || y < -IRX_COORD_BIAS || y >= IRX_COORD_BIAS ||
+        z < -IRX_COORD_BIAS || z >= IRX_COORD_BIAS)
+      r = -1;
+    else
+      r = irx_hash_lookup(tk, tv, mask, irx_make_key(x, y, z, c.w));
+  }
+  nbr[(size_t)k * ld + q] = r;
+}
+
+// ---- down-sampling by segmented scan over Morton-sorted keys ----------------------------
+#define DS_BLOCK 256
+#define DS_ITEMS 8
+#define DS_TILE (DS_BLOCK * DS_ITEMS)
+
+__device__ static inline uint64_t parent_key(uint64_t key, int level) {
+  return key & ~(7ull << (3 * level));
+}
+
+// pass 1: per-tile count of segment heads (parent key differs from predecessor's).
+__global__ void k_ds_count(const uint64_t* __restrict__ keys, int n, int level,
+                           int32_t* __restrict__ tile_counts) {
+  __shared__ int s_wave[DS_BLOCK / 64];
+  int base = blockIdx.x * DS_TILE;
+  int cnt = 0;
+  for (int it = 0; it < DS_ITEMS; ++it) {
+    int i = base + it * DS_BLOCK + threadIdx.x;
+    if (i < n) {
+      uint64_t pk = parent_key(keys[i], level);
+      bool head = (i == 0) || (parent_key(keys[i - 1], level) != pk);
+      cnt += head ? 1 : 0;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < DS_BLOCK / 64; ++w) t += s_wave[w];
+    tile_counts[blockIdx.x] = t;
+  }
+}
+
+// pass 2: every tile sums the counts of the tiles before it (<= a few hundred values), then an
+// in-tile ballot/prefix scan assigns parent rows; heads write the parent's coord/key.
+__global__ void k_ds_write(const uint64_t* __restrict__ keys, const int4* __restrict__ coords, int n,
+                           int level, int s2, const int32_t* __restrict__ tile_counts, int ntiles,
+                           int32_t* __restrict__ parent, uint8_t* __restrict__ koff,
+                           int4* __restrict__ out_coords, uint64_t* __restrict__ out_keys,
+                           int32_t* __restrict__ child, int ld, int32_t* __restrict__ n_out) {
+  __shared__ int s_red[DS_BLOCK / 64];
+  __shared__ int s_wave_base[DS_BLOCK / 64];
+  __shared__ int s_tile_base;
+  // exclusive prefix of tile counts for this tile
+  int acc = 0;
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += DS_BLOCK) acc += tile_counts[t];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < DS_BLOCK / 64; ++w) t += s_red[w];
+    s_tile_base = t;
+    if (blockIdx.x == (unsigned)ntiles - 1) *n_out = t + tile_counts[ntiles - 1];
+  }
+  __syncthreads();
+  int running = s_tile_base;  // heads seen before the current DS_BLOCK-wide strip
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int base = blockIdx.x * DS_TILE;
+  for (int it = 0; it < DS_ITEMS; ++it) {
+    int i = base + it * DS_BLOCK + threadIdx.x;
+    bool valid = i < n;
+    uint64_t key = valid ? keys[i] : 0ull;
+    uint64_t pk = parent_key(key, level);
+    bool head = valid && ((i == 0) || (parent_key(keys[i - 1], level) != pk));
+    unsigned long long ballot = __ballot(head);
+    if (lane == 0) s_wave_base[wave] = __popcll(ballot);
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int w = 0; w < DS_BLOCK / 64; ++w) {
+      int c = s_wave_base[w];
+      if (w < wave) wbase += c;
+      total += c;
+    }
+    // inclusive count of heads up to and including this lane, minus 1 = parent row
+    unsigned long long upto = ballot & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+    int p = running + wbase + __popcll(upto) - 1;
+    if (valid) {
+      parent[i] = p;
+      int bits = (int)((key >> (3 * level)) & 7ull);  // bit0 = x, bit1 = y, bit2 = z
+      int k = ((bits & 1) << 2) | (bits & 2) | ((bits >> 2) & 1);  // even kernel: z fastest
+      koff[i] = (uint8_t)k;
+      child[(size_t)k * ld + p] = i;
+      if (head) {
+        int4 c = coords[i];
+        int m = ~(s2 - 1);
+        // floor(c / s2) * s2 for two's-complement ints and power-of-two s2
+        out_coords[p] = make_int4(c.x & m, c.y & m, c.z & m, c.w);
+        out_keys[p] = pk;
+      }
+    }
+    running += total;
+    __syncthreads();
+  }
+}
+
+__global__ void k_fill_i32(int32_t* __restrict__ p, size_t n, int32_t v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+__global__ void k_down_transpose(const int32_t* __restrict__ parent, const uint8_t* __restrict__ koff,
+                                 int n, int32_t* __restrict__ tbl, int ld) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int p = parent[i];
+  int kk = koff[i];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tbl[(size_t)k * ld + i] = (k == kk) ? p : -1;
+}
+
+__global__ void k_bev_table(int s, int batch_size, int nx, int ny, int nz,
+                            const uint64_t* __restrict__ tk, const int32_t* __restrict__ tv,
+                            uint64_t mask, int32_t* __restrict__ tbl, int ld) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  int ncell = batch_size * nx * ny;
+  if (c >= ncell) return;
+  int b = c / (nx * ny);
+  int r = c - b * nx * ny;
+  int ix = r / ny, iy = r - ix * ny;
+  tbl[(size_t)k * ld + c] = irx_hash_lookup(tk, tv, mask, irx_make_key(ix * s, iy * s, k * s, b));
+}
+
+__global__ void k_bev_rows(const int4* __restrict__ coords, int n, int s, int batch_size, int nx,
+                           int ny, int nz, int32_t* __restrict__ cell_of_row,
+                           uint8_t* __restrict__ zbin_of_row) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  bool in = c.x >= 0 && c.y >= 0 && c.z >= 0 && c.x < nx * s && c.y < ny * s && c.z < nz * s &&
+            c.w >= 0 && c.w < batch_size;
+  int ix = c.x / s, iy = c.y / s, iz = c.z / s;
+  cell_of_row[i] = in ? (c.w * nx * ny + ix * ny + iy) : -1;
+  zbin_of_row[i] = (uint8_t)(in ? iz : 0);
+}
+
+__global__ void k_batch_offsets(const int4* __restrict__ coords, int n, int nseg,
+                                int32_t* __restrict__ offsets) {
+  // offsets[b] = first row with batch >= b. One thread per row boundary.
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  int prev = (i == 0) ? -1 : coords[i - 1].w;
+  int cur = (i == n) ? nseg : coords[i].w;
+  if (cur > nseg) cur = nseg;
+  for (int b = prev + 1; b <= cur; ++b) offsets[b] = i;
+}
+
+// ------------------------------------------------------------------------- C entry points --
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+static inline int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+extern "C" int irx_coords_to_keys(const int32_t* coords, int n, uint64_t* keys, void* stream) {
+  IRX_REQUIRE(n >= 0, "irx_coords_to_keys: n < 0");
+  if (n == 0) return IRX_OK;
+  IRX_REQUIRE(coords && keys, "irx_coords_to_keys: null pointer");
+  k_coords_to_keys<<<irx_cdiv(n, 256), 256, 0, S(stream)>>>((const int4*)coords, n, keys);
+  IRX_CHECK_LAUNCH("irx_coords_to_keys");
+  return IRX_OK;
+}
+
+extern "C" int irx_quantize(const void* xyz, int xyz_is_f64, const int32_t* batch, int n, double vx,
+                            double vy, double vz, int32_t* coords, uint64_t* keys, void* stream) {
+  IRX_REQUIRE(n >= 0, "irx_quantize: n < 0");
+  if (n == 0) return IRX_OK;
+  IRX_REQUIRE(xyz && coords && keys, "irx_quantize: null pointer");
+  IRX_REQUIRE(vx > 0 && vy > 0 && vz > 0, "irx_quantize: voxel size must be > 0");
+  if (xyz_is_f64)
+    k_quantize<double><<<irx_cdiv(n, 256), 256, 0, S(stream)>>>((const double*)xyz, batch, n, vx, vy,
+                                                               vz, (int4*)coords, keys);
+  else
+    k_quantize<float><<<irx_cdiv(n, 256), 256, 0, S(stream)>>>((const float*)xyz, batch, n, vx, vy,
+                                                              vz, (int4*)coords, keys);
+  IRX_CHECK_LAUNCH("irx_quantize");
+  return IRX_OK;
+}
+
+static int check_table(const char* who, const void* tk, const void* tv, size_t cap, int n) {
+  IRX_REQUIRE(tk && tv, "%s: null hash table", who);
+  IRX_REQUIRE(cap >= 64 && (cap & (cap - 1)) == 0, "%s: capacity %zu is not a power of two", who, cap);
+  IRX_REQUIRE(cap >= (size_t)n + (size_t)n / 2 || cap >= 2 * (size_t)n,
+              "%s: capacity %zu too small for %d keys", who, cap, n);
+  return IRX_OK;
+}
+
+extern "C" int irx_voxel_insert(const uint64_t* keys, int n, uint64_t* tk, int32_t* tv, size_t cap,
+                                void* stream) {
+  IRX_REQUIRE(n >= 0, "irx_voxel_insert: n < 0");
+  int rc = check_table("irx_voxel_insert", tk, tv, cap, n);
+  if (rc) return rc;
+  int fb = irx_cdiv((long long)cap, 256);
+  if (fb > 2048) fb = 2048;
+  k_fill_table<<<fb, 256, 0, S(stream)>>>(tk, tv, cap);
+  IRX_CHECK_LAUNCH("irx_voxel_insert(fill)");
+  if (n == 0) return IRX_OK;
+  IRX_REQUIRE(keys, "irx_voxel_insert: null keys");
+  k_voxel_insert<<<irx_cdiv(n, 256), 256, 0, S(stream)>>>(keys, n, tk, tv, (uint64_t)cap - 1);
+  IRX_CHECK_LAUNCH("irx_voxel_insert");
+  return IRX_OK;
+}
+
+extern "C" int irx_voxel_select(const uint64_t* keys, int n, const uint64_t* tk, const int32_t* tv,
+                                size_t cap, int32_t* winners, int32_t* count, void* stream) {
+  IRX_REQUIRE(n >= 0 && count, "irx_voxel_select: bad arguments");
+  IRX_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), S(stream)), "irx_voxel_select(memset)");
+  if (n == 0) return IRX_OK;
+  int rc = check_table("irx_voxel_select", tk, tv, cap, n);
+  if (rc) return rc;
+  IRX_REQUIRE(keys && winners, "irx_voxel_select: null pointer");
+  k_voxel_select<<<irx_cdiv(n, 256), 256, 0, S(stream)>>>(keys, n, tk, tv, (uint64_t)cap - 1, winners,
+                                                         count);
+  IRX_CHECK_LAUNCH("irx_voxel_select");
+  return IRX_OK;
+}
+
+extern "C" int irx_hash_build(const uint64_t* keys, int n, uint64_t* tk, int32_t* tv, size_t cap,
+                              void* stream) {
+  IRX_REQUIRE(n >= 0, "irx_hash_build: n < 0");
+  int rc = check_table("irx_hash_build", tk, tv, cap, n);
+  if (rc) return rc;
+  int fb = irx_cdiv((long long)cap, 256);
+  if (fb > 2048) fb = 2048;
+  k_fill_table<<<fb, 256, 0, S(stream)>>>(tk, tv, cap);
+  IRX_CHECK_LAUNCH("irx_hash_build(fill)");
+  if (n == 0) return IRX_OK;
+  IRX_REQUIRE(keys, "irx_hash_build: null keys");
+  // unique keys: the first-occurrence insert degenerates to key -> row
+  k_voxel_insert<<<irx_cdiv(n, 256), 256, 0, S(stream)>>>(keys, n, tk, tv, (uint64_t)cap - 1);
+  IRX_CHECK_LAUNCH("irx_hash_build");
+  return IRX_OK;
+}
+
+extern "C" int irx_kmap_build_s1(const int32_t* coords, int n, int tensor_stride, const uint64_t* tk,
+                                 const int32_t* tv, size_t cap, int32_t* nbr, int ld, void* stream) {
+  IRX_REQUIRE(n >= 0 && ld >= n, "irx_kmap_build_s1: bad n/ld");
+  IRX_REQUIRE(tensor_stride >= 1 && (tensor_stride & (tensor_stride - 1)) == 0,
+              "irx_kmap_build_s1: tensor stride %d is not a power of two", tensor_stride);
+  if (n == 0) return IRX_OK;
+  int rc = check_table("irx_kmap_build_s1", tk, tv, cap, n);
+  if (rc) return rc;
+  IRX_REQUIRE(coords && nbr, "irx_kmap_build_s1: null pointer");
+  dim3 grid(irx_cdiv(n, 256), 27);
+  k_kmap_s1<<<grid, 256, 0, S(stream)>>>((const int4*)coords, n, tensor_stride, tk, tv,
+                                        (uint64_t)cap - 1, nbr, ld);
+  IRX_CHECK_LAUNCH("irx_kmap_build_s1");
+  return IRX_OK;
+}
+
+extern "C" size_t irx_downsample_workspace_bytes(int n) {
+  return (size_t)(irx_cdiv(n > 0 ? n : 1, DS_TILE)) * sizeof(int32_t) + 64;
+}
+
+extern "C" int irx_downsample(const uint64_t* keys, const int32_t* coords, int n, int tensor_stride,
+                              int32_t* parent, uint8_t* koff, int32_t* out_coords, uint64_t* out_keys,
+                              int32_t* child, int ld, int32_t* n_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  IRX_REQUIRE(n >= 0 && n_out, "irx_downsample: bad arguments");
+  IRX_REQUIRE(tensor_stride >= 1 && (tensor_stride & (tensor_stride - 1)) == 0 && tensor_stride <= 8192,
+              "irx_downsample: tensor stride %d unsupported", tensor_stride);
+  if (n == 0) {
+    IRX_CHECK_HIP(hipMemsetAsync(n_out, 0, sizeof(int32_t), S(stream)), "irx_downsample(memset)");
+    return IRX_OK;
+  }
+  IRX_REQUIRE(keys && coords && parent && koff && out_coords && out_keys && child,
+              "irx_downsample: null pointer");
+  IRX_REQUIRE(ld >= 1, "irx_downsample: ld < 1");
+  if (workspace_bytes < irx_downsample_workspace_bytes(n) || !workspace) {
+    irx_set_error("irx_downsample: workspace %zu < %zu", workspace_bytes,
+                  irx_downsample_workspace_bytes(n));
+    return IRX_ERR_WORKSPACE;
+  }
+  int ntiles = irx_cdiv(n, DS_TILE);
+  int level = ilog2(tensor_stride);
+  int32_t* tile_counts = (int32_t*)workspace;
+  size_t fill = (size_t)8 * ld;
+  int fb = irx_cdiv((long long)fill, 256);
+  if (fb > 2048) fb = 2048;
+  k_fill_i32<<<fb, 256, 0, S(stream)>>>(child, fill, -1);
+  IRX_CHECK_LAUNCH("irx_downsample(fill)");
+  k_ds_count<<<ntiles, DS_BLOCK, 0, S(stream)>>>(keys, n, level, tile_counts);
+  IRX_CHECK_LAUNCH("irx_downsample(count)");
+  k_ds_write<<<ntiles, DS_BLOCK, 0, S(stream)>>>(keys, (const int4*)coords, n, level,
+                                                2 * tensor_stride, tile_counts, ntiles, parent, koff,
+                                                (int4*)out_coords, out_keys, child, ld, n_out);
+  IRX_CHECK_LAUNCH("irx_downsample(write)");
+  return IRX_OK;
+}
+
+extern "C" int irx_kmap_down_transpose(const int32_t* parent, const uint8_t* koff, int n, int32_t* tbl,
+                                       int ld, void* stream) {
+  IRX_REQUIRE(n >= 0 && ld >= n, "irx_kmap_down_transpose: bad n/ld");
+  if (n == 0) return IRX_OK;
+  IRX_REQUIRE(parent && koff && tbl, "irx_kmap_down_transpose: null pointer");
+  k_down_transpose<<<irx_cdiv(n, 256), 256, 0, S(stream)>>>(parent, koff, n, tbl, ld);
+  IRX_CHECK_LAUNCH("irx_kmap_down_transpose");
+  return IRX_OK;
+}
+
+extern "C" int irx_bev_table(const int32_t* coords, int n, int tensor_stride, int batch_size, int nx,
+                             int ny, int nz, const uint64_t* tk, const int32_t* tv, size_t cap,
+                             int32_t* tbl, int ld, int32_t* cell_of_row, uint8_t* zbin_of_row,
+                             void* stream) {
+  IRX_REQUIRE(n >= 0 && batch_size >= 1 && nx >= 1 && ny >= 1 && nz >= 1 && nz <= 255,
+              "irx_bev_table: bad sizes");
+  int ncell = batch_size * nx * ny;
+  IRX_REQUIRE(ld >= ncell, "irx_bev_table: ld %d < cells %d", ld, ncell);
+  int rc = check_table("irx_bev_table", tk, tv, cap, n);
+  if (rc) return rc;
+  IRX_REQUIRE(tbl, "irx_bev_table: null table");
+  dim3 grid(irx_cdiv(ncell, 256), nz);
+  k_bev_table<<<grid, 256, 0, S(stream)>>>(tensor_stride, batch_size, nx, ny, nz, tk, tv,
+                                          (uint64_t)cap - 1, tbl, ld);
+  IRX_CHECK_LAUNCH("irx_bev_table");
+  if (n > 0 && cell_of_row && zbin_of_row) {
+    IRX_REQUIRE(coords, "irx_bev_table: null coords");
+    k_bev_rows<<<irx_cdiv(n, 256), 256, 0, S(stream)>>>((const int4*)coords, n, tensor_stride,
+                                                       batch_size, nx, ny, nz, cell_of_row,
+                                                       zbin_of_row);
+    IRX_CHECK_LAUNCH("irx_bev_table(rows)");
+  }
+  return IRX_OK;
+}
+
+extern "C" int irx_batch_offsets(const int32_t* coords, int n, int nseg, int32_t* offsets,
+                                 void* stream) {
+  IRX_REQUIRE(n >= 0 && nseg >= 0 && offsets, "irx_batch_offsets: bad arguments");
+  IRX_REQUIRE(n == 0 || coords, "irx_batch_offsets: null coords");
+  k_batch_offsets<<<irx_cdiv(n + 1, 256), 256, 0, S(stream)>>>((const int4*)coords, n, nseg, offsets);
+  IRX_CHECK_LAUNCH("irx_batch_offsets");
+  return IRX_OK;
+}

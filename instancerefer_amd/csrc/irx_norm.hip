@@ -1,0 +1,335 @@
+// irx_norm.hip — BatchNorm over voxel rows with fused residual add and ReLU, forward + backward.
+// HBM-bound streaming kernels: 16-byte loads, one pass for statistics, one pass for apply.
+// Replaces spnn.BatchNorm + spnn.ReLU + the SparseTensor `+` of ResidualBlock
+// (reference models/basic_blocks.py:20-21,37-38,44,52,55).
+#include "irx_common.h"
+
+#define BN_ROWS 256  // voxel rows per statistics workgroup
+
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+__host__ __device__ static inline int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// Per-workgroup partial sums over BN_ROWS rows.
+//   MODE 0: (sum x, sum x^2)
+//   MODE 1: (sum g, sum g*xhat), g = dy * (RELU ? y > 0 : 1), xhat = (x - mean) * invstd
+// V = vector width (4 when c % 4 == 0 else 1). part layout [blk][2][c].
+template <int MODE, int V>
+__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
+                                                    const float* __restrict__ y,
+                                                    const float* __restrict__ dy, int n, int c,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, int relu,
+                                                    int qpad, float* __restrict__ part) {
+  __shared__ float s0[256 * V];
+  __shared__ float s1[256 * V];
+  const int cq = c / V;
+  const int qd = threadIdx.x % qpad;
+  const int rg = threadIdx.x / qpad;
+  const int nrg = 256 / qpad;
+  const int r0 = blockIdx.x * BN_ROWS;
+  int r1 = r0 + BN_ROWS;
+  if (r1 > n) r1 = n;
+  float a0[V], a1[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) a0[j] = a1[j] = 0.f;
+  if (qd < cq) {
+    float mu[V], is[V];
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        mu[j] = mean[qd * V + j];
+        is[j] = invstd[qd * V + j];
+      }
+    }
+    for (int r = r0 + rg; r < r1; r += nrg) {
+      const size_t off = (size_t)r * c + (size_t)qd * V;
+      float xv[V], yv[V], dv[V];
+      if (V == 4) {
+        *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + off);
+        if (MODE == 1) {
+          *reinterpret_cast<float4*>(dv) = *reinterpret_cast<const float4*>(dy + off);
+          if (relu) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + off);
+        }
+      } else {
+        xv[0] = x[off];
+        if (MODE == 1) {
+          dv[0] = dy[off];
+          if (relu) yv[0] = y[off];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        if (MODE == 0) {
+          a0[j] += xv[j];
+          a1[j] += xv[j] * xv[j];
+        } else {
+          float gval = dv[j];
+          if (relu && !(yv[j] > 0.f)) gval = 0.f;
+          a0[j] += gval;
+          a1[j] += gval * ((xv[j] - mu[j]) * is[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    s0[threadIdx.x * V + j] = a0[j];
+    s1[threadIdx.x * V + j] = a1[j];
+  }
+  __syncthreads();
+  // thread (rg == 0, qd) folds the row groups
+  if (rg == 0 && qd < cq) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int g2 = 0; g2 < nrg; ++g2) {
+        t0 += s0[(g2 * qpad + qd) * V + j];
+        t1 += s1[(g2 * qpad + qd) * V + j];
+      }
+      part[((size_t)blockIdx.x * 2 + 0) * c + qd * V + j] = t0;
+      part[((size_t)blockIdx.x * 2 + 1) * c + qd * V + j] = t1;
+    }
+  }
+}
+
+// Fold partials in float64. One workgroup per 32 channels: 32 channels x 8 slices.
+//   MODE 0: mean / invstd (+ running stats);  MODE 1: out0 = sum g (dbeta), out1 = sum g*xhat (dgamma)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ part, int nblk, int n,
+                                                     int c, float eps, float momentum,
+                                                     float* __restrict__ out0, float* __restrict__ out1,
+                                                     float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var) {
+  __shared__ double d0[256];
+  __shared__ double d1[256];
+  const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int slice = threadIdx.x >> 5;
+  double t0 = 0.0, t1 = 0.0;
+  if (ch < c) {
+    for (int b = slice; b < nblk; b += 8) {
+      t0 += (double)part[((size_t)b * 2 + 0) * c + ch];
+      t1 += (double)part[((size_t)b * 2 + 1) * c + ch];
+    }
+  }
+  d0[threadIdx.x] = t0;
+  d1[threadIdx.x] = t1;
+  __syncthreads();
+  if (slice == 0 && ch < c) {
+    for (int s2 = 1; s2 < 8; ++s2) {
+      t0 += d0[s2 * 32 + (threadIdx.x & 31)];
+      t1 += d1[s2 * 32 + (threadIdx.x & 31)];
+    }
+    if (MODE == 0) {
+      const double mu = t0 / (double)n;
+      double var = t1 / (double)n - mu * mu;
+      if (var < 0.0) var = 0.0;
+      out0[ch] = (float)mu;
+      out1[ch] = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        const double unbiased = (n > 1) ? var * (double)n / (double)(n - 1) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mu);
+        running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
+      }
+    } else {
+      out0[ch] = (float)t0;
+      out1[ch] = (float)t1;
+    }
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, size_t total, int c,
+                                                  const float* __restrict__ mean,
+                                                  const float* __restrict__ invstd,
+                                                  const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta,
+                                                  const float* __restrict__ res, int relu,
+                                                  float* __restrict__ y) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * V;
+  for (; i < total; i += stride) {
+    const int ch = (int)(i % (size_t)c);
+    float xv[V], rv[V], ov[V];
+    if (V == 4) {
+      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + i);
+      if (res) *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(res + i);
+    } else {
+      xv[0] = x[i];
+      if (res) rv[0] = res[i];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float sc = invstd[ch + j] * gamma[ch + j];
+      float o = (xv[j] - mean[ch + j]) * sc + beta[ch + j];
+      if (res) o += rv[j];
+      if (relu) o = o > 0.f ? o : 0.f;
+      ov[j] = o;
+    }
+    if (V == 4)
+      *reinterpret_cast<float4*>(y + i) = *reinterpret_cast<float4*>(ov);
+    else
+      y[i] = ov[0];
+  }
+}
+
+// dx = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n);  dres = g
+template <int V>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x,
+                                                      const float* __restrict__ y,
+                                                      const float* __restrict__ dy, size_t total,
+                                                      int n, int c, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ sum_g,
+                                                      const float* __restrict__ sum_gx, int relu,
+                                                      float* __restrict__ dx, float* __restrict__ dres) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * V;
+  const float inv_n = 1.f / (float)n;
+  for (; i < total; i += stride) {
+    const int ch = (int)(i % (size_t)c);
+    float xv[V], yv[V], dv[V], ox[V], og[V];
+    if (V == 4) {
+      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + i);
+      *reinterpret_cast<float4*>(dv) = *reinterpret_cast<const float4*>(dy + i);
+      if (relu) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + i);
+    } else {
+      xv[0] = x[i];
+      dv[0] = dy[i];
+      if (relu) yv[0] = y[i];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float gval = dv[j];
+      if (relu && !(yv[j] > 0.f)) gval = 0.f;
+      const float is = invstd[ch + j];
+      const float xh = (xv[j] - mean[ch + j]) * is;
+      ox[j] = gamma[ch + j] * is * (gval - sum_g[ch + j] * inv_n - xh * sum_gx[ch + j] * inv_n);
+      og[j] = gval;
+    }
+    if (V == 4) {
+      *reinterpret_cast<float4*>(dx + i) = *reinterpret_cast<float4*>(ox);
+      if (dres) *reinterpret_cast<float4*>(dres + i) = *reinterpret_cast<float4*>(og);
+    } else {
+      dx[i] = ox[0];
+      if (dres) dres[i] = og[0];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ C entry ------
+extern "C" size_t irx_bn_workspace_bytes(int n, int c) {
+  if (n <= 0 || c <= 0) return 0;
+  return (size_t)irx_cdiv(n, BN_ROWS) * 2 * (size_t)c * sizeof(float);
+}
+
+static int bn_check(const char* who, int n, int c, const void* ws, size_t ws_bytes) {
+  IRX_REQUIRE(n >= 0 && c >= 1 && c <= 1024, "%s: unsupported sizes n=%d c=%d", who, n, c);
+  const int v = (c % 4 == 0) ? 4 : 1;
+  IRX_REQUIRE(c / v <= 256, "%s: c=%d too large for the statistics kernel", who, c);
+  if (n > 0 && (ws == nullptr || ws_bytes < irx_bn_workspace_bytes(n, c))) {
+    irx_set_error("%s: workspace %zu < %zu", who, ws_bytes, irx_bn_workspace_bytes(n, c));
+    return IRX_ERR_WORKSPACE;
+  }
+  return IRX_OK;
+}
+
+static inline int elem_grid(size_t total, int v) {
+  long long b = (long long)((total / v + 255) / 256);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int irx_bn_stats(const float* x, int n, int c, float eps, float momentum, float* mean,
+                            float* invstd, float* running_mean, float* running_var, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  int rc = bn_check("irx_bn_stats", n, c, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (n == 0) return IRX_OK;
+  IRX_REQUIRE(x && mean && invstd, "irx_bn_stats: null pointer");
+  const int nblk = irx_cdiv(n, BN_ROWS);
+  float* part = (float*)workspace;
+  const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  if (v4)
+    k_bn_partial<0, 4><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+                                                   next_pow2(c / 4), part);
+  else {
+    IRX_REQUIRE(c <= 256, "irx_bn_stats: c=%d needs c %% 4 == 0 or c <= 256", c);
+    k_bn_partial<0, 1><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+                                                   next_pow2(c), part);
+  }
+  IRX_CHECK_LAUNCH("irx_bn_stats(partial)");
+  k_bn_finalize<0><<<irx_cdiv(c, 32), 256, 0, S(stream)>>>(part, nblk, n, c, eps, momentum, mean,
+                                                          invstd, running_mean, running_var);
+  IRX_CHECK_LAUNCH("irx_bn_stats(finalize)");
+  return IRX_OK;
+}
+
+extern "C" int irx_bn_apply(const float* x, int n, int c, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, const float* residual, int relu,
+                            float* y, void* stream) {
+  IRX_REQUIRE(n >= 0 && c >= 1, "irx_bn_apply: bad sizes");
+  if (n == 0) return IRX_OK;
+  IRX_REQUIRE(x && mean && invstd && gamma && beta && y, "irx_bn_apply: null pointer");
+  const size_t total = (size_t)n * c;
+  const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
+                  (residual == nullptr || ((uintptr_t)residual & 15) == 0);
+  if (v4)
+    k_bn_apply<4><<<elem_grid(total, 4), 256, 0, S(stream)>>>(x, total, c, mean, invstd, gamma, beta,
+                                                             residual, relu, y);
+  else
+    k_bn_apply<1><<<elem_grid(total, 1), 256, 0, S(stream)>>>(x, total, c, mean, invstd, gamma, beta,
+                                                             residual, relu, y);
+  IRX_CHECK_LAUNCH("irx_bn_apply");
+  return IRX_OK;
+}
+
+extern "C" int irx_bn_backward(const float* x, const float* y, const float* dy, int n, int c,
+                               const float* mean, const float* invstd, const float* gamma, int relu,
+                               float* dx, float* dgamma, float* dbeta, float* dresidual,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = bn_check("irx_bn_backward", n, c, workspace, workspace_bytes);
+  if (rc) return rc;
+  IRX_REQUIRE(dgamma && dbeta, "irx_bn_backward: null dgamma/dbeta");
+  if (n == 0) {
+    IRX_CHECK_HIP(hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream)), "irx_bn_backward(memset)");
+    IRX_CHECK_HIP(hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream)), "irx_bn_backward(memset)");
+    return IRX_OK;
+  }
+  IRX_REQUIRE(x && dy && mean && invstd && gamma && dx, "irx_bn_backward: null pointer");
+  IRX_REQUIRE(!relu || y, "irx_bn_backward: relu needs y");
+  const int nblk = irx_cdiv(n, BN_ROWS);
+  float* part = (float*)workspace;
+  const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)dy & 15) == 0) &&
+                  (((uintptr_t)dx & 15) == 0) && (!relu || ((uintptr_t)y & 15) == 0) &&
+                  (dresidual == nullptr || ((uintptr_t)dresidual & 15) == 0);
+  if (v4)
+    k_bn_partial<1, 4><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
+                                                   next_pow2(c / 4), part);
+  else {
+    IRX_REQUIRE(c <= 256, "irx_bn_backward: c=%d needs c %% 4 == 0 or c <= 256", c);
+    k_bn_partial<1, 1><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, next_pow2(c),
+                                                   part);
+  }
+  IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
+  k_bn_finalize<1><<<irx_cdiv(c, 32), 256, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
+                                                          nullptr, nullptr);
+  IRX_CHECK_LAUNCH("irx_bn_backward(finalize)");
+  const size_t total = (size_t)n * c;
+  if (v4)
+    k_bn_bwd_apply<4><<<elem_grid(total, 4), 256, 0, S(stream)>>>(x, y, dy, total, n, c, mean, invstd,
+                                                                 gamma, dbeta, dgamma, relu, dx,
+                                                                 dresidual);
+  else
+    k_bn_bwd_apply<1><<<elem_grid(total, 1), 256, 0, S(stream)>>>(x, y, dy, total, n, c, mean, invstd,
+                                                                 gamma, dbeta, dgamma, relu, dx,
+                                                                 dresidual);
+  IRX_CHECK_LAUNCH("irx_bn_backward(apply)");
+  return IRX_OK;
+}

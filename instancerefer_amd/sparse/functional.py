@@ -1,0 +1,287 @@
+"""Raw operator wrappers over libirx.so plus the autograd Functions built from them.
+
+Each Function stands in for one torchsparse / torch_scatter operator the reference reaches from
+models/basic_blocks.py (reference tree); see include/irx.h for the per-symbol call sites.
+Everything here requires a HIP device: there is no CPU fallback (see _lib.py).
+"""
+import torch
+
+from .. import _lib
+
+_i32 = torch.int32
+_i64 = torch.int64
+_f32 = torch.float32
+
+
+def _stream():
+    return _lib.stream_ptr()
+
+
+def _f32c(t):
+    if t.dtype != _f32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------- coordinates --
+def coords_to_keys(coords):
+    n = coords.shape[0]
+    keys = torch.empty(n, dtype=_i64, device=coords.device)
+    _lib.call("irx_coords_to_keys", _lib.ptr(coords), n, _lib.ptr(keys), _stream())
+    return keys
+
+
+def quantize(xyz, batch, voxel):
+    """xyz (N,3) f32/f64 cuda, batch (N,) int32 or None, voxel: 3 floats -> coords (N,4) i32, keys (N,) i64."""
+    n = xyz.shape[0]
+    xyz = xyz.contiguous()
+    assert xyz.dtype in (torch.float32, torch.float64)
+    coords = torch.empty((n, 4), dtype=_i32, device=xyz.device)
+    keys = torch.empty(n, dtype=_i64, device=xyz.device)
+    _lib.call("irx_quantize", _lib.ptr(xyz), int(xyz.dtype == torch.float64), _lib.ptr(batch), n,
+              float(voxel[0]), float(voxel[1]), float(voxel[2]), _lib.ptr(coords), _lib.ptr(keys), _stream())
+    return coords, keys
+
+
+def new_table(n, device):
+    cap = _lib.hash_capacity(n)
+    return (torch.empty(cap, dtype=_i64, device=device), torch.empty(cap, dtype=_i32, device=device), cap)
+
+
+def voxel_unique(keys):
+    """First-occurrence voxel de-duplication. Returns int64 indices (unordered) of the winning points."""
+    n = keys.shape[0]
+    tk, tv, cap = new_table(n, keys.device)
+    _lib.call("irx_voxel_insert", _lib.ptr(keys), n, _lib.ptr(tk), _lib.ptr(tv), cap, _stream())
+    winners = torch.empty(max(n, 1), dtype=_i32, device=keys.device)
+    count = torch.empty(1, dtype=_i32, device=keys.device)
+    _lib.call("irx_voxel_select", _lib.ptr(keys), n, _lib.ptr(tk), _lib.ptr(tv), cap, _lib.ptr(winners),
+              _lib.ptr(count), _stream())
+    m = int(count.item())  # host sync: the voxel count sizes every later buffer
+    return winners[:m].long()
+
+
+def hash_build(keys):
+    n = keys.shape[0]
+    tk, tv, cap = new_table(n, keys.device)
+    _lib.call("irx_hash_build", _lib.ptr(keys), n, _lib.ptr(tk), _lib.ptr(tv), cap, _stream())
+    return tk, tv, cap
+
+
+def kmap_build_s1(coords, stride, table):
+    n = coords.shape[0]
+    tk, tv, cap = table
+    nbr = torch.empty((27, max(n, 1)), dtype=_i32, device=coords.device)
+    _lib.call("irx_kmap_build_s1", _lib.ptr(coords), n, int(stride), _lib.ptr(tk), _lib.ptr(tv), cap,
+              _lib.ptr(nbr), max(n, 1), _stream())
+    return nbr
+
+
+def downsample(keys, coords, stride):
+    """-> parent (n,) i32, koff (n,) u8, out_coords (n_out,4), out_keys (n_out,), child (8, ld) i32, ld, n_out."""
+    n = coords.shape[0]
+    dev = coords.device
+    ld = max(n, 1)
+    parent = torch.empty(ld, dtype=_i32, device=dev)
+    koff = torch.empty(ld, dtype=torch.uint8, device=dev)
+    out_coords = torch.empty((ld, 4), dtype=_i32, device=dev)
+    out_keys = torch.empty(ld, dtype=_i64, device=dev)
+    child = torch.empty((8, ld), dtype=_i32, device=dev)
+    n_out = torch.empty(1, dtype=_i32, device=dev)
+    wsb = int(_lib.load().irx_downsample_workspace_bytes(n))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.call("irx_downsample", _lib.ptr(keys), _lib.ptr(coords), n, int(stride), _lib.ptr(parent),
+              _lib.ptr(koff), _lib.ptr(out_coords), _lib.ptr(out_keys), _lib.ptr(child), ld,
+              _lib.ptr(n_out), _lib.ptr(ws), wsb, _stream())
+    m = int(n_out.item())  # host sync (one per pyramid level)
+    return parent[:n], koff[:n], out_coords[:m], out_keys[:m], child, ld, m
+
+
+def kmap_down_transpose(parent, koff):
+    n = parent.shape[0]
+    tbl = torch.empty((8, max(n, 1)), dtype=_i32, device=parent.device)
+    _lib.call("irx_kmap_down_transpose", _lib.ptr(parent), _lib.ptr(koff), n, _lib.ptr(tbl), max(n, 1),
+              _stream())
+    return tbl
+
+
+def bev_table(coords, stride, batch_size, nx, ny, nz, table):
+    n = coords.shape[0]
+    tk, tv, cap = table
+    ncell = batch_size * nx * ny
+    tbl = torch.empty((nz, ncell), dtype=_i32, device=coords.device)
+    cell = torch.empty(max(n, 1), dtype=_i32, device=coords.device)
+    zbin = torch.empty(max(n, 1), dtype=torch.uint8, device=coords.device)
+    _lib.call("irx_bev_table", _lib.ptr(coords), n, int(stride), batch_size, nx, ny, nz, _lib.ptr(tk),
+              _lib.ptr(tv), cap, _lib.ptr(tbl), ncell, _lib.ptr(cell), _lib.ptr(zbin), _stream())
+    return tbl, cell[:n], zbin[:n]
+
+
+def batch_offsets(coords, nseg):
+    off = torch.empty(nseg + 1, dtype=_i32, device=coords.device)
+    _lib.call("irx_batch_offsets", _lib.ptr(coords), coords.shape[0], nseg, _lib.ptr(off), _stream())
+    return off
+
+
+# ------------------------------------------------------------------------------ sparse conv ---
+def spconv_gather_gemm(x, w, tbl, ld, n_out, K, cin, cout, flip_k, trans_w):
+    y = torch.empty((n_out, cout), dtype=_f32, device=x.device)
+    _lib.call("irx_spconv_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(tbl), ld, n_out, K, cin, cout,
+              int(flip_k), int(trans_w), _lib.ptr(y), _stream())
+    return y
+
+
+def spconv_wgrad(x, dy, tbl, ld, n_out, K, cin, cout):
+    dw = torch.empty((K, cin, cout), dtype=_f32, device=x.device)
+    wsb = int(_lib.load().irx_spconv_wgrad_workspace_bytes(n_out, K, cin, cout))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    _lib.call("irx_spconv_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(tbl), ld, n_out, K, cin, cout,
+              _lib.ptr(dw), _lib.ptr(ws), wsb, _stream())
+    return dw
+
+
+class SparseConvFn(torch.autograd.Function):
+    """y[q] = sum_k x[tbl_f[k][q]] @ w[k].  Backward: data-gradient through `tbl_b` (the same table
+    with flipped offsets for a stride-1 conv, the transposed child table for a strided one) and the
+    weight-gradient through `tbl_f`."""
+
+    @staticmethod
+    def forward(ctx, x, w, tbl_f, ld_f, n_out, tbl_b_fn, flip_b):
+        x = _f32c(x)
+        w = _f32c(w)
+        K, cin, cout = w.shape
+        assert x.shape[1] == cin
+        y = spconv_gather_gemm(x, w, tbl_f, ld_f, n_out, K, cin, cout, 0, 0)
+        ctx.save_for_backward(x, w, tbl_f)
+        ctx.meta = (ld_f, n_out, tbl_b_fn, flip_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, tbl_f = ctx.saved_tensors
+        ld_f, n_out, tbl_b_fn, flip_b = ctx.meta
+        K, cin, cout = w.shape
+        dy = _f32c(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            tbl_b, ld_b = tbl_b_fn()
+            dx = spconv_gather_gemm(dy, w, tbl_b, ld_b, x.shape[0], K, cout, cin, flip_b, 1)
+        if ctx.needs_input_grad[1]:
+            dw = spconv_wgrad(x, dy, tbl_f, ld_f, n_out, K, cin, cout)
+        return dx, dw, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------- batchnorm --
+def _bn_ws(n, c, device):
+    wsb = int(_lib.load().irx_bn_workspace_bytes(n, c))
+    return torch.empty(max(wsb, 4), dtype=torch.uint8, device=device), wsb
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """Train-mode BatchNorm over rows (+ residual) (+ ReLU), one statistics pass + one apply pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu):
+        x = _f32c(x)
+        n, c = x.shape
+        dev = x.device
+        mean = torch.empty(c, dtype=_f32, device=dev)
+        invstd = torch.empty(c, dtype=_f32, device=dev)
+        ws, wsb = _bn_ws(n, c, dev)
+        res = _f32c(residual) if residual is not None else None
+        _lib.call("irx_bn_stats", _lib.ptr(x), n, c, float(eps), float(momentum), _lib.ptr(mean),
+                  _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ws), wsb,
+                  _stream())
+        y = torch.empty_like(x)
+        g = _f32c(gamma)
+        b = _f32c(beta)
+        _lib.call("irx_bn_apply", _lib.ptr(x), n, c, _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(g),
+                  _lib.ptr(b), _lib.ptr(res), int(relu), _lib.ptr(y), _stream())
+        ctx.save_for_backward(x, y, mean, invstd, g)
+        ctx.relu = bool(relu)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, g = ctx.saved_tensors
+        n, c = x.shape
+        dev = x.device
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=_f32, device=dev)
+        dbeta = torch.empty(c, dtype=_f32, device=dev)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        ws, wsb = _bn_ws(n, c, dev)
+        _lib.call("irx_bn_backward", _lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), n, c, _lib.ptr(mean),
+                  _lib.ptr(invstd), _lib.ptr(g), int(ctx.relu), _lib.ptr(dx), _lib.ptr(dgamma),
+                  _lib.ptr(dbeta), _lib.ptr(dres), _lib.ptr(ws), wsb, _stream())
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
+
+
+def bn_eval(x, gamma, beta, residual, running_mean, running_var, eps, relu):
+    """Inference-mode BN(+res)(+ReLU) with running statistics: the apply kernel, autograd through torch."""
+    invstd = torch.rsqrt(running_var.float() + eps)
+    if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad):
+        y = (x - running_mean) * (invstd * gamma) + beta
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
+    x = _f32c(x)
+    n, c = x.shape
+    y = torch.empty_like(x)
+    res = _f32c(residual) if residual is not None else None
+    _lib.call("irx_bn_apply", _lib.ptr(x), n, c, _lib.ptr(_f32c(running_mean)), _lib.ptr(invstd),
+              _lib.ptr(_f32c(gamma)), _lib.ptr(_f32c(beta)), _lib.ptr(res), int(relu), _lib.ptr(y), _stream())
+    return y
+
+
+# ------------------------------------------------------------------------- segmented max -------
+class SegmentMaxFn(torch.autograd.Function):
+    """Channel-wise max over contiguous row segments; gradient goes to the arg-max row."""
+
+    @staticmethod
+    def forward(ctx, x, offsets, nseg):
+        x = _f32c(x)
+        c = x.shape[1]
+        y = torch.empty((nseg, c), dtype=_f32, device=x.device)
+        arg = torch.empty((nseg, c), dtype=_i32, device=x.device)
+        _lib.call("irx_segment_max", _lib.ptr(x), _lib.ptr(offsets), nseg, c, _lib.ptr(y), _lib.ptr(arg),
+                  _stream())
+        ctx.save_for_backward(arg)
+        ctx.shape = tuple(x.shape)
+        ctx.mark_non_differentiable(arg)
+        return y, arg
+
+    @staticmethod
+    def backward(ctx, dy, _darg):
+        (arg,) = ctx.saved_tensors
+        n, c = ctx.shape
+        dx = torch.zeros((n, c), dtype=_f32, device=dy.device)
+        dy = _f32c(dy)
+        _lib.call("irx_segment_max_backward", _lib.ptr(dy), _lib.ptr(arg), arg.shape[0], c, _lib.ptr(dx),
+                  _stream())
+        return dx, None, None
+
+
+def segment_max(x, offsets, nseg):
+    return SegmentMaxFn.apply(x, offsets, nseg)[0]
+
+
+def segment_mean(x):
+    """x (nseg, len, c) f32 cuda -> (nseg, c)."""
+    x = _f32c(x)
+    nseg, ln, c = x.shape
+    y = torch.empty((nseg, c), dtype=_f32, device=x.device)
+    _lib.call("irx_segment_mean", _lib.ptr(x), nseg, ln, c, _lib.ptr(y), _stream())
+    return y
+
+
+def knn_batched(sup_xyz, sup_offsets, qry_xyz, qry_batch, k):
+    sup_xyz = _f32c(sup_xyz)
+    qry_xyz = _f32c(qry_xyz)
+    nq = qry_xyz.shape[0]
+    out = torch.empty((nq, k), dtype=_i32, device=sup_xyz.device)
+    _lib.call("irx_knn_batched", _lib.ptr(sup_xyz), _lib.ptr(sup_offsets), _lib.ptr(qry_xyz),
+              _lib.ptr(qry_batch), nq, k, _lib.ptr(out), _stream())
+    return out

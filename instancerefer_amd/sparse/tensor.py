@@ -1,0 +1,165 @@
+"""SparseTensor + coordinate manager — the torchsparse-shaped container the reference code builds
+(`SparseTensor(feats, coords[, stride])`, attributes `.F .C .s`, `.cuda()`, `+`; reference
+models/attribute_module.py:70, models/basic_blocks.py:175-182, lib/dataset.py:234,261).
+
+MI355X-first difference from torchsparse: rows are kept in *Morton (Z-order) key order* once a tensor
+enters a convolution. That makes (i) down-sampling a segmented scan instead of a hash + unique,
+(ii) 64-row output tiles spatially compact so whole kernel offsets can be skipped per tile, and
+(iii) gathers L2-friendly. Everything downstream in the reference (BatchNorm, max-pool, BEV
+scatter-add) is invariant to row order, so only the *set* of (coord, feature) rows is contractual.
+"""
+import numpy as np
+import torch
+
+from . import functional as F_
+
+
+class DownMap:
+    """Kernel map of a kernel-2 / stride-2 convolution between two pyramid levels."""
+
+    def __init__(self, parent, koff, child, ld, out_level):
+        self.parent = parent      # (n_in,) int32
+        self.koff = koff          # (n_in,) uint8
+        self.child = child        # (8, ld) int32
+        self.ld = ld
+        self.out_level = out_level
+        self._child_t = None
+
+    def child_t(self):
+        """(8, n_in) table for the data-gradient: tbl[k][i] = parent[i] if koff[i] == k else -1."""
+        if self._child_t is None:
+            self._child_t = F_.kmap_down_transpose(self.parent, self.koff)
+        return self._child_t, max(self.parent.shape[0], 1)
+
+
+class Level:
+    """One tensor stride of a coordinate pyramid: coords in ascending Morton-key order + cached maps
+    (torchsparse caches `coord_maps` / `kernel_maps` on the tensor; here they live on the level and are
+    shared by every tensor of that stride, including both convs of a ResidualBlock and the backward)."""
+
+    def __init__(self, coords, keys, stride, batch_size):
+        self.coords = coords      # (n,4) int32, (x,y,z,b)
+        self.keys = keys          # (n,) int64 (uint64 bit pattern), ascending
+        self.stride = int(stride)
+        self.batch_size = int(batch_size)
+        self._table = None
+        self._nbr27 = None
+        self._down = None
+        self._offsets = None
+        self._bev = {}
+
+    @property
+    def n(self):
+        return self.coords.shape[0]
+
+    def table(self):
+        if self._table is None:
+            self._table = F_.hash_build(self.keys)
+        return self._table
+
+    def nbr27(self):
+        if self._nbr27 is None:
+            self._nbr27 = F_.kmap_build_s1(self.coords, self.stride, self.table())
+        return self._nbr27, max(self.n, 1)
+
+    def down(self):
+        if self._down is None:
+            parent, koff, oc, ok, child, ld, m = F_.downsample(self.keys, self.coords, self.stride)
+            out = Level(oc, ok, self.stride * 2, self.batch_size)
+            self._down = DownMap(parent, koff, child, ld, out)
+        return self._down
+
+    def offsets(self):
+        if self._offsets is None:
+            self._offsets = F_.batch_offsets(self.coords, self.batch_size)
+        return self._offsets
+
+    def bev(self, nx, ny, nz):
+        key = (nx, ny, nz)
+        if key not in self._bev:
+            self._bev[key] = F_.bev_table(self.coords, self.stride, self.batch_size, nx, ny, nz, self.table())
+        return self._bev[key]
+
+
+class SparseTensor:
+    def __init__(self, feats, coords, stride=1, batch_size=None, _level=None):
+        self.F = feats
+        self.C = coords
+        self.s = stride
+        self.coord_maps = {}
+        self.kernel_maps = {}
+        self._batch_size = batch_size
+        self._level = _level
+
+    # --- torchsparse surface ---------------------------------------------------------------
+    def check(self):
+        if self.s not in self.coord_maps:
+            self.coord_maps[self.s] = self.C
+
+    def _as_torch(self):
+        F, C = self.F, self.C
+        if isinstance(F, np.ndarray):
+            F = torch.from_numpy(np.ascontiguousarray(F)).float()
+        if isinstance(C, np.ndarray):
+            C = torch.from_numpy(np.ascontiguousarray(C)).int()
+        return F, C
+
+    def to(self, device, non_blocking=True):
+        F, C = self._as_torch()
+        return SparseTensor(F.to(device, non_blocking=non_blocking), C.to(device, non_blocking=non_blocking),
+                            self.s, self._batch_size, None)
+
+    def cuda(self):
+        if isinstance(self.C, torch.Tensor) and self.C.is_cuda:
+            return self
+        return self.to(torch.device("cuda", torch.cuda.current_device()))
+
+    def cpu(self):
+        F, C = self._as_torch()
+        return SparseTensor(F.cpu(), C.cpu(), self.s, self._batch_size, None)
+
+    def detach(self):
+        return SparseTensor(self.F.detach(), self.C, self.s, self._batch_size, self._level)
+
+    def __add__(self, other):
+        if self._level is not other._level or self._level is None:
+            raise RuntimeError("SparseTensor + SparseTensor needs both operands on the same coordinate level")
+        return SparseTensor(self.F + other.F, self.C, self.s, self._batch_size, self._level)
+
+    def __repr__(self):
+        n = self.F.shape[0] if hasattr(self.F, "shape") else "?"
+        return "SparseTensor(n=%s, stride=%s)" % (n, self.s)
+
+    # --- irx ------------------------------------------------------------------------------
+    @property
+    def batch_size(self):
+        if self._batch_size is None:
+            # the reference infers it the same way (a host sync): models/basic_blocks.py:235
+            self._batch_size = int(self.C[:, 3].max().item()) + 1 if self.C.shape[0] else 0
+        return self._batch_size
+
+    def level(self):
+        if self._level is None:
+            raise RuntimeError("SparseTensor is not canonical yet; call .canonical()")
+        return self._level
+
+    def with_feats(self, feats, level=None):
+        lv = level if level is not None else self._level
+        return SparseTensor(feats, lv.coords, lv.stride, lv.batch_size, lv)
+
+    def canonical(self):
+        """Rows re-ordered to ascending Morton key (device tensors). No-op when already canonical."""
+        if self._level is not None:
+            return self
+        F, C = self._as_torch()
+        if not C.is_cuda:
+            raise RuntimeError("irx sparse ops need the SparseTensor on a HIP device (call .cuda())")
+        C = C.int().contiguous()
+        F = F.float()
+        keys = F_.coords_to_keys(C)
+        skeys, perm = torch.sort(keys)
+        C = C.index_select(0, perm).contiguous()
+        F = F.index_select(0, perm)
+        bs = self._batch_size if self._batch_size is not None else (int(C[-1, 3].item()) + 1 if C.shape[0] else 0)
+        lv = Level(C, skeys, self.s, bs)
+        return SparseTensor(F, C, self.s, bs, lv)

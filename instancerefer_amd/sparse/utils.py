@@ -1,0 +1,102 @@
+"""torchsparse.utils surface: sparse_quantize / sparse_collate / sparse_collate_tensors /
+sparse_collate_fn (reference call sites: models/attribute_module.py:65-70,101;
+lib/dataset.py:229-234,256-261,458), plus the batched device voxeliser the drop-in modules use."""
+from collections.abc import Sequence
+
+import numpy as np
+import torch
+
+from . import functional as F_
+from .tensor import Level, SparseTensor
+
+
+def _voxel3(quantization_size):
+    if isinstance(quantization_size, (Sequence, np.ndarray, torch.Tensor)):
+        v = [float(q) for q in quantization_size]
+        assert len(v) == 3
+        return v
+    return [float(quantization_size)] * 3
+
+
+def voxelize(xyz, feats, batch, voxel_size, batch_size):
+    """Device voxeliser: one representative (FIRST-occurrence) point per voxel, features NOT averaged —
+    torchsparse.sparse_quantize semantics — for a whole batch of clouds in one pass.
+
+    xyz (N,3) f32/f64 cuda; feats (N,C) cuda; batch (N,) int32 cuda or None; returns a canonical
+    SparseTensor (rows in Morton order) at stride 1.
+    """
+    coords, keys = F_.quantize(xyz, batch, _voxel3(voxel_size))
+    win = F_.voxel_unique(keys)
+    wkeys = keys.index_select(0, win)
+    skeys, order = torch.sort(wkeys)
+    idx = win.index_select(0, order)
+    C = coords.index_select(0, idx).contiguous()
+    Fv = feats.index_select(0, idx).float().contiguous()
+    lv = Level(C, skeys, 1, batch_size)
+    return SparseTensor(Fv, C, 1, batch_size, lv)
+
+
+def sparse_quantize(coords, feats=None, labels=None, ignore_label=255, return_index=False,
+                    return_invs=False, hash_type='fnv', quantization_size=1):
+    """torchsparse.utils.sparse_quantize on the GPU. numpy / torch in; (coords, feats) out as device
+    tensors: coords float64-floored int32 (M,3), feats (M,C) of the first point falling in each voxel.
+    Row order is ascending Morton key (torchsparse: ascending FNV hash) — consumers are order-free.
+    """
+    if labels is not None or return_invs:
+        raise NotImplementedError("irx sparse_quantize: labels / inverse maps are not on the hot path")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xyz = torch.as_tensor(coords).to(dev)
+    if xyz.dtype not in (torch.float32, torch.float64):
+        xyz = xyz.double()
+    c4, keys = F_.quantize(xyz, None, _voxel3(quantization_size))
+    win = F_.voxel_unique(keys)
+    wkeys = keys.index_select(0, win)
+    _, order = torch.sort(wkeys)
+    idx = win.index_select(0, order)
+    if return_index or feats is None:
+        return idx
+    f = torch.as_tensor(feats).to(dev)
+    return c4.index_select(0, idx)[:, :3].contiguous(), f.index_select(0, idx)
+
+
+def sparse_collate(coords, feats, labels=None, is_double=False, coord_float=False):
+    """Concatenate per-sample (coords, feats) adding the batch index as the 4th coord column."""
+    cs, fs = [], []
+    for b, (c, f) in enumerate(zip(coords, feats)):
+        c = torch.as_tensor(c)
+        f = torch.as_tensor(f)
+        c = c.float() if coord_float else c.int()
+        f = f.double() if is_double else f.float()
+        bcol = torch.full((c.shape[0], 1), b, dtype=c.dtype, device=c.device)
+        cs.append(torch.cat([c[:, :3], bcol], 1))
+        fs.append(f)
+    if not cs:
+        return torch.zeros((0, 4), dtype=torch.int32), torch.zeros((0, 0))
+    return torch.cat(cs, 0), torch.cat(fs, 0)
+
+
+def sparse_collate_tensors(sparse_tensors):
+    if len(sparse_tensors) == 0:
+        raise ValueError("sparse_collate_tensors: empty list")
+    coords, feats = sparse_collate([x.C for x in sparse_tensors], [x.F for x in sparse_tensors])
+    return SparseTensor(feats, coords, sparse_tensors[0].s, batch_size=len(sparse_tensors))
+
+
+def sparse_collate_fn(batch):
+    """dict collate: ndarray -> stacked tensor, SparseTensor -> batched SparseTensor, rest -> list."""
+    if isinstance(batch[0], dict):
+        out = {}
+        for name in batch[0].keys():
+            v0 = batch[0][name]
+            if isinstance(v0, dict):
+                out[name] = sparse_collate_fn([s[name] for s in batch])
+            elif isinstance(v0, np.ndarray):
+                out[name] = torch.stack([torch.from_numpy(s[name]) for s in batch], 0)
+            elif isinstance(v0, torch.Tensor):
+                out[name] = torch.stack([s[name] for s in batch], 0)
+            elif isinstance(v0, SparseTensor):
+                out[name] = sparse_collate_tensors([s[name] for s in batch])
+            else:
+                out[name] = [s[name] for s in batch]
+        return out
+    return {"input": sparse_collate_tensors(list(batch))}

@@ -1,0 +1,223 @@
+"""GPU parity of every libirx operator against the CPU oracle (oracle/torchsparse, oracle/torch_geometric)
+on seeded inputs. Integer/index work must be bit-exact; fp32 arithmetic within the tolerance stated at
+each assert (north star: 1e-4 fp32). All calls go through the C-ABI (instancerefer_amd._lib -> libirx.so)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import align, device_batch, oracle_batch, pack_coords, surface_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def clouds():
+    rng = np.random.default_rng(7)
+    out = []
+    for i in range(5):
+        ctr = rng.uniform(-1.5, 1.5, 3)  # straddles the origin: negative voxel coordinates
+        out.append(surface_cloud(rng, 1024 if i else 3000, ctr, rng.uniform(0.4, 1.2, 3)))
+    return out
+
+
+def test_single_hip_runtime(lib):
+    """libirx must share torch's HIP runtime (one libamdhip64 mapped), else streams/pointers are foreign."""
+    torch.zeros(1, device="cuda")
+    libs = {l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}
+    assert len(libs) == 1, libs
+
+
+def test_device_props(lib):
+    import ctypes
+    out = (ctypes.c_int * 8)()
+    assert lib.irx_device_props(0, out) == 0
+    assert out[1] == 64 and out[5] == 950, list(out)
+
+
+def test_voxelize_matches_sparse_quantize(lib, clouds):
+    o = oracle_batch(clouds, 0.05)
+    d = device_batch(clouds, 0.05)
+    ia, ib = align(d.C.cpu().numpy(), o.C.numpy())
+    # first-occurrence representative per voxel: features bit-identical (fp64 -> fp32 cast on both sides)
+    assert np.array_equal(d.F.cpu().numpy()[ia], o.F.numpy()[ib])
+    k = d.level().keys.cpu().numpy()
+    assert np.all(k[1:] > k[:-1]), "rows must be in strictly ascending Morton-key order"
+
+
+def test_sparse_quantize_api(lib, clouds):
+    from instancerefer_amd.sparse.utils import sparse_quantize
+    from oracle.torchsparse.utils import sparse_quantize as oq
+    pc = clouds[0]
+    c, f = sparse_quantize(pc[:, :3], pc, quantization_size=np.array([0.02] * 3))
+    oc, of = oq(pc[:, :3], pc, quantization_size=np.array([0.02] * 3))
+    c4 = np.concatenate([c.cpu().numpy(), np.zeros((len(c), 1), np.int32)], 1)
+    oc4 = np.concatenate([oc, np.zeros((len(oc), 1))], 1)
+    ia, ib = align(c4, oc4)
+    assert np.array_equal(f.cpu().numpy()[ia], of[ib])
+
+
+def _oracle_maps(o, ks, stride):
+    from oracle.torchsparse.nn import functional as spf
+    off = spf.kernel_offsets(ks, o.s)
+    if stride > 1:
+        newc = spf.spdownsample(o.C, stride * o.s)
+        return newc, spf.build_kernel_map(o.C, newc, off)
+    return o.C, spf.build_kernel_map(o.C, o.C, off)
+
+
+def test_kmap_s1_bit_exact(lib, clouds):
+    o = oracle_batch(clouds, 0.05)
+    d = device_batch(clouds, 0.05)
+    _, maps = _oracle_maps(o, 3, 1)
+    ia, ib = align(d.C.cpu().numpy(), o.C.numpy())
+    nbr, ld = d.level().nbr27()
+    nbr = nbr.cpu().numpy()
+    # translate oracle pairs into the device's row numbering
+    rank_o2d = np.empty(len(ib), np.int64)
+    rank_o2d[ib] = ia
+    for k, (i_idx, o_idx) in enumerate(maps):
+        exp = np.full(len(ia), -1, np.int64)
+        exp[rank_o2d[o_idx.numpy()]] = rank_o2d[i_idx.numpy()]
+        assert np.array_equal(nbr[k, :len(ia)], exp), "offset %d" % k
+
+
+def test_downsample_bit_exact(lib, clouds):
+    o = oracle_batch(clouds, 0.05)
+    d = device_batch(clouds, 0.05)
+    lv = d.level()
+    for _ in range(3):  # strides 1->2->4->8
+        newc, maps = _oracle_maps(o, 2, 2)
+        dm = lv.down()
+        out = dm.out_level
+        ia_in, ib_in = align(lv.coords.cpu().numpy(), o.C.numpy())
+        ia_o, ib_o = align(out.coords.cpu().numpy(), newc.numpy())
+        o2d_in = np.empty(len(ib_in), np.int64); o2d_in[ib_in] = ia_in
+        o2d_out = np.empty(len(ib_o), np.int64); o2d_out[ib_o] = ia_o
+        child = dm.child.cpu().numpy()
+        for k, (i_idx, o_idx) in enumerate(maps):
+            exp = np.full(out.n, -1, np.int64)
+            exp[o2d_out[o_idx.numpy()]] = o2d_in[i_idx.numpy()]
+            assert np.array_equal(child[k, :out.n], exp), "offset %d" % k
+        kk = out.keys.cpu().numpy()
+        assert np.all(kk[1:] > kk[:-1])
+        # next level
+        from oracle.torchsparse import SparseTensor as OT
+        o = OT(torch.zeros(len(newc), 1), newc, o.s * 2)
+        lv = out
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride", [(7, 32, 3, 1), (32, 64, 2, 2), (64, 64, 3, 1),
+                                                (64, 128, 2, 2), (128, 128, 3, 1), (20, 48, 3, 1)])
+def test_conv_fwd_bwd(lib, clouds, cin, cout, ks, stride):
+    import oracle.torchsparse.nn as ospnn
+    from oracle.torchsparse import SparseTensor as OT
+    from instancerefer_amd.sparse import nn as spnn
+    torch.manual_seed(cin * 1000 + cout)
+    o = oracle_batch(clouds, 0.05)
+    d = device_batch(clouds, 0.05)
+    ia, ib = align(d.C.cpu().numpy(), o.C.numpy())
+    n = len(ia)
+    feats = torch.randn(n, cin)
+    fo = torch.empty(n, cin); fo[ib] = feats
+    fd = torch.empty(n, cin); fd[ia] = feats
+    oconv = ospnn.Conv3d(cin, cout, ks, stride=stride)
+    dconv = spnn.Conv3d(cin, cout, ks, stride=stride).cuda()
+    dconv.kernel.data.copy_(oconv.kernel.data)
+    xo = fo.clone().requires_grad_(True)
+    xd = fd.clone().cuda().requires_grad_(True)
+    yo = oconv(OT(xo, o.C, 1))
+    yd = dconv(d.with_feats(xd))
+    ja, jb = align(yd.C.cpu().numpy(), yo.C.numpy())
+    got, exp = yd.F.detach().cpu()[ja], yo.F.detach()[jb]
+    scale = exp.abs().max().item()
+    assert (got - exp).abs().max().item() <= 1e-5 * max(scale, 1.0), "forward"
+    # backward with a fixed upstream gradient
+    g = torch.randn(len(ja), cout)
+    go = torch.empty_like(g); go[jb] = g
+    gd = torch.empty_like(g); gd[ja] = g
+    yo.F.backward(go)
+    yd.F.backward(gd.cuda())
+    dxo, dxd = xo.grad[ib], xd.grad.cpu()[ia]
+    assert (dxd - dxo).abs().max().item() <= 1e-5 * max(dxo.abs().max().item(), 1.0), "dgrad"
+    dwo, dwd = oconv.kernel.grad, dconv.kernel.grad.cpu()
+    assert (dwd - dwo).abs().max().item() <= 2e-5 * max(dwo.abs().max().item(), 1.0), "wgrad"
+
+
+@pytest.mark.parametrize("n,c,relu,res", [(5000, 32, True, False), (777, 64, True, True), (3001, 128, False, True),
+                                          (260, 128, True, False), (1500, 20, True, True)])
+def test_batchnorm_act(lib, n, c, relu, res):
+    from instancerefer_amd.sparse import nn as spnn
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c) * 2 + 0.5
+    r = torch.randn(n, c) if res else None
+    ref = torch.nn.BatchNorm1d(c)
+    ref.weight.data.uniform_(0.5, 1.5); ref.bias.data.uniform_(-0.5, 0.5)
+    bn = spnn.BatchNorm(c).cuda()
+    bn.load_state_dict(ref.state_dict())
+    xo = x.clone().requires_grad_(True)
+    ro = r.clone().requires_grad_(True) if res else None
+    yo = ref(xo)
+    if res: yo = yo + ro
+    if relu: yo = torch.relu(yo)
+    xd = x.clone().cuda().requires_grad_(True)
+    rd = r.clone().cuda().requires_grad_(True) if res else None
+    yd = bn.feats(xd, rd, relu)
+    assert (yd.detach().cpu() - yo.detach()).abs().max().item() <= 1e-5
+    assert (bn.running_mean.cpu() - ref.running_mean).abs().max().item() <= 1e-6
+    assert (bn.running_var.cpu() - ref.running_var).abs().max().item() <= 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    g = torch.randn(n, c)
+    yo.backward(g); yd.backward(g.cuda())
+    assert (xd.grad.cpu() - xo.grad).abs().max().item() <= 2e-5
+    assert (bn.weight.grad.cpu() - ref.weight.grad).abs().max().item() <= 1e-4 * max(1.0, ref.weight.grad.abs().max().item())
+    assert (bn.bias.grad.cpu() - ref.bias.grad).abs().max().item() <= 1e-4 * max(1.0, ref.bias.grad.abs().max().item())
+    if res:
+        assert (rd.grad.cpu() - ro.grad).abs().max().item() <= 1e-6
+    # eval mode uses running stats
+    ref.eval(); bn.eval()
+    with torch.no_grad():
+        ye = bn.feats(x.cuda(), None, False).cpu()
+        assert (ye - ref(x)).abs().max().item() <= 1e-5
+
+
+def test_global_max_pool(lib, clouds):
+    import oracle.torchsparse.nn as ospnn
+    from instancerefer_amd.sparse import nn as spnn
+    o = oracle_batch(clouds, 0.05)
+    d = device_batch(clouds, 0.05)
+    ia, ib = align(d.C.cpu().numpy(), o.C.numpy())
+    n = len(ia)
+    feats = torch.randn(n, 128)
+    fo = torch.empty(n, 128); fo[ib] = feats
+    fd = torch.empty(n, 128); fd[ia] = feats
+    from oracle.torchsparse import SparseTensor as OT
+    xo = fo.requires_grad_(True)
+    xd = fd.cuda().requires_grad_(True)
+    yo = ospnn.GlobalMaxPooling()(OT(xo, o.C, 1))
+    yd = spnn.GlobalMaxPooling()(d.with_feats(xd))
+    assert torch.equal(yd.detach().cpu(), yo.detach())
+    g = torch.randn_like(yo)
+    yo.backward(g); yd.backward(g.cuda())
+    assert torch.equal(xd.grad.cpu()[ia], xo.grad[ib])
+
+
+def test_knn_and_segment_mean(lib):
+    from instancerefer_amd.sparse import functional as F_
+    from oracle.torch_geometric.nn import knn
+    rng = np.random.default_rng(3)
+    counts = [5, 12, 40, 1, 9]  # fewer than k support rows in two batch items
+    sup = rng.uniform(0, 8, (sum(counts), 3)).astype(np.float32)
+    bidx = np.concatenate([np.full(c, i) for i, c in enumerate(counts)])
+    qsel = np.sort(rng.choice(len(sup), 30, replace=False))
+    x, y = torch.from_numpy(sup), torch.from_numpy(sup[qsel])
+    bx, by = torch.from_numpy(bidx), torch.from_numpy(bidx[qsel])
+    row, col = knn(x, y, 8, bx, by)
+    off = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32).cuda()
+    nb = F_.knn_batched(x.cuda(), off, y.cuda(), by.int().cuda(), 8).cpu().numpy()
+    for qi in range(len(qsel)):
+        exp = col[row == qi].numpy()
+        got = nb[qi][nb[qi] >= 0]
+        assert np.array_equal(got, exp), (qi, got, exp)
+    pts = rng.uniform(-2, 2, (17, 1024, 7))
+    m = F_.segment_mean(torch.from_numpy(pts).float().cuda()).cpu().numpy()
+    assert np.abs(m - pts.astype(np.float32).astype(np.float64).mean(1)).max() <= 1e-6
