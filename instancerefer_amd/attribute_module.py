@@ -1,0 +1,83 @@
+"""AttributeModule — drop-in for the reference's models/attribute_module.py:11-131.
+
+Per same-class candidate instance: voxelise (2 cm) -> SparseConvEncoder -> global max-pool -> MLP ->
+cosine score against the language attribute vector. The reference voxelises each candidate with numpy
+inside forward (a host double loop, attribute_module.py:59-71) and uploads the collated voxels every
+step; here all candidates of the batch are voxelised by ONE hash-voxelisation pass on the GPU
+(float64 floor(x / v), first-occurrence representative, batch index = candidate index).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .basic_blocks import SparseConvEncoder
+from .data import idx_tensor, upload_instances
+from .sparse import nn as spnn
+from .sparse.utils import voxelize
+
+
+class AttributeModule(nn.Module):
+    def __init__(self, input_feature_dim, args, v_dim=128, h_dim=256, l_dim=256):
+        super().__init__()
+        self.args = args
+        self.input_feature_dim = input_feature_dim
+        self.voxel_size = np.array([args.voxel_size_ap] * 3)
+        self.net = SparseConvEncoder(self.input_feature_dim)
+        self.pooling = spnn.GlobalMaxPooling()
+        self.vis_emb_fc = nn.Sequential(nn.Linear(v_dim, h_dim), nn.LayerNorm(h_dim), nn.ReLU(),
+                                        nn.Linear(h_dim, h_dim))
+        self.lang_emb_fc = nn.Sequential(nn.Linear(l_dim, h_dim), nn.BatchNorm1d(h_dim), nn.ReLU(),
+                                         nn.Linear(h_dim, h_dim))
+        self.weight_initialization()
+
+    def weight_initialization(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def filter_candidates(self, data_dict, lang_cls_pred):
+        """-> (SparseTensor of all candidates' voxels, pred_obb_batch, num_filtered_objs); same selection
+        rule as the reference (class match; scenes with < 2 candidates contribute no voxels)."""
+        pack = upload_instances(data_dict)
+        sel = pack.select(lang_cls_pred)
+        dev = pack.pts32.device
+        cand = idx_tensor(sel['cand'], dev)
+        nc = len(sel['cand'])
+        if nc == 0:
+            return None, sel
+        xyz = pack.xyz64.index_select(0, cand)                 # (Nc, P, 3) float64
+        pts = pack.pts32.index_select(0, cand)                 # (Nc, P, C0) float32
+        p = xyz.shape[1]
+        batch = torch.arange(nc, device=dev, dtype=torch.int32).repeat_interleave(p)
+        st = voxelize(xyz.view(-1, 3), pts.view(nc * p, -1), batch, self.voxel_size, nc)
+        return st, sel
+
+    def forward(self, data_dict):
+        lang_feats = data_dict['lang_attr_feats']
+        lang_feats = self.lang_emb_fc(lang_feats)
+        lang_feats = nn.functional.normalize(lang_feats, p=2, dim=1)          # (B, h_dim)
+
+        if not self.args.use_gt_lang:
+            lang_cls_pred = torch.argmax(data_dict["lang_scores"], dim=1)
+        else:
+            lang_cls_pred = data_dict['object_cat']
+        lang_cls_pred = lang_cls_pred.tolist()   # one D2H of B ints (the reference syncs per instance)
+
+        st, sel = self.filter_candidates(data_dict, lang_cls_pred)
+        data_dict['num_filtered_objs'] = sel['num_filtered_objs']
+        data_dict['pred_obb_batch'] = sel['pred_obb_batch']
+        dev = lang_feats.device
+        if st is None:   # no scene with >= 2 candidates (the reference crashes here: torch.cat([]))
+            data_dict['obj_feats'] = lang_feats.new_zeros((0, 128))
+            data_dict['attribute_scores'] = lang_feats.new_zeros((0,))
+            return data_dict
+
+        feats = self.net(st)
+        feats = self.pooling(feats)                       # (Nc, 128)
+        data_dict['obj_feats'] = feats
+        feats = self.vis_emb_fc(feats)
+        feats = nn.functional.normalize(feats, p=2, dim=1)
+        lang_flat = lang_feats.index_select(0, idx_tensor(sel['cand_scene'], dev))
+        data_dict['attribute_scores'] = torch.sum(feats * lang_flat, dim=1)
+        return data_dict

@@ -1,0 +1,96 @@
+"""Host-side helpers around the reference's `data_dict` contract.
+
+`upload_instances` moves the ragged python lists of per-instance (1024, C0) float64 point arrays that
+lib/dataset.py:201-298 (reference) produces to the GPU ONCE per batch, so that candidate filtering, both
+voxelisations and the per-instance means run on device. The drop-in modules accept a plain reference
+data_dict too (they call this themselves when the `irx` entry is absent)."""
+import numpy as np
+import torch
+
+
+class InstancePack:
+    """All instances of a batch, flattened scene-major.
+      xyz64   (S, P, 3)  float64 cuda — exact voxel assignment needs float64 (np.floor(x / v) parity)
+      pts32   (S, P, C0) float32 cuda — features (first-point voxel features, per-instance means)
+      obbs    (S, 7)     float64 numpy (host; returned to callers as pred_obb_batch)
+      centres (S, 3)     float32 cuda
+      classes list[int] length S ; scene_of list[int] length S ; scene_start list[int] length B+1
+    """
+
+    def __init__(self, data_dict, device):
+        ipts = data_dict['instance_points']
+        iobb = data_dict['instance_obbs']
+        icls = data_dict['instance_class']
+        self.batch_size = len(ipts)
+        flat, obbs, classes, scene_of, start = [], [], [], [], [0]
+        for i in range(self.batch_size):
+            for j in range(len(ipts[i])):
+                flat.append(np.asarray(ipts[i][j]))
+                obbs.append(np.asarray(iobb[i][j], dtype=np.float64))
+                classes.append(int(icls[i][j]))
+                scene_of.append(i)
+            start.append(len(flat))
+        self.classes = classes
+        self.scene_of = scene_of
+        self.scene_start = start
+        self.obbs = np.stack(obbs, 0) if obbs else np.zeros((0, 7))
+        if flat:
+            pts = torch.from_numpy(np.stack(flat, 0))            # (S, P, C0) float64, one H2D copy
+            pts = pts.to(device, non_blocking=True)
+            self.xyz64 = pts[:, :, :3].double().contiguous()
+            self.pts32 = pts.float().contiguous()
+        else:
+            self.xyz64 = torch.zeros((0, 1, 3), dtype=torch.float64, device=device)
+            self.pts32 = torch.zeros((0, 1, 3), dtype=torch.float32, device=device)
+        self.centres = torch.from_numpy(self.obbs[:, :3].astype(np.float32)).to(device)
+        self._sel_cache = {}
+
+    def select(self, lang_cls_pred):
+        """Candidate filtering of AttributeModule.filter_candidates / RelationModule.filter_candidates
+        (reference attribute_module.py:42-81, relation_module.py:38-78) on host integers only.
+        -> dict with
+             cand        flat indices of same-class instances of scenes with >= 2 candidates (batch-major)
+             cand_scene  scene index per candidate
+             pred_obb_batch list[B] of (c_i, 7) float64 arrays ((0,) when c_i == 0)
+             num_filtered_objs list[B]
+             support     flat indices of ALL instances of scenes with >= 2 candidates
+             support_scene_offsets int list (len = #kept scenes + 1), support_batch list (scene idx)
+             query_in_support index of every candidate inside `support`
+        """
+        key = tuple(int(v) for v in lang_cls_pred)
+        if key in self._sel_cache:
+            return self._sel_cache[key]
+        cand, cand_scene, pred_obb_batch, nfo = [], [], [], []
+        support, support_batch, query_in_support, sup_off = [], [], [], [0]
+        for i in range(self.batch_size):
+            lo, hi = self.scene_start[i], self.scene_start[i + 1]
+            mine = [s for s in range(lo, hi) if self.classes[s] == key[i]]
+            nfo.append(len(mine))
+            pred_obb_batch.append(np.asarray([self.obbs[s] for s in mine]))
+            if len(mine) < 2:
+                continue
+            cand += mine
+            cand_scene += [i] * len(mine)
+            base = len(support)
+            support += list(range(lo, hi))
+            support_batch += [i] * (hi - lo)
+            query_in_support += [base + (s - lo) for s in mine]
+            sup_off.append(len(support))
+        sel = dict(cand=cand, cand_scene=cand_scene, pred_obb_batch=pred_obb_batch, num_filtered_objs=nfo,
+                   support=support, support_batch=support_batch, query_in_support=query_in_support,
+                   support_scene_offsets=sup_off)
+        self._sel_cache[key] = sel
+        return sel
+
+
+def upload_instances(data_dict, device=None):
+    """Attach the device-resident instance pack as data_dict['irx'] (idempotent)."""
+    if 'irx' not in data_dict:
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        data_dict['irx'] = InstancePack(data_dict, device)
+    return data_dict['irx']
+
+
+def idx_tensor(values, device, dtype=torch.int64):
+    return torch.as_tensor(values, dtype=dtype, device=device)

@@ -1,0 +1,40 @@
+"""InstanceRefer — drop-in for the reference's models/instancerefer.py:14-70: same ctor
+(`InstanceRefer(input_feature_dim, args)`), same plug-in mechanism (module names from the YAML config are
+imported and must export LangModule / AttributeModule / RelationModule / SceneModule) and the same
+`forward(data_dict) -> data_dict` contract."""
+import importlib
+
+import torch.nn as nn
+
+_PKG = __name__.rsplit('.', 1)[0]
+
+
+def _import(name):
+    """YAML names are bare ('attribute_module'); resolve inside this package first, then globally."""
+    try:
+        return importlib.import_module(_PKG + '.' + name)
+    except ModuleNotFoundError:
+        return importlib.import_module(name)
+
+
+class InstanceRefer(nn.Module):
+    def __init__(self, input_feature_dim=0, args=None):
+        super().__init__()
+        self.args = args
+        self.lang = _import(args.language_module).LangModule(args.num_classes, True, args.use_bidir, 300, 128)
+        if args.attribute_module:
+            self.attribute = _import(args.attribute_module).AttributeModule(input_feature_dim, args)
+        if args.relation_module:
+            self.relation = _import(args.relation_module).RelationModule(input_feature_dim, args)
+        if args.scene_module:
+            self.scene = _import(args.scene_module).SceneModule(input_feature_dim, args)
+
+    def forward(self, data_dict):
+        data_dict = self.lang(data_dict)
+        if self.args.attribute_module:
+            data_dict = self.attribute(data_dict)
+        if self.args.relation_module:
+            data_dict = self.relation(data_dict)
+        if self.args.scene_module:
+            data_dict = self.scene(data_dict)
+        return data_dict

@@ -1,0 +1,169 @@
+"""get_loss — drop-in for the reference's lib/loss_helper.py:196-269 (+ ContrastiveLoss :93-107,
+compute_scene_mask_loss :131-161, compute_lang_classification_loss :189-193).
+
+loss = 10 * ref_loss + lang_loss + seg_loss.  ref_loss: per sample with >= 2 candidates and max IoU >= 0.2,
+ContrastiveLoss(margin .2, gamma 5) between the summed scores and the one-hot of the candidate with the
+highest IoU against the GT box, divided by the FULL batch size. IoU labelling is float64 numpy on the
+host exactly as in the reference (axis-aligned IoU of box corners, utils/box_util.py:154-175,310-333).
+`config` is duck-typed: anything with `param2obb_batch` (the reference's ScannetDatasetConfig works).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class DatasetConfig:
+    """Minimal stand-in for data/scannet/model_util_scannet.py:85-181 (ScannetDatasetConfig): only what
+    get_loss / get_eval use. mean_size_arr (num_class, 3); ScanNet boxes are axis-aligned (heading 0)."""
+
+    def __init__(self, mean_size_arr=None, num_class=18):
+        self.num_class = num_class
+        self.num_heading_bin = 1
+        self.num_size_cluster = num_class
+        self.mean_size_arr = np.ones((num_class, 3)) if mean_size_arr is None else np.asarray(mean_size_arr)
+
+    def class2angle_batch(self, pred_cls, residual, to_label_format=True):
+        return np.zeros(pred_cls.shape[0])
+
+    def class2size_batch(self, pred_cls, residual):
+        return self.mean_size_arr[pred_cls] + residual
+
+    def param2obb_batch(self, center, heading_class, heading_residual, size_class, size_residual):
+        heading_angle = self.class2angle_batch(heading_class, heading_residual)
+        obb = np.zeros((heading_class.shape[0], 7))
+        obb[:, 0:3] = center
+        obb[:, 3:6] = self.class2size_batch(size_class, size_residual)
+        obb[:, 6] = heading_angle * -1
+        return obb
+
+
+def _roty_batch(t):
+    out = np.zeros(tuple(list(t.shape) + [3, 3]))
+    c, s = np.cos(t), np.sin(t)
+    out[..., 0, 0] = c
+    out[..., 0, 2] = s
+    out[..., 1, 1] = 1
+    out[..., 2, 0] = -s
+    out[..., 2, 2] = c
+    return out
+
+
+def get_3d_box_batch(box_size, heading_angle, center):
+    """(…,3),(…),(…,3) -> (…,8,3) corners (same corner order / rotation as the reference's box_util)."""
+    shape = heading_angle.shape
+    R = _roty_batch(heading_angle)
+    l = np.expand_dims(box_size[..., 0], -1)
+    w = np.expand_dims(box_size[..., 1], -1)
+    h = np.expand_dims(box_size[..., 2], -1)
+    corners = np.zeros(tuple(list(shape) + [8, 3]))
+    corners[..., :, 0] = np.concatenate((l / 2, l / 2, -l / 2, -l / 2, l / 2, l / 2, -l / 2, -l / 2), -1)
+    corners[..., :, 1] = np.concatenate((w / 2, -w / 2, -w / 2, w / 2, w / 2, -w / 2, -w / 2, w / 2), -1)
+    corners[..., :, 2] = np.concatenate((h / 2, h / 2, h / 2, h / 2, -h / 2, -h / 2, -h / 2, -h / 2), -1)
+    t = list(range(len(shape))) + [len(shape) + 1, len(shape)]
+    corners = np.matmul(corners, np.transpose(R, tuple(t)))
+    corners += np.expand_dims(center, -2)
+    return corners
+
+
+def box3d_iou_batch(corners1, corners2):
+    """Axis-aligned IoU from (N,8,3) corners."""
+    mn1, mx1 = corners1.min(axis=1), corners1.max(axis=1)
+    mn2, mx2 = corners2.min(axis=1), corners2.max(axis=1)
+    lo = np.maximum(mn1, mn2)
+    hi = np.minimum(mx1, mx2)
+    inter = np.maximum(hi[:, 0] - lo[:, 0], 0) * np.maximum(hi[:, 1] - lo[:, 1], 0) * np.maximum(hi[:, 2] - lo[:, 2], 0)
+    v1 = (mx1[:, 0] - mn1[:, 0]) * (mx1[:, 1] - mn1[:, 1]) * (mx1[:, 2] - mn1[:, 2])
+    v2 = (mx2[:, 0] - mn2[:, 0]) * (mx2[:, 1] - mn2[:, 1]) * (mx2[:, 2] - mn2[:, 2])
+    return inter / (v1 + v2 - inter + 1e-8)
+
+
+class ContrastiveLoss(nn.Module):
+    """clamp(logsumexp(gamma*score * (1-label)) - sum(gamma*score*label) + margin, 0): the positive slot
+    enters the log-sum-exp as exp(0), not -inf — reference quirk kept (loss_helper.py:101-106). Unlike the
+    reference this does not scale `score` in place."""
+
+    def __init__(self, margin=0.2, gamma=5, reduction='mean'):
+        super().__init__()
+        self.margin = margin
+        self.gamma = gamma
+        self.reduction = reduction
+
+    def forward(self, score, label):
+        score = score * self.gamma
+        sim = (score * label).sum()
+        neg_sim = torch.logsumexp(score * label.logical_not(), dim=0)
+        return torch.clamp(neg_sim - sim + self.margin, min=0).sum()
+
+
+def compute_scene_mask_loss(data_dict):
+    """9-area label of the GT centre on the 3x3 xy grid of the scene's bounding box + CE."""
+    pred = data_dict['seg_scores']
+    dev = pred.device
+    c = data_dict["ref_center_label"].to(dev)
+    point_min = data_dict['point_min'].to(dev)
+    point_max = data_dict['point_max'].to(dev)
+    first = point_min + (point_max - point_min) / 3
+    second = point_min + (point_max - point_min) / 3 * 2
+    rf = torch.le(c, first)
+    rs = torch.le(c, second)
+    # column bin bx: 0 if x<=first, 1 if first<x<=second, 2 otherwise (same for y); label table as reference
+    bx = (~rf[:, 0]).long() + (~rs[:, 0]).long()
+    by = (~rf[:, 1]).long() + (~rs[:, 1]).long()
+    label = by * 3 + bx
+    loss = nn.functional.cross_entropy(pred, label)
+    acc = (torch.argmax(pred, 1) == label).sum() / float(label.numel())
+    return loss, acc
+
+
+def compute_lang_classification_loss(data_dict):
+    return nn.functional.cross_entropy(data_dict["lang_scores"], data_dict["object_cat"].to(data_dict["lang_scores"].device))
+
+
+def get_loss(data_dict, config):
+    lang_loss = compute_lang_classification_loss(data_dict)
+    data_dict["lang_loss"] = lang_loss
+    seg_loss, seg_acc = compute_scene_mask_loss(data_dict)
+    dev = lang_loss.device
+
+    def _np(k):
+        return data_dict[k].detach().cpu().numpy()
+
+    ref_gt_obb = config.param2obb_batch(_np("ref_center_label"), _np("ref_heading_class_label"),
+                                        _np("ref_heading_residual_label"), _np("ref_size_class_label"),
+                                        _np("ref_size_residual_label"))
+    ref_gt_bbox = get_3d_box_batch(ref_gt_obb[:, 3:6], ref_gt_obb[:, 6], ref_gt_obb[:, 0:3])
+
+    score_all = data_dict['attribute_scores'] + data_dict['relation_scores'] + data_dict['scene_scores']
+    pred_obb_batch = data_dict['pred_obb_batch']
+    batch_size = len(pred_obb_batch)
+    cluster_label = []
+    criterion = ContrastiveLoss(margin=0.2, gamma=5)
+    ref_loss = torch.zeros(1, device=dev)
+    start_idx = 0
+    for i in range(batch_size):
+        pred_obb = pred_obb_batch[i]
+        n = pred_obb.shape[0]
+        if n == 0:
+            cluster_label.append([])
+            continue
+        label = np.zeros(n)
+        pred_bbox = get_3d_box_batch(pred_obb[:, 3:6], pred_obb[:, 6], pred_obb[:, 0:3])
+        ious = box3d_iou_batch(pred_bbox, np.tile(ref_gt_bbox[i], (n, 1, 1)))
+        label[ious.argmax()] = 1
+        label = torch.as_tensor(label, dtype=torch.float32, device=dev)
+        cluster_label.append(label)
+        if n == 1:
+            continue
+        score = score_all[start_idx:start_idx + n]
+        start_idx += n
+        if ious.max() < 0.2:
+            continue
+        ref_loss = ref_loss + criterion(score, label)
+
+    ref_loss = ref_loss / batch_size
+    data_dict['ref_loss'] = ref_loss
+    data_dict['loss'] = 10 * ref_loss + lang_loss + seg_loss
+    data_dict['seg_loss'] = seg_loss
+    data_dict['seg_acc'] = seg_acc
+    data_dict['cluster_label'] = cluster_label
+    return data_dict

@@ -1,0 +1,74 @@
+"""SceneModule — drop-in for the reference's models/scene_module.py:9-108.
+
+Whole-scene BEVEncoder (5 cm voxels) -> crop [0,240)x[0,400)x[0,80) -> dense BEV (15x25, per-z 128x128
+kernels summed over 5 z-bins) -> BN2d/ReLU -> 2 x Conv2d 3x3 -> language-guided attention over the 11x21
+cells -> 9-way area classifier + cosine score between the scene vector and each candidate's obj_feats.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .basic_blocks import BEVEncoder, SparseCrop, ToDenseBEVConvolution
+from .data import idx_tensor
+from .sparse import nn as spnn
+
+
+class SceneModule(nn.Module):
+    def __init__(self, input_feature_dim, args, v_dim=128, h_dim=128, l_dim=256, dropout_rate=0.15):
+        super().__init__()
+        self.args = args
+        self.input_feature_dim = input_feature_dim
+        self.net = BEVEncoder(self.input_feature_dim)
+        self.pooling = spnn.GlobalMaxPooling()   # constructed but unused, as in the reference (:20)
+        loc_max = [240, 400, 80]
+        loc_min = [0, 0, 0]
+        shape = [(a - b) // 16 for a, b in zip(loc_max, loc_min)]
+        self.to_bev = nn.Sequential(
+            SparseCrop(loc_min=loc_min, loc_max=loc_max),
+            ToDenseBEVConvolution(128, 128, shape=shape, z_dim=2, offset=loc_min),
+            nn.BatchNorm2d(128),
+            nn.ReLU(True),
+        )
+        self.h_dim = h_dim
+        self.vis_emb_fc = nn.Sequential(nn.Conv2d(v_dim, h_dim, 3), nn.BatchNorm2d(h_dim), nn.ReLU(),
+                                        nn.Dropout(dropout_rate), nn.Conv2d(h_dim, h_dim, 3))
+        self.vis_emb_fc1 = nn.Sequential(nn.Linear(128, h_dim), nn.LayerNorm(h_dim), nn.ReLU(),
+                                         nn.Dropout(dropout_rate), nn.Linear(h_dim, h_dim))
+        self.lang_emb_fc = nn.Sequential(nn.Linear(l_dim, h_dim), nn.LayerNorm(h_dim), nn.ReLU(),
+                                         nn.Dropout(dropout_rate), nn.Linear(h_dim, h_dim))
+        self.cls = nn.Sequential(nn.Linear(h_dim, h_dim), nn.BatchNorm1d(h_dim), nn.ReLU(), nn.Linear(h_dim, 9))
+
+    def forward(self, data_dict):
+        feats = data_dict['lidar']
+        batch_size = data_dict['point_min'].shape[0]
+        pred_obb_batch = data_dict['pred_obb_batch']
+        obj_feats_flatten = data_dict['obj_feats']
+        lang_feats = data_dict['lang_scene_feats']
+
+        if feats._batch_size is None:
+            feats._batch_size = batch_size       # known from the collate; avoids the reference's .item() sync
+        feats = self.net(feats)
+        # SparseCrop (to_bev[0]) is folded into the BEV gather: only voxels inside the window are looked up
+        feats = self.to_bev[3](self.to_bev[2](self.to_bev[1](feats)))          # (B, 128, 15, 25)
+        feats = self.vis_emb_fc(feats)                                          # (B, D, 11, 21)
+
+        h, w = feats.shape[-2:]
+        feats = feats.reshape(batch_size, self.h_dim, -1).permute(0, 2, 1)     # (B, n_vis, D)
+        lang_feats = self.lang_emb_fc(lang_feats).unsqueeze(2)
+        atten = torch.bmm(feats, lang_feats) / math.sqrt(feats.shape[2])
+        atten = torch.softmax(atten.squeeze(2), dim=1)
+        data_dict['vis_atten'] = atten.reshape(batch_size, h, w)
+
+        scene_feats = torch.sum(feats * atten.unsqueeze(2), dim=1)
+        data_dict['seg_scores'] = self.cls(scene_feats)
+
+        cand_scene = [i for i in range(batch_size) for _ in range(len(pred_obb_batch[i]))
+                      if len(pred_obb_batch[i]) >= 2]
+        if len(cand_scene) == 0:
+            data_dict['scene_scores'] = scene_feats.new_zeros((0,))
+            return data_dict
+        scene_flat = scene_feats.index_select(0, idx_tensor(cand_scene, scene_feats.device))
+        obj = self.vis_emb_fc1(obj_feats_flatten)
+        data_dict['scene_scores'] = nn.functional.cosine_similarity(obj, scene_flat, dim=1)
+        return data_dict

@@ -4,6 +4,12 @@ import numpy as np
 import torch
 
 
+# configuration of tests/golden/model.npz (see tests/golden/make_golden.py)
+GOLDEN_CFG = dict(batch_size=3, seed=123, num_points=6000, num_instances=6, num_candidates=[4, 1, 3],
+                  tokens=[30, 12, 21], points_per_instance=256, variant="corner")
+WEIGHT_SEED = 2024
+
+
 def pack_coords(c):
     c = np.asarray(c).astype(np.int64)
     R, OFF = 1 << 17, 1 << 16
