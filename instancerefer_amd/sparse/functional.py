@@ -8,6 +8,11 @@ import torch
 
 from .. import _lib
 
+# bench.py sets PROFILE to a list to collect (kind, n_out, K, cin, cout, M, start_event, end_event) per sparse-conv
+# launch, with events recorded on the launch stream. None (default) = no instrumentation at all.
+PROFILE = None
+_PAIR_COUNT = {}
+
 _i32 = torch.int32
 _i64 = torch.int64
 _f32 = torch.float32
@@ -124,10 +129,28 @@ def batch_offsets(coords, nseg):
 
 
 # ------------------------------------------------------------------------------ sparse conv ---
+def _pairs(tbl, K):
+    """Number of valid (input, output) pairs M of a table (profiling only; cached per table storage)."""
+    key = (tbl.data_ptr(), tuple(tbl.shape), K)
+    if key not in _PAIR_COUNT:
+        if len(_PAIR_COUNT) > 4096:
+            _PAIR_COUNT.clear()
+        _PAIR_COUNT[key] = int((tbl[:K] >= 0).sum().item())
+    return _PAIR_COUNT[key]
+
+
 def spconv_gather_gemm(x, w, tbl, ld, n_out, K, cin, cout, flip_k, trans_w):
     y = torch.empty((n_out, cout), dtype=_f32, device=x.device)
+    if PROFILE is not None:
+        m = _pairs(tbl, K)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("irx_spconv_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(tbl), ld, n_out, K, cin, cout,
               int(flip_k), int(trans_w), _lib.ptr(y), _stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("dgrad" if trans_w else "fwd", n_out, K, cin, cout, m, e0, e1))
     return y
 
 
@@ -135,8 +158,16 @@ def spconv_wgrad(x, dy, tbl, ld, n_out, K, cin, cout):
     dw = torch.empty((K, cin, cout), dtype=_f32, device=x.device)
     wsb = int(_lib.load().irx_spconv_wgrad_workspace_bytes(n_out, K, cin, cout))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    if PROFILE is not None:
+        m = _pairs(tbl, K)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("irx_spconv_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(tbl), ld, n_out, K, cin, cout,
               _lib.ptr(dw), _lib.ptr(ws), wsb, _stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("wgrad", n_out, K, cin, cout, m, e0, e1))
     return dw
 
 

@@ -1,0 +1,80 @@
+"""Pin the oracle (CPU restatement) against the golden vectors produced by the reference's own code, and
+cross-check its sparse conv against an independent dense formulation (F.conv3d on a densified grid)."""
+import os
+
+import numpy as np
+import torch
+
+from helpers import GOLDEN_CFG, WEIGHT_SEED, surface_cloud, oracle_batch
+from instancerefer_amd import synthetic as S
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_oracle_model_matches_reference_golden():
+    from oracle.model_ref import InstanceRefer, oracle_data_dict
+    from instancerefer_amd.loss_helper import DatasetConfig, get_loss
+    gold = np.load(os.path.join(G, "model.npz"))
+    model = InstanceRefer(7, S.default_args())
+    ref_keys = {k[len("grad_norm/"):] for k in gold.files if k.startswith("grad_norm/")}
+    assert ref_keys == {n for n, _ in model.named_parameters()}
+    model.load_state_dict(S.seeded_state_dict(model, WEIGHT_SEED))
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train()
+    dd = get_loss(model(oracle_data_dict(S.make_batch(**dict(GOLDEN_CFG)))), DatasetConfig())
+    for k in ("lang_scores", "obj_feats", "attribute_scores", "relation_scores", "scene_scores", "seg_scores",
+              "vis_atten", "loss", "ref_loss"):
+        assert np.abs(dd[k].detach().numpy() - gold["train/" + k]).max() <= 2e-5, k
+    dd["loss"].backward()
+    total = float(np.sqrt(sum(float(gold[k]) ** 2 for k in gold.files if k.startswith("grad_norm/"))))
+    for n, p in model.named_parameters():
+        exp = float(gold["grad_norm/" + n])   # biases feeding a BatchNorm have pure round-off gradients
+        assert abs(float(p.grad.double().norm()) - exp) <= 1e-3 * max(exp, 1e-3 * total), n
+
+
+def _dense_conv_check(ks, stride, cin, cout, seed):
+    import oracle.torchsparse.nn as ospnn
+    from oracle.torchsparse import SparseTensor as OT
+    rng = np.random.default_rng(seed)
+    clouds = [surface_cloud(rng, 600, rng.uniform(-0.4, 0.4, 3), rng.uniform(0.3, 0.6, 3)) for _ in range(2)]
+    o = oracle_batch(clouds, 0.05)
+    n = o.C.shape[0]
+    torch.manual_seed(seed)
+    x = torch.randn(n, cin)
+    conv = ospnn.Conv3d(cin, cout, ks, stride=stride)
+    y = conv(OT(x, o.C, 1))
+    C = o.C.long()
+    lo = C[:, :3].min(0)[0]
+    lo = lo - (lo % 2)                      # keep the even alignment of the stride-2 grid (floor semantics)
+    idx = C[:, :3] - lo + 1
+    size = (idx.max(0)[0] + 3).tolist()
+    size = [s + (s % 2) for s in size]
+    B = int(C[:, 3].max()) + 1
+    dense = torch.zeros(B, cin, *size)
+    dense[C[:, 3], :, idx[:, 0], idx[:, 1], idx[:, 2]] = x
+    if ks == 3:
+        # kernel (K, Cin, Cout), K enumerates x fastest -> weight[co, ci, dx, dy, dz] = kernel[dz*9+dy*3+dx]
+        w = conv.kernel.view(3, 3, 3, cin, cout).permute(4, 3, 2, 1, 0)
+        out = torch.nn.functional.conv3d(dense, w, padding=1)
+        got = out[C[:, 3], :, idx[:, 0], idx[:, 1], idx[:, 2]]
+        assert (got - y.F).abs().max().item() <= 1e-5
+    else:
+        # even kernel enumerates z fastest: kernel[dx*4+dy*2+dz]; the +1 shift keeps parity: use offset 1
+        w = conv.kernel.view(2, 2, 2, cin, cout).permute(4, 3, 0, 1, 2)
+        out = torch.nn.functional.conv3d(dense[:, :, 1:, 1:, 1:], w, stride=2)
+        oc = y.C.long()
+        oi = (oc[:, :3] - lo) // 2
+        got = out[oc[:, 3], :, oi[:, 0], oi[:, 1], oi[:, 2]]
+        assert (got - y.F).abs().max().item() <= 1e-5
+        # every non-zero dense output site must be an oracle output voxel (same coordinate set)
+        assert int((out.abs().sum(1) > 0).sum()) <= oc.shape[0]
+
+
+def test_oracle_conv_k3_vs_dense():
+    _dense_conv_check(3, 1, 5, 8, 1)
+
+
+def test_oracle_conv_k2s2_vs_dense():
+    _dense_conv_check(2, 2, 6, 4, 2)
