@@ -1,0 +1,67 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/irx.h declares; pure-host entry
+points (version, capacities, workspace sizes, argument validation + error strings) behave. No compute calls."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "irx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(irx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    from instancerefer_amd import _lib
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libirx.so does not export %s" % n
+    assert sorted(_lib.EXPORTED_SYMBOLS) == names, set(names) ^ set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_host_only_entry_points(lib):
+    assert lib.irx_version() == 1
+    assert lib.irx_hash_capacity(1000) == 2048 and lib.irx_hash_capacity(0) == 64
+    assert lib.irx_hash_capacity(1 << 20) == 1 << 21
+    assert lib.irx_bn_workspace_bytes(1000, 128) == 4 * 2 * 128 * 4
+    assert lib.irx_downsample_workspace_bytes(5000) >= 3 * 4
+    small = lib.irx_spconv_wgrad_workspace_bytes(100, 27, 128, 128)
+    big = lib.irx_spconv_wgrad_workspace_bytes(500000, 27, 128, 128)
+    assert small == 0 and big > 0 and big % (27 * 128 * 128 * 4) == 0
+
+
+def test_argument_validation_and_error_string(lib):
+    rc = lib.irx_spconv_fwd(None, None, None, 0, 10, 27, 0, 32, 0, 0, None, None)
+    assert rc == -1
+    assert b"irx_spconv_fwd" in lib.irx_last_error()
+    rc = lib.irx_kmap_build_s1(None, 5, 3, None, None, 64, None, 5, None)   # stride 3 is not a power of two
+    assert rc == -1 and b"power of two" in lib.irx_last_error()
+    assert lib.irx_spconv_fwd(None, None, None, 0, 0, 27, 7, 32, 0, 0, None, None) == 0   # empty input is fine
+    out = (ctypes.c_int * 8)()
+    assert lib.irx_device_props(0, out) in (0, -4)
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle or any CPU fallback."""
+    pkg = os.path.join(ROOT, "instancerefer_amd")
+    bad = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                s = open(os.path.join(d, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M) or "from .. import oracle" in s:
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_ops_fail_loudly_on_cpu_tensors(lib):
+    import pytest
+    import torch
+    from instancerefer_amd.sparse import SparseTensor, nn as spnn
+    conv = spnn.Conv3d(4, 16, 3)
+    st = SparseTensor(torch.randn(5, 4), torch.zeros(5, 4, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        conv(st)
