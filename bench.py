@@ -287,6 +287,18 @@ def summarise_roofline(recs):
         a["bytes"] += byts
         a["launches"] += 1
         a["bound_ms"] += max(byts / (PEAK_HBM_GBS * 1e9), flops / (PEAK_F32_TFLOPS * 1e12)) * 1e3
+    if os.environ.get("IRX_BENCH_LAYERS"):
+        lay = {}
+        for kind, n_out, K, cin, cout, M, e0, e1 in recs:
+            a = lay.setdefault((kind, n_out, K, cin, cout, M), [0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+        print("kind   n_out      K  cin cout        M   calls  avg_us   TFLOP/s  algoGB/s", file=sys.stderr)
+        for (kind, n_out, K, cin, cout, M), (c, ms) in sorted(lay.items(), key=lambda kv: -kv[1][1]):
+            us = 1e3 * ms / c
+            fl = 2.0 * M * cin * cout
+            by = 4.0 * (M * (cin + cout if kind == "wgrad" else cin) + (0 if kind == "wgrad" else n_out * cout) + K * cin * cout) + 8.0 * M
+            print("%-6s %7d %4d %4d %4d %9d %6d %8.1f %8.2f %9.1f" % (kind, n_out, K, cin, cout, M, c, us, fl / us / 1e6, by / us / 1e3), file=sys.stderr)
     if not agg:
         return None
     dom = max(agg, key=lambda k: agg[k]["ms"])

@@ -150,9 +150,13 @@ int irx_bev_table(const int32_t* coords, int n, int tensor_stride, int batch_siz
  *             cin = conv's Cout, cout = conv's Cin, w = the forward weight unchanged)
  * Output-stationary: every output row is written exactly once (no atomics; deterministic).
  * fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
- * Requirements: cout % 16 == 0 (cin arbitrary). y: [n_out][cout]. */
+ * Any cin / cout; channel counts in {32,64,128} take the pair-compacting, weight-stationary fast path,
+ * which for the forward needs a workspace (irx_spconv_fwd_workspace_bytes) for an n-major weight image.
+ * y: [n_out][cout]. */
+size_t irx_spconv_fwd_workspace_bytes(int K, int cin, int cout, int trans_w);
 int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr, int ld, int n_out,
-                   int K, int cin, int cout, int flip_k, int trans_w, float* y, void* stream);
+                   int K, int cin, int cout, int flip_k, int trans_w, float* y, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* dw[k][ci][co] = sum_q x[nbr[k][q]][ci] * dy[q][co].  Deterministic two-stage reduction
  * through `workspace` (irx_spconv_wgrad_workspace_bytes). */
@@ -201,6 +205,20 @@ int irx_segment_mean(const float* x, int nseg, int len, int c, float* y, void* s
 
 /* offsets[b] = first row whose batch index >= b, for b in [0, nseg]  (rows sorted by batch). */
 int irx_batch_offsets(const int32_t* coords, int n, int nseg, int32_t* offsets, void* stream);
+
+/* ---- language encoder recurrence (nn.GRU on a packed sequence, reference models/lang_module.py:22-28,53-57) -- */
+
+/* One GRU layer, ndir (1|2) directions, hidden size H in {64,128}: the sequential part only.
+ * gi [B][T][ndir][3H] = x W_ih^T + b_ih (gate order r,z,n), lengths int32 [B], w_hh [ndir][3H][H],
+ * b_hh [ndir][3H]. out [B][T][ndir*H] (zero at t >= length, reverse direction starts at t = length-1);
+ * gates [B][T][ndir][4H] = (r, z, n, W_hn h + b_hn) saved for the backward pass. */
+int irx_gru_forward(const float* gi, const int32_t* lengths, const float* w_hh, const float* b_hh,
+                    int B, int T, int ndir, int H, float* out, float* gates, void* stream);
+/* BPTT of the recurrence: dout [B][T][ndir*H] -> dgi, dgh [B][T][ndir][3H] (gradients of the input /
+ * hidden projections, biases included); dW_ih, dW_hh, dX are GEMMs of these in the host layer. */
+int irx_gru_backward(const float* dout, const float* out, const float* gates, const int32_t* lengths,
+                     const float* w_hh, int B, int T, int ndir, int H, float* dgi, float* dgh,
+                     void* stream);
 
 /* ---- instance graph ------------------------------------------------------------------- */
 

@@ -34,7 +34,8 @@ _SIGNATURES = {
     "irx_downsample": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
     "irx_kmap_down_transpose": (_I, [_P, _P, _I, _P, _I, _P]),
     "irx_bev_table": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _I, _P, _P, _P]),
-    "irx_spconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "irx_spconv_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "irx_spconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "irx_spconv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "irx_spconv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "irx_bn_workspace_bytes": (_Z, [_I, _I]),
@@ -45,6 +46,8 @@ _SIGNATURES = {
     "irx_segment_max_backward": (_I, [_P, _P, _I, _I, _P, _P]),
     "irx_segment_mean": (_I, [_P, _I, _I, _I, _P, _P]),
     "irx_batch_offsets": (_I, [_P, _I, _I, _P, _P]),
+    "irx_gru_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "irx_gru_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "irx_knn_batched": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
 }
 

@@ -178,7 +178,8 @@ class ToDenseBEVConvolution(nn.Module):
         std = 1. / math.sqrt(self.in_channels)
         self.kernel.data.uniform_(-std, std)
 
-    def forward(self, inputs, batch_size=None):
+    def rows(self, inputs):
+        """-> (B * nx * ny, Cout) channels-last cell rows (row = b*nx*ny + ix*ny + iy), batch size."""
         x = inputs.canonical()
         lv = x.level()
         nx, ny = self.bev_shape
@@ -189,5 +190,62 @@ class ToDenseBEVConvolution(nn.Module):
         def tbl_b():
             return F_.kmap_down_transpose(cell, zbin), max(lv.n, 1)
 
-        bev = F_.SparseConvFn.apply(x.F, self.kernel, tbl, ncell, ncell, tbl_b, 0)
-        return bev.view(lv.batch_size, nx, ny, -1).permute(0, 3, 1, 2).contiguous()  # BCHW
+        return F_.SparseConvFn.apply(x.F, self.kernel, tbl, ncell, ncell, tbl_b, 0), lv.batch_size
+
+    def forward(self, inputs, batch_size=None):
+        bev, b = self.rows(inputs)
+        nx, ny = self.bev_shape
+        return bev.view(b, nx, ny, -1).permute(0, 3, 1, 2).contiguous()  # BCHW
+
+
+# ---- dense 2D head on channels-last cell rows --------------------------------------------------------------
+# The scene head (reference scene_module.py:25-38: BatchNorm2d/ReLU, Conv2d 3x3, BatchNorm2d/ReLU, Dropout,
+# Conv2d 3x3 on a (B,128,15,25) map) is run on (cells, C) rows with the same HIP kernels as the sparse path:
+# a 3x3 "valid" Conv2d is the gather-MFMA conv with a constant 9-offset table over the dense grid, BatchNorm2d
+# is BatchNorm over rows. No NCHW<->NHWC permutes, no MIOpen fp32 conv (its solver choice is timing dependent
+# and includes Winograd, i.e. run-to-run different numerics). nn.Conv2d / nn.BatchNorm2d modules only hold
+# the parameters (state-dict keys unchanged).
+_GRID_TABLES = {}
+
+
+def _grid_tables(b, h, w, ks, device):
+    """Constant kernel maps of a ks x ks valid convolution on a dense (b, h, w) grid of rows.
+    fwd[k][out_row] = in_row,  bwd[k][in_row] = out_row or -1;  k = di*ks + dj (cross-correlation)."""
+    key = (b, h, w, ks, str(device))
+    if key not in _GRID_TABLES:
+        ho, wo = h - ks + 1, w - ks + 1
+        bb, ii, jj = torch.meshgrid(torch.arange(b), torch.arange(ho), torch.arange(wo), indexing="ij")
+        fwd = torch.empty((ks * ks, b * ho * wo), dtype=torch.int32)
+        bwd = torch.full((ks * ks, b * h * w), -1, dtype=torch.int32)
+        out_row = (bb * ho * wo + ii * wo + jj).reshape(-1)
+        for di in range(ks):
+            for dj in range(ks):
+                in_row = (bb * h * w + (ii + di) * w + (jj + dj)).reshape(-1)
+                fwd[di * ks + dj] = in_row.int()
+                bwd[di * ks + dj, in_row] = out_row.int()
+        _GRID_TABLES[key] = (fwd.to(device).contiguous(), bwd.to(device).contiguous(), b * ho * wo, b * h * w)
+    return _GRID_TABLES[key]
+
+
+def conv2d_rows(conv: nn.Conv2d, x, b, h, w):
+    """nn.Conv2d (square kernel, stride 1, no padding) applied to channels-last rows x (b*h*w, Cin)."""
+    ks = conv.kernel_size[0]
+    assert conv.kernel_size == (ks, ks) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+    fwd, bwd, n_out, n_in = _grid_tables(b, h, w, ks, x.device)
+    wk = conv.weight.permute(2, 3, 1, 0).reshape(ks * ks, conv.in_channels, conv.out_channels)
+    y = F_.SparseConvFn.apply(x, wk, fwd, n_out, n_out, lambda: (bwd, n_in), 0)
+    if conv.bias is not None:
+        y = y + conv.bias
+    return y
+
+
+def batchnorm_rows(bn, x, relu=False):
+    """nn.BatchNorm1d/2d semantics on (rows, C) with the fused statistics + apply(+ReLU) kernels."""
+    if bn.training or not bn.track_running_stats:
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        mom = 0.0 if bn.momentum is None else bn.momentum
+        return F_.BatchNormActFn.apply(x, bn.weight, bn.bias, None,
+                                       bn.running_mean if bn.track_running_stats else None,
+                                       bn.running_var if bn.track_running_stats else None, bn.eps, mom, relu)
+    return F_.bn_eval(x, bn.weight, bn.bias, None, bn.running_mean, bn.running_var, bn.eps, relu)

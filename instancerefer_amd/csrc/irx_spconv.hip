@@ -279,13 +279,35 @@ static void launch_fwd(int bn, dim3 grid, hipStream_t st, const float* x, const 
     k_spconv_fwd<32, TRANS_W, VEC><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, cin, cout, flip_k, y);
 }
 
+extern "C" size_t irx_spconv_fwd_workspace_bytes(int K, int cin, int cout, int trans_w) {
+  // the fast path reads "n-major" weights [K][cout][cin]; the forward needs a transposed copy
+  if (K <= 0 || cin <= 0 || cout <= 0) return 0;
+  if (!trans_w && irx_spconv2_supported(cin, cout)) return (size_t)K * cin * cout * sizeof(float);
+  return 0;
+}
+
 extern "C" int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr, int ld, int n_out,
                               int K, int cin, int cout, int flip_k, int trans_w, float* y,
-                              void* stream) {
+                              void* workspace, size_t workspace_bytes, void* stream) {
   IRX_REQUIRE(n_out >= 0 && K >= 1 && cin >= 1 && cout >= 1, "irx_spconv_fwd: bad sizes");
   if (n_out == 0) return IRX_OK;
   IRX_REQUIRE(x && w && nbr && y, "irx_spconv_fwd: null pointer");
   IRX_REQUIRE(ld >= n_out, "irx_spconv_fwd: ld %d < n_out %d", ld, n_out);
+  const bool aligned = (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0;
+  if (aligned && irx_spconv2_supported(cin, cout) && irx_spconv2_enabled(trans_w ? 'd' : 'f')) {
+    const float* wn = w;
+    if (!trans_w) {
+      const size_t need = irx_spconv_fwd_workspace_bytes(K, cin, cout, 0);
+      if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+        irx_set_error("irx_spconv_fwd: workspace %zu < %zu", workspace_bytes, need);
+        return IRX_ERR_WORKSPACE;
+      }
+      int rc = irx_transpose_w_launch(w, K, cin, cout, (float*)workspace, S(stream));
+      if (rc) return rc;
+      wn = (const float*)workspace;
+    }
+    return irx_spconv2_launch(x, wn, nbr, ld, n_out, K, cin, cout, flip_k, y, S(stream));
+  }
   const int bn = cout > 64 ? 128 : (cout > 32 ? 64 : 32);
   dim3 grid(irx_cdiv(n_out, SC_TM), irx_cdiv(cout, bn));
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
@@ -303,7 +325,7 @@ extern "C" int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr
 
 // number of row splits: enough workgroups to fill 256 CUs a few times over, >= 256 rows each
 static int wgrad_splits(int n_out, int K, int cin, int cout) {
-  const int tiles = irx_cdiv(cin, 64) * irx_cdiv(cout, 64);
+  const int tiles = irx_spconv2_supported(cin, cout) ? 1 : irx_cdiv(cin, 64) * irx_cdiv(cout, 64);
   int s = irx_cdiv(1536, (long long)K * tiles);
   const int max_s = irx_cdiv(n_out, 256);
   if (s > max_s) s = max_s;
@@ -341,7 +363,10 @@ extern "C" int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* 
   float* part = (s > 1) ? (float*)workspace : dw;
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
                    (((uintptr_t)dy & 15) == 0);
-  if (vec)
+  if (vec && irx_spconv2_supported(cin, cout) && irx_spconv2_enabled('w')) {
+    int rc = irx_spconv2_wgrad_launch(x, dy, nbr, ld, n_out, K, cin, cout, s, rps, part, S(stream));
+    if (rc) return rc;
+  } else if (vec)
     k_spconv_wgrad<true><<<grid, 256, 0, S(stream)>>>(x, dy, nbr, ld, n_out, K, cin, cout, rps, nct_n, part);
   else
     k_spconv_wgrad<false><<<grid, 256, 0, S(stream)>>>(x, dy, nbr, ld, n_out, K, cin, cout, rps, nct_n, part);

@@ -1,0 +1,304 @@
+// irx_spconv2.hip — second-generation sparse-conv kernels for the channel counts of the encoder
+// (Cin, Cout in {32, 64, 128}); irx_spconv.hip keeps the generic fallbacks (odd channel counts).
+//
+// Forward / data-gradient  k_spconv2<CIN, COUT>:
+//   * workgroup = 64 consecutive (Morton-ordered) output rows, 4 waves; the fp32 output tile lives in LDS.
+//   * per kernel offset k: ONE coalesced table read (lane == row), wave ballot -> the valid (input row,
+//     output row) pairs are COMPACTED in-register with ds_permute (rank = prefix popcount), so the MFMA only
+//     ever sees ceil(v/16) dense 16-row groups instead of every row of the tile (executed rows / useful pairs
+//     drop from 1.6-2.6x to ~1.2x on ScanNet-like surfaces);
+//   * weight-stationary: each wave owns a slice of output channels and keeps W[k][:, slice] in VGPRs
+//     (16-byte loads from an "n-major" weight image), so weights never pass through LDS and all four waves
+//     share one gathered A tile;
+//   * A rows are gathered with 16 B/lane coalesced loads (whole 128-512 B rows) into LDS, read back as
+//     ds_read_b128 fragments (the MFMA k index is permuted so a lane's 4 consecutive floats feed 4 MFMAs);
+//   * v_mfma_f32_16x16x4_f32 (exact fp32), results added into the LDS output tile (each wave owns its
+//     channel slice -> no atomics), tile written once with 16 B/lane stores: deterministic.
+// Weight-gradient  k_spconv2_wgrad<CIN, COUT>: same compaction; gathered x rows and dy rows of the valid
+//   pairs are the MFMA reduction dimension; per (row split, offset) partial sums, deterministic reduction.
+#include <stdlib.h>
+#include <string.h>
+#include "irx_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define S2_TM 64
+
+struct PairList {
+  int in_of_pair;   // lane p holds the input row of pair p (p < v)
+  int row_of_pair;  // lane p holds the tile-local output row of pair p
+  int v;            // number of valid pairs (wave-uniform)
+};
+
+// lane == tile row; `my` = table entry (input row or -1). Full permutation: valid lanes go to their rank,
+// invalid lanes fill the tail, so every destination has exactly one writer.
+__device__ static inline PairList compact_pairs(int my, int lane) {
+  const unsigned long long valid = __ballot(my >= 0);
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int v = __popcll(valid);
+  const int dst = (my >= 0) ? __popcll(valid & lt) : v + __popcll(~valid & lt);
+  PairList p;
+  p.in_of_pair = __builtin_amdgcn_ds_permute(dst << 2, my);
+  p.row_of_pair = __builtin_amdgcn_ds_permute(dst << 2, lane);
+  p.v = v;
+  return p;
+}
+
+// wn: "n-major" weights [K][COUT][CIN] (forward: transposed copy of Conv3d.kernel; data-gradient: the kernel itself)
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn,
+                                                    const int32_t* __restrict__ nbr, int ld, int n_out, int K,
+                                                    int flip_k, float* __restrict__ y) {
+  constexpr int NT = (COUT >= 128) ? 2 : 1;       // 16-column tiles per wave
+  constexpr int NCS = COUT / (16 * NT);           // channel slices (waves along N)
+  constexpr int NGP = 4 / NCS;                    // waves along the pair-group dimension
+  constexpr int LDA = CIN + 4;
+  constexpr int LDO = COUT + 8;
+  constexpr int LPR = CIN / 4;                    // lanes (float4) per gathered row
+  constexpr int PPI = 64 / LPR;                   // pairs per wave-instruction
+  constexpr int NJ = CIN / 16;
+  static_assert(NCS * NGP == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float sOut[S2_TM * LDO];
+  __shared__ __attribute__((aligned(16))) float sA[S2_TM * LDA];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g4 = lane >> 4;
+  const int cs = wave % NCS, gp = wave / NCS;
+  const int n_base = cs * 16 * NT;
+  const int q0 = blockIdx.x * S2_TM;
+
+  for (int i = tid; i < S2_TM * LDO; i += 256) sOut[i] = 0.f;
+
+  for (int k = 0; k < K; ++k) {
+    const int kt = flip_k ? (K - 1 - k) : k;
+    int my = -1;
+    if (q0 + lane < n_out) my = nbr[(size_t)kt * ld + q0 + lane];
+    const PairList pl = compact_pairs(my, lane);
+    if (pl.v == 0) continue;                       // block-uniform: every wave read the same 64 entries
+    const int vpad = (pl.v + 15) & ~15;
+
+    // weight slice of this wave -> registers (consumed after the gather barrier)
+    float4 wreg[NJ][NT];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        wreg[j][t] = *reinterpret_cast<const float4*>(
+            wn + ((size_t)k * COUT + n_base + 16 * t + m) * CIN + 16 * j + 4 * g4);
+
+    __syncthreads();                               // previous offset's fragment reads are done (also: sOut zeroed)
+    // ---- gather the compacted input rows; rows v..vpad-1 are zero ----
+    {
+      const int sub = lane / LPR;                  // which of the PPI pairs this lane serves
+      const int c4 = (lane % LPR) * 4;
+      for (int p0 = wave * PPI; p0 < vpad; p0 += 4 * PPI) {
+        const int p = p0 + sub;
+        const int idx = __shfl(pl.in_of_pair, p & 63);
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < pl.v) val = *reinterpret_cast<const float4*>(x + (size_t)idx * CIN + c4);
+        if (p < vpad) *reinterpret_cast<float4*>(&sA[p * LDA + c4]) = val;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over dense 16-pair groups; this wave's channel slice ----
+    for (int g = gp; g * 16 < vpad; g += NGP) {
+      f32x4 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* pa = &sA[(16 * g + m) * LDA + 4 * g4];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float4 a4 = *reinterpret_cast<const float4*>(pa + 16 * j);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wreg[j][t].x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wreg[j][t].y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wreg[j][t].z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wreg[j][t].w, acc[t], 0, 0, 0);
+        }
+      }
+      // D layout: col = lane&15, row = (lane>>4)*4 + r  -> pair 16g + 4*g4 + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = 16 * g + 4 * g4 + r;
+        const int orow = __shfl(pl.row_of_pair, p & 63);
+        if (p < pl.v) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) sOut[orow * LDO + n_base + 16 * t + m] += acc[t][r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- write the tile: COUT/4 float4 per row ----
+  constexpr int F4 = COUT / 4;
+  for (int f = tid; f < S2_TM * F4; f += 256) {
+    const int row = f / F4, c4 = (f % F4) * 4;
+    if (q0 + row < n_out)
+      *reinterpret_cast<float4*>(y + (size_t)(q0 + row) * COUT + c4) =
+          *reinterpret_cast<const float4*>(&sOut[row * LDO + c4]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// part[s][k][c][n] = sum over valid pairs of split s:  x[in][c] * dy[out][n]
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void k_spconv2_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const int32_t* __restrict__ nbr, int ld, int n_out,
+                                                          int K, int rows_per_split, float* __restrict__ part) {
+  constexpr int TC = CIN / 16, TN = COUT / 16;
+  constexpr int CW = (TC >= 4) ? TC / 4 : 1;             // c-tiles per wave
+  constexpr int NW = (TC >= 4) ? TN : TN / (4 / TC);     // n-tiles per wave
+  constexpr int LDX = CIN + 16, LDD = COUT + 16;         // consecutive pairs 16 banks apart
+  constexpr int LPX = CIN / 4, LPD = COUT / 4;
+  __shared__ __attribute__((aligned(16))) float sX[S2_TM * LDX];
+  __shared__ __attribute__((aligned(16))) float sD[S2_TM * LDD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g4 = lane >> 4;
+  const int s = blockIdx.x, k = blockIdx.y;
+  const int ct0 = (TC >= 4) ? wave * CW : (wave % TC);
+  const int nt0 = (TC >= 4) ? 0 : (wave / TC) * NW;
+  const int qbeg = s * rows_per_split;
+  int qend = qbeg + rows_per_split;
+  if (qend > n_out) qend = n_out;
+
+  f32x4 acc[CW][NW];
+#pragma unroll
+  for (int a = 0; a < CW; ++a)
+#pragma unroll
+    for (int b = 0; b < NW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int q0 = qbeg; q0 < qend; q0 += S2_TM) {
+    int my = -1;
+    if (q0 + lane < qend) my = nbr[(size_t)k * ld + q0 + lane];
+    const PairList pl = compact_pairs(my, lane);
+    if (pl.v == 0) continue;
+    const int vpad = (pl.v + 3) & ~3;
+    __syncthreads();
+    {  // x rows of the pairs
+      constexpr int PPI = 64 / LPX;
+      const int sub = lane / LPX, c4 = (lane % LPX) * 4;
+      for (int p0 = wave * PPI; p0 < vpad; p0 += 4 * PPI) {
+        const int p = p0 + sub;
+        const int idx = __shfl(pl.in_of_pair, p & 63);
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < pl.v) val = *reinterpret_cast<const float4*>(x + (size_t)idx * CIN + c4);
+        if (p < vpad) *reinterpret_cast<float4*>(&sX[p * LDX + c4]) = val;
+      }
+    }
+    {  // dy rows of the pairs
+      constexpr int PPI = 64 / LPD;
+      const int sub = lane / LPD, c4 = (lane % LPD) * 4;
+      for (int p0 = wave * PPI; p0 < vpad; p0 += 4 * PPI) {
+        const int p = p0 + sub;
+        const int orow = __shfl(pl.row_of_pair, p & 63);
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < pl.v) val = *reinterpret_cast<const float4*>(dy + (size_t)(q0 + orow) * COUT + c4);
+        if (p < vpad) *reinterpret_cast<float4*>(&sD[p * LDD + c4]) = val;
+      }
+    }
+    __syncthreads();
+    for (int ks = 0; ks * 4 < vpad; ++ks) {
+      const int pp = ks * 4 + g4;
+      float a[CW], b[NW];
+#pragma unroll
+      for (int i = 0; i < CW; ++i) a[i] = sX[pp * LDX + (ct0 + i) * 16 + m];   // A[m = c][kk = pair]
+#pragma unroll
+      for (int i = 0; i < NW; ++i) b[i] = sD[pp * LDD + (nt0 + i) * 16 + m];   // B[kk = pair][n]
+#pragma unroll
+      for (int i = 0; i < CW; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NW; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+    }
+  }
+  float* out = part + ((size_t)s * K + k) * CIN * COUT;
+#pragma unroll
+  for (int i = 0; i < CW; ++i)
+#pragma unroll
+    for (int jn = 0; jn < NW; ++jn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = (ct0 + i) * 16 + g4 * 4 + r;
+        const int n = (nt0 + jn) * 16 + m;
+        out[(size_t)c * COUT + n] = acc[i][jn][r];
+      }
+}
+
+// [K][cin][cout] -> [K][cout][cin]
+__global__ void k_transpose_w(const float* __restrict__ w, int K, int cin, int cout, float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int k = blockIdx.z;
+  const int c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const float* src = w + (size_t)k * cin * cout;
+  float* dst = wt + (size_t)k * cin * cout;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, n = n0 + threadIdx.x;
+    if (c < cin && n < cout) tile[i][threadIdx.x] = src[(size_t)c * cout + n];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int n = n0 + i, c = c0 + threadIdx.x;
+    if (c < cin && n < cout) dst[(size_t)n * cin + c] = tile[threadIdx.x][i];
+  }
+}
+
+// ---------------------------------------------------------------------------- host dispatch ---
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+// A/B switch for tests and profiling: IRX_SPCONV_V1 = any of "f" (forward), "d" (data-gradient), "w" (weight-
+// gradient) or "1"/"all" -> those passes use the first-generation kernels.
+bool irx_spconv2_enabled(char pass) {
+  static const char* e = getenv("IRX_SPCONV_V1");
+  if (!e) return true;
+  if (strchr(e, '1') || strchr(e, 'a')) return false;
+  return strchr(e, pass) == nullptr;
+}
+
+bool irx_spconv2_supported(int cin, int cout) {
+  return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128);
+}
+
+template <int CIN>
+static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
+                        int ld, int n_out, int K, int flip_k, float* y) {
+  if (cout == 128) k_spconv2<CIN, 128><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y);
+  else if (cout == 64) k_spconv2<CIN, 64><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y);
+  else k_spconv2<CIN, 32><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y);
+}
+
+// wn must already be n-major ([K][cout][cin]).
+int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
+                       int cout, int flip_k, float* y, hipStream_t st) {
+  dim3 grid(irx_cdiv(n_out, S2_TM));
+  if (cin == 128) launch_fwd2<128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y);
+  else if (cin == 64) launch_fwd2<64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y);
+  else launch_fwd2<32>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y);
+  IRX_CHECK_LAUNCH("irx_spconv_fwd(v2)");
+  return IRX_OK;
+}
+
+int irx_transpose_w_launch(const float* w, int K, int cin, int cout, float* wt, hipStream_t st) {
+  dim3 grid(irx_cdiv(cout, 32), irx_cdiv(cin, 32), K);
+  k_transpose_w<<<grid, dim3(32, 8), 0, st>>>(w, K, cin, cout, wt);
+  IRX_CHECK_LAUNCH("irx_spconv_fwd(transpose)");
+  return IRX_OK;
+}
+
+template <int CIN>
+static void launch_wg2(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* nbr,
+                       int ld, int n_out, int K, int rps, float* part) {
+  if (cout == 128) k_spconv2_wgrad<CIN, 128><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part);
+  else if (cout == 64) k_spconv2_wgrad<CIN, 64><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part);
+  else k_spconv2_wgrad<CIN, 32><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part);
+}
+
+int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
+                             int cin, int cout, int splits, int rps, float* part, hipStream_t st) {
+  dim3 grid(splits, K);
+  if (cin == 128) launch_wg2<128>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part);
+  else if (cin == 64) launch_wg2<64>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part);
+  else launch_wg2<32>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part);
+  IRX_CHECK_LAUNCH("irx_spconv_wgrad(v2)");
+  return IRX_OK;
+}

@@ -1,0 +1,70 @@
+"""Dense sequence ops of the language encoder on the irx kernels: a persistent GRU recurrence
+(csrc/irx_gru.hip) with the time-parallel projections as hipBLASLt GEMMs.
+
+`gru_packed(gru, x, lengths)` reproduces `pad_packed_sequence(gru(pack_padded_sequence(x, lengths)))` of an
+`nn.GRU(batch_first=True)` (reference models/lang_module.py:53-57) using that module's own parameters
+(state-dict keys unchanged)."""
+import torch
+
+from . import _lib
+
+_f32 = torch.float32
+
+
+class GRULayerFn(torch.autograd.Function):
+    """One GRU layer, both directions. x (B,T,I); w_ih (ndir*3H, I); b_ih (ndir*3H); w_hh (ndir,3H,H); b_hh (ndir,3H)."""
+
+    @staticmethod
+    def forward(ctx, x, lengths_i32, w_ih, b_ih, w_hh, b_hh):
+        B, T, I = x.shape
+        ndir, threeH, H = w_hh.shape
+        x2 = x.reshape(B * T, I)
+        gi = torch.addmm(b_ih, x2, w_ih.t()).contiguous()                  # (B*T, ndir*3H)
+        out = torch.empty((B, T, ndir * H), dtype=_f32, device=x.device)
+        gates = torch.empty((B, T, ndir, 4 * H), dtype=_f32, device=x.device)
+        w_hh_c = w_hh.contiguous()
+        b_hh_c = b_hh.contiguous()
+        _lib.call("irx_gru_forward", _lib.ptr(gi), _lib.ptr(lengths_i32), _lib.ptr(w_hh_c), _lib.ptr(b_hh_c),
+                  B, T, ndir, H, _lib.ptr(out), _lib.ptr(gates), _lib.stream_ptr())
+        ctx.save_for_backward(x2, lengths_i32, w_ih, w_hh_c, out, gates)
+        ctx.dims = (B, T, I, ndir, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, lengths_i32, w_ih, w_hh, out, gates = ctx.saved_tensors
+        B, T, I, ndir, H = ctx.dims
+        dout = dout.contiguous().float()
+        dgi = torch.empty((B, T, ndir, 3 * H), dtype=_f32, device=dout.device)
+        dgh = torch.empty((B, T, ndir, 3 * H), dtype=_f32, device=dout.device)
+        _lib.call("irx_gru_backward", _lib.ptr(dout), _lib.ptr(out), _lib.ptr(gates), _lib.ptr(lengths_i32),
+                  _lib.ptr(w_hh), B, T, ndir, H, _lib.ptr(dgi), _lib.ptr(dgh), _lib.stream_ptr())
+        dgi2 = dgi.view(B * T, ndir * 3 * H)
+        dx = dgi2.mm(w_ih).view(B, T, I)
+        dw_ih = dgi2.t().mm(x2)
+        db_ih = dgi2.sum(0)
+        # h_{t-1} in each direction's own order: forward = out shifted right, reverse = out shifted left
+        o = out.view(B, T, ndir, H)
+        hprev = torch.zeros_like(o)
+        hprev[:, 1:, 0] = o[:, :-1, 0]
+        if ndir == 2:
+            hprev[:, :-1, 1] = o[:, 1:, 1]
+        dw_hh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
+        db_hh = dgh.sum((0, 1))
+        return dx, None, dw_ih, db_ih, dw_hh, db_hh
+
+
+def gru_packed(gru: torch.nn.GRU, x, lengths, t_max):
+    """x (B, >=t_max, I) on a HIP device; lengths (B,) int tensor on the same device. -> (B, t_max, ndir*H)."""
+    assert gru.batch_first and gru.bias and gru.dropout == 0.0
+    ndir = 2 if gru.bidirectional else 1
+    len32 = lengths.to(torch.int32)
+    h = x[:, :t_max].contiguous().float()
+    for layer in range(gru.num_layers):
+        sfx = ["", "_reverse"][:ndir]
+        w_ih = torch.cat([getattr(gru, "weight_ih_l%d%s" % (layer, s)) for s in sfx], 0)
+        b_ih = torch.cat([getattr(gru, "bias_ih_l%d%s" % (layer, s)) for s in sfx], 0)
+        w_hh = torch.stack([getattr(gru, "weight_hh_l%d%s" % (layer, s)) for s in sfx], 0)
+        b_hh = torch.stack([getattr(gru, "bias_hh_l%d%s" % (layer, s)) for s in sfx], 0)
+        h = GRULayerFn.apply(h, len32, w_ih, b_ih, w_hh, b_hh)
+    return h

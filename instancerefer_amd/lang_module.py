@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
+from .dense import gru_packed
+
 
 class LangModule(nn.Module):
     def __init__(self, num_text_classes, use_lang_classifier=True, use_bidir=False, emb_size=300,
@@ -33,11 +35,16 @@ class LangModule(nn.Module):
 
     def rnn_encoding(self, embed, length, data_dict):
         embed = self.word_projection(embed)
-        # pack_padded_sequence wants host lengths (reference passes the CUDA tensor, legal on torch 1.6)
-        len_cpu = length.detach().to("cpu", torch.int64)
-        feats = pack_padded_sequence(embed, len_cpu, batch_first=True, enforce_sorted=False)
-        feats, _ = self.gru(feats)
-        feats, _ = pad_packed_sequence(feats, batch_first=True)  # (B, T_max, o_dim)
+        if embed.is_cuda:
+            # HIP path: persistent GRU recurrence kernel (csrc/irx_gru.hip) + GEMM projections; one D2H of max(len)
+            t_max = int(length.max().item()) if "lang_len_max" not in data_dict else int(data_dict["lang_len_max"])
+            feats = gru_packed(self.gru, embed, length, t_max)     # (B, T_max, o_dim), zeros at t >= len
+        else:
+            # host tensors (CPU unit tests of the head logic): the reference's own formulation
+            len_cpu = length.detach().to("cpu", torch.int64)
+            feats = pack_padded_sequence(embed, len_cpu, batch_first=True, enforce_sorted=False)
+            feats, _ = self.gru(feats)
+            feats, _ = pad_packed_sequence(feats, batch_first=True)  # (B, T_max, o_dim)
         data_dict['lang_feat'] = feats
         t_max = feats.shape[1]
         mask = (torch.arange(t_max, device=feats.device).unsqueeze(0) <

@@ -9,7 +9,7 @@ import math
 import torch
 import torch.nn as nn
 
-from .basic_blocks import BEVEncoder, SparseCrop, ToDenseBEVConvolution
+from .basic_blocks import BEVEncoder, SparseCrop, ToDenseBEVConvolution, batchnorm_rows, conv2d_rows
 from .data import idx_tensor
 from .sparse import nn as spnn
 
@@ -49,12 +49,17 @@ class SceneModule(nn.Module):
         if feats._batch_size is None:
             feats._batch_size = batch_size       # known from the collate; avoids the reference's .item() sync
         feats = self.net(feats)
-        # SparseCrop (to_bev[0]) is folded into the BEV gather: only voxels inside the window are looked up
-        feats = self.to_bev[3](self.to_bev[2](self.to_bev[1](feats)))          # (B, 128, 15, 25)
-        feats = self.vis_emb_fc(feats)                                          # (B, D, 11, 21)
-
-        h, w = feats.shape[-2:]
-        feats = feats.reshape(batch_size, self.h_dim, -1).permute(0, 2, 1)     # (B, n_vis, D)
+        # SparseCrop (to_bev[0]) is folded into the BEV gather: only voxels inside the window are looked up.
+        # The dense head runs on channels-last cell rows (cells, C) with the irx conv / BatchNorm kernels.
+        nx, ny = self.to_bev[1].bev_shape
+        rows, _ = self.to_bev[1].rows(feats)                                    # (B*15*25, 128)
+        rows = batchnorm_rows(self.to_bev[2], rows, relu=True)                  # BatchNorm2d + ReLU
+        rows = conv2d_rows(self.vis_emb_fc[0], rows, batch_size, nx, ny)        # Conv2d 3x3 -> (B*13*23, D)
+        rows = batchnorm_rows(self.vis_emb_fc[1], rows, relu=True)
+        rows = self.vis_emb_fc[3](rows)                                         # Dropout
+        rows = conv2d_rows(self.vis_emb_fc[4], rows, batch_size, nx - 2, ny - 2)  # -> (B*11*21, D)
+        h, w = nx - 4, ny - 4
+        feats = rows.view(batch_size, h * w, self.h_dim)                        # (B, n_vis, D)
         lang_feats = self.lang_emb_fc(lang_feats).unsqueeze(2)
         atten = torch.bmm(feats, lang_feats) / math.sqrt(feats.shape[2])
         atten = torch.softmax(atten.squeeze(2), dim=1)

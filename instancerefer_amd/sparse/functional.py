@@ -141,13 +141,15 @@ def _pairs(tbl, K):
 
 def spconv_gather_gemm(x, w, tbl, ld, n_out, K, cin, cout, flip_k, trans_w):
     y = torch.empty((n_out, cout), dtype=_f32, device=x.device)
+    wsb = int(_lib.load().irx_spconv_fwd_workspace_bytes(K, cin, cout, int(trans_w)))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     if PROFILE is not None:
         m = _pairs(tbl, K)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.call("irx_spconv_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(tbl), ld, n_out, K, cin, cout,
-              int(flip_k), int(trans_w), _lib.ptr(y), _stream())
+              int(flip_k), int(trans_w), _lib.ptr(y), _lib.ptr(ws), wsb, _stream())
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("dgrad" if trans_w else "fwd", n_out, K, cin, cout, m, e0, e1))

@@ -186,8 +186,8 @@ class RelationModule(nn.Module):
                 if dd['instance_class'][i][j] == int(cls[i]):
                     fidx.append(len(bidx))
                 bidx.append(i)
-        feats = torch.tensor(np.asarray(feats), dtype=torch.float32)
-        xyz = torch.tensor(np.asarray(centres), dtype=torch.float32)
+        feats = torch.tensor(np.asarray(feats), dtype=torch.get_default_dtype())
+        xyz = torch.tensor(np.asarray(centres), dtype=torch.get_default_dtype())
         out = self.vis_emb_fc(self.gcn(xyz, torch.tensor(bidx), torch.tensor(fidx), feats))
         dd['relation_scores'] = nn.functional.cosine_similarity(out, torch.cat(rep, 0), dim=1)
         return dd

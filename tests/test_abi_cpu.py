@@ -34,12 +34,12 @@ def test_host_only_entry_points(lib):
 
 
 def test_argument_validation_and_error_string(lib):
-    rc = lib.irx_spconv_fwd(None, None, None, 0, 10, 27, 0, 32, 0, 0, None, None)
+    rc = lib.irx_spconv_fwd(None, None, None, 0, 10, 27, 0, 32, 0, 0, None, None, 0, None)
     assert rc == -1
     assert b"irx_spconv_fwd" in lib.irx_last_error()
     rc = lib.irx_kmap_build_s1(None, 5, 3, None, None, 64, None, 5, None)   # stride 3 is not a power of two
     assert rc == -1 and b"power of two" in lib.irx_last_error()
-    assert lib.irx_spconv_fwd(None, None, None, 0, 0, 27, 7, 32, 0, 0, None, None) == 0   # empty input is fine
+    assert lib.irx_spconv_fwd(None, None, None, 0, 0, 27, 7, 32, 0, 0, None, None, 0, None) == 0   # empty input is fine
     out = (ctypes.c_int * 8)()
     assert lib.irx_device_props(0, out) in (0, -4)
 

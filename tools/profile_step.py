@@ -1,5 +1,6 @@
 """Host-side profile of one bench step (cProfile + per-section cuda sync timing). Dev tool."""
 import cProfile, pstats, sys, os, time, io
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = ["bench.py"] + sys.argv[1:]
 import torch, bench
 args = bench.parse()
