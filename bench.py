@@ -70,7 +70,7 @@ def step_fn(model, resident, workload, reducer, opt):
     if "lidar_F" in resident:
         # a FRESH un-canonical SparseTensor every step: sort, hash and kernel maps are rebuilt in the timed region
         dd["lidar"] = SparseTensor(resident["lidar_F"], resident["lidar_C"], 1, batch_size=resident["B"])
-    reducer.zero_grad()
+    opt.zero_grad()
     dd = model(dd)
     if workload == "full":
         loss = get_loss(dd, step_fn.cfg)["loss"]
@@ -86,8 +86,7 @@ def step_fn(model, resident, workload, reducer, opt):
                 loss = loss + 10.0 * crit(dd["attribute_scores"][o:o + n], lab) / len(dd["num_filtered_objs"])
                 o += n
     loss.backward()
-    reducer.all_reduce()
-    opt.step()
+    opt.backward_step()          # one cat -> one all-reduce (N > 1) -> one fused Adam launch
     return loss
 
 
@@ -203,8 +202,9 @@ def main():
     resident["lidar_C"] = lidar.C[perm].contiguous()
     resident["B"] = B
     n_scene_vox = int(lidar.F.shape[0])
-    reducer = FlatGradAllReduce(model.parameters(), world)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    from instancerefer_amd.optim import FlatAdam
+    reducer = None
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=world)
 
     def barrier():
         torch.cuda.synchronize()

@@ -220,6 +220,15 @@ int irx_gru_backward(const float* dout, const float* out, const float* gates, co
                      const float* w_hh, int B, int T, int ndir, int H, float* dgi, float* dgh,
                      void* stream);
 
+/* ---- optimizer -------------------------------------------------------------------------------------- */
+
+/* torch.optim.Adam(lr, betas, eps, weight_decay) (reference scripts/train.py:121) as ONE launch over flat,
+ * 16-byte aligned fp32 buffers of n elements; `step` counts from 1; gradients are multiplied by grad_scale
+ * first (1/world_size after a sum all-reduce). */
+int irx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  void* stream);
+
 /* ---- instance graph ------------------------------------------------------------------- */
 
 /* torch_cluster.knn(x=support, y=query, k, batch_x, batch_y) (models/basic_blocks.py:120):

@@ -48,6 +48,7 @@ _SIGNATURES = {
     "irx_batch_offsets": (_I, [_P, _I, _I, _P, _P]),
     "irx_gru_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "irx_gru_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "irx_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P]),
     "irx_knn_batched": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
 }
 
@@ -87,7 +88,8 @@ def check(rc: int, what: str):
 
 
 def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # raw handle of torch's current stream on the current device (fast path; no Stream object round trip)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def ptr(t):

@@ -44,11 +44,28 @@ __device__ static inline PairList compact_pairs(int my, int lane) {
   return p;
 }
 
+// Per-wave compaction of one table column into LDS lists (wave-private region: no barrier needed, only the
+// wave's own lgkmcnt): list_in[p] = input row of pair p, list_row[p] = tile-local output row. Returns v.
+__device__ static inline int compact_to_lds(int my, int lane, int* __restrict__ list_in, int* __restrict__ list_row) {
+  const unsigned long long valid = __ballot(my >= 0);
+  const int v = __popcll(valid);
+  if (my >= 0) {
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int dst = __popcll(valid & lt);
+    list_in[dst] = my;
+    list_row[dst] = lane;
+  }
+  return v;
+}
+
 // wn: "n-major" weights [K][COUT][CIN] (forward: transposed copy of Conv3d.kernel; data-gradient: the kernel itself)
+// Software pipeline per workgroup: the tile's whole table column block ([K][64] ints) is fetched into LDS once; for
+// every active offset the gathered rows are staged global -> VGPR -> LDS, and the NEXT active offset's gather and
+// weight-slice loads are issued before the current offset's MFMA phase, so HBM/L2 latency hides behind the MFMAs.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn,
                                                     const int32_t* __restrict__ nbr, int ld, int n_out, int K,
-                                                    int flip_k, float* __restrict__ y) {
+                                                    int flip_k, float* __restrict__ y, int dbg) {
   constexpr int NT = (COUT >= 128) ? 2 : 1;       // 16-column tiles per wave
   constexpr int NCS = COUT / (16 * NT);           // channel slices (waves along N)
   constexpr int NGP = 4 / NCS;                    // waves along the pair-group dimension
@@ -56,87 +73,143 @@ __global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x,
   constexpr int LDO = COUT + 8;
   constexpr int LPR = CIN / 4;                    // lanes (float4) per gathered row
   constexpr int PPI = 64 / LPR;                   // pairs per wave-instruction
+  constexpr int PPP = 4 * PPI;                    // pairs per workgroup pass
+  constexpr int NIT = S2_TM / PPP;                // gather passes for a full 64-pair tile
   constexpr int NJ = CIN / 16;
+  constexpr int KMAX = 27;
   static_assert(NCS * NGP == 4, "4 waves");
   __shared__ __attribute__((aligned(16))) float sOut[S2_TM * LDO];
   __shared__ __attribute__((aligned(16))) float sA[S2_TM * LDA];
+  __shared__ int sTbl[KMAX * S2_TM];
+  __shared__ int sList[4][2][2][S2_TM];           // [wave][parity][in|row][pair]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g4 = lane >> 4;
   const int cs = wave % NCS, gp = wave / NCS;
   const int n_base = cs * 16 * NT;
   const int q0 = blockIdx.x * S2_TM;
+  const int sub = lane / LPR;                     // which of the PPI pairs of a pass this lane serves
+  const int c4 = (lane % LPR) * 4;
+  const int pbase = wave * PPI + sub;             // this lane's pair in pass 0
 
-  for (int i = tid; i < S2_TM * LDO; i += 256) sOut[i] = 0.f;
-
-  for (int k = 0; k < K; ++k) {
+  for (int i = tid; i < K * S2_TM; i += 256) {
+    const int k = i >> 6, r = i & 63;
     const int kt = flip_k ? (K - 1 - k) : k;
-    int my = -1;
-    if (q0 + lane < n_out) my = nbr[(size_t)kt * ld + q0 + lane];
-    const PairList pl = compact_pairs(my, lane);
-    if (pl.v == 0) continue;                       // block-uniform: every wave read the same 64 entries
-    const int vpad = (pl.v + 15) & ~15;
+    sTbl[i] = (q0 + r < n_out) ? nbr[(size_t)kt * ld + q0 + r] : -1;
+  }
+  for (int i = tid; i < S2_TM * LDO; i += 256) sOut[i] = 0.f;
+  __syncthreads();
 
-    // weight slice of this wave -> registers (consumed after the gather barrier)
-    float4 wreg[NJ][NT];
+  // ---- find the first active offset and issue its loads ----
+  int k = 0, v = 0, par = 0;
+  for (; k < K; ++k) {
+    v = compact_to_lds(sTbl[k * S2_TM + lane], lane, sList[wave][par][0], sList[wave][par][1]);
+    if (v) break;
+  }
+  float4 stage[NIT];
+  float4 wreg[NJ][NT];
+  if (k < K) {
+    const int npass = (v + PPP - 1) / PPP;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < npass) {
+        const int p = pbase + it * PPP;
+        if (p < v && !(dbg & 2)) stage[it] = *reinterpret_cast<const float4*>(x + (size_t)sList[wave][par][0][p] * CIN + c4);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         wreg[j][t] = *reinterpret_cast<const float4*>(
             wn + ((size_t)k * COUT + n_base + 16 * t + m) * CIN + 16 * j + 4 * g4);
+  }
 
-    __syncthreads();                               // previous offset's fragment reads are done (also: sOut zeroed)
-    // ---- gather the compacted input rows; rows v..vpad-1 are zero ----
-    {
-      const int sub = lane / LPR;                  // which of the PPI pairs this lane serves
-      const int c4 = (lane % LPR) * 4;
-      for (int p0 = wave * PPI; p0 < vpad; p0 += 4 * PPI) {
-        const int p = p0 + sub;
-        const int idx = __shfl(pl.in_of_pair, p & 63);
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < pl.v) val = *reinterpret_cast<const float4*>(x + (size_t)idx * CIN + c4);
-        if (p < vpad) *reinterpret_cast<float4*>(&sA[p * LDA + c4]) = val;
-      }
-    }
+  while (k < K) {
+    const int vpad = (v + 15) & ~15;
+    const int npass = (vpad + PPP - 1) / PPP;      // block-uniform
+    __syncthreads();                               // previous offset's fragment reads are done
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (it < npass) *reinterpret_cast<float4*>(&sA[(pbase + it * PPP) * LDA + c4]) = stage[it];
     __syncthreads();
+    // ---- look ahead: next active offset; issue its gather + weight loads now ----
+    int kn = k + 1, vn = 0;
+    const int parn = par ^ 1;
+    for (; kn < K; ++kn) {
+      vn = compact_to_lds(sTbl[kn * S2_TM + lane], lane, sList[wave][parn][0], sList[wave][parn][1]);
+      if (vn) break;
+    }
+    float4 wnext[NJ][NT];
+    if (kn < K) {
+      const int npn = (vn + PPP - 1) / PPP;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it < npn) {
+          const int p = pbase + it * PPP;
+          if (p < vn && !(dbg & 2)) stage[it] = *reinterpret_cast<const float4*>(x + (size_t)sList[wave][parn][0][p] * CIN + c4);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          wnext[j][t] = (dbg & 4) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(
+              wn + ((size_t)kn * COUT + n_base + 16 * t + m) * CIN + 16 * j + 4 * g4);
+    }
     // ---- MFMA over dense 16-pair groups; this wave's channel slice ----
-    for (int g = gp; g * 16 < vpad; g += NGP) {
+    const int* lrow = sList[wave][par][1];
+    for (int g = gp; g * 16 < vpad && !(dbg & 1); g += NGP) {
       f32x4 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* pa = &sA[(16 * g + m) * LDA + 4 * g4];
+      int orow[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) orow[r] = lrow[(16 * g + 4 * g4 + r) & 63];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const float4 a4 = *reinterpret_cast<const float4*>(pa + 16 * j);
+        // alternate the accumulators so consecutive MFMAs never depend on each other
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wreg[j][t].x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wreg[j][t].y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wreg[j][t].z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wreg[j][t].w, acc[t], 0, 0, 0);
-        }
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wreg[j][t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wreg[j][t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wreg[j][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wreg[j][t].w, acc[t], 0, 0, 0);
       }
       // D layout: col = lane&15, row = (lane>>4)*4 + r  -> pair 16g + 4*g4 + r
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int p = 16 * g + 4 * g4 + r;
-        const int orow = __shfl(pl.row_of_pair, p & 63);
-        if (p < pl.v) {
+        if (16 * g + 4 * g4 + r < v && !(dbg & 8)) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) sOut[orow * LDO + n_base + 16 * t + m] += acc[t][r];
+          for (int t = 0; t < NT; ++t)
+            sOut[orow[r] * LDO + n_base + 16 * t + m] += acc[t][r];   // this wave owns the channel slice: no race
         }
       }
+    }
+    k = kn;
+    v = vn;
+    par = parn;
+    if (kn < K) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wreg[j][t] = wnext[j][t];
     }
   }
   __syncthreads();
   // ---- write the tile: COUT/4 float4 per row ----
   constexpr int F4 = COUT / 4;
   for (int f = tid; f < S2_TM * F4; f += 256) {
-    const int row = f / F4, c4 = (f % F4) * 4;
+    const int row = f / F4, cc = (f % F4) * 4;
     if (q0 + row < n_out)
-      *reinterpret_cast<float4*>(y + (size_t)(q0 + row) * COUT + c4) =
-          *reinterpret_cast<const float4*>(&sOut[row * LDO + c4]);
+      *reinterpret_cast<float4*>(y + (size_t)(q0 + row) * COUT + cc) =
+          *reinterpret_cast<const float4*>(&sOut[row * LDO + cc]);
   }
 }
 
@@ -262,14 +335,16 @@ bool irx_spconv2_supported(int cin, int cout) {
 template <int CIN>
 static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
                         int ld, int n_out, int K, int flip_k, float* y) {
-  if (cout == 128) k_spconv2<CIN, 128><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y);
-  else if (cout == 64) k_spconv2<CIN, 64><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y);
-  else k_spconv2<CIN, 32><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y);
+  static const int dbg = getenv("IRX_SPCONV_DBG") ? atoi(getenv("IRX_SPCONV_DBG")) : 0;
+  if (cout == 128) k_spconv2<CIN, 128><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg);
+  else if (cout == 64) k_spconv2<CIN, 64><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg);
+  else k_spconv2<CIN, 32><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg);
 }
 
 // wn must already be n-major ([K][cout][cin]).
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
                        int cout, int flip_k, float* y, hipStream_t st) {
+  IRX_REQUIRE(K <= 27, "irx_spconv_fwd: K = %d > 27 unsupported by the fast path", K);
   dim3 grid(irx_cdiv(n_out, S2_TM));
   if (cin == 128) launch_fwd2<128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y);
   else if (cin == 64) launch_fwd2<64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y);

@@ -111,6 +111,11 @@ def to_device(data_dict, device, voxel_size_glp=0.05):
     scene of the batch in one GPU pass + upload the instance pack once."""
     from .data import upload_instances
     from .sparse.utils import voxelize
+    # labels originate on the host: keep numpy copies so get_loss needs no D2H round trip
+    data_dict["_host"] = {k: data_dict[k].numpy() for k in ("ref_center_label", "ref_size_residual_label",
+                                                            "ref_heading_class_label", "ref_heading_residual_label",
+                                                            "ref_size_class_label")}
+    data_dict["lang_len_max"] = int(data_dict["lang_len"].max())
     for k in ("lang_feat", "lang_len", "object_cat", "point_min", "point_max", "ref_center_label",
               "ref_size_residual_label"):
         data_dict[k] = data_dict[k].to(device)

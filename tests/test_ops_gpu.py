@@ -264,3 +264,20 @@ def test_gru_recurrence_matches_torch_and_reference_golden(lib):
         dd = lm({"lang_feat": torch.from_numpy(feat).cuda(), "lang_len": torch.from_numpy(lens).cuda()})
     for k in gold.files:
         assert np.abs(dd[k].cpu().numpy() - gold[k]).max() <= 1e-5, k
+
+
+def test_flat_adam_matches_torch_adam(lib):
+    from instancerefer_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.ReLU(), torch.nn.Linear(19, 3))   # odd sizes: tail path
+    mine = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.ReLU(), torch.nn.Linear(19, 3))
+    mine.load_state_dict(ref.state_dict())
+    mine.cuda()
+    o_ref = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=1e-3)
+    o_mine = FlatAdam(mine.parameters(), lr=1e-2, weight_decay=1e-3, world_size=1)
+    x = torch.randn(11, 37)
+    for _ in range(5):
+        o_ref.zero_grad(); ref(x).pow(2).sum().backward(); o_ref.step()
+        o_mine.zero_grad(); mine(x.cuda()).pow(2).sum().backward(); o_mine.backward_step()
+    for a, b in zip(ref.parameters(), mine.parameters()):
+        assert (a.detach() - b.detach().cpu()).abs().max().item() <= 2e-6

@@ -16,8 +16,9 @@ host = S.make_batch(B, seed=123, num_points=args.points, num_instances=args.inst
 res = S.to_device(host, device)
 lidar = res.pop("lidar"); perm = torch.randperm(lidar.F.shape[0], device=device)
 res["lidar_F"] = lidar.F[perm].contiguous(); res["lidar_C"] = lidar.C[perm].contiguous(); res["B"] = B
-red = FlatGradAllReduce(model.parameters(), 1)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+from instancerefer_amd.optim import FlatAdam
+red = None
+opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
 for _ in range(3): bench.step_fn(model, res, args.workload, red, opt)
 torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
