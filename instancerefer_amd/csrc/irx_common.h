@@ -91,3 +91,11 @@ int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int 
 int irx_transpose_w_launch(const float* w, int K, int cin, int cout, float* wt, hipStream_t st);
 int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
                              int cin, int cout, int splits, int rps, float* part, hipStream_t st);
+
+// ---- stem (small-Cin) launchers (irx_stem.hip) ------------------------------------------------------
+bool irx_stem_supported(int K, int cin, int cout);
+int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin,
+                        float* y, hipStream_t st);
+int irx_stem_wgrad_blocks(int n_out);
+int irx_stem_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int cin,
+                          int blocks, float* part, hipStream_t st);

@@ -294,6 +294,8 @@ extern "C" int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr
   IRX_REQUIRE(x && w && nbr && y, "irx_spconv_fwd: null pointer");
   IRX_REQUIRE(ld >= n_out, "irx_spconv_fwd: ld %d < n_out %d", ld, n_out);
   const bool aligned = (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0;
+  if (!trans_w && !flip_k && irx_stem_supported(K, cin, cout) && (((uintptr_t)y & 15) == 0))
+    return irx_stem_fwd_launch(x, w, nbr, ld, n_out, K, cin, y, S(stream));
   if (aligned && irx_spconv2_supported(cin, cout) && irx_spconv2_enabled(trans_w ? 'd' : 'f')) {
     const float* wn = w;
     if (!trans_w) {
@@ -335,6 +337,7 @@ static int wgrad_splits(int n_out, int K, int cin, int cout) {
 
 extern "C" size_t irx_spconv_wgrad_workspace_bytes(int n_out, int K, int cin, int cout) {
   if (n_out <= 0 || K <= 0 || cin <= 0 || cout <= 0) return 0;
+  if (irx_stem_supported(K, cin, cout)) return (size_t)irx_stem_wgrad_blocks(n_out) * K * cin * cout * sizeof(float);
   const int s = wgrad_splits(n_out, K, cin, cout);
   return s <= 1 ? 0 : (size_t)s * K * cin * cout * sizeof(float);
 }
@@ -355,6 +358,14 @@ extern "C" int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* 
   if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
     irx_set_error("irx_spconv_wgrad: workspace %zu < %zu", workspace_bytes, need);
     return IRX_ERR_WORKSPACE;
+  }
+  if (irx_stem_supported(K, cin, cout)) {
+    const int blocks = irx_stem_wgrad_blocks(n_out);
+    int rc = irx_stem_wgrad_launch(x, dy, nbr, ld, n_out, cin, blocks, (float*)workspace, S(stream));
+    if (rc) return rc;
+    k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>((const float*)workspace, blocks, elems, dw);
+    IRX_CHECK_LAUNCH("irx_spconv_wgrad(stem reduce)");
+    return IRX_OK;
   }
   int rps = irx_cdiv(n_out, s);
   rps = irx_cdiv(rps, WG_TQ) * WG_TQ;

@@ -1,0 +1,166 @@
+// irx_stem.hip — the stem convolution (3^3, Cin = C0 <= 8 input features -> 32 channels; reference
+// models/basic_blocks.py:63-65) is HBM/gather-bound (7 flop/B): a 28-byte input row per pair. MFMA tiles would be
+// 78 % padding, so these are plain VALU kernels organised for coalescing:
+//   forward : 8 threads per output row (4 channels each); the 27 x Cin x 32 weights live in LDS; per valid
+//             neighbour one broadcast read of the input row and Cin LDS float4 reads.
+//   wgrad   : dense im2col tile assembled in LDS per 64-row chunk, MFMA with the rows as the reduction dimension
+//             (see k_stem_wgrad); per-workgroup partial sums are reduced by k_wgrad_reduce (deterministic).
+#include "irx_common.h"
+
+#define ST_COUT 32
+
+template <int CIN>
+__global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                  const int32_t* __restrict__ nbr, int ld, int n_out, int K,
+                                                  float* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) float sW[27 * CIN * ST_COUT];
+  for (int i = threadIdx.x; i < K * CIN * ST_COUT; i += 256) sW[i] = w[i];
+  __syncthreads();
+  const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int c4 = (threadIdx.x & 7) * 4;
+  if (row >= n_out) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < K; ++k) {
+    const int idx = nbr[(size_t)k * ld + row];
+    if (idx < 0) continue;
+    const float* xr = x + (size_t)idx * CIN;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const float xv = xr[c];
+      const float4 wv = *reinterpret_cast<const float4*>(&sW[(k * CIN + c) * ST_COUT + c4]);
+      acc.x = fmaf(xv, wv.x, acc.x);
+      acc.y = fmaf(xv, wv.y, acc.y);
+      acc.z = fmaf(xv, wv.z, acc.z);
+      acc.w = fmaf(xv, wv.w, acc.w);
+    }
+  }
+  *reinterpret_cast<float4*>(y + (size_t)row * ST_COUT + c4) = acc;
+}
+
+// part[blk][k*CIN + c][n].  Per 64-row chunk the dense im2col tile X[row][k*CIN + c] (zeros where the neighbour is
+// missing) is assembled directly in LDS from one coalesced table read + the valid neighbours' CIN-float rows, and
+// dW += X^T * dY runs on MFMA with the 64 rows as the reduction dimension (16x16x4 fp32; M = 27*CIN padded to 192).
+// The im2col matrix is never materialised in HBM and there are no atomics; workgroup partials are reduced by
+// k_wgrad_reduce (deterministic). Wave w owns M-tiles {w, w+4, w+8} x both N-tiles (6 accumulators).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const int32_t* __restrict__ nbr, int ld, int n_out,
+                                                       int rows_per_block, float* __restrict__ part) {
+  constexpr int K = 27;
+  constexpr int MREAL = K * CIN;                 // 189 for CIN = 7
+  constexpr int MT = (MREAL + 15) / 16;          // 12
+  constexpr int MPW = (MT + 3) / 4;              // M-tiles per wave (3)
+  constexpr int LDX = MT * 16 + 16;              // 208: consecutive rows 16 banks apart
+  constexpr int LDD = ST_COUT + 16;              // 48
+  __shared__ __attribute__((aligned(16))) float sX[64 * LDX];
+  __shared__ __attribute__((aligned(16))) float sD[64 * LDD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mm = lane & 15, g4 = lane >> 4;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > n_out) r1 = n_out;
+  f32x4 acc[MPW][2];
+#pragma unroll
+  for (int a = 0; a < MPW; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 64 * LDX; i += 256) sX[i] = 0.f;     // pad columns stay zero for the whole kernel
+
+  for (int q0 = r0; q0 < r1; q0 += 64) {
+    __syncthreads();                                         // previous chunk's fragment reads are done
+    for (int i = tid; i < K * 64; i += 256) {
+      const int k = i >> 6, r = i & 63;
+      int idx = -1;
+      if (q0 + r < r1) idx = nbr[(size_t)k * ld + q0 + r];
+      float v[CIN];
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) v[c] = 0.f;
+      if (idx >= 0) {
+        const float* xr = x + (size_t)idx * CIN;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) v[c] = xr[c];
+      }
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) sX[r * LDX + k * CIN + c] = v[c];
+    }
+    for (int f = tid; f < 64 * (ST_COUT / 4); f += 256) {
+      const int r = f >> 3, c4 = (f & 7) * 4;
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q0 + r < r1) d = *reinterpret_cast<const float4*>(dy + (size_t)(q0 + r) * ST_COUT + c4);
+      *reinterpret_cast<float4*>(&sD[r * LDD + c4]) = d;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const int rr = ks * 4 + g4;
+      const float b0 = sD[rr * LDD + mm], b1 = sD[rr * LDD + 16 + mm];
+#pragma unroll
+      for (int a = 0; a < MPW; ++a) {
+        const int mt = wave + 4 * a;
+        if (mt < MT) {
+          const float av = sX[rr * LDX + mt * 16 + mm];      // A[m][kk = row]
+          acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[a][0], 0, 0, 0);
+          acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[a][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* out = part + (size_t)blockIdx.x * MREAL * ST_COUT;
+#pragma unroll
+  for (int a = 0; a < MPW; ++a) {
+    const int mt = wave + 4 * a;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mrow = mt * 16 + g4 * 4 + r;               // = k*CIN + c
+        if (mt < MT && mrow < MREAL) out[(size_t)mrow * ST_COUT + t * 16 + mm] = acc[a][t][r];
+      }
+  }
+}
+
+bool irx_stem_supported(int K, int cin, int cout) { return K == 27 && cout == ST_COUT && cin >= 1 && cin <= 8; }
+
+int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin,
+                        float* y, hipStream_t st) {
+  const int grid = irx_cdiv(n_out, 32);
+  switch (cin) {
+    case 1: k_stem_fwd<1><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
+    case 2: k_stem_fwd<2><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
+    case 3: k_stem_fwd<3><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
+    case 4: k_stem_fwd<4><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
+    case 5: k_stem_fwd<5><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
+    case 6: k_stem_fwd<6><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
+    case 7: k_stem_fwd<7><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
+    default: k_stem_fwd<8><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
+  }
+  IRX_CHECK_LAUNCH("irx_spconv_fwd(stem)");
+  return IRX_OK;
+}
+
+int irx_stem_wgrad_blocks(int n_out) {
+  int b = irx_cdiv(n_out, 256);          // >= 4 chunks of 64 rows per workgroup
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return b;
+}
+
+int irx_stem_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int cin,
+                          int blocks, float* part, hipStream_t st) {
+  int rpb = irx_cdiv(n_out, blocks);
+  rpb = irx_cdiv(rpb, 64) * 64;
+  switch (cin) {
+    case 1: k_stem_wgrad<1><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
+    case 2: k_stem_wgrad<2><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
+    case 3: k_stem_wgrad<3><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
+    case 4: k_stem_wgrad<4><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
+    case 5: k_stem_wgrad<5><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
+    case 6: k_stem_wgrad<6><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
+    case 7: k_stem_wgrad<7><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
+    default: k_stem_wgrad<8><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
+  }
+  IRX_CHECK_LAUNCH("irx_spconv_wgrad(stem)");
+  return IRX_OK;
+}

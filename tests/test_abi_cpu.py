@@ -29,6 +29,7 @@ def test_host_only_entry_points(lib):
     assert lib.irx_bn_workspace_bytes(1000, 128) == 4 * 2 * 128 * 4
     assert lib.irx_downsample_workspace_bytes(5000) >= 3 * 4
     small = lib.irx_spconv_wgrad_workspace_bytes(100, 27, 128, 128)
+    assert lib.irx_spconv_wgrad_workspace_bytes(5000, 27, 7, 32) == 20 * 27 * 7 * 32 * 4   # stem path: per-workgroup partials
     big = lib.irx_spconv_wgrad_workspace_bytes(500000, 27, 128, 128)
     assert small == 0 and big > 0 and big % (27 * 128 * 128 * 4) == 0
 
