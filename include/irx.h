@@ -150,10 +150,11 @@ int irx_bev_table(const int32_t* coords, int n, int tensor_stride, int batch_siz
  *             cin = conv's Cout, cout = conv's Cin, w = the forward weight unchanged)
  * Output-stationary: every output row is written exactly once (no atomics; deterministic).
  * fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
- * Any cin / cout; channel counts in {32,64,128} take the pair-compacting, weight-stationary fast path,
- * which for the forward needs a workspace (irx_spconv_fwd_workspace_bytes) for an n-major weight image.
+ * Any cin / cout; channel counts in {32,64,128} take the pair-compacting, weight-stationary fast path, which
+ * needs a workspace (irx_spconv_fwd_workspace_bytes) for a fragment-major weight image and, for small layers,
+ * the partial-sum slabs of the offset splits (summed deterministically).
  * y: [n_out][cout]. */
-size_t irx_spconv_fwd_workspace_bytes(int K, int cin, int cout, int trans_w);
+size_t irx_spconv_fwd_workspace_bytes(int n_out, int K, int cin, int cout, int trans_w);
 int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr, int ld, int n_out,
                    int K, int cin, int cout, int flip_k, int trans_w, float* y, void* workspace,
                    size_t workspace_bytes, void* stream);

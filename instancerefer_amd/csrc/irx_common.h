@@ -86,9 +86,10 @@ __device__ static inline int irx_hash_lookup(const uint64_t* __restrict__ tk,
 // ---- second-generation sparse-conv launchers (irx_spconv2.hip) ---------------------------------
 bool irx_spconv2_supported(int cin, int cout);
 bool irx_spconv2_enabled(char pass);
+int irx_spconv2_splits(int n_out, int K);
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                       int cout, int flip_k, float* y, hipStream_t st);
-int irx_transpose_w_launch(const float* w, int K, int cin, int cout, float* wt, hipStream_t st);
+                       int cout, int flip_k, float* y, int splits, hipStream_t st);
+int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st);
 int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
                              int cin, int cout, int splits, int rps, float* part, hipStream_t st);
 

@@ -15,6 +15,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t elems, float* __restrict__ dw);
+
 #define SC_TM 64  // output rows per workgroup (4 waves x 16 rows)
 #define SC_KC 32  // reduction (input-channel) chunk staged per barrier pair
 #define SC_LDA (SC_KC + 2)   // LDS row stride (dwords) of the gathered A tile: (2m+g)%32 distinct
@@ -279,11 +281,16 @@ static void launch_fwd(int bn, dim3 grid, hipStream_t st, const float* x, const 
     k_spconv_fwd<32, TRANS_W, VEC><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, cin, cout, flip_k, y);
 }
 
-extern "C" size_t irx_spconv_fwd_workspace_bytes(int K, int cin, int cout, int trans_w) {
-  // the fast path reads "n-major" weights [K][cout][cin]; the forward needs a transposed copy
-  if (K <= 0 || cin <= 0 || cout <= 0) return 0;
-  if (!trans_w && irx_spconv2_supported(cin, cout)) return (size_t)K * cin * cout * sizeof(float);
-  return 0;
+static size_t fwd_ws_weights(int K, int cin, int cout) { return ((size_t)K * cin * cout * sizeof(float) + 255) & ~(size_t)255; }
+
+extern "C" size_t irx_spconv_fwd_workspace_bytes(int n_out, int K, int cin, int cout, int trans_w) {
+  // fast path: a fragment-major weight image (one coalesced 1 KiB load per wave fragment) + the partial-sum slabs
+  // of the offset splits used for small layers
+  if (n_out <= 0 || K <= 0 || cin <= 0 || cout <= 0) return 0;
+  (void)trans_w;
+  if (!irx_spconv2_supported(cin, cout)) return 0;
+  const int splits = irx_spconv2_splits(n_out, K);
+  return fwd_ws_weights(K, cin, cout) + (splits > 1 ? (size_t)splits * n_out * cout * sizeof(float) : 0);
 }
 
 extern "C" int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr, int ld, int n_out,
@@ -297,18 +304,24 @@ extern "C" int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr
   if (!trans_w && !flip_k && irx_stem_supported(K, cin, cout) && (((uintptr_t)y & 15) == 0))
     return irx_stem_fwd_launch(x, w, nbr, ld, n_out, K, cin, y, S(stream));
   if (aligned && irx_spconv2_supported(cin, cout) && irx_spconv2_enabled(trans_w ? 'd' : 'f')) {
-    const float* wn = w;
-    if (!trans_w) {
-      const size_t need = irx_spconv_fwd_workspace_bytes(K, cin, cout, 0);
-      if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
-        irx_set_error("irx_spconv_fwd: workspace %zu < %zu", workspace_bytes, need);
-        return IRX_ERR_WORKSPACE;
-      }
-      int rc = irx_transpose_w_launch(w, K, cin, cout, (float*)workspace, S(stream));
-      if (rc) return rc;
-      wn = (const float*)workspace;
+    const size_t need = irx_spconv_fwd_workspace_bytes(n_out, K, cin, cout, trans_w);
+    if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+      irx_set_error("irx_spconv_fwd: workspace %zu < %zu", workspace_bytes, need);
+      return IRX_ERR_WORKSPACE;
     }
-    return irx_spconv2_launch(x, wn, nbr, ld, n_out, K, cin, cout, flip_k, y, S(stream));
+    int rc = irx_permute_w_launch(w, K, cin, cout, trans_w, (float*)workspace, S(stream));
+    if (rc) return rc;
+    const int splits = irx_spconv2_splits(n_out, K);
+    float* slabs = (float*)((char*)workspace + fwd_ws_weights(K, cin, cout));
+    rc = irx_spconv2_launch(x, (const float*)workspace, nbr, ld, n_out, K, cin, cout, flip_k,
+                            splits > 1 ? slabs : y, splits, S(stream));
+    if (rc) return rc;
+    if (splits > 1) {
+      const size_t elems = (size_t)n_out * cout;
+      k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(slabs, splits, elems, y);
+      IRX_CHECK_LAUNCH("irx_spconv_fwd(split reduce)");
+    }
+    return IRX_OK;
   }
   const int bn = cout > 64 ? 128 : (cout > 32 ? 64 : 32);
   dim3 grid(irx_cdiv(n_out, SC_TM), irx_cdiv(cout, bn));

@@ -58,14 +58,21 @@ __device__ static inline int compact_to_lds(int my, int lane, int* __restrict__ 
   return v;
 }
 
-// wn: "n-major" weights [K][COUT][CIN] (forward: transposed copy of Conv3d.kernel; data-gradient: the kernel itself)
+// wn: FRAGMENT-MAJOR weights [K][NCS][NJ][NT][64 lanes][4]: element i of lane l holds
+//     W[k][c = 16j + 4(l>>4) + i][n = cs*16*NT + 16t + (l&15)]   (k_permute_w builds it from Conv3d.kernel),
+// so each wave-level weight load is one contiguous, fully coalesced 1 KiB read.
 // Software pipeline per workgroup: the tile's whole table column block ([K][64] ints) is fetched into LDS once; for
 // every active offset the gathered rows are staged global -> VGPR -> LDS, and the NEXT active offset's gather and
 // weight-slice loads are issued before the current offset's MFMA phase, so HBM/L2 latency hides behind the MFMAs.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn,
                                                     const int32_t* __restrict__ nbr, int ld, int n_out, int K,
-                                                    int flip_k, float* __restrict__ y, int dbg) {
+                                                    int flip_k, float* __restrict__ y, int dbg, int k_per_split) {
+  // blockIdx.y = offset split: this workgroup handles offsets [kb, ke) and writes its partial tile to slab
+  // blockIdx.y of y (slabs are summed by k_wgrad_reduce; a single split writes the result directly).
+  const int kb = blockIdx.y * k_per_split;
+  const int ke = (kb + k_per_split < K) ? kb + k_per_split : K;
+  y += (size_t)blockIdx.y * n_out * COUT;
   constexpr int NT = (COUT >= 128) ? 2 : 1;       // 16-column tiles per wave
   constexpr int NCS = COUT / (16 * NT);           // channel slices (waves along N)
   constexpr int NGP = 4 / NCS;                    // waves along the pair-group dimension
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x,
   const int c4 = (lane % LPR) * 4;
   const int pbase = wave * PPI + sub;             // this lane's pair in pass 0
 
-  for (int i = tid; i < K * S2_TM; i += 256) {
+  for (int i = tid + kb * S2_TM; i < ke * S2_TM; i += 256) {
     const int k = i >> 6, r = i & 63;
     const int kt = flip_k ? (K - 1 - k) : k;
     sTbl[i] = (q0 + r < n_out) ? nbr[(size_t)kt * ld + q0 + r] : -1;
@@ -101,7 +108,8 @@ __global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x,
   __syncthreads();
 
   // ---- find the first active offset and issue its loads ----
-  int k = 0, v = 0, par = 0;
+  K = ke;
+  int k = kb, v = 0, par = 0;
   for (; k < K; ++k) {
     v = compact_to_lds(sTbl[k * S2_TM + lane], lane, sList[wave][par][0], sList[wave][par][1]);
     if (v) break;
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x,
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         wreg[j][t] = *reinterpret_cast<const float4*>(
-            wn + ((size_t)k * COUT + n_base + 16 * t + m) * CIN + 16 * j + 4 * g4);
+            wn + (((((size_t)k * NCS + cs) * NJ + j) * NT + t) * 64 + lane) * 4);
   }
 
   while (k < K) {
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x,
 #pragma unroll
         for (int t = 0; t < NT; ++t)
           wnext[j][t] = (dbg & 4) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(
-              wn + ((size_t)kn * COUT + n_base + 16 * t + m) * CIN + 16 * j + 4 * g4);
+              wn + (((((size_t)kn * NCS + cs) * NJ + j) * NT + t) * 64 + lane) * 4);
     }
     // ---- MFMA over dense 16-pair groups; this wave's channel slice ----
     const int* lrow = sList[wave][par][1];
@@ -298,22 +306,30 @@ __global__ __launch_bounds__(256, 2) void k_spconv2_wgrad(const float* __restric
       }
 }
 
-// [K][cin][cout] -> [K][cout][cin]
-__global__ void k_transpose_w(const float* __restrict__ w, int K, int cin, int cout, float* __restrict__ wt) {
-  __shared__ float tile[32][33];
-  const int k = blockIdx.z;
-  const int c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  const float* src = w + (size_t)k * cin * cout;
-  float* dst = wt + (size_t)k * cin * cout;
-  for (int i = threadIdx.y; i < 32; i += 8) {
-    const int c = c0 + i, n = n0 + threadIdx.x;
-    if (c < cin && n < cout) tile[i][threadIdx.x] = src[(size_t)c * cout + n];
-  }
-  __syncthreads();
-  for (int i = threadIdx.y; i < 32; i += 8) {
-    const int n = n0 + i, c = c0 + threadIdx.x;
-    if (c < cin && n < cout) dst[(size_t)n * cin + c] = tile[threadIdx.x][i];
-  }
+// Conv3d.kernel w -> fragment-major image for k_spconv2.  Kernel-relative dims (cin_k = reduction, cout_k = outputs):
+//   forward      : W[k][c][n] = w[(k*cin_k + c)*cout_k + n]
+//   data-gradient: W[k][c][n] = w[(k*cout_k + n)*cin_k + c]   (w is the forward [K][conv Cin][conv Cout] tensor)
+__global__ void k_permute_w(const float* __restrict__ w, int K, int cin, int cout, int trans_w, float* __restrict__ wf) {
+  const int NT = cout >= 128 ? 2 : 1;
+  const int NCS = cout / (16 * NT);
+  const int NJ = cin / 16;
+  const size_t total = (size_t)K * cin * cout / 4;          // float4 elements
+  size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= total) return;
+  const int lane = (int)(f & 63);
+  size_t r = f >> 6;
+  const int t = (int)(r % NT); r /= NT;
+  const int j = (int)(r % NJ); r /= NJ;
+  const int cs = (int)(r % NCS); r /= NCS;
+  const int k = (int)r;
+  const int n = cs * 16 * NT + 16 * t + (lane & 15);
+  const int c0 = 16 * j + 4 * (lane >> 4);
+  float4 v;
+  float* pv = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    pv[i] = trans_w ? w[((size_t)k * cout + n) * cin + c0 + i] : w[((size_t)k * cin + c0 + i) * cout + n];
+  reinterpret_cast<float4*>(wf)[f] = v;
 }
 
 // ---------------------------------------------------------------------------- host dispatch ---
@@ -334,29 +350,45 @@ bool irx_spconv2_supported(int cin, int cout) {
 
 template <int CIN>
 static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
-                        int ld, int n_out, int K, int flip_k, float* y) {
+                        int ld, int n_out, int K, int flip_k, float* y, int kps) {
   static const int dbg = getenv("IRX_SPCONV_DBG") ? atoi(getenv("IRX_SPCONV_DBG")) : 0;
-  if (cout == 128) k_spconv2<CIN, 128><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg);
-  else if (cout == 64) k_spconv2<CIN, 64><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg);
-  else k_spconv2<CIN, 32><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg);
+  if (cout == 128) k_spconv2<CIN, 128><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
+  else if (cout == 64) k_spconv2<CIN, 64><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
+  else k_spconv2<CIN, 32><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
 }
 
-// wn must already be n-major ([K][cout][cin]).
+// wn must already be fragment-major (irx_permute_w_launch).
+// Offset splits for latency-bound (small) layers: a tile's 27 offsets form a serial chain of ~4 us each, so
+// when there are too few tiles to fill the chip the offsets are spread over `splits` workgroups per tile.
+int irx_spconv2_splits(int n_out, int K) {
+  static const char* e = getenv("IRX_SPCONV_KSPLIT");
+  if (e) { int s = atoi(e); return s < 1 ? 1 : (s > K ? K : s); }
+  const int tiles = irx_cdiv(n_out, S2_TM);
+  if (tiles >= 768 || K < 4) return 1;
+  int s = irx_cdiv(1024, tiles);
+  if (s > 9) s = 9;
+  if (s > K) s = K;
+  const int kps = irx_cdiv(K, s);
+  return irx_cdiv(K, kps);                       // no empty splits
+}
+
+// y: result (splits == 1) or `splits` slabs of [n_out][cout] partial sums
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                       int cout, int flip_k, float* y, hipStream_t st) {
+                       int cout, int flip_k, float* y, int splits, hipStream_t st) {
   IRX_REQUIRE(K <= 27, "irx_spconv_fwd: K = %d > 27 unsupported by the fast path", K);
-  dim3 grid(irx_cdiv(n_out, S2_TM));
-  if (cin == 128) launch_fwd2<128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y);
-  else if (cin == 64) launch_fwd2<64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y);
-  else launch_fwd2<32>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y);
+  dim3 grid(irx_cdiv(n_out, S2_TM), splits);
+  const int kps = irx_cdiv(K, splits);
+  if (cin == 128) launch_fwd2<128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+  else if (cin == 64) launch_fwd2<64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+  else launch_fwd2<32>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(v2)");
   return IRX_OK;
 }
 
-int irx_transpose_w_launch(const float* w, int K, int cin, int cout, float* wt, hipStream_t st) {
-  dim3 grid(irx_cdiv(cout, 32), irx_cdiv(cin, 32), K);
-  k_transpose_w<<<grid, dim3(32, 8), 0, st>>>(w, K, cin, cout, wt);
-  IRX_CHECK_LAUNCH("irx_spconv_fwd(transpose)");
+int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st) {
+  const size_t total = (size_t)K * cin * cout / 4;
+  k_permute_w<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(w, K, cin, cout, trans_w, wf);
+  IRX_CHECK_LAUNCH("irx_spconv_fwd(permute)");
   return IRX_OK;
 }
 

@@ -141,7 +141,7 @@ def _pairs(tbl, K):
 
 def spconv_gather_gemm(x, w, tbl, ld, n_out, K, cin, cout, flip_k, trans_w):
     y = torch.empty((n_out, cout), dtype=_f32, device=x.device)
-    wsb = int(_lib.load().irx_spconv_fwd_workspace_bytes(K, cin, cout, int(trans_w)))
+    wsb = int(_lib.load().irx_spconv_fwd_workspace_bytes(n_out, K, cin, cout, int(trans_w)))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     if PROFILE is not None:
         m = _pairs(tbl, K)
