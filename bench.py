@@ -173,10 +173,15 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d != WORLD_SIZE %d" % (args.gpus, world))
     import torch.distributed as dist
-    device = torch.device("cuda", local_rank)
+    # IRX_BENCH_SHARE_GPU=1 (test only): all ranks use cuda:0 and gloo, to exercise the multi-rank logic on a 1-GPU box
+    share = os.environ.get("IRX_BENCH_SHARE_GPU") == "1"
+    device = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from instancerefer_amd import _build, _lib
     _build.build_lib()
@@ -235,9 +240,11 @@ def main():
     roof = None
     if rank == 0:
         F_.PROFILE = []
+        saved_world, opt.world_size = opt.world_size, 1     # rank-0-only steps: no collective (others are not in it)
         for _ in range(max(1, args.profile_steps)):
             step_fn(model, resident, args.workload, reducer, opt)
         torch.cuda.synchronize()
+        opt.world_size = saved_world
         recs = F_.PROFILE
         F_.PROFILE = None
         roof = summarise_roofline(recs)

@@ -30,8 +30,22 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 and link csrc/libirx.so. Returns the library path."""
     if not force and not _stale():
         return LIB_PATH
+    import fcntl
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
+    # one builder at a time (torchrun starts N ranks at once); late arrivals find a fresh library and return
+    lock = open(os.path.join(objdir, ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not _stale():
+            return LIB_PATH
+        return _build_locked(objdir, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(objdir, verbose):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -45,10 +59,12 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    os.replace(tmp, LIB_PATH)          # atomic: a concurrent loader never sees a half-written library
     return LIB_PATH
 
 
