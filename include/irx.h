@@ -166,6 +166,19 @@ int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int ld
                      int K, int cin, int cout, float* dw, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Per-offset compacted pair lists of a neighbour table, built on the device without a host sync:
+ * in_list / out_list int32 [K][ldp] (ldp >= n_out): for offset k the valid entries of nbr[k][0..n_out) in
+ * ascending output-row order; counts int32 [K] (device). Reused by every weight-gradient on that table. */
+size_t irx_pairs_workspace_bytes(int n_out, int K);
+int irx_pairs_build(const int32_t* nbr, int ld, int n_out, int K, int32_t* in_list, int32_t* out_list,
+                    int ldp, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+/* Weight-gradient over pair lists in DENSE 64-pair MFMA stages (cin, cout in {32,64,128}); same result as
+ * irx_spconv_wgrad up to fp32 summation order; deterministic. */
+size_t irx_spconv_wgrad_pairs_workspace_bytes(int n_out, int K, int cin, int cout);
+int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int32_t* in_list, const int32_t* out_list,
+                           int ldp, const int32_t* counts, int n_out, int K, int cin, int cout, float* dw,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- BatchNorm(+residual)(+ReLU) over voxel rows (spnn.BatchNorm / spnn.ReLU and the
  *      residual add at models/basic_blocks.py:20-21,37-38,44,52,55) ----------------------- */
 

@@ -4,7 +4,7 @@
 // (reference models/basic_blocks.py:20-21,37-38,44,52,55).
 #include "irx_common.h"
 
-#define BN_ROWS 256  // voxel rows per statistics workgroup
+#define BN_ROWS 512  // voxel rows per statistics workgroup
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
@@ -97,21 +97,23 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
   }
 }
 
-// Fold partials in float64. One workgroup per 32 channels: 32 channels x 8 slices.
+// Fold partials in float64. One workgroup per 32 channels: 32 channels x 32 slices (1024 threads), so even the
+// largest level (~2000 partial blocks) is ~60 dependent loads deep.
 //   MODE 0: mean / invstd (+ running stats);  MODE 1: out0 = sum g (dbeta), out1 = sum g*xhat (dgamma)
+#define BN_FIN_SLICES 32
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ part, int nblk, int n,
+__global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ part, int nblk, int n,
                                                      int c, float eps, float momentum,
                                                      float* __restrict__ out0, float* __restrict__ out1,
                                                      float* __restrict__ running_mean,
                                                      float* __restrict__ running_var) {
-  __shared__ double d0[256];
-  __shared__ double d1[256];
+  __shared__ double d0[32 * BN_FIN_SLICES];
+  __shared__ double d1[32 * BN_FIN_SLICES];
   const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
   const int slice = threadIdx.x >> 5;
   double t0 = 0.0, t1 = 0.0;
   if (ch < c) {
-    for (int b = slice; b < nblk; b += 8) {
+    for (int b = slice; b < nblk; b += BN_FIN_SLICES) {
       t0 += (double)part[((size_t)b * 2 + 0) * c + ch];
       t1 += (double)part[((size_t)b * 2 + 1) * c + ch];
     }
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
   d1[threadIdx.x] = t1;
   __syncthreads();
   if (slice == 0 && ch < c) {
-    for (int s2 = 1; s2 < 8; ++s2) {
+    for (int s2 = 1; s2 < BN_FIN_SLICES; ++s2) {
       t0 += d0[s2 * 32 + (threadIdx.x & 31)];
       t1 += d1[s2 * 32 + (threadIdx.x & 31)];
     }
@@ -265,7 +267,7 @@ extern "C" int irx_bn_stats(const float* x, int n, int c, float eps, float momen
                                                    next_pow2(c), part);
   }
   IRX_CHECK_LAUNCH("irx_bn_stats(partial)");
-  k_bn_finalize<0><<<irx_cdiv(c, 32), 256, 0, S(stream)>>>(part, nblk, n, c, eps, momentum, mean,
+  k_bn_finalize<0><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, eps, momentum, mean,
                                                           invstd, running_mean, running_var);
   IRX_CHECK_LAUNCH("irx_bn_stats(finalize)");
   return IRX_OK;
@@ -318,7 +320,7 @@ extern "C" int irx_bn_backward(const float* x, const float* y, const float* dy, 
                                                    part);
   }
   IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
-  k_bn_finalize<1><<<irx_cdiv(c, 32), 256, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
+  k_bn_finalize<1><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
                                                           nullptr, nullptr);
   IRX_CHECK_LAUNCH("irx_bn_backward(finalize)");
   const size_t total = (size_t)n * c;

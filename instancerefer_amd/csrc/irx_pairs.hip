@@ -1,0 +1,282 @@
+// irx_pairs.hip — per-offset compacted pair lists ("rulebook") of a neighbour table and the weight-gradient that
+// streams them.  For offset k the valid entries of nbr[k][:] become in_list[k][0..cnt_k) (input rows) and
+// out_list[k][0..cnt_k) (output rows), in ascending output-row order. Built once per (level, table) on the device
+// (tile counts -> prefix -> ballot/popcount scatter; counts stay in device memory, no host sync) and reused by every
+// weight-gradient of that level (both convs of a ResidualBlock).
+//
+// k_wgrad_pairs: workgroup (split s, offset k) takes an equal share of list k and processes it in DENSE stages of 64
+// pairs (the table-driven kernel gets only ~1/3 of a 64-row chunk filled): gather x[in] and dy[out] rows (16 B/lane)
+// -> LDS -> v_mfma_f32_16x16x4_f32 with the pairs as the reduction dimension; the next stage's indices and rows are
+// prefetched into registers before the current stage's MFMAs. Per-(split, offset) partial sums, deterministic reduce.
+#include "irx_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+#define PB_TILE 2048   // rows per count/scatter workgroup (256 threads x 8)
+
+__global__ __launch_bounds__(256) void k_pairs_count(const int32_t* __restrict__ nbr, int ld, int n_out,
+                                                     int32_t* __restrict__ tile_counts, int ntiles) {
+  __shared__ int s_w[4];
+  const int k = blockIdx.y, tile = blockIdx.x;
+  int cnt = 0;
+  for (int it = 0; it < 8; ++it) {
+    const int q = tile * PB_TILE + it * 256 + threadIdx.x;
+    if (q < n_out && nbr[(size_t)k * ld + q] >= 0) ++cnt;
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_counts[k * ntiles + tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void k_pairs_write(const int32_t* __restrict__ nbr, int ld, int n_out,
+                                                     const int32_t* __restrict__ tile_counts, int ntiles,
+                                                     int32_t* __restrict__ in_list, int32_t* __restrict__ out_list,
+                                                     int ldp, int32_t* __restrict__ counts) {
+  __shared__ int s_red[4];
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int k = blockIdx.y, tile = blockIdx.x;
+  int acc = 0;
+  for (int t = threadIdx.x; t < tile; t += 256) acc += tile_counts[k * ntiles + t];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (tile == ntiles - 1) counts[k] = s_base + tile_counts[k * ntiles + tile];
+  }
+  __syncthreads();
+  int running = s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int it = 0; it < 8; ++it) {
+    const int q = tile * PB_TILE + it * 256 + threadIdx.x;
+    int idx = -1;
+    if (q < n_out) idx = nbr[(size_t)k * ld + q];
+    const unsigned long long b = __ballot(idx >= 0);
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+      const int c = s_wave[w];
+      if (w < wave) wbase += c;
+      total += c;
+    }
+    if (idx >= 0) {
+      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int pos = running + wbase + __popcll(b & lt);
+      in_list[(size_t)k * ldp + pos] = idx;
+      out_list[(size_t)k * ldp + pos] = q;
+    }
+    running += total;
+    __syncthreads();
+  }
+}
+
+// part[s][k][c][n] = sum over this split's share of list k:  x[in][c] * dy[out][n]
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const int32_t* __restrict__ in_list,
+                                                        const int32_t* __restrict__ out_list, int ldp,
+                                                        const int32_t* __restrict__ counts, int K, int nsplit,
+                                                        float* __restrict__ part) {
+  constexpr int TC = CIN / 16, TN = COUT / 16;
+  constexpr int CW = (TC >= 4) ? TC / 4 : 1;             // c-tiles per wave
+  constexpr int NW = (TC >= 4) ? TN : TN / (4 / TC);     // n-tiles per wave
+  constexpr int LDX = CIN + 16, LDD = COUT + 16;         // consecutive pairs 16 banks apart
+  constexpr int LPX = CIN / 4, LPD = COUT / 4;           // lanes (float4) per row
+  constexpr int PX = 256 / LPX, PD = 256 / LPD;          // pairs per workgroup pass
+  constexpr int NX = 64 / PX, ND = 64 / PD;              // passes per 64-pair stage
+  __shared__ __attribute__((aligned(16))) float sX[64 * LDX];
+  __shared__ __attribute__((aligned(16))) float sD[64 * LDD];
+  __shared__ int sIn[2][64];
+  __shared__ int sOutRow[2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g4 = lane >> 4;
+  const int s = blockIdx.x, k = blockIdx.y;
+  const int ct0 = (TC >= 4) ? wave * CW : (wave % TC);
+  const int nt0 = (TC >= 4) ? 0 : (wave / TC) * NW;
+  const int cnt = counts[k];
+  // equal shares, stage-aligned
+  const int nst = (cnt + 63) / 64;
+  const int st0 = (int)(((long long)nst * s) / nsplit), st1 = (int)(((long long)nst * (s + 1)) / nsplit);
+  const int32_t* il = in_list + (size_t)k * ldp;
+  const int32_t* ol = out_list + (size_t)k * ldp;
+  const int xr = tid / LPX, xc = (tid % LPX) * 4;        // this thread's pair / column in an x pass
+  const int dr = tid / LPD, dc = (tid % LPD) * 4;
+
+  f32x4 acc[CW][NW];
+#pragma unroll
+  for (int a = 0; a < CW; ++a)
+#pragma unroll
+    for (int b = 0; b < NW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 rx[NX], rd[ND];
+  int par = 0;
+  // prologue: indices + rows of the first stage
+  if (st0 < st1) {
+    if (tid < 64) {
+      const int p = st0 * 64 + tid;
+      sIn[0][tid] = p < cnt ? il[p] : -1;
+      sOutRow[0][tid] = p < cnt ? ol[p] : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = sIn[0][xr + i * PX];
+      rx[i] = idx >= 0 ? *reinterpret_cast<const float4*>(x + (size_t)idx * CIN + xc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int idx = sOutRow[0][dr + i * PD];
+      rd[i] = idx >= 0 ? *reinterpret_cast<const float4*>(dy + (size_t)idx * COUT + dc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int st = st0; st < st1; ++st) {
+    __syncthreads();                                     // previous stage's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < NX; ++i) *reinterpret_cast<float4*>(&sX[(xr + i * PX) * LDX + xc]) = rx[i];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) *reinterpret_cast<float4*>(&sD[(dr + i * PD) * LDD + dc]) = rd[i];
+    // next stage's indices (other parity buffer), visible after the barrier below
+    const int parn = par ^ 1;
+    if (st + 1 < st1 && tid < 64) {
+      const int p = (st + 1) * 64 + tid;
+      sIn[parn][tid] = p < cnt ? il[p] : -1;
+      sOutRow[parn][tid] = p < cnt ? ol[p] : -1;
+    }
+    __syncthreads();
+    if (st + 1 < st1) {                                  // prefetch next stage's rows; they land during the MFMAs
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int idx = sIn[parn][xr + i * PX];
+        rx[i] = idx >= 0 ? *reinterpret_cast<const float4*>(x + (size_t)idx * CIN + xc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int idx = sOutRow[parn][dr + i * PD];
+        rd[i] = idx >= 0 ? *reinterpret_cast<const float4*>(dy + (size_t)idx * COUT + dc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    int npairs = cnt - st * 64;
+    if (npairs > 64) npairs = 64;
+    const int nks = (npairs + 3) >> 2;
+    for (int ks = 0; ks < nks; ++ks) {
+      const int pp = ks * 4 + g4;
+      float a[CW], b[NW];
+#pragma unroll
+      for (int i = 0; i < CW; ++i) a[i] = sX[pp * LDX + (ct0 + i) * 16 + m];   // A[m = c][kk = pair]
+#pragma unroll
+      for (int i = 0; i < NW; ++i) b[i] = sD[pp * LDD + (nt0 + i) * 16 + m];   // B[kk = pair][n]
+#pragma unroll
+      for (int i = 0; i < CW; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NW; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+    }
+    par = parn;
+  }
+  float* out = part + ((size_t)s * K + k) * CIN * COUT;
+#pragma unroll
+  for (int i = 0; i < CW; ++i)
+#pragma unroll
+    for (int jn = 0; jn < NW; ++jn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = (ct0 + i) * 16 + g4 * 4 + r;
+        const int n = (nt0 + jn) * 16 + m;
+        out[(size_t)c * COUT + n] = acc[i][jn][r];
+      }
+}
+
+__global__ void k_pairs_reduce(const float* __restrict__ part, int S, size_t elems, float* __restrict__ dw) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= elems) return;
+  float s = 0.f;
+  for (int j = 0; j < S; ++j) s += part[(size_t)j * elems + i];
+  dw[i] = s;
+}
+
+// ------------------------------------------------------------------------------------ C entry points ---
+extern "C" size_t irx_pairs_workspace_bytes(int n_out, int K) {
+  if (n_out <= 0 || K <= 0) return 0;
+  return (size_t)K * irx_cdiv(n_out, PB_TILE) * sizeof(int32_t) + 64;
+}
+
+extern "C" int irx_pairs_build(const int32_t* nbr, int ld, int n_out, int K, int32_t* in_list, int32_t* out_list,
+                               int ldp, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
+  IRX_REQUIRE(n_out >= 0 && K >= 1 && K <= 65535 && counts, "irx_pairs_build: bad arguments");
+  if (n_out == 0) {
+    IRX_CHECK_HIP(hipMemsetAsync(counts, 0, K * sizeof(int32_t), S(stream)), "irx_pairs_build(memset)");
+    return IRX_OK;
+  }
+  IRX_REQUIRE(nbr && in_list && out_list, "irx_pairs_build: null pointer");
+  IRX_REQUIRE(ld >= n_out && ldp >= n_out, "irx_pairs_build: ld %d / ldp %d < n_out %d", ld, ldp, n_out);
+  if (workspace == nullptr || workspace_bytes < irx_pairs_workspace_bytes(n_out, K)) {
+    irx_set_error("irx_pairs_build: workspace %zu < %zu", workspace_bytes, irx_pairs_workspace_bytes(n_out, K));
+    return IRX_ERR_WORKSPACE;
+  }
+  const int ntiles = irx_cdiv(n_out, PB_TILE);
+  dim3 grid(ntiles, K);
+  k_pairs_count<<<grid, 256, 0, S(stream)>>>(nbr, ld, n_out, (int32_t*)workspace, ntiles);
+  IRX_CHECK_LAUNCH("irx_pairs_build(count)");
+  k_pairs_write<<<grid, 256, 0, S(stream)>>>(nbr, ld, n_out, (const int32_t*)workspace, ntiles, in_list, out_list,
+                                            ldp, counts);
+  IRX_CHECK_LAUNCH("irx_pairs_build(write)");
+  return IRX_OK;
+}
+
+static int pairs_splits(int n_out, int K) {
+  int s = irx_cdiv(1024, K);
+  const int max_s = irx_cdiv(n_out, 512);     // >= ~8 stages of useful work per workgroup on average
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return s;
+}
+
+extern "C" size_t irx_spconv_wgrad_pairs_workspace_bytes(int n_out, int K, int cin, int cout) {
+  if (n_out <= 0 || K <= 0 || cin <= 0 || cout <= 0) return 0;
+  const int s = pairs_splits(n_out, K);
+  return s <= 1 ? 0 : (size_t)s * K * cin * cout * sizeof(float);
+}
+
+template <int CIN>
+static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* il,
+                      const int32_t* ol, int ldp, const int32_t* counts, int K, int ns, float* part) {
+  if (cout == 128) k_wgrad_pairs<CIN, 128><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, ns, part);
+  else if (cout == 64) k_wgrad_pairs<CIN, 64><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, ns, part);
+  else k_wgrad_pairs<CIN, 32><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, ns, part);
+}
+
+extern "C" int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int32_t* in_list,
+                                      const int32_t* out_list, int ldp, const int32_t* counts, int n_out, int K,
+                                      int cin, int cout, float* dw, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  IRX_REQUIRE(n_out >= 0 && K >= 1 && dw, "irx_spconv_wgrad_pairs: bad arguments");
+  IRX_REQUIRE(irx_spconv2_supported(cin, cout), "irx_spconv_wgrad_pairs: channels (%d, %d) unsupported (32/64/128)", cin, cout);
+  const size_t elems = (size_t)K * cin * cout;
+  if (n_out == 0) {
+    IRX_CHECK_HIP(hipMemsetAsync(dw, 0, elems * sizeof(float), S(stream)), "irx_spconv_wgrad_pairs(memset)");
+    return IRX_OK;
+  }
+  IRX_REQUIRE(x && dy && in_list && out_list && counts, "irx_spconv_wgrad_pairs: null pointer");
+  IRX_REQUIRE(((((uintptr_t)x | (uintptr_t)dy)) & 15) == 0, "irx_spconv_wgrad_pairs: x / dy must be 16-byte aligned");
+  const int s = pairs_splits(n_out, K);
+  const size_t need = irx_spconv_wgrad_pairs_workspace_bytes(n_out, K, cin, cout);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+    irx_set_error("irx_spconv_wgrad_pairs: workspace %zu < %zu", workspace_bytes, need);
+    return IRX_ERR_WORKSPACE;
+  }
+  float* part = s > 1 ? (float*)workspace : dw;
+  dim3 grid(s, K);
+  if (cin == 128) launch_wp<128>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, s, part);
+  else if (cin == 64) launch_wp<64>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, s, part);
+  else launch_wp<32>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, s, part);
+  IRX_CHECK_LAUNCH("irx_spconv_wgrad_pairs");
+  if (s > 1) {
+    k_pairs_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(part, s, elems, dw);
+    IRX_CHECK_LAUNCH("irx_spconv_wgrad_pairs(reduce)");
+  }
+  return IRX_OK;
+}

@@ -173,26 +173,61 @@ def spconv_wgrad(x, dy, tbl, ld, n_out, K, cin, cout):
     return dw
 
 
+def pairs_build(tbl, ld, n_out, K):
+    """Compacted per-offset pair lists of a table (device-side, no host sync) -> (in_list, out_list, counts, ldp)."""
+    dev = tbl.device
+    ldp = max(n_out, 1)
+    in_list = torch.empty((K, ldp), dtype=_i32, device=dev)
+    out_list = torch.empty((K, ldp), dtype=_i32, device=dev)
+    counts = torch.empty(K, dtype=_i32, device=dev)
+    wsb = int(_lib.load().irx_pairs_workspace_bytes(n_out, K))
+    ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
+    _lib.call("irx_pairs_build", _lib.ptr(tbl), ld, n_out, K, _lib.ptr(in_list), _lib.ptr(out_list), ldp,
+              _lib.ptr(counts), _lib.ptr(ws), wsb, _stream())
+    return in_list, out_list, counts, ldp
+
+
+_PAIR_CHANNELS = (32, 64, 128)
+
+
+def spconv_wgrad_pairs(x, dy, pairs, n_out, K, cin, cout, m_for_profile=None):
+    in_list, out_list, counts, ldp = pairs
+    dw = torch.empty((K, cin, cout), dtype=_f32, device=x.device)
+    wsb = int(_lib.load().irx_spconv_wgrad_pairs_workspace_bytes(n_out, K, cin, cout))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    if PROFILE is not None:
+        m = int(counts.sum().item())
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("irx_spconv_wgrad_pairs", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_list), _lib.ptr(out_list), ldp,
+              _lib.ptr(counts), n_out, K, cin, cout, _lib.ptr(dw), _lib.ptr(ws), wsb, _stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("wgrad", n_out, K, cin, cout, m, e0, e1))
+    return dw
+
+
 class SparseConvFn(torch.autograd.Function):
     """y[q] = sum_k x[tbl_f[k][q]] @ w[k].  Backward: data-gradient through `tbl_b` (the same table
     with flipped offsets for a stride-1 conv, the transposed child table for a strided one) and the
     weight-gradient through `tbl_f`."""
 
     @staticmethod
-    def forward(ctx, x, w, tbl_f, ld_f, n_out, tbl_b_fn, flip_b):
+    def forward(ctx, x, w, tbl_f, ld_f, n_out, tbl_b_fn, flip_b, pairs_fn=None):
         x = _f32c(x)
         w = _f32c(w)
         K, cin, cout = w.shape
         assert x.shape[1] == cin
         y = spconv_gather_gemm(x, w, tbl_f, ld_f, n_out, K, cin, cout, 0, 0)
         ctx.save_for_backward(x, w, tbl_f)
-        ctx.meta = (ld_f, n_out, tbl_b_fn, flip_b)
+        ctx.meta = (ld_f, n_out, tbl_b_fn, flip_b, pairs_fn)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, tbl_f = ctx.saved_tensors
-        ld_f, n_out, tbl_b_fn, flip_b = ctx.meta
+        ld_f, n_out, tbl_b_fn, flip_b, pairs_fn = ctx.meta
         K, cin, cout = w.shape
         dy = _f32c(dy)
         dx = dw = None
@@ -200,8 +235,11 @@ class SparseConvFn(torch.autograd.Function):
             tbl_b, ld_b = tbl_b_fn()
             dx = spconv_gather_gemm(dy, w, tbl_b, ld_b, x.shape[0], K, cout, cin, flip_b, 1)
         if ctx.needs_input_grad[1]:
-            dw = spconv_wgrad(x, dy, tbl_f, ld_f, n_out, K, cin, cout)
-        return dx, dw, None, None, None, None, None
+            if pairs_fn is not None and cin in _PAIR_CHANNELS and cout in _PAIR_CHANNELS:
+                dw = spconv_wgrad_pairs(x, dy, pairs_fn(), n_out, K, cin, cout)    # dense 64-pair stages
+            else:
+                dw = spconv_wgrad(x, dy, tbl_f, ld_f, n_out, K, cin, cout)
+        return dx, dw, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------- batchnorm --

@@ -57,12 +57,12 @@ class Conv3d(nn.Module):
             out = lv
         elif self.kernel_size == 3:
             tbl, ld = lv.nbr27()
-            y = F_.SparseConvFn.apply(x.F, self.kernel, tbl, ld, lv.n, lv.nbr27, 1)
+            y = F_.SparseConvFn.apply(x.F, self.kernel, tbl, ld, lv.n, lv.nbr27, 1, lv.pairs27)
             out = lv
         else:
             dm = lv.down()
             out = dm.out_level
-            y = F_.SparseConvFn.apply(x.F, self.kernel, dm.child, dm.ld, out.n, dm.child_t, 0)
+            y = F_.SparseConvFn.apply(x.F, self.kernel, dm.child, dm.ld, out.n, dm.child_t, 0, dm.pairs)
         if self.bias is not None:
             y = y + self.bias
         return y, out

@@ -24,6 +24,13 @@ class DownMap:
         self.ld = ld
         self.out_level = out_level
         self._child_t = None
+        self._pairs = None
+
+    def pairs(self):
+        """Compacted pair lists of the child table (for the weight-gradient); built once, no host sync."""
+        if self._pairs is None:
+            self._pairs = F_.pairs_build(self.child, self.ld, self.out_level.n, 8)
+        return self._pairs
 
     def child_t(self):
         """(8, n_in) table for the data-gradient: tbl[k][i] = parent[i] if koff[i] == k else -1."""
@@ -44,6 +51,7 @@ class Level:
         self.batch_size = int(batch_size)
         self._table = None
         self._nbr27 = None
+        self._pairs27 = None
         self._down = None
         self._offsets = None
         self._bev = {}
@@ -61,6 +69,13 @@ class Level:
         if self._nbr27 is None:
             self._nbr27 = F_.kmap_build_s1(self.coords, self.stride, self.table())
         return self._nbr27, max(self.n, 1)
+
+    def pairs27(self):
+        """Compacted pair lists of the 27-neighbour table (weight-gradients of both convs of a ResidualBlock)."""
+        if self._pairs27 is None:
+            tbl, ld = self.nbr27()
+            self._pairs27 = F_.pairs_build(tbl, ld, self.n, 27)
+        return self._pairs27
 
     def down(self):
         if self._down is None:

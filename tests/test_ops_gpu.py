@@ -281,3 +281,28 @@ def test_flat_adam_matches_torch_adam(lib):
         o_mine.zero_grad(); mine(x.cuda()).pow(2).sum().backward(); o_mine.backward_step()
     for a, b in zip(ref.parameters(), mine.parameters()):
         assert (a.detach() - b.detach().cpu()).abs().max().item() <= 2e-6
+
+
+def test_pair_lists_and_dense_stage_wgrad(lib, clouds):
+    """irx_pairs_build reproduces the table's valid entries per offset in output-row order (bit-exact) and the
+    dense-stage weight-gradient equals the table-driven one up to fp32 summation order."""
+    from instancerefer_amd.sparse import functional as F_
+    d = device_batch(clouds, 0.05)
+    lv = d.level()
+    for tbl, ld, n_out, K, n_in in ((lv.nbr27()[0], lv.nbr27()[1], lv.n, 27, lv.n),
+                                    (lv.down().child, lv.down().ld, lv.down().out_level.n, 8, lv.n)):
+        il, ol, counts, ldp = F_.pairs_build(tbl, ld, n_out, K)
+        t = tbl.cpu().numpy()[:, :n_out]
+        cnt = counts.cpu().numpy()
+        for k in range(K):
+            rows = np.nonzero(t[k] >= 0)[0]
+            assert cnt[k] == len(rows)
+            assert np.array_equal(ol[k, :cnt[k]].cpu().numpy(), rows)
+            assert np.array_equal(il[k, :cnt[k]].cpu().numpy(), t[k][rows])
+        torch.manual_seed(K)
+        for cin, cout in ((128, 128), (64, 64), (32, 64), (64, 128), (128, 32)):
+            x = torch.randn(n_in, cin, device="cuda")
+            dy = torch.randn(n_out, cout, device="cuda")
+            ref = F_.spconv_wgrad(x, dy, tbl, ld, n_out, K, cin, cout)
+            got = F_.spconv_wgrad_pairs(x, dy, (il, ol, counts, ldp), n_out, K, cin, cout)
+            assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (K, cin, cout)
