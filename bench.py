@@ -275,25 +275,41 @@ def main():
 
 
 def summarise_roofline(recs):
-    """recs: (kind, n_out, K, cin, cout, M, start_event, end_event). Dominant kernel = k_spconv_fwd (forward +
-    data-gradient launches). Algorithmic figures per launch (formula A, e = 4):
-       FLOPs = 2*M*Cin*Cout ;  Bytes_A = 4*(M*Cin + N_out*Cout + K*Cin*Cout) + 8*M
-    achieved = the binding resource's algorithmic amount / measured time, summed over the launches."""
+    """recs: (kind, n_out, K, cin, cout, M, start_event, end_event), one per C-ABI conv call, events recorded on the
+    launch stream. The dominant HIP kernel is k_spconv2<128,128> (forward + data-gradient of every 128->128 layer:
+    the largest total in the rocprofv3 kernel stats). Algorithmic figures per launch (SURVEY §8d formula A, e = 4):
+        FLOPs = 2*M*Cin*Cout ;  Bytes_A = 4*(M*Cin + N_out*Cout + K*Cin*Cout) + 8*M      (wgrad: 4*(M*(Cin+Cout) + ...))
+    with M counted from the actual tables. achieved = sum(algorithmic flops or bytes of the binding resource) /
+    sum(measured time). The event bracket also covers the 4 us weight-permute launch and, for small layers, the
+    split-reduce launch that belong to the same C-ABI call."""
     agg = {}
+
+    def klass(kind, cin, cout):
+        if kind in ("fwd", "dgrad"):
+            if cin in (32, 64, 128) and cout in (32, 64, 128):
+                return "k_spconv2<%d,%d>" % (cin, cout)
+            return "k_stem_fwd" if (cin <= 8 and cout == 32) else "k_spconv_fwd(generic)"
+        if cin in (32, 64, 128) and cout in (32, 64, 128):
+            return "k_wgrad_pairs<%d,%d>" % (cin, cout)
+        return "k_stem_wgrad" if (cin <= 8 and cout == 32) else "k_spconv_wgrad(generic)"
+
+    tot = dict(ms=0.0, bound_ms=0.0)
     for kind, n_out, K, cin, cout, M, e0, e1 in recs:
         ms = e0.elapsed_time(e1)
+        flops = 2.0 * M * cin * cout
         if kind == "wgrad":
-            flops = 2.0 * M * cin * cout
             byts = 4.0 * (M * (cin + cout) + K * cin * cout) + 8.0 * M
         else:
-            flops = 2.0 * M * cin * cout
             byts = 4.0 * (M * cin + n_out * cout + K * cin * cout) + 8.0 * M
-        a = agg.setdefault(kind, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, bound_ms=0.0))
+        a = agg.setdefault(klass(kind, cin, cout), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, bound_ms=0.0))
         a["ms"] += ms
         a["flops"] += flops
         a["bytes"] += byts
         a["launches"] += 1
-        a["bound_ms"] += max(byts / (PEAK_HBM_GBS * 1e9), flops / (PEAK_F32_TFLOPS * 1e12)) * 1e3
+        b_ms = max(byts / (PEAK_HBM_GBS * 1e9), flops / (PEAK_F32_TFLOPS * 1e12)) * 1e3
+        a["bound_ms"] += b_ms
+        tot["ms"] += ms
+        tot["bound_ms"] += b_ms
     if os.environ.get("IRX_BENCH_LAYERS"):
         lay = {}
         for kind, n_out, K, cin, cout, M, e0, e1 in recs:
@@ -313,18 +329,16 @@ def summarise_roofline(recs):
     tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
     gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
     mfma_bound = a["flops"] / (PEAK_F32_TFLOPS * 1e12) >= a["bytes"] / (PEAK_HBM_GBS * 1e9)
-    per_kernel = {k: {"launches": v["launches"], "avg_us": 1e3 * v["ms"] / v["launches"],
-                      "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "algo_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
-                      "frac_of_bound": v["bound_ms"] / v["ms"]} for k, v in agg.items()}
-    return {"kernel": {"fwd": "k_spconv_fwd (forward)", "dgrad": "k_spconv_fwd (data-gradient)",
-                       "wgrad": "k_spconv_wgrad"}[dom],
-            "bound": "mfma" if mfma_bound else "hbm",
+    per_kernel = {k: {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
+                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                      "algo_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                      "frac_of_bound": round(v["bound_ms"] / v["ms"], 4)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    return {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm",
             "achieved": tf if mfma_bound else gbs, "peak": PEAK_F32_TFLOPS if mfma_bound else PEAK_HBM_GBS,
             "unit": "TFLOP/s" if mfma_bound else "GB/s",
             "frac": (tf / PEAK_F32_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS),
             "traffic": None, "avg_launch_us": 1e3 * a["ms"] / a["launches"], "launches": a["launches"],
-            "path_frac_of_roofline": sum(v["bound_ms"] for v in agg.values()) / sum(v["ms"] for v in agg.values()),
-            "per_kernel": per_kernel}
+            "path_frac_of_roofline": tot["bound_ms"] / tot["ms"], "per_kernel": per_kernel}
 
 
 if __name__ == "__main__":

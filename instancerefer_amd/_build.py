@@ -69,4 +69,4 @@ def _build_locked(objdir, verbose):
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))

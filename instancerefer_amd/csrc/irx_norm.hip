@@ -4,7 +4,7 @@
 // (reference models/basic_blocks.py:20-21,37-38,44,52,55).
 #include "irx_common.h"
 
-#define BN_ROWS 512  // voxel rows per statistics workgroup
+#define BN_ROWS 256  // voxel rows per statistics workgroup
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
