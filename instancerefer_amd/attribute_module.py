@@ -53,18 +53,32 @@ class AttributeModule(nn.Module):
         st = voxelize(xyz.view(-1, 3), pts.view(nc * p, -1), batch, self.voxel_size, nc)
         return st, sel
 
+    def prepare(self, data_dict, lang_cls_pred):
+        """Everything of this module that needs a host sync (class list -> candidate selection -> voxel count ->
+        pyramid level sizes) and depends only on the inputs. InstanceRefer.forward runs it BEFORE queueing the heavy
+        GPU work (when use_gt_lang), so these syncs never wait behind a long queue."""
+        st, sel = self.filter_candidates(data_dict, lang_cls_pred)
+        if st is not None:
+            st.level().build_pyramid(4)
+        data_dict['_attr_prepared'] = (st, sel)
+        data_dict['_lang_cls_pred_list'] = list(lang_cls_pred)
+        return data_dict
+
     def forward(self, data_dict):
         lang_feats = data_dict['lang_attr_feats']
         lang_feats = self.lang_emb_fc(lang_feats)
         lang_feats = nn.functional.normalize(lang_feats, p=2, dim=1)          # (B, h_dim)
 
-        if not self.args.use_gt_lang:
-            lang_cls_pred = torch.argmax(data_dict["lang_scores"], dim=1)
+        if '_attr_prepared' in data_dict:
+            st, sel = data_dict.pop('_attr_prepared')
         else:
-            lang_cls_pred = data_dict['object_cat']
-        lang_cls_pred = lang_cls_pred.tolist()   # one D2H of B ints (the reference syncs per instance)
-
-        st, sel = self.filter_candidates(data_dict, lang_cls_pred)
+            if not self.args.use_gt_lang:
+                lang_cls_pred = torch.argmax(data_dict["lang_scores"], dim=1)
+            else:
+                lang_cls_pred = data_dict['object_cat']
+            lang_cls_pred = lang_cls_pred.tolist()   # one D2H of B ints (the reference syncs per instance)
+            data_dict['_lang_cls_pred_list'] = lang_cls_pred      # reused by the relation module (no second sync)
+            st, sel = self.filter_candidates(data_dict, lang_cls_pred)
         data_dict['num_filtered_objs'] = sel['num_filtered_objs']
         data_dict['pred_obb_batch'] = sel['pred_obb_batch']
         dev = lang_feats.device

@@ -14,6 +14,7 @@ import torch.nn as nn
 from .sparse import SparseTensor
 from .sparse import functional as F_
 from .sparse import nn as spnn
+from .sparse import encoder_fn
 
 
 class BasicConvolutionBlock(nn.Module):
@@ -68,6 +69,10 @@ class SparseConvEncoder(nn.Module):
         self.stage4 = nn.Sequential(BasicConvolutionBlock(128, 128, ks=2, stride=2), ResidualBlock(128, 128, 3))
 
     def forward(self, x):
+        x = x.canonical()
+        x.level().build_pyramid(4)       # all level-size syncs up front, while the GPU queue is still empty
+        if encoder_fn.can_fuse(self):
+            return encoder_fn.run_encoder(self, x)     # training: the whole encoder as one autograd node
         x = self.stem(x)
         x = self.stage1(x)
         x = self.stage2(x)

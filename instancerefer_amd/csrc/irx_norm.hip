@@ -4,7 +4,8 @@
 // (reference models/basic_blocks.py:20-21,37-38,44,52,55).
 #include "irx_common.h"
 
-#define BN_ROWS 256  // voxel rows per statistics workgroup
+// voxel rows per statistics workgroup: 256, or 512 for the largest levels (keeps ~1000 partial blocks)
+static inline int bn_rows(int n) { return n > 262144 ? 512 : 256; }
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
@@ -24,15 +25,15 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
                                                     const float* __restrict__ dy, int n, int c,
                                                     const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, int relu,
-                                                    int qpad, float* __restrict__ part) {
+                                                    int qpad, int rows_per_block, float* __restrict__ part) {
   __shared__ float s0[256 * V];
   __shared__ float s1[256 * V];
   const int cq = c / V;
   const int qd = threadIdx.x % qpad;
   const int rg = threadIdx.x / qpad;
   const int nrg = 256 / qpad;
-  const int r0 = blockIdx.x * BN_ROWS;
-  int r1 = r0 + BN_ROWS;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
   if (r1 > n) r1 = n;
   float a0[V], a1[V];
 #pragma unroll
@@ -144,38 +145,49 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
   }
 }
 
+// Apply kernels: every thread owns ONE channel group of V channels (its scale / shift live in registers) and walks
+// rows with a fixed stride, so the inner loop is load - fma - store with no index arithmetic beyond an add.
+// qpad = power of two >= c / V threads per row; rows_per_pass = 256 / qpad per workgroup.
 template <int V>
-__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, size_t total, int c,
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, int n, int c, int qpad,
                                                   const float* __restrict__ mean,
                                                   const float* __restrict__ invstd,
                                                   const float* __restrict__ gamma,
                                                   const float* __restrict__ beta,
                                                   const float* __restrict__ res, int relu,
                                                   float* __restrict__ y) {
-  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
-  const size_t stride = (size_t)gridDim.x * blockDim.x * V;
-  for (; i < total; i += stride) {
-    const int ch = (int)(i % (size_t)c);
+  const int cq = c / V;
+  const int qd = threadIdx.x % qpad;
+  if (qd >= cq) return;
+  const int rpp = 256 / qpad;
+  float sc[V], sh[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    sc[j] = invstd[qd * V + j] * gamma[qd * V + j];
+    sh[j] = beta[qd * V + j] - mean[qd * V + j] * sc[j];
+  }
+  const int row_stride = gridDim.x * rpp;
+  for (int r = blockIdx.x * rpp + threadIdx.x / qpad; r < n; r += row_stride) {
+    const size_t off = (size_t)r * c + (size_t)qd * V;
     float xv[V], rv[V], ov[V];
     if (V == 4) {
-      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + i);
-      if (res) *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(res + i);
+      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + off);
+      if (res) *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(res + off);
     } else {
-      xv[0] = x[i];
-      if (res) rv[0] = res[i];
+      xv[0] = x[off];
+      if (res) rv[0] = res[off];
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const float sc = invstd[ch + j] * gamma[ch + j];
-      float o = (xv[j] - mean[ch + j]) * sc + beta[ch + j];
+      float o = fmaf(xv[j], sc[j], sh[j]);
       if (res) o += rv[j];
       if (relu) o = o > 0.f ? o : 0.f;
       ov[j] = o;
     }
     if (V == 4)
-      *reinterpret_cast<float4*>(y + i) = *reinterpret_cast<float4*>(ov);
+      *reinterpret_cast<float4*>(y + off) = *reinterpret_cast<float4*>(ov);
     else
-      y[i] = ov[0];
+      y[off] = ov[0];
   }
 }
 
@@ -183,43 +195,54 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, s
 template <int V>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x,
                                                       const float* __restrict__ y,
-                                                      const float* __restrict__ dy, size_t total,
-                                                      int n, int c, const float* __restrict__ mean,
+                                                      const float* __restrict__ dy, int n, int c, int qpad,
+                                                      const float* __restrict__ mean,
                                                       const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ sum_g,
                                                       const float* __restrict__ sum_gx, int relu,
                                                       float* __restrict__ dx, float* __restrict__ dres) {
-  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
-  const size_t stride = (size_t)gridDim.x * blockDim.x * V;
+  const int cq = c / V;
+  const int qd = threadIdx.x % qpad;
+  if (qd >= cq) return;
+  const int rpp = 256 / qpad;
   const float inv_n = 1.f / (float)n;
-  for (; i < total; i += stride) {
-    const int ch = (int)(i % (size_t)c);
+  float mu[V], is[V], gi[V], sg[V], sgx[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    mu[j] = mean[qd * V + j];
+    is[j] = invstd[qd * V + j];
+    gi[j] = gamma[qd * V + j] * is[j];
+    sg[j] = sum_g[qd * V + j] * inv_n;
+    sgx[j] = sum_gx[qd * V + j] * inv_n;
+  }
+  const int row_stride = gridDim.x * rpp;
+  for (int r = blockIdx.x * rpp + threadIdx.x / qpad; r < n; r += row_stride) {
+    const size_t off = (size_t)r * c + (size_t)qd * V;
     float xv[V], yv[V], dv[V], ox[V], og[V];
     if (V == 4) {
-      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + i);
-      *reinterpret_cast<float4*>(dv) = *reinterpret_cast<const float4*>(dy + i);
-      if (relu) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + i);
+      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + off);
+      *reinterpret_cast<float4*>(dv) = *reinterpret_cast<const float4*>(dy + off);
+      if (relu) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + off);
     } else {
-      xv[0] = x[i];
-      dv[0] = dy[i];
-      if (relu) yv[0] = y[i];
+      xv[0] = x[off];
+      dv[0] = dy[off];
+      if (relu) yv[0] = y[off];
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float gval = dv[j];
       if (relu && !(yv[j] > 0.f)) gval = 0.f;
-      const float is = invstd[ch + j];
-      const float xh = (xv[j] - mean[ch + j]) * is;
-      ox[j] = gamma[ch + j] * is * (gval - sum_g[ch + j] * inv_n - xh * sum_gx[ch + j] * inv_n);
+      const float xh = (xv[j] - mu[j]) * is[j];
+      ox[j] = gi[j] * (gval - sg[j] - xh * sgx[j]);
       og[j] = gval;
     }
     if (V == 4) {
-      *reinterpret_cast<float4*>(dx + i) = *reinterpret_cast<float4*>(ox);
-      if (dres) *reinterpret_cast<float4*>(dres + i) = *reinterpret_cast<float4*>(og);
+      *reinterpret_cast<float4*>(dx + off) = *reinterpret_cast<float4*>(ox);
+      if (dres) *reinterpret_cast<float4*>(dres + off) = *reinterpret_cast<float4*>(og);
     } else {
-      dx[i] = ox[0];
-      if (dres) dres[i] = og[0];
+      dx[off] = ox[0];
+      if (dres) dres[off] = og[0];
     }
   }
 }
@@ -227,7 +250,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 // ------------------------------------------------------------------------------ C entry ------
 extern "C" size_t irx_bn_workspace_bytes(int n, int c) {
   if (n <= 0 || c <= 0) return 0;
-  return (size_t)irx_cdiv(n, BN_ROWS) * 2 * (size_t)c * sizeof(float);
+  return (size_t)irx_cdiv(n, bn_rows(n)) * 2 * (size_t)c * sizeof(float);
 }
 
 static int bn_check(const char* who, int n, int c, const void* ws, size_t ws_bytes) {
@@ -241,8 +264,9 @@ static int bn_check(const char* who, int n, int c, const void* ws, size_t ws_byt
   return IRX_OK;
 }
 
-static inline int elem_grid(size_t total, int v) {
-  long long b = (long long)((total / v + 255) / 256);
+static inline int row_grid(int n, int qpad) {
+  const int rpp = 256 / qpad;
+  long long b = ((long long)n + rpp - 1) / rpp;
   if (b > 4096) b = 4096;
   if (b < 1) b = 1;
   return (int)b;
@@ -255,16 +279,16 @@ extern "C" int irx_bn_stats(const float* x, int n, int c, float eps, float momen
   if (rc) return rc;
   if (n == 0) return IRX_OK;
   IRX_REQUIRE(x && mean && invstd, "irx_bn_stats: null pointer");
-  const int nblk = irx_cdiv(n, BN_ROWS);
+  const int nblk = irx_cdiv(n, bn_rows(n));
   float* part = (float*)workspace;
   const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0);
   if (v4)
     k_bn_partial<0, 4><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                   next_pow2(c / 4), part);
+                                                   next_pow2(c / 4), bn_rows(n), part);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_stats: c=%d needs c %% 4 == 0 or c <= 256", c);
     k_bn_partial<0, 1><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                   next_pow2(c), part);
+                                                   next_pow2(c), bn_rows(n), part);
   }
   IRX_CHECK_LAUNCH("irx_bn_stats(partial)");
   k_bn_finalize<0><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, eps, momentum, mean,
@@ -279,15 +303,16 @@ extern "C" int irx_bn_apply(const float* x, int n, int c, const float* mean, con
   IRX_REQUIRE(n >= 0 && c >= 1, "irx_bn_apply: bad sizes");
   if (n == 0) return IRX_OK;
   IRX_REQUIRE(x && mean && invstd && gamma && beta && y, "irx_bn_apply: null pointer");
-  const size_t total = (size_t)n * c;
-  const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
+  const bool v4 = (c % 4 == 0) && (c / 4 <= 256) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
                   (residual == nullptr || ((uintptr_t)residual & 15) == 0);
-  if (v4)
-    k_bn_apply<4><<<elem_grid(total, 4), 256, 0, S(stream)>>>(x, total, c, mean, invstd, gamma, beta,
-                                                             residual, relu, y);
-  else
-    k_bn_apply<1><<<elem_grid(total, 1), 256, 0, S(stream)>>>(x, total, c, mean, invstd, gamma, beta,
-                                                             residual, relu, y);
+  if (v4) {
+    const int qpad = next_pow2(c / 4);
+    k_bn_apply<4><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y);
+  } else {
+    IRX_REQUIRE(c <= 256, "irx_bn_apply: c=%d needs c %% 4 == 0 or c <= 256", c);
+    const int qpad = next_pow2(c);
+    k_bn_apply<1><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y);
+  }
   IRX_CHECK_LAUNCH("irx_bn_apply");
   return IRX_OK;
 }
@@ -306,32 +331,32 @@ extern "C" int irx_bn_backward(const float* x, const float* y, const float* dy, 
   }
   IRX_REQUIRE(x && dy && mean && invstd && gamma && dx, "irx_bn_backward: null pointer");
   IRX_REQUIRE(!relu || y, "irx_bn_backward: relu needs y");
-  const int nblk = irx_cdiv(n, BN_ROWS);
+  const int nblk = irx_cdiv(n, bn_rows(n));
   float* part = (float*)workspace;
   const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)dy & 15) == 0) &&
                   (((uintptr_t)dx & 15) == 0) && (!relu || ((uintptr_t)y & 15) == 0) &&
                   (dresidual == nullptr || ((uintptr_t)dresidual & 15) == 0);
   if (v4)
     k_bn_partial<1, 4><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                   next_pow2(c / 4), part);
+                                                   next_pow2(c / 4), bn_rows(n), part);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_backward: c=%d needs c %% 4 == 0 or c <= 256", c);
     k_bn_partial<1, 1><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, next_pow2(c),
-                                                   part);
+                                                   bn_rows(n), part);
   }
   IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
   k_bn_finalize<1><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
                                                           nullptr, nullptr);
   IRX_CHECK_LAUNCH("irx_bn_backward(finalize)");
-  const size_t total = (size_t)n * c;
-  if (v4)
-    k_bn_bwd_apply<4><<<elem_grid(total, 4), 256, 0, S(stream)>>>(x, y, dy, total, n, c, mean, invstd,
-                                                                 gamma, dbeta, dgamma, relu, dx,
-                                                                 dresidual);
-  else
-    k_bn_bwd_apply<1><<<elem_grid(total, 1), 256, 0, S(stream)>>>(x, y, dy, total, n, c, mean, invstd,
-                                                                 gamma, dbeta, dgamma, relu, dx,
-                                                                 dresidual);
+  if (v4) {
+    const int qpad = next_pow2(c / 4);
+    k_bn_bwd_apply<4><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
+                                                               dgamma, relu, dx, dresidual);
+  } else {
+    const int qpad = next_pow2(c);
+    k_bn_bwd_apply<1><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
+                                                               dgamma, relu, dx, dresidual);
+  }
   IRX_CHECK_LAUNCH("irx_bn_backward(apply)");
   return IRX_OK;
 }

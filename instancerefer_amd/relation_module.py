@@ -42,7 +42,8 @@ class RelationModule(nn.Module):
         else:
             lang_cls_pred = data_dict['object_cat']
         pack = upload_instances(data_dict)
-        sel = pack.select(lang_cls_pred.tolist())
+        cls_list = data_dict.get('_lang_cls_pred_list')
+        sel = pack.select(cls_list if cls_list is not None else lang_cls_pred.tolist())
         dev = lang_feats.device
         if len(sel['cand']) == 0:
             data_dict['relation_scores'] = lang_feats.new_zeros((0,))

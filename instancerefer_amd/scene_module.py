@@ -39,6 +39,16 @@ class SceneModule(nn.Module):
                                          nn.Dropout(dropout_rate), nn.Linear(h_dim, h_dim))
         self.cls = nn.Sequential(nn.Linear(h_dim, h_dim), nn.BatchNorm1d(h_dim), nn.ReLU(), nn.Linear(h_dim, 9))
 
+    def encode(self, data_dict):
+        """Run the whole-scene BEVEncoder now (it depends on `lidar` only). InstanceRefer.forward calls this before the
+        language / attribute / relation modules so that this ~5 ms of GPU work overlaps their host-side work; the
+        result is identical to running it inside forward()."""
+        feats = data_dict['lidar']
+        if feats._batch_size is None:
+            feats._batch_size = data_dict['point_min'].shape[0]
+        data_dict['_scene_encoded'] = self.net(feats)
+        return data_dict
+
     def forward(self, data_dict):
         feats = data_dict['lidar']
         batch_size = data_dict['point_min'].shape[0]
@@ -46,9 +56,12 @@ class SceneModule(nn.Module):
         obj_feats_flatten = data_dict['obj_feats']
         lang_feats = data_dict['lang_scene_feats']
 
-        if feats._batch_size is None:
-            feats._batch_size = batch_size       # known from the collate; avoids the reference's .item() sync
-        feats = self.net(feats)
+        if '_scene_encoded' in data_dict:
+            feats = data_dict.pop('_scene_encoded')
+        else:
+            if feats._batch_size is None:
+                feats._batch_size = batch_size   # known from the collate; avoids the reference's .item() sync
+            feats = self.net(feats)
         # SparseCrop (to_bev[0]) is folded into the BEV gather: only voxels inside the window are looked up.
         # The dense head runs on channels-last cell rows (cells, C) with the irx conv / BatchNorm kernels.
         nx, ny = self.to_bev[1].bev_shape

@@ -84,6 +84,15 @@ class Level:
             self._down = DownMap(parent, koff, child, ld, out)
         return self._down
 
+    def build_pyramid(self, levels):
+        """Down-sample `levels` times now. Each level costs one tiny D2H (its row count); doing them back to back
+        BEFORE any convolution is queued keeps those syncs cheap (the queue is empty) and leaves the rest of the
+        forward pass free of host syncs."""
+        lv = self
+        for _ in range(levels):
+            lv = lv.down().out_level
+        return lv
+
     def offsets(self):
         if self._offsets is None:
             self._offsets = F_.batch_offsets(self.coords, self.batch_size)

@@ -85,3 +85,39 @@ def test_backward_matches_reference(lib):
     for k in gold.files:
         if k.startswith("running/"):
             assert np.abs(sd[k[len("running/"):]].cpu().numpy() - gold[k]).max() <= 1e-5, k
+
+
+def test_encoder_executor_equals_per_layer_path(lib):
+    """The one-node encoder executor issues the same kernels in the same order as the per-layer modules: outputs,
+    input gradient and every parameter gradient must be bit-identical."""
+    from helpers import device_batch, surface_cloud
+    from instancerefer_amd.basic_blocks import SparseConvEncoder
+    from instancerefer_amd.sparse import encoder_fn
+    rng = np.random.default_rng(5)
+    clouds = [surface_cloud(rng, 3000, rng.uniform(0, 3, 3), rng.uniform(0.8, 2.0, 3)) for _ in range(3)]
+    torch.manual_seed(1)
+    enc = SparseConvEncoder(7).cuda().train()
+    res = {}
+    for mode in ("fused", "layers"):
+        enc.zero_grad()
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        st = device_batch(clouds, 0.05)
+        x = st.F.clone().requires_grad_(True)
+        st = st.with_feats(x)
+        if mode == "layers":
+            saved, encoder_fn.can_fuse = encoder_fn.can_fuse, (lambda e: False)
+        out = enc(st)
+        if mode == "layers":
+            encoder_fn.can_fuse = saved
+        g = torch.linspace(-1, 1, out.F.numel(), device="cuda").view_as(out.F)
+        out.F.backward(g)
+        res[mode] = (out.F.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in enc.named_parameters()},
+                     {n: b.clone() for n, b in enc.named_buffers()})
+    assert torch.equal(res["fused"][0], res["layers"][0])
+    assert torch.equal(res["fused"][1], res["layers"][1])
+    for n in res["fused"][2]:
+        assert torch.equal(res["fused"][2][n], res["layers"][2][n]), n
+    for n in res["fused"][3]:
+        assert torch.equal(res["fused"][3][n], res["layers"][3][n]), n
