@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-scenes", type=int, default=2)
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do the input preparation of each step inline instead of on a side stream during the previous backward")
     return ap.parse_args()
 
 
@@ -61,15 +63,37 @@ def build_model(args_ns, workload, device):
     return model.to(device).train()
 
 
-def step_fn(model, resident, workload, reducer, opt):
-    """One training step on the resident batch. Returns the loss tensor (no host sync)."""
-    from instancerefer_amd.loss_helper import DatasetConfig, get_loss, ContrastiveLoss, compute_lang_classification_loss
+def fresh_batch(resident):
+    """The next batch as a training loop would hand it over: a FRESH un-canonical scene SparseTensor (Morton sort, hash,
+    kernel maps, pair lists are rebuilt every step) and no cached candidate selection."""
     from instancerefer_amd.sparse import SparseTensor
     dd = dict(resident)
     dd["irx"]._sel_cache.clear()
     if "lidar_F" in resident:
-        # a FRESH un-canonical SparseTensor every step: sort, hash and kernel maps are rebuilt in the timed region
         dd["lidar"] = SparseTensor(resident["lidar_F"], resident["lidar_C"], 1, batch_size=resident["B"])
+    return dd
+
+
+def prepare_next(model, resident, state):
+    """Input preparation of the NEXT step (candidate voxelisation, Morton sort, coordinate pyramids: the part of the
+    forward that needs host syncs) issued on a side HIP stream so that it overlaps the current step's backward —
+    the usual input-pipeline prefetch. Every step still does exactly one preparation; nothing is cached."""
+    side = state.setdefault("side", torch.cuda.Stream())
+    main = torch.cuda.current_stream()
+    with torch.cuda.stream(side):
+        nxt = model.prepare(fresh_batch(resident))
+    model.hand_over(nxt, main)
+    state["next"] = nxt
+
+
+def step_fn(model, resident, workload, reducer, opt, state=None):
+    """One training step on the resident batch. Returns the loss tensor (no host sync)."""
+    from instancerefer_amd.loss_helper import DatasetConfig, get_loss, ContrastiveLoss, compute_lang_classification_loss
+    if state is not None and state.get("next") is not None:
+        dd = state.pop("next")
+        torch.cuda.current_stream().wait_stream(state["side"])      # the prepared tensors are complete
+    else:
+        dd = fresh_batch(resident)
     opt.zero_grad()
     dd = model(dd)
     if workload == "full":
@@ -87,6 +111,8 @@ def step_fn(model, resident, workload, reducer, opt):
                 o += n
     loss.backward()
     opt.backward_step()          # one cat -> one all-reduce (N > 1) -> one fused Adam launch
+    if state is not None and state.get("pipeline"):
+        prepare_next(model, resident, state)
     return loss
 
 
@@ -192,6 +218,7 @@ def main():
     from instancerefer_amd.sparse import functional as F_
 
     B = args.batch or (16 if args.workload == "full" else 8)
+    torch.manual_seed(1234 + rank)                       # dropout masks reproducible run to run
     model = build_model(args, args.workload, device)
     step_fn.cfg = DatasetConfig()
     # weak scaling: every rank owns B distinct scenes (seeds offset by rank)
@@ -217,8 +244,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    state = {"pipeline": not args.no_pipeline}
     for i in range(args.warmup):
-        step_fn(model, resident, args.workload, reducer, opt)
+        step_fn(model, resident, args.workload, reducer, opt, state)
         if i == 0:
             torch.cuda.synchronize()
             log("first warmup step done")
@@ -226,7 +254,7 @@ def main():
     log("warmup done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step_fn(model, resident, args.workload, reducer, opt)
+        loss = step_fn(model, resident, args.workload, reducer, opt, state)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -260,7 +288,8 @@ def main():
                                     "BASELINE configs[1]: SparseConv3d + attribute_module only, fwd+bwd+Adam, fp32"),
                        "scenes_per_gpu": B, "global_batch": world * B, "points_per_scene": args.points,
                        "instances": args.instances, "candidates": args.candidates, "tokens": args.tokens,
-                       "scene_voxels_per_gpu": n_scene_vox, "parallelism": "dp%d" % world, "loss": final_loss},
+                       "scene_voxels_per_gpu": n_scene_vox, "parallelism": "dp%d" % world, "loss": final_loss,
+                       "input_prep": "inline" if args.no_pipeline else "side-stream prefetch of step N+1 during step N"},
             "roofline": roof,
         }
         if not args.no_cpu_baseline:
@@ -333,11 +362,21 @@ def summarise_roofline(recs):
                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                       "algo_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
                       "frac_of_bound": round(v["bound_ms"] / v["ms"], 4)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json; see its _note)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        key = dom.replace(",", ", ")
+        if key in pmc:
+            traffic = pmc[key]["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     return {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm",
             "achieved": tf if mfma_bound else gbs, "peak": PEAK_F32_TFLOPS if mfma_bound else PEAK_HBM_GBS,
             "unit": "TFLOP/s" if mfma_bound else "GB/s",
             "frac": (tf / PEAK_F32_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS),
-            "traffic": None, "avg_launch_us": 1e3 * a["ms"] / a["launches"], "launches": a["launches"],
+            "traffic": traffic, "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
+            "algorithmic_flops_per_launch": a["flops"] / a["launches"],
+            "avg_launch_us": 1e3 * a["ms"] / a["launches"], "launches": a["launches"],
             "path_frac_of_roofline": tot["bound_ms"] / tot["ms"], "per_kernel": per_kernel}
 
 

@@ -29,25 +29,42 @@ class InstanceRefer(nn.Module):
         if args.scene_module:
             self.scene = _import(args.scene_module).SceneModule(input_feature_dim, args)
 
-    def forward(self, data_dict):
-        # Phase 0 — everything that needs a host sync and depends only on the inputs, while the GPU queue is empty:
-        # candidate selection + voxelisation + pyramid of the attribute path (needs the class list, i.e. GT classes),
-        # then Morton sort + pyramid of the scene tensor. After this the forward issues work without draining the GPU.
+    def prepare(self, data_dict):
+        """Phase 0 — everything that needs a host sync and depends only on the inputs: candidate selection +
+        voxelisation + coordinate pyramid of the attribute path (needs the class list, i.e. GT classes), then Morton
+        sort + pyramid of the scene tensor. forward() calls it when the caller has not; a training loop can call it
+        for batch N+1 on a side stream while batch N's backward runs (bench.py does), after which forward() issues
+        its work without ever draining the GPU queue. Returns data_dict (marked prepared)."""
+        if data_dict.get('_prepared'):
+            return data_dict
         if self.args.attribute_module and self.args.use_gt_lang and hasattr(self.attribute, 'prepare'):
             cls = data_dict['object_cat']
             cls_list = data_dict['_host']['object_cat'] if 'object_cat' in data_dict.get('_host', {}) else cls.tolist()
             data_dict = self.attribute.prepare(data_dict, [int(v) for v in cls_list])
         if self.args.scene_module and 'lidar' in data_dict:
-            # Morton-sort the scene tensor and build its coordinate pyramid first: the only host syncs of the scene
-            # path happen here, before any heavy kernel is queued, so the rest of the forward never drains the GPU
             lidar = data_dict['lidar']
             if lidar._batch_size is None and 'point_min' in data_dict:
                 lidar._batch_size = data_dict['point_min'].shape[0]
             lidar = lidar.canonical()
             lidar.level().build_pyramid(4)
             data_dict['lidar'] = lidar
-            if hasattr(self.scene, 'encode'):
-                data_dict = self.scene.encode(data_dict)     # queue the biggest GPU job first
+        data_dict['_prepared'] = True
+        return data_dict
+
+    @staticmethod
+    def hand_over(data_dict, stream):
+        """After prepare() ran on another stream: register its surviving tensors with `stream` (the compute stream)."""
+        st = data_dict.get('lidar')
+        if st is not None and hasattr(st, 'record_stream'):
+            st.record_stream(stream)
+        prep = data_dict.get('_attr_prepared')
+        if prep is not None and prep[0] is not None:
+            prep[0].record_stream(stream)
+
+    def forward(self, data_dict):
+        data_dict = self.prepare(data_dict)
+        if self.args.scene_module and 'lidar' in data_dict and hasattr(self.scene, 'encode'):
+            data_dict = self.scene.encode(data_dict)         # queue the biggest GPU job first
         data_dict = self.lang(data_dict)
         if self.args.attribute_module:
             data_dict = self.attribute(data_dict)

@@ -84,6 +84,29 @@ class Level:
             self._down = DownMap(parent, koff, child, ld, out)
         return self._down
 
+    def tensors(self):
+        """Every device tensor reachable from this level (for stream hand-over, see SparseTensor.record_stream)."""
+        out = [self.coords, self.keys]
+        if self._table is not None:
+            out += [self._table[0], self._table[1]]
+        if self._nbr27 is not None:
+            out.append(self._nbr27)
+        if self._pairs27 is not None:
+            out += list(self._pairs27[:3])
+        if self._offsets is not None:
+            out.append(self._offsets)
+        for v in self._bev.values():
+            out += list(v)
+        if self._down is not None:
+            d = self._down
+            out += [d.parent, d.koff, d.child]
+            if d._child_t is not None:
+                out.append(d._child_t)
+            if d._pairs is not None:
+                out += list(d._pairs[:3])
+            out += d.out_level.tensors()
+        return out
+
     def build_pyramid(self, levels):
         """Down-sample `levels` times now. Each level costs one tiny D2H (its row count); doing them back to back
         BEFORE any convolution is queued keeps those syncs cheap (the queue is empty) and leaves the rest of the
@@ -170,6 +193,16 @@ class SparseTensor:
     def with_feats(self, feats, level=None):
         lv = level if level is not None else self._level
         return SparseTensor(feats, lv.coords, lv.stride, lv.batch_size, lv)
+
+    def record_stream(self, stream):
+        """Tell the caching allocator that `stream` will use the tensors of this SparseTensor and of its coordinate
+        pyramid (they were produced on another stream, e.g. the input-preparation side stream)."""
+        ts = [t for t in (self.F, self.C) if isinstance(t, torch.Tensor)]
+        if self._level is not None:
+            ts += self._level.tensors()
+        for t in ts:
+            if t.is_cuda:
+                t.record_stream(stream)
 
     def canonical(self):
         """Rows re-ordered to ascending Morton key (device tensors). No-op when already canonical."""
