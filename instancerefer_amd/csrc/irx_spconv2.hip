@@ -44,30 +44,40 @@ __device__ static inline PairList compact_pairs(int my, int lane) {
   return p;
 }
 
-// Per-wave compaction of one table column into LDS lists (wave-private region: no barrier needed, only the
-// wave's own lgkmcnt): list_in[p] = input row of pair p, list_row[p] = tile-local output row. Returns v.
-__device__ static inline int compact_to_lds(int my, int lane, int* __restrict__ list_in, int* __restrict__ list_row) {
-  const unsigned long long valid = __ballot(my >= 0);
-  const int v = __popcll(valid);
-  if (my >= 0) {
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int dst = __popcll(valid & lt);
-    list_in[dst] = my;
-    list_row[dst] = lane;
+// Per-wave compaction of one table column block (TM rows, TM/64 entries per lane) into LDS lists (wave-private
+// region: no barrier needed, only the wave's own lgkmcnt): list_in[p] = input row of pair p, list_row[p] = tile-local
+// output row, pairs in ascending row order. Returns v.
+template <int TM>
+__device__ static inline int compact_to_lds(const int* __restrict__ col, int lane, int* __restrict__ list_in,
+                                            int* __restrict__ list_row) {
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int base = 0;
+#pragma unroll
+  for (int h = 0; h < TM / 64; ++h) {
+    const int my = col[h * 64 + lane];
+    const unsigned long long valid = __ballot(my >= 0);
+    if (my >= 0) {
+      const int dst = base + __popcll(valid & lt);
+      list_in[dst] = my;
+      list_row[dst] = h * 64 + lane;
+    }
+    base += __popcll(valid);
   }
-  return v;
+  return base;
 }
 
 // wn: FRAGMENT-MAJOR weights [K][NCS][NJ][NT][64 lanes][4]: element i of lane l holds
 //     W[k][c = 16j + 4(l>>4) + i][n = cs*16*NT + 16t + (l&15)]   (k_permute_w builds it from Conv3d.kernel),
 // so each wave-level weight load is one contiguous, fully coalesced 1 KiB read.
-// Software pipeline per workgroup: the tile's whole table column block ([K][64] ints) is fetched into LDS once; for
-// every active offset the gathered rows are staged global -> VGPR -> LDS, and the NEXT active offset's gather and
-// weight-slice loads are issued before the current offset's MFMA phase, so HBM/L2 latency hides behind the MFMAs.
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn,
-                                                    const int32_t* __restrict__ nbr, int ld, int n_out, int K,
-                                                    int flip_k, float* __restrict__ y, int dbg, int k_per_split) {
+// TM = output rows per workgroup (64 or 128). Work items are (offset, stage of <= 64 compacted pairs); the weight slice
+// is (re)loaded only when the offset changes, so a 128-row tile streams half the weight bytes per useful FLOP.
+// Software pipeline per workgroup: the tile's whole table column block ([K][TM] ints) is fetched into LDS once; for
+// every item the gathered rows are staged global -> VGPR -> LDS, and the NEXT item's gather (and, on an offset change,
+// weight-slice) loads are issued before the current item's MFMA phase, so HBM/L2 latency hides behind the MFMAs.
+template <int CIN, int COUT, int TM>
+__global__ __launch_bounds__(256, (TM == 128 && COUT == 128) ? 1 : 2)
+void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const int32_t* __restrict__ nbr, int ld,
+               int n_out, int K, int flip_k, float* __restrict__ y, int dbg, int k_per_split) {
   // blockIdx.y = offset split: this workgroup handles offsets [kb, ke) and writes its partial tile to slab
   // blockIdx.y of y (slabs are summed by k_wgrad_reduce; a single split writes the result directly).
   const int kb = blockIdx.y * k_per_split;
@@ -81,43 +91,43 @@ __global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x,
   constexpr int LPR = CIN / 4;                    // lanes (float4) per gathered row
   constexpr int PPI = 64 / LPR;                   // pairs per wave-instruction
   constexpr int PPP = 4 * PPI;                    // pairs per workgroup pass
-  constexpr int NIT = S2_TM / PPP;                // gather passes for a full 64-pair tile
+  constexpr int NIT = 64 / PPP;                   // gather passes for a full 64-pair stage
   constexpr int NJ = CIN / 16;
   constexpr int KMAX = 27;
   static_assert(NCS * NGP == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float sOut[S2_TM * LDO];
-  __shared__ __attribute__((aligned(16))) float sA[S2_TM * LDA];
-  __shared__ int sTbl[KMAX * S2_TM];
-  __shared__ int sList[4][2][2][S2_TM];           // [wave][parity][in|row][pair]
+  __shared__ __attribute__((aligned(16))) float sOut[TM * LDO];
+  __shared__ __attribute__((aligned(16))) float sA[64 * LDA];
+  __shared__ int sTbl[KMAX * TM];
+  __shared__ int sList[4][2][2][TM];              // [wave][parity][in|row][pair]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g4 = lane >> 4;
   const int cs = wave % NCS, gp = wave / NCS;
   const int n_base = cs * 16 * NT;
-  const int q0 = blockIdx.x * S2_TM;
+  const int q0 = blockIdx.x * TM;
   const int sub = lane / LPR;                     // which of the PPI pairs of a pass this lane serves
   const int c4 = (lane % LPR) * 4;
-  const int pbase = wave * PPI + sub;             // this lane's pair in pass 0
+  const int pbase = wave * PPI + sub;             // this lane's stage-local pair in pass 0
 
-  for (int i = tid + kb * S2_TM; i < ke * S2_TM; i += 256) {
-    const int k = i >> 6, r = i & 63;
+  for (int i = tid + kb * TM; i < ke * TM; i += 256) {
+    const int k = i / TM, r = i % TM;
     const int kt = flip_k ? (K - 1 - k) : k;
     sTbl[i] = (q0 + r < n_out) ? nbr[(size_t)kt * ld + q0 + r] : -1;
   }
-  for (int i = tid; i < S2_TM * LDO; i += 256) sOut[i] = 0.f;
+  for (int i = tid; i < TM * LDO; i += 256) sOut[i] = 0.f;
   __syncthreads();
 
   // ---- find the first active offset and issue its loads ----
   K = ke;
-  int k = kb, v = 0, par = 0;
+  int k = kb, v = 0, par = 0, p0 = 0;
   for (; k < K; ++k) {
-    v = compact_to_lds(sTbl[k * S2_TM + lane], lane, sList[wave][par][0], sList[wave][par][1]);
+    v = compact_to_lds<TM>(&sTbl[k * TM], lane, sList[wave][par][0], sList[wave][par][1]);
     if (v) break;
   }
   float4 stage[NIT];
   float4 wreg[NJ][NT];
   if (k < K) {
-    const int npass = (v + PPP - 1) / PPP;
+    const int npass = ((v < 64 ? v : 64) + PPP - 1) / PPP;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -135,40 +145,51 @@ __global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x,
   }
 
   while (k < K) {
-    const int vpad = (v + 15) & ~15;
+    int vs = v - p0;                               // pairs of this stage
+    if (vs > 64) vs = 64;
+    const int vpad = (vs + 15) & ~15;
     const int npass = (vpad + PPP - 1) / PPP;      // block-uniform
-    __syncthreads();                               // previous offset's fragment reads are done
+    __syncthreads();                               // previous item's fragment reads are done
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
       if (it < npass) *reinterpret_cast<float4*>(&sA[(pbase + it * PPP) * LDA + c4]) = stage[it];
     __syncthreads();
-    // ---- look ahead: next active offset; issue its gather + weight loads now ----
-    int kn = k + 1, vn = 0;
-    const int parn = par ^ 1;
-    for (; kn < K; ++kn) {
-      vn = compact_to_lds(sTbl[kn * S2_TM + lane], lane, sList[wave][parn][0], sList[wave][parn][1]);
-      if (vn) break;
+    // ---- look ahead: next item = next stage of this offset, else the next active offset ----
+    int kn = k, vn = v, p0n = p0 + 64, parn = par;
+    if (TM == 64 || p0n >= v) {
+      p0n = 0;
+      parn = par ^ 1;
+      vn = 0;
+      for (kn = k + 1; kn < K; ++kn) {
+        vn = compact_to_lds<TM>(&sTbl[kn * TM], lane, sList[wave][parn][0], sList[wave][parn][1]);
+        if (vn) break;
+      }
     }
     float4 wnext[NJ][NT];
     if (kn < K) {
-      const int npn = (vn + PPP - 1) / PPP;
+      int vsn = vn - p0n;
+      if (vsn > 64) vsn = 64;
+      const int npn = (vsn + PPP - 1) / PPP;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (it < npn) {
           const int p = pbase + it * PPP;
-          if (p < vn && !(dbg & 2)) stage[it] = *reinterpret_cast<const float4*>(x + (size_t)sList[wave][parn][0][p] * CIN + c4);
+          if (p < vsn && !(dbg & 2))
+            stage[it] = *reinterpret_cast<const float4*>(x + (size_t)sList[wave][parn][0][p0n + p] * CIN + c4);
         }
       }
+      if (kn != k) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          wnext[j][t] = (dbg & 4) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(
-              wn + (((((size_t)kn * NCS + cs) * NJ + j) * NT + t) * 64 + lane) * 4);
+          for (int t = 0; t < NT; ++t)
+            wnext[j][t] = (dbg & 4) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(
+                wn + (((((size_t)kn * NCS + cs) * NJ + j) * NT + t) * 64 + lane) * 4);
+      }
     }
     // ---- MFMA over dense 16-pair groups; this wave's channel slice ----
-    const int* lrow = sList[wave][par][1];
+    const int* lrow = sList[wave][par][1] + p0;
     for (int g = gp; g * 16 < vpad && !(dbg & 1); g += NGP) {
       f32x4 acc[NT];
 #pragma unroll
@@ -190,30 +211,31 @@ __global__ __launch_bounds__(256, 2) void k_spconv2(const float* __restrict__ x,
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wreg[j][t].w, acc[t], 0, 0, 0);
       }
-      // D layout: col = lane&15, row = (lane>>4)*4 + r  -> pair 16g + 4*g4 + r
+      // D layout: col = lane&15, row = (lane>>4)*4 + r  -> stage pair 16g + 4*g4 + r
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (16 * g + 4 * g4 + r < v && !(dbg & 8)) {
+        if (16 * g + 4 * g4 + r < vs && !(dbg & 8)) {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
             sOut[orow[r] * LDO + n_base + 16 * t + m] += acc[t][r];   // this wave owns the channel slice: no race
         }
       }
     }
-    k = kn;
-    v = vn;
-    par = parn;
-    if (kn < K) {
+    if (kn < K && kn != k) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int t = 0; t < NT; ++t) wreg[j][t] = wnext[j][t];
     }
+    k = kn;
+    v = vn;
+    p0 = p0n;
+    par = parn;
   }
   __syncthreads();
   // ---- write the tile: COUT/4 float4 per row ----
   constexpr int F4 = COUT / 4;
-  for (int f = tid; f < S2_TM * F4; f += 256) {
+  for (int f = tid; f < TM * F4; f += 256) {
     const int row = f / F4, cc = (f % F4) * 4;
     if (q0 + row < n_out)
       *reinterpret_cast<float4*>(y + (size_t)(q0 + row) * COUT + cc) =
@@ -348,22 +370,32 @@ bool irx_spconv2_supported(int cin, int cout) {
   return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128);
 }
 
-template <int CIN>
+template <int CIN, int TM>
 static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
                         int ld, int n_out, int K, int flip_k, float* y, int kps) {
   static const int dbg = getenv("IRX_SPCONV_DBG") ? atoi(getenv("IRX_SPCONV_DBG")) : 0;
-  if (cout == 128) k_spconv2<CIN, 128><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
-  else if (cout == 64) k_spconv2<CIN, 64><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
-  else k_spconv2<CIN, 32><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
+  if (cout == 128) k_spconv2<CIN, 128, TM><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
+  else if (cout == 64) k_spconv2<CIN, 64, TM><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
+  else k_spconv2<CIN, 32, TM><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
 }
 
 // wn must already be fragment-major (irx_permute_w_launch).
+// Output rows per workgroup. 128-row tiles stream half the weight bytes per useful FLOP, but MEASURED SLOWER on
+// MI355X (N = 81 k, 128->128: 498 vs 441 us; 64->64: 431 vs 364 us): fewer independent workgroups per CU hurts more
+// than the smaller weight stream helps. Default 64; IRX_SPCONV_TM=128 selects the variant for experiments.
+int irx_spconv2_tile(int n_out) {
+  static const char* e = getenv("IRX_SPCONV_TM");
+  (void)n_out;
+  if (e) return atoi(e) == 128 ? 128 : 64;
+  return 64;
+}
+
 // Offset splits for latency-bound (small) layers: a tile's 27 offsets form a serial chain of ~4 us each, so
 // when there are too few tiles to fill the chip the offsets are spread over `splits` workgroups per tile.
 int irx_spconv2_splits(int n_out, int K) {
   static const char* e = getenv("IRX_SPCONV_KSPLIT");
   if (e) { int s = atoi(e); return s < 1 ? 1 : (s > K ? K : s); }
-  const int tiles = irx_cdiv(n_out, S2_TM);
+  const int tiles = irx_cdiv(n_out, irx_spconv2_tile(n_out));
   if (tiles >= 768 || K < 4) return 1;
   int s = irx_cdiv(1024, tiles);
   if (s > 9) s = 9;
@@ -376,11 +408,18 @@ int irx_spconv2_splits(int n_out, int K) {
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
                        int cout, int flip_k, float* y, int splits, hipStream_t st) {
   IRX_REQUIRE(K <= 27, "irx_spconv_fwd: K = %d > 27 unsupported by the fast path", K);
-  dim3 grid(irx_cdiv(n_out, S2_TM), splits);
+  const int tm = irx_spconv2_tile(n_out);
+  dim3 grid(irx_cdiv(n_out, tm), splits);
   const int kps = irx_cdiv(K, splits);
-  if (cin == 128) launch_fwd2<128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-  else if (cin == 64) launch_fwd2<64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-  else launch_fwd2<32>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+  if (tm == 128) {
+    if (cin == 128) launch_fwd2<128, 128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+    else if (cin == 64) launch_fwd2<64, 128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+    else launch_fwd2<32, 128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+  } else {
+    if (cin == 128) launch_fwd2<128, 64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+    else if (cin == 64) launch_fwd2<64, 64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+    else launch_fwd2<32, 64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+  }
   IRX_CHECK_LAUNCH("irx_spconv_fwd(v2)");
   return IRX_OK;
 }
