@@ -64,7 +64,7 @@ def make_scene(seed, num_points=50000, num_instances=8, num_candidates=4, target
         instance_obbs.append(np.concatenate([0.5 * (lo + hi), hi - lo, np.array([0.0])]))
         sel = rng.choice(x.shape[0], points_per_instance, replace=x.shape[0] < points_per_instance)
         instance_points.append(x[sel])
-        instance_class.append(target_class if j < num_candidates else (target_class + 1 + j) % num_classes)
+        instance_class.append(target_class if j < num_candidates else (target_class + 1 + j % (num_classes - 1)) % num_classes)
     lang = np.zeros((MAX_DES_LEN, 300), np.float32)
     lang[:tokens] = (rng.standard_normal((tokens, 300)) * 0.4).astype(np.float32)
     gt = instance_obbs[0]
