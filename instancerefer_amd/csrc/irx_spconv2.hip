@@ -87,7 +87,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   constexpr int NCS = COUT / (16 * NT);           // channel slices (waves along N)
   constexpr int NGP = 4 / NCS;                    // waves along the pair-group dimension
   constexpr int LDA = CIN + 4;
-  constexpr int LDO = COUT + 8;
+  constexpr int LDO = COUT + 4;                  // row stride = 4 banks: two rows of a half-wave collide only if equal mod 8
   constexpr int LPR = CIN / 4;                    // lanes (float4) per gathered row
   constexpr int PPI = 64 / LPR;                   // pairs per wave-instruction
   constexpr int PPP = 4 * PPI;                    // pairs per workgroup pass

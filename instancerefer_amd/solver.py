@@ -1,0 +1,167 @@
+"""Solver — DDP-aware sibling of the reference's lib/solver.py:139-342.
+
+Same contract: iterate dataloaders that yield reference-format `data_dict`s (lib/dataset.py collate), move the tensor
+keys to the GPU (lib/solver.py:242-245), forward -> get_loss -> backward -> step, get_eval for the metrics, log every
+`verbose` iterations, save `model_last.pth` every epoch, `model.pth` on the best Acc@0.25 and `checkpoint.tar`
+({epoch, model_state_dict, optimizer_state_dict}) at the end — the reference's file names and state-dict keys, so
+checkpoints are interchangeable with scripts/eval.py:54-55 / scripts/train.py:114-119.
+
+Differences, all below the API: one process per GPU with a single flat-gradient RCCL all-reduce and one fused Adam
+launch per step (optim.FlatAdam); rank 0 alone logs and writes files; timers are taken around device syncs only at
+logging points (the reference's `time.time()` pairs measure host time without a sync)."""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .eval_helper import get_eval
+from .loss_helper import get_loss
+from .optim import FlatAdam
+
+GPU_KEYS = ("lang_feat", "lang_len", "object_cat", "lidar", "point_min", "point_max", "ref_center_label",
+            "ref_size_residual_label")
+HOST_LABELS = ("ref_center_label", "ref_size_residual_label", "ref_heading_class_label",
+               "ref_heading_residual_label", "ref_size_class_label", "object_cat", "unique_multiple")
+
+
+def to_device(data_dict, device):
+    """lib/solver.py:242-245 + host copies of the label tensors (they originate on the host) for get_loss / get_eval."""
+    data_dict["_host"] = {k: data_dict[k].detach().cpu().numpy() for k in HOST_LABELS
+                          if k in data_dict and isinstance(data_dict[k], torch.Tensor)}
+    if "lang_len" in data_dict:
+        data_dict["lang_len_max"] = int(data_dict["lang_len"].max())
+    for k in GPU_KEYS:
+        v = data_dict.get(k)
+        if isinstance(v, torch.Tensor):
+            data_dict[k] = v.to(device, non_blocking=True)
+        elif v is not None and hasattr(v, "cuda") and not isinstance(v, (list, tuple)):
+            data_dict[k] = v.to(device)          # SparseTensor
+    return data_dict
+
+
+class Solver:
+    def __init__(self, model, config, dataloader, lr=1e-3, weight_decay=1e-5, lr_decay_step=(15, 20), lr_decay_rate=0.1,
+                 out_dir=None, verbose=20, device=None):
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.model = model.to(self.device)
+        self.config = config
+        self.dataloader = dataloader               # {"train": iterable, "val": iterable (optional)}
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.optimizer = FlatAdam(self.model.parameters(), lr=lr, weight_decay=weight_decay, world_size=self.world)
+        self.base_lr, self.lr_decay_step, self.lr_decay_rate = lr, tuple(lr_decay_step or ()), lr_decay_rate
+        self.out_dir = out_dir
+        self.verbose = verbose
+        self.best = {"epoch": 0, "iou_rate_0.25": -float("inf"), "iou_rate_0.5": -float("inf"), "ref_acc": -float("inf")}
+        self.log = {"train": [], "val": []}
+        self.global_iter = 0
+        if self.rank == 0 and out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+
+    # ------------------------------------------------------------------------------------------
+    def _say(self, msg):
+        if self.rank == 0:
+            print(msg, flush=True)
+            if self.out_dir:
+                with open(os.path.join(self.out_dir, "log.txt"), "a") as f:
+                    f.write(msg + "\n")
+
+    def _forward(self, data_dict):
+        return get_loss(self.model(to_device(data_dict, self.device)), self.config)
+
+    def train_epoch(self, epoch):
+        self.model.train()
+        self.optimizer.lr = self.base_lr * (self.lr_decay_rate ** sum(epoch >= s for s in self.lr_decay_step))
+        t0, seen = time.perf_counter(), 0
+        for data_dict in self.dataloader["train"]:
+            self.optimizer.zero_grad()
+            data_dict = self._forward(data_dict)
+            data_dict["loss"].backward()
+            self.optimizer.backward_step()
+            self.global_iter += 1
+            seen += data_dict["lang_scores"].shape[0]
+            if self.global_iter % self.verbose == 0:
+                with torch.no_grad():
+                    ev = get_eval(data_dict, self.config)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                rec = dict(epoch=epoch, iter=self.global_iter, loss=float(data_dict["loss"]), ref_loss=float(data_dict["ref_loss"]),
+                           lang_loss=float(data_dict["lang_loss"]), seg_loss=float(data_dict["seg_loss"]),
+                           lang_acc=float(ev["lang_acc"]), ref_acc=float(np.mean(ev["ref_acc"])),
+                           iou_rate_25=ev["ref_iou_rate_0.25"], iou_rate_5=ev["ref_iou_rate_0.5"],
+                           scenes_per_sec=self.world * seen / dt)
+                self.log["train"].append(rec)
+                self._say("[train] epoch %d iter %d loss %.4f (ref %.4f lang %.4f seg %.4f) ref_acc %.3f Acc@.25 %.3f "
+                          "%.1f scenes/s" % (epoch, rec["iter"], rec["loss"], rec["ref_loss"], rec["lang_loss"],
+                                             rec["seg_loss"], rec["ref_acc"], rec["iou_rate_25"], rec["scenes_per_sec"]))
+                t0, seen = time.perf_counter(), 0
+
+    @torch.no_grad()
+    def validate(self, epoch):
+        if not self.dataloader.get("val"):
+            return None
+        self.model.eval()
+        acc, ious = [], []
+        for data_dict in self.dataloader["val"]:
+            ev = get_eval(self._forward(data_dict), self.config)
+            acc += ev["ref_acc"]
+            ious += ev["ref_iou"]
+        stats = torch.tensor([np.sum(acc), len(acc), np.sum(np.asarray(ious) >= 0.25), np.sum(np.asarray(ious) >= 0.5),
+                              len(ious)], dtype=torch.float64, device=self.device)
+        if self.world > 1:
+            dist.all_reduce(stats)                 # metrics over the whole validation set, not one shard
+        s = stats.tolist()
+        rec = {"epoch": epoch, "ref_acc": s[0] / max(s[1], 1), "iou_rate_0.25": s[2] / max(s[4], 1),
+               "iou_rate_0.5": s[3] / max(s[4], 1)}
+        self.log["val"].append(rec)
+        self._say("[val] epoch %d ref_acc %.4f Acc@0.25 %.4f Acc@0.5 %.4f" % (epoch, rec["ref_acc"], rec["iou_rate_0.25"],
+                                                                           rec["iou_rate_0.5"]))
+        return rec
+
+    def __call__(self, epochs):
+        for epoch in range(epochs):
+            self.train_epoch(epoch)
+            self.save("model_last.pth")
+            rec = self.validate(epoch)
+            if rec is not None and rec["iou_rate_0.25"] > self.best["iou_rate_0.25"]:
+                self.best = dict(rec)
+                self.save("model.pth")
+        self.finish(epochs)
+
+    # ------------------------------------------------------------------------------------------
+    def save(self, name):
+        if self.rank == 0 and self.out_dir:
+            torch.save(self.model.state_dict(), os.path.join(self.out_dir, name))
+
+    def finish(self, epoch):
+        if self.rank == 0 and self.out_dir:
+            o = self.optimizer
+            torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(),
+                        "optimizer_state_dict": {"flat_exp_avg": o.exp_avg, "flat_exp_avg_sq": o.exp_avg_sq,
+                                                 "step": o.step_count, "lr": o.lr}},
+                       os.path.join(self.out_dir, "checkpoint.tar"))
+            with open(os.path.join(self.out_dir, "best.txt"), "w") as f:
+                for k, v in self.best.items():
+                    f.write("%s: %s\n" % (k, v))
+
+
+class SyntheticLoader:
+    """Iterable of reference-format batches from instancerefer_amd.synthetic (no network for the real dataset):
+    `lidar` is built the way lib/dataset.py does — per-scene sparse_quantize + collate — but on the GPU."""
+
+    def __init__(self, batches, batch_size, seed=123, rank=0, world=1, **scene_kw):
+        self.batches, self.batch_size, self.seed, self.rank, self.world, self.kw = batches, batch_size, seed, rank, world, scene_kw
+
+    def __iter__(self):
+        from . import synthetic as S
+        from .sparse.utils import voxelize
+        dev = torch.device("cuda", torch.cuda.current_device())
+        for b in range(self.batches):
+            dd = S.make_batch(self.batch_size, seed=self.seed + (b * self.world + self.rank) * self.batch_size, **dict(self.kw))
+            pts = [torch.from_numpy(p) for p in dd["scene_points"]]
+            allp = torch.cat(pts, 0).to(dev)
+            batch = torch.cat([torch.full((p.shape[0],), i, dtype=torch.int32) for i, p in enumerate(pts)]).to(dev)
+            dd["lidar"] = voxelize(allp[:, :3].contiguous(), allp.float(), batch, [0.05] * 3, len(pts))
+            yield dd

@@ -68,6 +68,7 @@ def main():
     os.chdir(REF)
     from models.instancerefer import InstanceRefer   # the reference's model
     from lib.loss_helper import get_loss             # the reference's loss
+    from lib.eval_helper import get_eval             # the reference's metric
     from instancerefer_amd.loss_helper import DatasetConfig
     os.chdir(ROOT)
 
@@ -168,6 +169,18 @@ def main():
     lo["out/cluster_label"] = np.concatenate([np.asarray(t2n(c)) if len(c) else np.zeros(0) for c in dd["cluster_label"]])
     for k, v in keep.items():
         lo["grad/" + k] = t2n(v.grad)
+    # the reference's get_eval on the same dict (needs unique_multiple; scores detached)
+    lo["unique_multiple"] = rng.integers(0, 2, B)
+    dd["unique_multiple"] = torch.from_numpy(lo["unique_multiple"])
+    for k in sc:
+        dd[k] = dd[k].detach()
+    get_eval(dd, DatasetConfig())
+    lo["eval/ref_acc"] = np.asarray(dd["ref_acc"], np.float64)
+    lo["eval/ref_iou"] = np.asarray(dd["ref_iou"], np.float64)
+    lo["eval/rates"] = np.asarray([dd["ref_iou_rate_0.25"], dd["ref_iou_rate_0.5"], float(dd["lang_acc"])])
+    lo["eval/masks"] = np.asarray([dd["ref_multiple_mask"], dd["ref_others_mask"]])
+    lo["eval/pred_bboxes"] = np.asarray(dd["pred_bboxes"])
+    lo["eval/gt_bboxes"] = np.asarray(dd["gt_bboxes"])
     np.savez_compressed(os.path.join(HERE, "loss.npz"), **lo)
     print("loss.npz: loss", lo["out/loss"], "ref", lo["out/ref_loss"], "labels", lo["out/cluster_label"])
 
