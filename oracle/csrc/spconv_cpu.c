@@ -1,0 +1,189 @@
+/* spconv_cpu.c — TEST ORACLE / CPU BASELINE (see oracle/__init__.py). Plain C + OpenMP restatement of the CPU
+ * sparse-convolution path the reference reaches through torchsparse (models/basic_blocks.py:10-95 of the reference:
+ * SparseConvEncoder = stem 3^3 C0->32, 4 x {2^3/2 down conv + ResidualBlock(2 x 3^3)}, every conv followed by
+ * train-mode BatchNorm + ReLU; models/attribute_module.py:104-105: encoder + global max pooling), forward AND backward:
+ *   hash table over packed (x,y,z,b) -> row;  kernel maps by hash query (27 offsets, x fastest / 8 offsets, z fastest);
+ *   per offset: gather -> (1 x Cin)(Cin x Cout) products -> scatter-add   (torchsparse's CPU algorithm);
+ *   backward: per-offset data gradient (W^T) and weight gradient (gather^T . grad); BatchNorm batch statistics.
+ * Used by bench.py's cpu_baseline (kind "port") and checked against oracle/torchsparse by tests/test_oracle_cpu.py.
+ * Build: gcc -O3 -march=native -fopenmp -shared -fPIC (oracle/build_c.py). */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <omp.h>
+
+typedef struct { uint64_t* keys; int32_t* vals; uint64_t mask; } hmap;
+
+static inline uint64_t pack(const int32_t* c) {
+  return ((uint64_t)(uint16_t)(c[3]) << 48) | ((uint64_t)(uint16_t)(c[0] + 32768) << 32) |
+         ((uint64_t)(uint16_t)(c[1] + 32768) << 16) | (uint64_t)(uint16_t)(c[2] + 32768);
+}
+static inline uint64_t mix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k; }
+static hmap hm_build(const int32_t* coords, int n) {
+  hmap h; uint64_t cap = 64; while (cap < (uint64_t)2 * (n > 0 ? n : 1)) cap <<= 1;
+  h.mask = cap - 1; h.keys = (uint64_t*)malloc(cap * 8); h.vals = (int32_t*)malloc(cap * 4);
+  memset(h.keys, 0xff, cap * 8);
+  for (int i = 0; i < n; ++i) {
+    uint64_t k = pack(coords + 4 * i), s = mix(k) & h.mask;
+    while (h.keys[s] != ~0ULL && h.keys[s] != k) s = (s + 1) & h.mask;
+    if (h.keys[s] == ~0ULL) { h.keys[s] = k; h.vals[s] = i; }
+  }
+  return h;
+}
+static inline int hm_get(const hmap* h, const int32_t* c) {
+  uint64_t k = pack(c), s = mix(k) & h->mask;
+  while (h->keys[s] != ~0ULL) { if (h->keys[s] == k) return h->vals[s]; s = (s + 1) & h->mask; }
+  return -1;
+}
+static void hm_free(hmap* h) { free(h->keys); free(h->vals); }
+
+/* kernel map: for offset k, pairs (in[k][p], out[k][p]), p < cnt[k] */
+typedef struct { int K; int* cnt; int** in; int** out; } kmap;
+static kmap km_build(const int32_t* cin, int nin, const int32_t* cout, int nout, int ks, int stride) {
+  kmap m; m.K = ks * ks * ks; m.cnt = (int*)calloc(m.K, sizeof(int)); m.in = (int**)malloc(m.K * sizeof(int*)); m.out = (int**)malloc(m.K * sizeof(int*));
+  hmap h = hm_build(cin, nin);
+#pragma omp parallel for schedule(dynamic)
+  for (int k = 0; k < m.K; ++k) {
+    int dx, dy, dz;
+    if (ks == 3) { dx = (k % 3 - 1) * stride; dy = ((k / 3) % 3 - 1) * stride; dz = (k / 9 - 1) * stride; }   /* x fastest */
+    else { dz = (k & 1) * stride; dy = ((k >> 1) & 1) * stride; dx = ((k >> 2) & 1) * stride; }                /* z fastest */
+    int* pi = (int*)malloc((size_t)nout * sizeof(int)); int* po = (int*)malloc((size_t)nout * sizeof(int)); int c = 0;
+    for (int q = 0; q < nout; ++q) {
+      int32_t t[4] = {cout[4 * q] + dx, cout[4 * q + 1] + dy, cout[4 * q + 2] + dz, cout[4 * q + 3]};
+      int r = hm_get(&h, t);
+      if (r >= 0) { pi[c] = r; po[c] = q; ++c; }
+    }
+    m.cnt[k] = c; m.in[k] = pi; m.out[k] = po;
+  }
+  hm_free(&h);
+  return m;
+}
+static void km_free(kmap* m) { for (int k = 0; k < m->K; ++k) { free(m->in[k]); free(m->out[k]); } free(m->cnt); free(m->in); free(m->out); }
+
+/* unique(floor(c / s2) * s2, b), first-seen order */
+static int downsample(const int32_t* c, int n, int s2, int32_t** out) {
+  int32_t* o = (int32_t*)malloc((size_t)n * 16); int m = 0;
+  uint64_t cap = 64; while (cap < (uint64_t)2 * n) cap <<= 1;
+  uint64_t* keys = (uint64_t*)malloc(cap * 8); memset(keys, 0xff, cap * 8);
+  for (int i = 0; i < n; ++i) {
+    int32_t t[4]; for (int d = 0; d < 3; ++d) { int v = c[4 * i + d]; int f = v >= 0 ? v / s2 : -((-v + s2 - 1) / s2); t[d] = f * s2; } t[3] = c[4 * i + 3];
+    uint64_t k = pack(t), s = mix(k) & (cap - 1);
+    while (keys[s] != ~0ULL && keys[s] != k) s = (s + 1) & (cap - 1);
+    if (keys[s] == ~0ULL) { keys[s] = k; memcpy(o + 4 * m, t, 16); ++m; }
+  }
+  free(keys); *out = o; return m;
+}
+
+static void conv_fwd(const float* x, const float* w, const kmap* m, int cin, int cout, int nout, float* y) {
+  memset(y, 0, (size_t)nout * cout * sizeof(float));
+  for (int k = 0; k < m->K; ++k) {
+    const float* wk = w + (size_t)k * cin * cout;
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < m->cnt[k]; ++p) {          /* one output row per pair within an offset: no race */
+      const float* xi = x + (size_t)m->in[k][p] * cin; float* yo = y + (size_t)m->out[k][p] * cout;
+      for (int c = 0; c < cin; ++c) { const float a = xi[c]; const float* wr = wk + (size_t)c * cout; for (int n = 0; n < cout; ++n) yo[n] += a * wr[n]; }
+    }
+  }
+}
+static void conv_bwd(const float* x, const float* w, const float* dy, const kmap* m, int cin, int cout, int nin, float* dx, float* dw) {
+  if (dx) memset(dx, 0, (size_t)nin * cin * sizeof(float));
+  for (int k = 0; k < m->K; ++k) {
+    const float* wk = w + (size_t)k * cin * cout; float* dwk = dw + (size_t)k * cin * cout;
+    if (dx) {
+#pragma omp parallel for schedule(static)
+      for (int p = 0; p < m->cnt[k]; ++p) {
+        const float* g = dy + (size_t)m->out[k][p] * cout; float* di = dx + (size_t)m->in[k][p] * cin;
+        for (int c = 0; c < cin; ++c) { const float* wr = wk + (size_t)c * cout; float s = 0.f; for (int n = 0; n < cout; ++n) s += g[n] * wr[n]; di[c] += s; }
+      }
+    }
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < cin; ++c) {                 /* each thread owns rows of dW[k]: no race */
+      float* dr = dwk + (size_t)c * cout; for (int n = 0; n < cout; ++n) dr[n] = 0.f;
+      for (int p = 0; p < m->cnt[k]; ++p) { const float a = x[(size_t)m->in[k][p] * cin + c]; const float* g = dy + (size_t)m->out[k][p] * cout; for (int n = 0; n < cout; ++n) dr[n] += a * g[n]; }
+    }
+  }
+}
+
+/* y = relu(bn(x) (+res)) with batch statistics; saves mean / invstd */
+static void bn_fwd(const float* x, int n, int c, const float* gamma, const float* beta, const float* res, float* y, float* mean, float* invstd) {
+#pragma omp parallel for
+  for (int j = 0; j < c; ++j) { double s = 0, s2 = 0; for (int i = 0; i < n; ++i) { double v = x[(size_t)i * c + j]; s += v; s2 += v * v; }
+    double mu = s / n, var = s2 / n - mu * mu; if (var < 0) var = 0; mean[j] = (float)mu; invstd[j] = (float)(1.0 / sqrt(var + 1e-5)); }
+#pragma omp parallel for
+  for (int i = 0; i < n; ++i) for (int j = 0; j < c; ++j) { float o = (x[(size_t)i * c + j] - mean[j]) * invstd[j] * gamma[j] + beta[j]; if (res) o += res[(size_t)i * c + j]; y[(size_t)i * c + j] = o > 0 ? o : 0; }
+}
+static void bn_bwd(const float* x, const float* y, const float* dy, int n, int c, const float* gamma, const float* mean, const float* invstd,
+                   float* dx, float* dgamma, float* dbeta, float* dres) {
+#pragma omp parallel for
+  for (int j = 0; j < c; ++j) { double sg = 0, sgx = 0; for (int i = 0; i < n; ++i) { size_t o = (size_t)i * c + j; float g = y[o] > 0 ? dy[o] : 0; sg += g; sgx += g * (double)((x[o] - mean[j]) * invstd[j]); } dbeta[j] = (float)sg; dgamma[j] = (float)sgx; }
+#pragma omp parallel for
+  for (int i = 0; i < n; ++i) for (int j = 0; j < c; ++j) { size_t o = (size_t)i * c + j; float g = y[o] > 0 ? dy[o] : 0; float xh = (x[o] - mean[j]) * invstd[j];
+      dx[o] = gamma[j] * invstd[j] * (g - dbeta[j] / n - xh * dgamma[j] / n); if (dres) dres[o] = g; }
+}
+
+/* Encoder: 13 layers. Parameters packed per layer: kernel [K][cin][cout], gamma [cout], beta [cout] (in that order).
+ * Forward to stride 16, global max pool per batch item, loss = sum(pool * gpool); backward to all parameter gradients.
+ * Returns the loss; pooled [nbatch][128]; grads packed like the parameters. threads <= 0 keeps the OpenMP default. */
+double irx_oracle_encoder_fwd_bwd(const int32_t* coords, const float* feats, int n, int c0, int nbatch, const float* params,
+                                  const float* gpool, float* pooled, float* grads, int threads) {
+  if (threads > 0) omp_set_num_threads(threads);
+  static const int CO[13] = {32, 64, 64, 64, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+  static const int DOWN[13] = {0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0};
+  static const int RES[13] = {-1, -1, -1, 1, -1, -1, 4, -1, -1, 7, -1, -1, 10};
+  const int32_t* lc[5]; int ln[5]; int32_t* own[5] = {0};
+  lc[0] = coords; ln[0] = n;
+  for (int l = 1; l < 5; ++l) { ln[l] = downsample(lc[l - 1], ln[l - 1], 2 << (l - 1), &own[l]); lc[l] = own[l]; }
+  kmap m27[5], m8[5];
+  for (int l = 0; l < 5; ++l) m27[l] = km_build(lc[l], ln[l], lc[l], ln[l], 3, 1 << l);
+  for (int l = 1; l < 5; ++l) m8[l] = km_build(lc[l - 1], ln[l - 1], lc[l], ln[l], 2, 1 << (l - 1));
+  float *X[13], *C[13], *Y[13], *MU[13], *IS[13]; const float* W[13]; const float* G[13]; const float* B[13]; float* DW[13]; float* DG[13]; float* DB[13];
+  int lev[13], cin[13]; size_t off = 0; int level = 0, ci = c0;
+  for (int i = 0; i < 13; ++i) {
+    if (DOWN[i]) ++level; lev[i] = level; cin[i] = ci; int K = DOWN[i] ? 8 : 27;
+    W[i] = params + off; DW[i] = grads + off; off += (size_t)K * ci * CO[i];
+    G[i] = params + off; DG[i] = grads + off; off += CO[i]; B[i] = params + off; DB[i] = grads + off; off += CO[i]; ci = CO[i];
+  }
+  const float* x = feats;
+  for (int i = 0; i < 13; ++i) {
+    int no = ln[lev[i]], co = CO[i]; const kmap* m = DOWN[i] ? &m8[lev[i]] : &m27[lev[i]];
+    C[i] = (float*)malloc((size_t)no * co * 4); Y[i] = (float*)malloc((size_t)no * co * 4); MU[i] = (float*)malloc(co * 4); IS[i] = (float*)malloc(co * 4);
+    X[i] = (float*)x;
+    conv_fwd(x, W[i], m, cin[i], co, no, C[i]);
+    bn_fwd(C[i], no, co, G[i], B[i], RES[i] >= 0 ? Y[RES[i]] : 0, Y[i], MU[i], IS[i]);
+    x = Y[i];
+  }
+  /* global max pool + loss */
+  int n4 = ln[4]; int* arg = (int*)malloc((size_t)nbatch * 128 * sizeof(int)); double loss = 0;
+  for (int b = 0; b < nbatch; ++b) for (int j = 0; j < 128; ++j) { pooled[b * 128 + j] = 0.f; arg[b * 128 + j] = -1; }
+  for (int i = 0; i < n4; ++i) { int b = lc[4][4 * i + 3]; for (int j = 0; j < 128; ++j) { float v = Y[12][(size_t)i * 128 + j]; int* a = &arg[b * 128 + j]; if (*a < 0 || v > pooled[b * 128 + j]) { pooled[b * 128 + j] = v; *a = i; } } }
+  for (int i = 0; i < nbatch * 128; ++i) loss += (double)pooled[i] * gpool[i];
+  /* backward */
+  float* gy[13]; for (int i = 0; i < 13; ++i) gy[i] = 0;
+  gy[12] = (float*)calloc((size_t)n4 * 128, 4);
+  for (int b = 0; b < nbatch; ++b) for (int j = 0; j < 128; ++j) if (arg[b * 128 + j] >= 0) gy[12][(size_t)arg[b * 128 + j] * 128 + j] = gpool[b * 128 + j];
+  for (int i = 12; i >= 0; --i) {
+    int no = ln[lev[i]], co = CO[i], ni = (i == 0) ? n : ln[lev[i - 1]]; const kmap* m = DOWN[i] ? &m8[lev[i]] : &m27[lev[i]];
+    float* dc = (float*)malloc((size_t)no * co * 4); float* dres = RES[i] >= 0 ? (float*)malloc((size_t)no * co * 4) : 0;
+    bn_bwd(C[i], Y[i], gy[i], no, co, G[i], MU[i], IS[i], dc, DG[i], DB[i], dres);
+    if (dres) gy[RES[i]] = dres;
+    float* dx = (i > 0) ? (float*)malloc((size_t)ni * cin[i] * 4) : 0;
+    conv_bwd(X[i], W[i], dc, m, cin[i], co, ni, dx, DW[i]);
+    if (i > 0) { if (gy[i - 1]) { size_t t = (size_t)ni * cin[i]; for (size_t q = 0; q < t; ++q) gy[i - 1][q] += dx[q]; free(dx); } else gy[i - 1] = dx; }
+    free(dc); free(gy[i]);
+  }
+  for (int i = 0; i < 13; ++i) { free(C[i]); free(Y[i]); free(MU[i]); free(IS[i]); }
+  for (int l = 0; l < 5; ++l) km_free(&m27[l]);
+  for (int l = 1; l < 5; ++l) { km_free(&m8[l]); free(own[l]); }
+  free(arg);
+  return loss;
+}
+
+/* number of packed parameter floats for input width c0 */
+long irx_oracle_encoder_param_count(int c0) {
+  static const int CO[13] = {32, 64, 64, 64, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+  static const int DOWN[13] = {0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0};
+  long off = 0; int ci = c0;
+  for (int i = 0; i < 13; ++i) { off += (long)(DOWN[i] ? 8 : 27) * ci * CO[i] + 2 * CO[i]; ci = CO[i]; }
+  return off;
+}

@@ -78,3 +78,35 @@ def test_oracle_conv_k3_vs_dense():
 
 def test_oracle_conv_k2s2_vs_dense():
     _dense_conv_check(2, 2, 6, 4, 2)
+
+
+def test_c_openmp_port_matches_python_oracle():
+    """oracle/csrc/spconv_cpu.c (the C/OpenMP CPU baseline) vs the CPU-PyTorch oracle encoder: pooled features and every
+    parameter gradient of a SparseConvEncoder + GlobalMaxPooling forward/backward."""
+    import oracle.torchsparse.nn as ospnn
+    from oracle import cpu_port
+    from oracle.model_ref import SparseConvEncoder
+    rng = np.random.default_rng(11)
+    clouds = [surface_cloud(rng, 1500, rng.uniform(-1, 1, 3), rng.uniform(0.5, 1.2, 3)) for _ in range(3)]
+    o = oracle_batch(clouds, 0.05)
+    torch.manual_seed(3)
+    enc = SparseConvEncoder(7).train()
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.2, 0.2)
+    g = torch.randn(3, 128)
+    pooled = ospnn.GlobalMaxPooling()(enc(o))
+    loss = (pooled * g).sum()
+    loss.backward()
+    params, order = cpu_port.pack_encoder_params(enc.state_dict(), "")
+    closs, cpooled, cgrads = cpu_port.encoder_fwd_bwd(o.C.numpy(), o.F.numpy(), 3, params, g.numpy(), threads=4)
+    assert abs(closs - float(loss)) <= 1e-4 * max(1.0, abs(float(loss)))
+    assert np.abs(cpooled - pooled.detach().numpy()).max() <= 1e-4
+    off = 0
+    named = dict(enc.named_parameters())
+    for conv, bn in order:
+        for name in (conv + ".kernel", bn + ".weight", bn + ".bias"):
+            ref = named[name].grad.numpy().reshape(-1)
+            got = cgrads[off:off + ref.size]
+            off += ref.size
+            assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), name
