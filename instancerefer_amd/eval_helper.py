@@ -35,7 +35,8 @@ def get_eval(data_dict, config):
         lmax = max(counts[i] for i in scored)
         rows = np.concatenate([np.full(counts[i], r) for r, i in enumerate(scored)])
         cols = np.concatenate([np.arange(counts[i]) for i in scored])
-        flat = torch.from_numpy(rows * lmax + cols).to(dev)
+        from .data import idx_tensor
+        flat = idx_tensor(rows * lmax + cols, dev)
         pad = torch.full((len(scored) * lmax,), float("-inf"), device=dev, dtype=score.dtype).index_put((flat,), score)
         labels = torch.cat([torch.as_tensor(data_dict['cluster_label'][i], device=dev).float() for i in scored])
         lpad = torch.full((len(scored) * lmax,), float("-inf"), device=dev).index_put((flat,), labels)

@@ -173,16 +173,17 @@ def get_loss(data_dict, config):
                 cols.append(np.arange(n))
                 keep.append(1.0 if seg.max() >= 0.2 else 0.0)
                 srow += 1
-        label_dev = torch.from_numpy(label_all).to(dev, non_blocking=True)
+        from .data import idx_tensor
+        label_dev = idx_tensor(label_all, dev, torch.float32)
         cluster_label = [label_dev[starts[i]:starts[i + 1]] if counts[i] else [] for i in range(batch_size)]
         if srow == 0:
             ref_loss = torch.zeros(1, device=dev)
         else:
             scored = np.concatenate([np.arange(starts[i], starts[i + 1]) for i in range(batch_size) if counts[i] >= 2])
             lmax = max(c for c in counts if c >= 2)
-            flat = torch.from_numpy(np.concatenate(rows) * lmax + np.concatenate(cols)).to(dev, non_blocking=True)
-            lab = label_dev.index_select(0, torch.from_numpy(scored).to(dev, non_blocking=True))
-            keep_dev = torch.tensor(keep, dtype=torch.float32, device=dev)
+            flat = idx_tensor(np.concatenate(rows) * lmax + np.concatenate(cols), dev)
+            lab = label_dev.index_select(0, idx_tensor(scored, dev))
+            keep_dev = idx_tensor(np.asarray(keep, np.float32), dev, torch.float32)
             score = (data_dict['attribute_scores'] + data_dict['relation_scores'] + data_dict['scene_scores']) * gamma
             sim = torch.zeros(srow * lmax, dtype=score.dtype, device=dev).index_put((flat,), score * lab).view(srow, lmax).sum(1)
             neg = torch.full((srow * lmax,), float("-inf"), dtype=score.dtype, device=dev).index_put(
