@@ -9,7 +9,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(CSRC, "libirx.so")
+LIB_PATH = os.environ.get("IRX_LIB_PATH") or os.path.join(CSRC, "libirx.so")   # override: dev-only instrumented builds
 SOURCES = ["irx_coords.hip", "irx_spconv.hip", "irx_spconv2.hip", "irx_pairs.hip", "irx_stem.hip", "irx_norm.hip", "irx_pool.hip", "irx_gru.hip", "irx_optim.hip"]
 HEADERS = ["irx_common.h", os.path.join("..", "..", "include", "irx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -28,6 +28,8 @@ def _stale() -> bool:
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 and link csrc/libirx.so. Returns the library path."""
+    if os.environ.get("IRX_LIB_PATH"):
+        return LIB_PATH                # a hand-built variant: never rebuilt here
     if not force and not _stale():
         return LIB_PATH
     import fcntl

@@ -309,10 +309,10 @@ extern "C" int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr
       irx_set_error("irx_spconv_fwd: workspace %zu < %zu", workspace_bytes, need);
       return IRX_ERR_WORKSPACE;
     }
-    int rc = irx_permute_w_launch(w, K, cin, cout, trans_w, (float*)workspace, S(stream));
-    if (rc) return rc;
     const int splits = irx_spconv2_splits(n_out, K);
     float* slabs = (float*)((char*)workspace + fwd_ws_weights(K, cin, cout));
+    int rc = irx_permute_w_launch(w, K, cin, cout, trans_w, (float*)workspace, S(stream));
+    if (rc) return rc;
     rc = irx_spconv2_launch(x, (const float*)workspace, nbr, ld, n_out, K, cin, cout, flip_k,
                             splits > 1 ? slabs : y, splits, S(stream));
     if (rc) return rc;

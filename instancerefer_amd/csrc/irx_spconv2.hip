@@ -18,11 +18,27 @@
 //   pairs are the MFMA reduction dimension; per (row split, offset) partial sums, deterministic reduction.
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "irx_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define S2_TM 64
+
+// Dev-only per-phase cycle attribution of k_spconv2 (tools/conv_phase_prof.py builds a -DIRX_S2_PROF variant).
+#ifdef IRX_S2_PROF
+__device__ unsigned long long g_s2_prof[16];
+extern "C" int irx_debug_s2_prof(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_s2_prof), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s2_prof), 16 * 8);
+}
+#define S2_TICK(i) do { const long long t_ = clock64(); prof[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define S2_TICK(i) do { } while (0)
+#endif
 
 struct PairList {
   int in_of_pair;   // lane p holds the input row of pair p (p < v)
@@ -66,20 +82,118 @@ __device__ static inline int compact_to_lds(const int* __restrict__ col, int lan
   return base;
 }
 
+// One 16-pair group of the current item for this wave's channel slice: A fragments from the LDS tile, weights from
+// VGPRs, result added into the LDS output tile.  PREFETCH = the global loads of a LATER item (weight slice + gathered
+// rows) are issued from inside the MFMA chain, a few per MFMA block: the vector-memory pipe (~50 B/clk/CU) needs
+// ~0.4 us per workgroup-item just to ACCEPT the 24 KiB a wave requests, and a wave that issues them back to back sits
+// in that queue instead of feeding the MFMA pipe (measured: 34 % of all wave cycles).  The prefetch loads are
+// UNCONDITIONAL (padded pairs re-read row `nrow` = a valid row; their results go to the dump row), so every chain
+// issues exactly NJ * (NT + 1) loads and the consumer can wait with an exact s_waitcnt vmcnt(n).
+template <int CIN, int COUT, int NJ, int NT, int LDA, int LDO, bool PREFETCH>
+__device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __restrict__ sOut,
+                                         const unsigned char* __restrict__ lrow, int g, int vs, int m, int g4,
+                                         int n_base, const float4 (&wc)[NJ][NT], float4 (&wx)[NJ][NT],
+                                         float4 (&sx)[NJ], const int (&nrow)[NJ], const float* __restrict__ x, int c4,
+                                         const float* __restrict__ wnk) {
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* pa = &sA[(16 * g + m) * LDA + 4 * g4];
+  int orow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) orow[r] = lrow[(16 * g + 4 * g4 + r) & 63];
+  float4 a_nxt = *reinterpret_cast<const float4*>(pa);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const float4 a4 = a_nxt;                       // fragment j was requested one step ago
+    if (j + 1 < NJ) a_nxt = *reinterpret_cast<const float4*>(pa + 16 * (j + 1));
+    if (PREFETCH) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wx[j][t] = *reinterpret_cast<const float4*>(wnk + (size_t)(j * NT + t) * 256);
+      sx[j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
+    }
+    // alternate the accumulators so consecutive MFMAs never depend on each other
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wc[j][t].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wc[j][t].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wc[j][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wc[j][t].w, acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);             // keep this step's loads between the MFMA blocks
+  }
+  // D layout: col = lane&15, row = (lane>>4)*4 + r -> pair 16g + 4*g4 + r.  Branch-free, batched read-modify-write:
+  // padded pairs go to the dump row (row 64); this wave owns its channel slice, so there is no race.
+  float o[4][NT];
+  int oaddr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = (16 * g + 4 * g4 + r < vs) ? orow[r] : 64;
+    oaddr[r] = row * LDO + n_base + m;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o[r][t] = sOut[oaddr[r] + 16 * t];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sOut[oaddr[r] + 16 * t] = o[r][t] + acc[t][r];
+}
+
+// Pop the lowest active offset of the mask: kq = offset (or -1 past the end), vq = its pair count, kl = last real offset.
+__device__ __forceinline__ void s2_next_offset(unsigned& act, const int* __restrict__ sCnt, int& kq, int& vq, int& kl) {
+  if (act) {
+    kq = __builtin_ctz(act);
+    act &= act - 1;
+    vq = __builtin_amdgcn_readfirstlane(sCnt[kq]);
+    kl = kq;
+  } else {
+    kq = -1;
+    vq = 0;
+  }
+}
+
+// This lane's input rows of item (kl, vq), one per gather pass; padded pairs re-read row 0.
+template <int NIT, int PPP>
+__device__ __forceinline__ void s2_gather_rows(const int* __restrict__ list, int pbase, int vq, int (&nrow)[NIT]) {
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int p = pbase + it * PPP;                // < 64: always inside the list (entries >= vq are stale, unused)
+    const int r = list[p];
+    nrow[it] = (p < vq) ? r : 0;
+  }
+}
+
+// s_waitcnt vmcnt(n) with expcnt / lgkmcnt untouched (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4)
+template <int N>
+__device__ __forceinline__ void s2_wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
 // wn: FRAGMENT-MAJOR weights [K][NCS][NJ][NT][64 lanes][4]: element i of lane l holds
 //     W[k][c = 16j + 4(l>>4) + i][n = cs*16*NT + 16t + (l&15)]   (k_permute_w builds it from Conv3d.kernel),
 // so each wave-level weight load is one contiguous, fully coalesced 1 KiB read.
-// TM = output rows per workgroup (64 or 128). Work items are (offset, stage of <= 64 compacted pairs); the weight slice
-// is (re)loaded only when the offset changes, so a 128-row tile streams half the weight bytes per useful FLOP.
-// Software pipeline per workgroup: the tile's whole table column block ([K][TM] ints) is fetched into LDS once; for
-// every item the gathered rows are staged global -> VGPR -> LDS, and the NEXT item's gather (and, on an offset change,
-// weight-slice) loads are issued before the current item's MFMA phase, so HBM/L2 latency hides behind the MFMAs.
-template <int CIN, int COUT, int TM>
-__global__ __launch_bounds__(256, (TM == 128 && COUT == 128) ? 1 : 2)
+// Workgroup = 64 output rows.
+//   setup : the four waves compact the tile's table columns (lane == output row; ballot + prefix popcount) into the
+//           SHARED pair lists sIn[k][p] (input row) / sRow[k][p] (tile-local output row) and counts sCnt[k]; the set of
+//           active offsets is a 27-bit mask in SGPRs.
+//   items : the active offsets in order (<= 64 pairs each).  Per item: the rows gathered for it (prefetched into
+//           VGPRs DEPTH items ago) are written to the LDS A tile, then the MFMA groups run from VGPR-stationary weights
+//           while the loads of item i + DEPTH are issued from inside the first group's MFMA chain.
+//   DEPTH : 1 for Cin = 128 (two 64-VGPR weight sets), 2 for Cin <= 64 where an item's MFMA chain (~0.5-1 k cycles)
+//           is shorter than the L2 latency (measured before: 30 % of the 64->64 wave cycles waiting in vmcnt(0)).
+// Register discipline: the item loop is unrolled DEPTH + 1 times so that every register set is a compile-time name
+// (no copies), and the explicit exact vmcnt tells the compiler's waitcnt pass that nothing consumed is pending.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2)
 void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const int32_t* __restrict__ nbr, int ld,
-               int n_out, int K, int flip_k, float* __restrict__ y, int dbg, int k_per_split) {
+               int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split) {
   // blockIdx.y = offset split: this workgroup handles offsets [kb, ke) and writes its partial tile to slab
   // blockIdx.y of y (slabs are summed by k_wgrad_reduce; a single split writes the result directly).
+  constexpr int TM = S2_TM;
   const int kb = blockIdx.y * k_per_split;
   const int ke = (kb + k_per_split < K) ? kb + k_per_split : K;
   y += (size_t)blockIdx.y * n_out * COUT;
@@ -87,151 +201,174 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   constexpr int NCS = COUT / (16 * NT);           // channel slices (waves along N)
   constexpr int NGP = 4 / NCS;                    // waves along the pair-group dimension
   constexpr int LDA = CIN + 4;
-  constexpr int LDO = COUT + 4;                  // row stride = 4 banks: two rows of a half-wave collide only if equal mod 8
+  constexpr int LDO = COUT + 4;
   constexpr int LPR = CIN / 4;                    // lanes (float4) per gathered row
   constexpr int PPI = 64 / LPR;                   // pairs per wave-instruction
   constexpr int PPP = 4 * PPI;                    // pairs per workgroup pass
-  constexpr int NIT = 64 / PPP;                   // gather passes for a full 64-pair stage
+  constexpr int NIT = 64 / PPP;                   // gather passes for a full 64-pair item
   constexpr int NJ = CIN / 16;
   constexpr int KMAX = 27;
+  constexpr int DEPTH = (CIN >= 128) ? 1 : 2;     // items of prefetch distance
+  constexpr int NS = DEPTH + 1;                   // register sets
+  constexpr int LPC = NJ * (NT + 1);              // loads per prefetch chain (exact)
   static_assert(NCS * NGP == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float sOut[TM * LDO];
+  static_assert(NIT == NJ, "one gather pass per MFMA k-step");
+  __shared__ __attribute__((aligned(16))) float sOut[(TM + 1) * LDO];   // + dump row for padded pairs
   __shared__ __attribute__((aligned(16))) float sA[64 * LDA];
-  __shared__ int sTbl[KMAX * TM];
-  __shared__ int sList[4][2][2][TM];              // [wave][parity][in|row][pair]
+  __shared__ int sIn[KMAX * TM];
+  __shared__ unsigned char sRow[KMAX * TM];
+  __shared__ int sCnt[32];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: branches on it are uniform for the compiler too
   const int m = lane & 15, g4 = lane >> 4;
   const int cs = wave % NCS, gp = wave / NCS;
   const int n_base = cs * 16 * NT;
   const int q0 = blockIdx.x * TM;
   const int sub = lane / LPR;                     // which of the PPI pairs of a pass this lane serves
   const int c4 = (lane % LPR) * 4;
-  const int pbase = wave * PPI + sub;             // this lane's stage-local pair in pass 0
+  const int pbase = wave * PPI + sub;             // this lane's item-local pair in pass 0
 
-  for (int i = tid + kb * TM; i < ke * TM; i += 256) {
-    const int k = i / TM, r = i % TM;
-    const int kt = flip_k ? (K - 1 - k) : k;
-    sTbl[i] = (q0 + r < n_out) ? nbr[(size_t)kt * ld + q0 + r] : -1;
-  }
-  for (int i = tid; i < TM * LDO; i += 256) sOut[i] = 0.f;
-  __syncthreads();
-
-  // ---- find the first active offset and issue its loads ----
-  K = ke;
-  int k = kb, v = 0, par = 0, p0 = 0;
-  for (; k < K; ++k) {
-    v = compact_to_lds<TM>(&sTbl[k * TM], lane, sList[wave][par][0], sList[wave][par][1]);
-    if (v) break;
-  }
-  float4 stage[NIT];
-  float4 wreg[NJ][NT];
-  if (k < K) {
-    const int npass = ((v < 64 ? v : 64) + PPP - 1) / PPP;
+  // ---- setup: compact the table columns (wave w takes offsets kb + w, kb + w + 4, ...) ----
+  {
+    constexpr int KPW = (KMAX + 3) / 4;
+    int my[KPW];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < npass) {
-        const int p = pbase + it * PPP;
-        if (p < v && !(dbg & 2)) stage[it] = *reinterpret_cast<const float4*>(x + (size_t)sList[wave][par][0][p] * CIN + c4);
+    for (int i = 0; i < KPW; ++i) {
+      const int k = kb + wave + 4 * i;
+      const int kt = flip_k ? (K - 1 - k) : k;
+      my[i] = (k < ke && q0 + lane < n_out) ? nbr[(size_t)kt * ld + q0 + lane] : -1;
+    }
+    if (tid < 32) sCnt[tid] = 0;
+    for (int i = tid; i < (TM + 1) * LDO; i += 256) sOut[i] = 0.f;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+      const int k = kb + wave + 4 * i;
+      if (k < ke) {
+        const unsigned long long valid = __ballot(my[i] >= 0);
+        if (my[i] >= 0) {
+          const int dst = __popcll(valid & lt);
+          sIn[k * TM + dst] = my[i];
+          sRow[k * TM + dst] = (unsigned char)lane;
+        }
+        if (lane == 0) sCnt[k] = __popcll(valid);
       }
     }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        wreg[j][t] = *reinterpret_cast<const float4*>(
-            wn + (((((size_t)k * NCS + cs) * NJ + j) * NT + t) * 64 + lane) * 4);
+  }
+  __syncthreads();
+  // active offsets of [kb, ke) as a bit mask (wave-uniform, in SGPRs)
+  unsigned act;
+  {
+    const int c = (lane < 32) ? sCnt[lane] : 0;
+    act = (unsigned)__ballot(c > 0);
   }
 
-  while (k < K) {
-    int vs = v - p0;                               // pairs of this stage
-    if (vs > 64) vs = 64;
+  // ---- register sets and the prologue.  Sets are only ever indexed by compile-time constants (integral_constant
+  // arguments of the generic lambdas below): a run-time choice of set would demote the arrays to scratch memory. ----
+  float4 W[3][NJ][NT], S[3][NJ];
+  int kk[3] = {-1, -1, -1}, vv[3] = {0, 0, 0};     // offset / pair count of the item living in each set
+  // the item whose loads are issued next: offset kq, pair count vq (kq = -1: past the end -> dummy loads of offset kl)
+  int kq, vq, kl = kb;
+  auto issue = [&](auto T_) __attribute__((always_inline)) {   // prologue: plain back-to-back issue into set T
+    constexpr int T = decltype(T_)::value;
+    s2_next_offset(act, sCnt, kq, vq, kl);
+    kk[T] = kq;
+    vv[T] = vq;
+    int nrow[NJ];
+    s2_gather_rows<NIT, PPP>(sIn + kl * TM, pbase, vq, nrow);
+    const float* wnk = wn + ((((size_t)kl * NCS + cs) * NJ) * NT * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) W[T][j][t] = *reinterpret_cast<const float4*>(wnk + (size_t)(j * NT + t) * 256);
+      S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  issue(I0{});
+  if (DEPTH == 2) issue(I1{});
+#ifdef IRX_S2_PROF
+  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+  const long long tstart = tlast;
+#endif
+
+  // One item: consumes register set C, prefetches item i + DEPTH into register set T.
+  auto item = [&](auto C_, auto T_) __attribute__((always_inline)) {
+    constexpr int C = decltype(C_)::value, T = decltype(T_)::value;
+    S2_TICK(0);
+    const int k = kk[C], vs = vv[C];
     const int vpad = (vs + 15) & ~15;
     const int npass = (vpad + PPP - 1) / PPP;      // block-uniform
     __syncthreads();                               // previous item's fragment reads are done
+    S2_TICK(1);
+    s2_wait_vmcnt<(DEPTH - 1) * LPC>();            // this item's rows + weights have landed (later items may be in flight)
+    S2_TICK(2);
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
-      if (it < npass) *reinterpret_cast<float4*>(&sA[(pbase + it * PPP) * LDA + c4]) = stage[it];
+      if (it < npass)                              // (component-wise: a struct copy out of S[][] keeps the sets in scratch)
+        *reinterpret_cast<float4*>(&sA[(pbase + it * PPP) * LDA + c4]) =
+            make_float4(S[C][it].x, S[C][it].y, S[C][it].z, S[C][it].w);
+    S2_TICK(3);
     __syncthreads();
-    // ---- look ahead: next item = next stage of this offset, else the next active offset ----
-    int kn = k, vn = v, p0n = p0 + 64, parn = par;
-    if (TM == 64 || p0n >= v) {
-      p0n = 0;
-      parn = par ^ 1;
-      vn = 0;
-      for (kn = k + 1; kn < K; ++kn) {
-        vn = compact_to_lds<TM>(&sTbl[kn * TM], lane, sList[wave][parn][0], sList[wave][parn][1]);
-        if (vn) break;
-      }
-    }
-    float4 wnext[NJ][NT];
-    if (kn < K) {
-      int vsn = vn - p0n;
-      if (vsn > 64) vsn = 64;
-      const int npn = (vsn + PPP - 1) / PPP;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (it < npn) {
-          const int p = pbase + it * PPP;
-          if (p < vsn && !(dbg & 2))
-            stage[it] = *reinterpret_cast<const float4*>(x + (size_t)sList[wave][parn][0][p0n + p] * CIN + c4);
-        }
-      }
-      if (kn != k) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            wnext[j][t] = (dbg & 4) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(
-                wn + (((((size_t)kn * NCS + cs) * NJ + j) * NT + t) * 64 + lane) * 4);
-      }
-    }
+    S2_TICK(4);
+    // ---- the item to prefetch ----
+    s2_next_offset(act, sCnt, kq, vq, kl);
+    kk[T] = kq;
+    vv[T] = vq;
+    int nrow[NJ];
+    s2_gather_rows<NIT, PPP>(sIn + kl * TM, pbase, vq, nrow);
+    const float* wnk = wn + ((((size_t)kl * NCS + cs) * NJ) * NT * 64 + lane) * 4;
+    S2_TICK(5);
     // ---- MFMA over dense 16-pair groups; this wave's channel slice ----
-    const int* lrow = sList[wave][par][1] + p0;
-    for (int g = gp; g * 16 < vpad && !(dbg & 1); g += NGP) {
-      f32x4 acc[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const float* pa = &sA[(16 * g + m) * LDA + 4 * g4];
-      int orow[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) orow[r] = lrow[(16 * g + 4 * g4 + r) & 63];
+    const unsigned char* lrow = sRow + k * TM;
+    int g = gp;
+    if (NGP == 1 || g * 16 < vpad) {
+      s2_group<CIN, COUT, NJ, NT, LDA, LDO, true>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T], S[T], nrow, x, c4,
+                                                  wnk);
+      for (g += NGP; g * 16 < vpad; g += NGP)
+        s2_group<CIN, COUT, NJ, NT, LDA, LDO, false>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T], S[T], nrow, x,
+                                                     c4, wnk);
+    } else {                                       // a wave without a group in this item still prefetches its share
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const float4 a4 = *reinterpret_cast<const float4*>(pa + 16 * j);
-        // alternate the accumulators so consecutive MFMAs never depend on each other
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wreg[j][t].x, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wreg[j][t].y, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wreg[j][t].z, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wreg[j][t].w, acc[t], 0, 0, 0);
-      }
-      // D layout: col = lane&15, row = (lane>>4)*4 + r  -> stage pair 16g + 4*g4 + r
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (16 * g + 4 * g4 + r < vs && !(dbg & 8)) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            sOut[orow[r] * LDO + n_base + 16 * t + m] += acc[t][r];   // this wave owns the channel slice: no race
-        }
+        for (int t = 0; t < NT; ++t) W[T][j][t] = *reinterpret_cast<const float4*>(wnk + (size_t)(j * NT + t) * 256);
+        S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
       }
     }
-    if (kn < K && kn != k) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) wreg[j][t] = wnext[j][t];
+    S2_TICK(6);
+  };
+  if (kk[0] >= 0) {
+    if (DEPTH == 1) {
+      while (true) {
+        item(I0{}, I1{});
+        if (kk[1] < 0) break;
+        item(I1{}, I0{});
+        if (kk[0] < 0) break;
+      }
+    } else {
+      while (true) {
+        item(I0{}, I2{});
+        if (kk[1] < 0) break;
+        item(I1{}, I0{});
+        if (kk[2] < 0) break;
+        item(I2{}, I1{});
+        if (kk[0] < 0) break;
+      }
     }
-    k = kn;
-    v = vn;
-    p0 = p0n;
-    par = parn;
   }
+#ifdef IRX_S2_PROF
+  if (lane == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_s2_prof[i], (unsigned long long)prof[i]);
+    atomicAdd(&g_s2_prof[8], (unsigned long long)(clock64() - tstart));
+    atomicAdd(&g_s2_prof[9], 1ull);
+  }
+#endif
   __syncthreads();
   // ---- write the tile: COUT/4 float4 per row ----
   constexpr int F4 = COUT / 4;
@@ -370,24 +507,19 @@ bool irx_spconv2_supported(int cin, int cout) {
   return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128);
 }
 
-template <int CIN, int TM>
+template <int CIN>
 static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
                         int ld, int n_out, int K, int flip_k, float* y, int kps) {
-  static const int dbg = getenv("IRX_SPCONV_DBG") ? atoi(getenv("IRX_SPCONV_DBG")) : 0;
-  if (cout == 128) k_spconv2<CIN, 128, TM><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
-  else if (cout == 64) k_spconv2<CIN, 64, TM><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
-  else k_spconv2<CIN, 32, TM><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, dbg, kps);
+  if (cout == 128) k_spconv2<CIN, 128><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+  else if (cout == 64) k_spconv2<CIN, 64><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+  else k_spconv2<CIN, 32><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps);
 }
 
-// wn must already be fragment-major (irx_permute_w_launch).
-// Output rows per workgroup. 128-row tiles stream half the weight bytes per useful FLOP, but MEASURED SLOWER on
-// MI355X (N = 81 k, 128->128: 498 vs 441 us; 64->64: 431 vs 364 us): fewer independent workgroups per CU hurts more
-// than the smaller weight stream helps. Default 64; IRX_SPCONV_TM=128 selects the variant for experiments.
+// Output rows per workgroup: 64.  (128-row tiles stream half the weight bytes per useful FLOP but MEASURED SLOWER on
+// MI355X -- N = 81 k, 128->128: 498 vs 441 us -- one resident workgroup per CU leaves nothing to overlap with.)
 int irx_spconv2_tile(int n_out) {
-  static const char* e = getenv("IRX_SPCONV_TM");
   (void)n_out;
-  if (e) return atoi(e) == 128 ? 128 : 64;
-  return 64;
+  return S2_TM;
 }
 
 // Offset splits for latency-bound (small) layers: a tile's 27 offsets form a serial chain of ~4 us each, so
@@ -408,18 +540,11 @@ int irx_spconv2_splits(int n_out, int K) {
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
                        int cout, int flip_k, float* y, int splits, hipStream_t st) {
   IRX_REQUIRE(K <= 27, "irx_spconv_fwd: K = %d > 27 unsupported by the fast path", K);
-  const int tm = irx_spconv2_tile(n_out);
-  dim3 grid(irx_cdiv(n_out, tm), splits);
+  dim3 grid(irx_cdiv(n_out, S2_TM), splits);
   const int kps = irx_cdiv(K, splits);
-  if (tm == 128) {
-    if (cin == 128) launch_fwd2<128, 128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-    else if (cin == 64) launch_fwd2<64, 128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-    else launch_fwd2<32, 128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-  } else {
-    if (cin == 128) launch_fwd2<128, 64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-    else if (cin == 64) launch_fwd2<64, 64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-    else launch_fwd2<32, 64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-  }
+  if (cin == 128) launch_fwd2<128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+  else if (cin == 64) launch_fwd2<64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+  else launch_fwd2<32>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(v2)");
   return IRX_OK;
 }
