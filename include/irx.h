@@ -202,6 +202,35 @@ int irx_bn_backward(const float* x, const float* y, const float* dy, int n, int 
                     float* dx, float* dgamma, float* dbeta, float* dresidual, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* ---- whole-encoder executor ------------------------------------------------------------
+ * SparseConvEncoder.forward / BEVEncoder.forward (models/basic_blocks.py:59-95,136-171) and their backward as ONE
+ * call per direction: for every layer  c = conv(x);  (mean, invstd) = stats(c);  y = relu(bn(c) (+ y[res]))  — the
+ * same kernels, in the same order, as the per-layer entry points above (bit-identical results), walked by the host
+ * side of the library instead of the Python caller.
+ *
+ * desc: host array [n_layers][IRX_ENC_NFIELDS] of int64 (sizes, indices and DEVICE pointers cast to int64);
+ * fdesc: host array [n_layers][2] of double = {eps, momentum}.  The caller owns every buffer named in the table. */
+enum {
+  IRX_ENC_K = 0, IRX_ENC_CIN, IRX_ENC_COUT, IRX_ENC_N_IN, IRX_ENC_N_OUT,
+  IRX_ENC_RES,                      /* index of the layer whose OUTPUT is added before the ReLU, or -1 */
+  IRX_ENC_TBL, IRX_ENC_LD,          /* forward table int32 [K][ld]: nbr27 (stride 1) or child (2^3 stride 2) */
+  IRX_ENC_TBL_B, IRX_ENC_LD_B, IRX_ENC_FLIP_B,   /* data-gradient table: same table + flip (stride 1) or child_T */
+  IRX_ENC_PAIR_IN, IRX_ENC_PAIR_OUT, IRX_ENC_PAIR_COUNTS, IRX_ENC_LD_PAIRS,   /* irx_pairs_build lists, or 0 */
+  IRX_ENC_W, IRX_ENC_GAMMA, IRX_ENC_BETA, IRX_ENC_RUNNING_MEAN, IRX_ENC_RUNNING_VAR,
+  IRX_ENC_X, IRX_ENC_C, IRX_ENC_Y,  /* layer input [n_in][cin], conv output and layer output [n_out][cout] */
+  IRX_ENC_MEAN, IRX_ENC_INVSTD,     /* [cout] each */
+  IRX_ENC_DW, IRX_ENC_DGAMMA, IRX_ENC_DBETA,     /* backward outputs */
+  IRX_ENC_GY,                       /* backward: gradient w.r.t. the layer output [n_out][cout] */
+  IRX_ENC_NFIELDS
+};
+size_t irx_encoder_workspace_bytes(const int64_t* desc, const double* fdesc, int n_layers, int backward);
+int irx_encoder_forward(const int64_t* desc, const double* fdesc, int n_layers, void* workspace,
+                        size_t workspace_bytes, void* stream);
+/* On entry GY of the last layer = d(loss)/d(output). Writes DW/DGAMMA/DBETA of every layer and, when dx0 != NULL,
+ * dx0 [n_in0][cin0]; GY of the other layers and dc_scratch [max n_out*cout] are scratch. */
+int irx_encoder_backward(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch, float* dx0,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- segmented reductions ------------------------------------------------------------- */
 
 /* spnn.GlobalMaxPooling (models/attribute_module.py:20,105) and the `aggr='max'` of

@@ -88,7 +88,11 @@ bool irx_spconv2_supported(int cin, int cout);
 bool irx_spconv2_enabled(char pass);
 int irx_spconv2_splits(int n_out, int K);
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                       int cout, int flip_k, float* y, int splits, hipStream_t st);
+                       int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st);
+// irx_spconv_fwd with gradient accumulation (accumulate != 0: y += result; fast-path channel counts only)
+int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
+                        int flip_k, int trans_w, float* y, int accumulate, void* workspace, size_t workspace_bytes,
+                        void* stream);
 int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st);
 int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
                              int cin, int cout, int splits, int rps, float* part, hipStream_t st);

@@ -1,0 +1,142 @@
+// irx_encoder.hip — whole-encoder executor: the 13 Conv3d -> BatchNorm (-> + residual) -> ReLU groups of
+// SparseConvEncoder / BEVEncoder (reference models/basic_blocks.py:59-95,136-171) issued by ONE C-ABI call per direction.
+//
+// The Python executor (one ctypes call + ~2 tensor allocations per kernel) cost ~0.55 ms forward and ~0.9 ms backward
+// per encoder of pure host time; with the step host-bound at ~14 ms that was ~20 % of it.  Here the host walks a
+// descriptor table and launches the same kernels in the same order (results are bit-identical to the per-layer
+// C-ABI calls); the caller owns every buffer (one activation / gradient arena) and the workspace.
+#include "irx_common.h"
+#include "../../include/irx.h"
+
+static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+namespace {
+struct Layer {
+  int K, cin, cout, n_in, n_out, res;
+  const int32_t* tbl; int ld;
+  const int32_t* tbl_b; int ld_b, flip_b;
+  const int32_t *pair_in, *pair_out, *pair_counts; int ld_pairs;
+  const float *w, *gamma, *beta; float *running_mean, *running_var;
+  float *x, *c, *y, *mean, *invstd;
+  float *dw, *dgamma, *dbeta, *gy;
+  float eps, momentum;
+};
+
+Layer unpack(const int64_t* d, const double* f) {
+  Layer L;
+  L.K = (int)d[IRX_ENC_K]; L.cin = (int)d[IRX_ENC_CIN]; L.cout = (int)d[IRX_ENC_COUT];
+  L.n_in = (int)d[IRX_ENC_N_IN]; L.n_out = (int)d[IRX_ENC_N_OUT]; L.res = (int)d[IRX_ENC_RES];
+  L.tbl = (const int32_t*)d[IRX_ENC_TBL]; L.ld = (int)d[IRX_ENC_LD];
+  L.tbl_b = (const int32_t*)d[IRX_ENC_TBL_B]; L.ld_b = (int)d[IRX_ENC_LD_B]; L.flip_b = (int)d[IRX_ENC_FLIP_B];
+  L.pair_in = (const int32_t*)d[IRX_ENC_PAIR_IN]; L.pair_out = (const int32_t*)d[IRX_ENC_PAIR_OUT];
+  L.pair_counts = (const int32_t*)d[IRX_ENC_PAIR_COUNTS]; L.ld_pairs = (int)d[IRX_ENC_LD_PAIRS];
+  L.w = (const float*)d[IRX_ENC_W]; L.gamma = (const float*)d[IRX_ENC_GAMMA]; L.beta = (const float*)d[IRX_ENC_BETA];
+  L.running_mean = (float*)d[IRX_ENC_RUNNING_MEAN]; L.running_var = (float*)d[IRX_ENC_RUNNING_VAR];
+  L.x = (float*)d[IRX_ENC_X]; L.c = (float*)d[IRX_ENC_C]; L.y = (float*)d[IRX_ENC_Y];
+  L.mean = (float*)d[IRX_ENC_MEAN]; L.invstd = (float*)d[IRX_ENC_INVSTD];
+  L.dw = (float*)d[IRX_ENC_DW]; L.dgamma = (float*)d[IRX_ENC_DGAMMA]; L.dbeta = (float*)d[IRX_ENC_DBETA];
+  L.gy = (float*)d[IRX_ENC_GY];
+  L.eps = (float)f[0]; L.momentum = (float)f[1];
+  return L;
+}
+
+bool pairs_path(const Layer& L) {
+  auto ok = [](int c) { return c == 32 || c == 64 || c == 128; };
+  return L.pair_in != nullptr && ok(L.cin) && ok(L.cout);
+}
+
+// workspace regions: [conv | wgrad | bn]
+struct Regions { size_t conv, wgrad, bn; };
+Regions regions(const int64_t* desc, const double* fdesc, int n, bool backward) {
+  Regions r = {0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
+    size_t c, b = irx_bn_workspace_bytes(L.n_out, L.cout), wg = 0;
+    if (!backward) {
+      c = irx_spconv_fwd_workspace_bytes(L.n_out, L.K, L.cin, L.cout, 0);
+    } else {
+      c = irx_spconv_fwd_workspace_bytes(L.n_in, L.K, L.cout, L.cin, 1);
+      wg = pairs_path(L) ? irx_spconv_wgrad_pairs_workspace_bytes(L.n_out, L.K, L.cin, L.cout)
+                         : irx_spconv_wgrad_workspace_bytes(L.n_out, L.K, L.cin, L.cout);
+    }
+    if (c > r.conv) r.conv = c;
+    if (wg > r.wgrad) r.wgrad = wg;
+    if (b > r.bn) r.bn = b;
+  }
+  r.conv = align256(r.conv); r.wgrad = align256(r.wgrad); r.bn = align256(r.bn);
+  return r;
+}
+}  // namespace
+
+extern "C" size_t irx_encoder_workspace_bytes(const int64_t* desc, const double* fdesc, int n_layers, int backward) {
+  if (!desc || !fdesc || n_layers <= 0) return 0;
+  const Regions r = regions(desc, fdesc, n_layers, backward != 0);
+  return r.conv + r.wgrad + r.bn + 256;
+}
+
+extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int n_layers, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  IRX_REQUIRE(desc && fdesc && n_layers > 0, "irx_encoder_forward: empty descriptor table");
+  const Regions r = regions(desc, fdesc, n_layers, false);
+  IRX_REQUIRE(workspace && workspace_bytes >= r.conv + r.bn, "irx_encoder_forward: workspace %zu < %zu", workspace_bytes,
+              r.conv + r.bn);
+  char* ws_c = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  char* ws_b = ws_c + r.conv;
+  for (int i = 0; i < n_layers; ++i) {
+    const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
+    IRX_REQUIRE(L.res < i, "irx_encoder_forward: layer %d takes its residual from a later layer", i);
+    int rc = irx_spconv_fwd(L.x, L.w, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, 0, 0, L.c, ws_c, r.conv, stream);
+    if (rc) return rc;
+    rc = irx_bn_stats(L.c, L.n_out, L.cout, L.eps, L.momentum, L.mean, L.invstd, L.running_mean, L.running_var, ws_b,
+                      r.bn, stream);
+    if (rc) return rc;
+    const float* res = nullptr;
+    if (L.res >= 0) res = (const float*)desc[(size_t)L.res * IRX_ENC_NFIELDS + IRX_ENC_Y];
+    rc = irx_bn_apply(L.c, L.n_out, L.cout, L.mean, L.invstd, L.gamma, L.beta, res, 1, L.y, stream);
+    if (rc) return rc;
+  }
+  return IRX_OK;
+}
+
+// gy of the last layer holds d(loss)/d(output) on entry.  On return dw / dgamma / dbeta of every layer are written and,
+// when dx0 != NULL, dx0 [n_in0][cin0] = d(loss)/d(input features).  gy of the other layers is scratch.
+extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch,
+                                    float* dx0, void* workspace, size_t workspace_bytes, void* stream) {
+  IRX_REQUIRE(desc && fdesc && n_layers > 0 && dc_scratch, "irx_encoder_backward: bad arguments");
+  const Regions r = regions(desc, fdesc, n_layers, true);
+  IRX_REQUIRE(workspace && workspace_bytes >= r.conv + r.wgrad + r.bn, "irx_encoder_backward: workspace %zu < %zu",
+              workspace_bytes, r.conv + r.wgrad + r.bn);
+  char* ws_c = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  char* ws_w = ws_c + r.conv;
+  char* ws_b = ws_w + r.wgrad;
+  // a layer whose OUTPUT feeds a later layer's shortcut receives that share (dresidual) first; the main-path
+  // gradient of the layer after it is then accumulated on top
+  bool is_res_source[64] = {false};
+  IRX_REQUIRE(n_layers <= 64, "irx_encoder_backward: more than 64 layers");
+  for (int i = 0; i < n_layers; ++i) {
+    const int res = (int)desc[(size_t)i * IRX_ENC_NFIELDS + IRX_ENC_RES];
+    if (res >= 0) is_res_source[res] = true;
+  }
+  for (int i = n_layers - 1; i >= 0; --i) {
+    const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
+    float* dres = nullptr;
+    if (L.res >= 0) dres = (float*)desc[(size_t)L.res * IRX_ENC_NFIELDS + IRX_ENC_GY];
+    int rc = irx_bn_backward(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, dc_scratch, L.dgamma,
+                             L.dbeta, dres, ws_b, r.bn, stream);
+    if (rc) return rc;
+    if (pairs_path(L))
+      rc = irx_spconv_wgrad_pairs(L.x, dc_scratch, L.pair_in, L.pair_out, L.ld_pairs, L.pair_counts, L.n_out, L.K,
+                                  L.cin, L.cout, L.dw, ws_w, r.wgrad, stream);
+    else
+      rc = irx_spconv_wgrad(L.x, dc_scratch, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, L.dw, ws_w, r.wgrad, stream);
+    if (rc) return rc;
+    float* dx = (i > 0) ? (float*)desc[(size_t)(i - 1) * IRX_ENC_NFIELDS + IRX_ENC_GY] : dx0;
+    if (dx) {
+      const int acc = (i > 0 && is_res_source[i - 1]) ? 1 : 0;
+      rc = irx_spconv_fwd_impl(dc_scratch, L.w, L.tbl_b, L.ld_b, L.n_in, L.K, L.cout, L.cin, L.flip_b, 1, dx, acc, ws_c,
+                               r.conv, stream);
+      if (rc) return rc;
+    }
+  }
+  return IRX_OK;
+}

@@ -15,7 +15,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t elems, float* __restrict__ dw);
+__global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t elems, float* __restrict__ dw,
+                               int accumulate = 0);
 
 #define SC_TM 64  // output rows per workgroup (4 waves x 16 rows)
 #define SC_KC 32  // reduction (input-channel) chunk staged per barrier pair
@@ -258,12 +259,12 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float* __restrict__ 
 }
 
 __global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t elems,
-                               float* __restrict__ dw) {
+                               float* __restrict__ dw, int accumulate) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= elems) return;
   float s = 0.f;
   for (int j = 0; j < S; ++j) s += part[(size_t)j * elems + i];
-  dw[i] = s;
+  dw[i] = accumulate ? dw[i] + s : s;            // (old + sum), the order of the unfused `old.add_(sum)`
 }
 
 // ---------------------------------------------------------------------------- host side -----
@@ -296,12 +297,19 @@ extern "C" size_t irx_spconv_fwd_workspace_bytes(int n_out, int K, int cin, int 
 extern "C" int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr, int ld, int n_out,
                               int K, int cin, int cout, int flip_k, int trans_w, float* y,
                               void* workspace, size_t workspace_bytes, void* stream) {
+  return irx_spconv_fwd_impl(x, w, nbr, ld, n_out, K, cin, cout, flip_k, trans_w, y, 0, workspace, workspace_bytes,
+                             stream);
+}
+
+int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
+                        int flip_k, int trans_w, float* y, int accumulate, void* workspace, size_t workspace_bytes,
+                        void* stream) {
   IRX_REQUIRE(n_out >= 0 && K >= 1 && cin >= 1 && cout >= 1, "irx_spconv_fwd: bad sizes");
   if (n_out == 0) return IRX_OK;
   IRX_REQUIRE(x && w && nbr && y, "irx_spconv_fwd: null pointer");
   IRX_REQUIRE(ld >= n_out, "irx_spconv_fwd: ld %d < n_out %d", ld, n_out);
   const bool aligned = (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0;
-  if (!trans_w && !flip_k && irx_stem_supported(K, cin, cout) && (((uintptr_t)y & 15) == 0))
+  if (!accumulate && !trans_w && !flip_k && irx_stem_supported(K, cin, cout) && (((uintptr_t)y & 15) == 0))
     return irx_stem_fwd_launch(x, w, nbr, ld, n_out, K, cin, y, S(stream));
   if (aligned && irx_spconv2_supported(cin, cout) && irx_spconv2_enabled(trans_w ? 'd' : 'f')) {
     const size_t need = irx_spconv_fwd_workspace_bytes(n_out, K, cin, cout, trans_w);
@@ -314,15 +322,16 @@ extern "C" int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr
     int rc = irx_permute_w_launch(w, K, cin, cout, trans_w, (float*)workspace, S(stream));
     if (rc) return rc;
     rc = irx_spconv2_launch(x, (const float*)workspace, nbr, ld, n_out, K, cin, cout, flip_k,
-                            splits > 1 ? slabs : y, splits, S(stream));
+                            splits > 1 ? slabs : y, splits, accumulate, S(stream));
     if (rc) return rc;
     if (splits > 1) {
       const size_t elems = (size_t)n_out * cout;
-      k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(slabs, splits, elems, y);
+      k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(slabs, splits, elems, y, accumulate);
       IRX_CHECK_LAUNCH("irx_spconv_fwd(split reduce)");
     }
     return IRX_OK;
   }
+  IRX_REQUIRE(!accumulate, "irx_spconv_fwd: accumulation needs the fast path (aligned, channels in {32,64,128})");
   const int bn = cout > 64 ? 128 : (cout > 32 ? 64 : 32);
   dim3 grid(irx_cdiv(n_out, SC_TM), irx_cdiv(cout, bn));
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (((uintptr_t)x & 15) == 0) &&

@@ -190,7 +190,8 @@ __device__ __forceinline__ void s2_wait_vmcnt() {
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2)
 void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const int32_t* __restrict__ nbr, int ld,
-               int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split) {
+               int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate) {
+  // accumulate != 0 (single split only): the tile is ADDED to the rows already in y (gradient accumulation).
   // blockIdx.y = offset split: this workgroup handles offsets [kb, ke) and writes its partial tile to slab
   // blockIdx.y of y (slabs are summed by k_wgrad_reduce; a single split writes the result directly).
   constexpr int TM = S2_TM;
@@ -374,9 +375,15 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   constexpr int F4 = COUT / 4;
   for (int f = tid; f < TM * F4; f += 256) {
     const int row = f / F4, cc = (f % F4) * 4;
-    if (q0 + row < n_out)
-      *reinterpret_cast<float4*>(y + (size_t)(q0 + row) * COUT + cc) =
-          *reinterpret_cast<const float4*>(&sOut[row * LDO + cc]);
+    if (q0 + row < n_out) {
+      float4 o = *reinterpret_cast<const float4*>(&sOut[row * LDO + cc]);
+      float4* dst = reinterpret_cast<float4*>(y + (size_t)(q0 + row) * COUT + cc);
+      if (accumulate) {
+        const float4 e = *dst;
+        o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+      }
+      *dst = o;
+    }
   }
 }
 
@@ -509,10 +516,10 @@ bool irx_spconv2_supported(int cin, int cout) {
 
 template <int CIN>
 static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
-                        int ld, int n_out, int K, int flip_k, float* y, int kps) {
-  if (cout == 128) k_spconv2<CIN, 128><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-  else if (cout == 64) k_spconv2<CIN, 64><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-  else k_spconv2<CIN, 32><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+                        int ld, int n_out, int K, int flip_k, float* y, int kps, int acc) {
+  if (cout == 128) k_spconv2<CIN, 128><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  else if (cout == 64) k_spconv2<CIN, 64><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  else k_spconv2<CIN, 32><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
 }
 
 // Output rows per workgroup: 64.  (128-row tiles stream half the weight bytes per useful FLOP but MEASURED SLOWER on
@@ -536,15 +543,16 @@ int irx_spconv2_splits(int n_out, int K) {
   return irx_cdiv(K, kps);                       // no empty splits
 }
 
-// y: result (splits == 1) or `splits` slabs of [n_out][cout] partial sums
+// y: result (splits == 1; accumulate != 0 adds to it) or `splits` slabs of [n_out][cout] partial sums
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                       int cout, int flip_k, float* y, int splits, hipStream_t st) {
+                       int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st) {
+  const int acc = (splits == 1) ? accumulate : 0;
   IRX_REQUIRE(K <= 27, "irx_spconv_fwd: K = %d > 27 unsupported by the fast path", K);
   dim3 grid(irx_cdiv(n_out, S2_TM), splits);
   const int kps = irx_cdiv(K, splits);
-  if (cin == 128) launch_fwd2<128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-  else if (cin == 64) launch_fwd2<64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
-  else launch_fwd2<32>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps);
+  if (cin == 128) launch_fwd2<128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  else if (cin == 64) launch_fwd2<64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  else launch_fwd2<32>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(v2)");
   return IRX_OK;
 }

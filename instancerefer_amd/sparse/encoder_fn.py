@@ -3,11 +3,13 @@
 
 The per-layer path (sparse/nn.py: conv_bn_act) costs ~3 autograd nodes, ~10 tensor allocations and ~100 us of Python
 per layer and direction; with two encoders that was ~10 ms of host time per step, i.e. the step was host-bound.
-Here forward and backward are tight loops of C-ABI calls (the same kernels, in the same order, so results are
-bit-identical to the per-layer path) with shared workspaces; Python touches each layer once.
+Here forward and backward are ONE C-ABI call each (irx_encoder_forward / irx_encoder_backward, include/irx.h): the
+library walks a descriptor table and launches the same kernels in the same order as the per-layer path (bit-identical
+results); Python only fills the table and allocates three arenas.
 
 Layer list (index: conv, residual source): 0 stem | per stage s: 3s+1 down (2^3/2), 3s+2 res-a, 3s+3 res-b (+ out of 3s+1).
 """
+import numpy as np
 import torch
 
 from .. import _lib
@@ -55,122 +57,129 @@ def _ws(nbytes, dev):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
 
 
+# field order of the descriptor table: include/irx.h, enum IRX_ENC_* (tests/test_abi_cpu.py checks the two agree)
+ENC_FIELDS = ("K", "CIN", "COUT", "N_IN", "N_OUT", "RES", "TBL", "LD", "TBL_B", "LD_B", "FLIP_B", "PAIR_IN", "PAIR_OUT",
+              "PAIR_COUNTS", "LD_PAIRS", "W", "GAMMA", "BETA", "RUNNING_MEAN", "RUNNING_VAR", "X", "C", "Y", "MEAN",
+              "INVSTD", "DW", "DGAMMA", "DBETA", "GY")
+_E = {n: i for i, n in enumerate(ENC_FIELDS)}
+_NF = len(ENC_FIELDS)
+_ALIGN = 64                                           # float32 elements (256 B)
+
+
+def _up(n):
+    return (n + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
 class EncoderFn(torch.autograd.Function):
+    """forward / backward = one irx_encoder_forward / irx_encoder_backward call over a descriptor table; activations,
+    gradients-in-flight and parameter gradients live in three arenas allocated once per call."""
+
     @staticmethod
     def forward(ctx, feats, layers, *params):
         lib = _lib.load()
-        stream = _lib.stream_ptr()
         dev = feats.device
-        x = feats.contiguous().float()
+        x0 = feats.contiguous().float()
         nl = len(layers)
-        # shared workspaces (stream-ordered reuse)
-        conv_ws = max(lib.irx_spconv_fwd_workspace_bytes(L.n_out, L.K, L.cin, L.cout, 0) for L in layers)
-        bn_ws = max(lib.irx_bn_workspace_bytes(L.n_out, L.cout) for L in layers)
-        ws_c, ws_b = _ws(conv_ws, dev), _ws(bn_ws, dev)
-        pc, pb = ws_c.data_ptr(), ws_b.data_ptr()
+        # activation arena: conv output c_i and layer output y_i of every layer
+        offs, total = [], 0
+        for L in layers:
+            n = _up(L.n_out * L.cout)
+            offs.append((total, total + n))
+            total += 2 * n
+        arena = torch.empty(total, dtype=_f32, device=dev)
         stats = torch.empty((nl, 2, 128), dtype=_f32, device=dev)       # mean / invstd rows (cout <= 128)
-        xs, cs, ys = [], [], []
+        base, sbase = arena.data_ptr(), stats.data_ptr()
+        rows, frows, counters = [], [], []
         for i, L in enumerate(layers):
-            w, gamma, beta = params[3 * i], params[3 * i + 1], params[3 * i + 2]
-            c = torch.empty((L.n_out, L.cout), dtype=_f32, device=dev)
-            y = torch.empty((L.n_out, L.cout), dtype=_f32, device=dev)
-            rc = lib.irx_spconv_fwd(x.data_ptr(), w.data_ptr(), L.tbl.data_ptr(), L.ld, L.n_out, L.K, L.cin, L.cout,
-                                    0, 0, c.data_ptr(), pc, conv_ws, stream)
-            if rc:
-                _lib.check(rc, "irx_spconv_fwd")
             bn = L.bn
-            mean_p, inv_p = stats[i, 0].data_ptr(), stats[i, 1].data_ptr()
+            r = [0] * _NF
+            r[_E["K"]], r[_E["CIN"]], r[_E["COUT"]] = L.K, L.cin, L.cout
+            r[_E["N_IN"]], r[_E["N_OUT"]], r[_E["RES"]] = L.n_in, L.n_out, L.res
+            r[_E["TBL"]], r[_E["LD"]] = L.tbl.data_ptr(), L.ld
+            r[_E["W"]] = params[3 * i].data_ptr()
+            r[_E["GAMMA"]], r[_E["BETA"]] = params[3 * i + 1].data_ptr(), params[3 * i + 2].data_ptr()
+            r[_E["RUNNING_MEAN"]], r[_E["RUNNING_VAR"]] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            r[_E["C"]], r[_E["Y"]] = base + 4 * offs[i][0], base + 4 * offs[i][1]
+            r[_E["X"]] = x0.data_ptr() if i == 0 else rows[i - 1][_E["Y"]]
+            r[_E["MEAN"]], r[_E["INVSTD"]] = sbase + 4 * (i * 256), sbase + 4 * (i * 256 + 128)
+            rows.append(r)
+            frows.append((bn.eps, 0.0 if bn.momentum is None else bn.momentum))
             if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
-            rc = lib.irx_bn_stats(c.data_ptr(), L.n_out, L.cout, bn.eps, 0.0 if bn.momentum is None else bn.momentum,
-                                  mean_p, inv_p, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), pb, bn_ws, stream)
-            if rc:
-                _lib.check(rc, "irx_bn_stats")
-            res_p = ys[L.res].data_ptr() if L.res >= 0 else None
-            rc = lib.irx_bn_apply(c.data_ptr(), L.n_out, L.cout, mean_p, inv_p, gamma.data_ptr(), beta.data_ptr(),
-                                  res_p, 1, y.data_ptr(), stream)
-            if rc:
-                _lib.check(rc, "irx_bn_apply")
-            xs.append(x)
-            cs.append(c)
-            ys.append(y)
-            x = y
-        ctx.layers = layers
-        ctx.save_for_backward(stats, *xs, *cs, *ys, *params)
-        return x
+                counters.append(bn.num_batches_tracked)
+        desc = np.array(rows, dtype=np.int64)
+        fdesc = np.array(frows, dtype=np.float64)
+        nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 0)
+        ws = _ws(nbytes, dev)
+        rc = lib.irx_encoder_forward(desc.ctypes.data, fdesc.ctypes.data, nl, ws.data_ptr(), nbytes, _lib.stream_ptr())
+        if rc:
+            _lib.check(rc, "irx_encoder_forward")
+        if counters:
+            torch._foreach_add_(counters, 1)
+        ctx.layers, ctx.desc, ctx.fdesc = layers, desc, fdesc
+        ctx.save_for_backward(x0, arena, stats, *params)
+        o0 = offs[-1][1]
+        return arena[o0:o0 + layers[-1].n_out * layers[-1].cout].view(layers[-1].n_out, layers[-1].cout)
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        stream = _lib.stream_ptr()
-        layers = ctx.layers
-        nl = len(layers)
-        saved = ctx.saved_tensors
-        stats = saved[0]
-        xs, cs, ys = saved[1:1 + nl], saved[1 + nl:1 + 2 * nl], saved[1 + 2 * nl:1 + 3 * nl]
-        params = saved[1 + 3 * nl:]
+        layers, nl = ctx.layers, len(ctx.layers)
+        x0, arena, stats = ctx.saved_tensors[:3]
         dev = dout.device
-        conv_ws = max(lib.irx_spconv_fwd_workspace_bytes(L.n_in, L.K, L.cout, L.cin, 1) for L in layers)
-        wg_ws = 0
+        dout = dout.contiguous().float()
+        # gradients in flight: gy_i for every layer but the last (that one IS dout) + the shared dc scratch
+        goffs, total, dc_max = [], 0, 0
+        for L in layers[:-1]:
+            goffs.append(total)
+            total += _up(L.n_out * L.cout)
         for L in layers:
-            if L.cin in _PAIR and L.cout in _PAIR:
-                wg_ws = max(wg_ws, lib.irx_spconv_wgrad_pairs_workspace_bytes(L.n_out, L.K, L.cin, L.cout))
+            dc_max = max(dc_max, L.n_out * L.cout)
+        dc_off = total
+        total += _up(dc_max)
+        garena = torch.empty(total, dtype=_f32, device=dev)
+        # parameter gradients, in parameter order (kernel, gamma, beta per layer)
+        poffs, ptotal = [], 0
+        for L in layers:
+            o = [ptotal]
+            ptotal += _up(L.K * L.cin * L.cout)
+            o.append(ptotal)
+            ptotal += _up(L.cout)
+            o.append(ptotal)
+            ptotal += _up(L.cout)
+            poffs.append(o)
+        pgrad = torch.empty(ptotal, dtype=_f32, device=dev)
+        gbase, pbase = garena.data_ptr(), pgrad.data_ptr()
+        desc = ctx.desc.copy()
+        need_dx0 = ctx.needs_input_grad[0]
+        for i, L in enumerate(layers):
+            r = desc[i]
+            if L.down:
+                tbl_b, ld_b = L.lv_in.down().child_t()
+                r[_E["TBL_B"]], r[_E["LD_B"]], r[_E["FLIP_B"]] = tbl_b.data_ptr(), ld_b, 0
             else:
-                wg_ws = max(wg_ws, lib.irx_spconv_wgrad_workspace_bytes(L.n_out, L.K, L.cin, L.cout))
-        bn_ws = max(lib.irx_bn_workspace_bytes(L.n_out, L.cout) for L in layers)
-        ws_c, ws_w, ws_b = _ws(conv_ws, dev), _ws(wg_ws, dev), _ws(bn_ws, dev)
-        pc, pw, pb = ws_c.data_ptr(), ws_w.data_ptr(), ws_b.data_ptr()
-        grads = [None] * (3 * nl)
-        gy = [None] * nl                      # gradient w.r.t. each layer's output
-        gy[nl - 1] = dout.contiguous().float()
-        dfeats = None
-        for i in range(nl - 1, -1, -1):
-            L = layers[i]
-            w, gamma = params[3 * i], params[3 * i + 1]
-            g = gy[i]
-            dc = torch.empty((L.n_out, L.cout), dtype=_f32, device=dev)
-            dgamma = torch.empty(L.cout, dtype=_f32, device=dev)
-            dbeta = torch.empty(L.cout, dtype=_f32, device=dev)
-            dres = torch.empty((L.n_out, L.cout), dtype=_f32, device=dev) if L.res >= 0 else None
-            rc = lib.irx_bn_backward(cs[i].data_ptr(), ys[i].data_ptr(), g.data_ptr(), L.n_out, L.cout,
-                                     stats[i, 0].data_ptr(), stats[i, 1].data_ptr(), gamma.data_ptr(), 1,
-                                     dc.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                     dres.data_ptr() if dres is not None else None, pb, bn_ws, stream)
-            if rc:
-                _lib.check(rc, "irx_bn_backward")
-            if dres is not None:
-                gy[L.res] = dres              # the shortcut's share; the main path is added below when it arrives
-            # weight gradient
-            dw = torch.empty((L.K, L.cin, L.cout), dtype=_f32, device=dev)
+                r[_E["TBL_B"]], r[_E["LD_B"]], r[_E["FLIP_B"]] = L.tbl.data_ptr(), L.ld, 1
             if L.cin in _PAIR and L.cout in _PAIR:
                 il, ol, counts, ldp = L.lv_in.down().pairs() if L.down else L.lv_in.pairs27()
-                rc = lib.irx_spconv_wgrad_pairs(xs[i].data_ptr(), dc.data_ptr(), il.data_ptr(), ol.data_ptr(), ldp,
-                                                counts.data_ptr(), L.n_out, L.K, L.cin, L.cout, dw.data_ptr(), pw, wg_ws,
-                                                stream)
-            else:
-                rc = lib.irx_spconv_wgrad(xs[i].data_ptr(), dc.data_ptr(), L.tbl.data_ptr(), L.ld, L.n_out, L.K, L.cin,
-                                          L.cout, dw.data_ptr(), pw, wg_ws, stream)
-            if rc:
-                _lib.check(rc, "irx_spconv_wgrad")
-            grads[3 * i], grads[3 * i + 1], grads[3 * i + 2] = dw, dgamma, dbeta
-            # data gradient
-            if i > 0 or ctx.needs_input_grad[0]:
-                if L.down:
-                    tbl_b, ld_b = L.lv_in.down().child_t()
-                    flip = 0
-                else:
-                    tbl_b, ld_b, flip = L.tbl, L.ld, 1
-                dx = torch.empty((L.n_in, L.cin), dtype=_f32, device=dev)
-                rc = lib.irx_spconv_fwd(dc.data_ptr(), w.data_ptr(), tbl_b.data_ptr(), ld_b, L.n_in, L.K, L.cout, L.cin,
-                                        flip, 1, dx.data_ptr(), pc, conv_ws, stream)
-                if rc:
-                    _lib.check(rc, "irx_spconv_fwd(dgrad)")
-                if i == 0:
-                    dfeats = dx
-                elif gy[i - 1] is None:
-                    gy[i - 1] = dx
-                else:
-                    gy[i - 1] = gy[i - 1].add_(dx)   # shortcut share (dres) + main path
+                r[_E["PAIR_IN"]], r[_E["PAIR_OUT"]] = il.data_ptr(), ol.data_ptr()
+                r[_E["PAIR_COUNTS"]], r[_E["LD_PAIRS"]] = counts.data_ptr(), ldp
+            r[_E["DW"]], r[_E["DGAMMA"]], r[_E["DBETA"]] = (pbase + 4 * poffs[i][0], pbase + 4 * poffs[i][1],
+                                                          pbase + 4 * poffs[i][2])
+            r[_E["GY"]] = gbase + 4 * goffs[i] if i < nl - 1 else dout.data_ptr()
+        dfeats = torch.empty((layers[0].n_in, layers[0].cin), dtype=_f32, device=dev) if need_dx0 else None
+        fdesc = ctx.fdesc
+        nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 1)
+        ws = _ws(nbytes, dev)
+        rc = lib.irx_encoder_backward(desc.ctypes.data, fdesc.ctypes.data, nl, gbase + 4 * dc_off,
+                                      dfeats.data_ptr() if need_dx0 else None, ws.data_ptr(), nbytes,
+                                      _lib.stream_ptr())
+        if rc:
+            _lib.check(rc, "irx_encoder_backward")
+        grads = []
+        for i, L in enumerate(layers):
+            o = poffs[i]
+            grads.append(pgrad[o[0]:o[0] + L.K * L.cin * L.cout].view(L.K, L.cin, L.cout))
+            grads.append(pgrad[o[1]:o[1] + L.cout])
+            grads.append(pgrad[o[2]:o[2] + L.cout])
         return (dfeats, None) + tuple(grads)
 
 

@@ -22,6 +22,22 @@ def test_header_symbols_exported(lib):
     assert sorted(_lib.EXPORTED_SYMBOLS) == names, set(names) ^ set(_lib.EXPORTED_SYMBOLS)
 
 
+def test_encoder_descriptor_fields_match_header():
+    """The Python executor fills the descriptor table by field index: the order must be the header's enum."""
+    from instancerefer_amd.sparse.encoder_fn import ENC_FIELDS
+    src = open(os.path.join(ROOT, "include", "irx.h")).read()
+    body = re.search(r"enum\s*\{(.*?IRX_ENC_NFIELDS)\s*\}", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n for n in re.findall(r"IRX_ENC_([A-Z0-9_]+)", body) if n != "NFIELDS"]
+    assert tuple(names) == ENC_FIELDS
+
+
+def test_encoder_executor_validates(lib):
+    assert lib.irx_encoder_workspace_bytes(None, None, 0, 0) == 0
+    assert lib.irx_encoder_forward(None, None, 0, None, 0, None) == -1
+    assert b"irx_encoder_forward" in lib.irx_last_error()
+
+
 def test_host_only_entry_points(lib):
     assert lib.irx_version() == 1
     assert lib.irx_hash_capacity(1000) == 2048 and lib.irx_hash_capacity(0) == 64
