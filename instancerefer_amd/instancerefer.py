@@ -4,6 +4,7 @@ imported and must export LangModule / AttributeModule / RelationModule / SceneMo
 `forward(data_dict) -> data_dict` contract."""
 import importlib
 
+import torch
 import torch.nn as nn
 
 _PKG = __name__.rsplit('.', 1)[0]
@@ -63,13 +64,38 @@ class InstanceRefer(nn.Module):
 
     def forward(self, data_dict):
         data_dict = self.prepare(data_dict)
+        side = None
         if self.args.scene_module and 'lidar' in data_dict and hasattr(self.scene, 'encode'):
-            data_dict = self.scene.encode(data_dict)         # queue the biggest GPU job first
+            # The whole-scene BEVEncoder depends on `lidar` only. It is issued FIRST and, on a HIP device, on its own
+            # stream, so that it runs concurrently with the language / attribute / relation work of the main stream:
+            # the deep levels of both sparse encoders are far too small to fill 256 CUs on their own, and autograd
+            # replays each node's backward on its forward stream, so the two backward passes overlap as well.
+            lidar = data_dict['lidar']
+            if lidar.F.is_cuda and getattr(self.args, 'overlap_streams', True):
+                main = torch.cuda.current_stream()
+                side = self._encoder_stream(lidar.F.device)
+                side.wait_stream(main)                       # inputs and the optimizer's parameter update are complete
+                lidar.record_stream(side)
+                with torch.cuda.stream(side):
+                    data_dict = self.scene.encode(data_dict)
+            else:
+                data_dict = self.scene.encode(data_dict)
         data_dict = self.lang(data_dict)
         if self.args.attribute_module:
             data_dict = self.attribute(data_dict)
         if self.args.relation_module:
             data_dict = self.relation(data_dict)
+        if side is not None:
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            data_dict['_scene_encoded'].record_stream(main)
         if self.args.scene_module:
             data_dict = self.scene(data_dict)
         return data_dict
+
+    def _encoder_stream(self, device):
+        st = getattr(self, '_enc_stream', None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, '_enc_stream', st)      # not a module attribute: never pickled with the state
+        return st
