@@ -33,8 +33,8 @@ PEAK_F32_TFLOPS = 157.3      # fp32 vector == fp32-input MFMA peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="full", choices=["full", "attr"],
                     help="full = whole InstanceRefer (BASELINE configs[2]/[3] shape); attr = configs[1]")
     ap.add_argument("--batch", type=int, default=0, help="scenes per GPU (default 16 full / 8 attr)")
@@ -76,24 +76,48 @@ def fresh_batch(resident):
 
 def prepare_next(model, resident, state):
     """Input preparation of the NEXT step (candidate voxelisation, Morton sort, coordinate pyramids: the part of the
-    forward that needs host syncs) issued on a side HIP stream so that it overlaps the current step's backward —
-    the usual input-pipeline prefetch. Every step still does exactly one preparation; nothing is cached."""
+    forward that needs host syncs) on an input-pipeline thread with its own HIP stream, so that neither its kernels
+    nor its ~9 host syncs sit on the training thread — the usual DataLoader-worker arrangement. Every step still does
+    exactly one preparation of a fresh batch; nothing is cached."""
+    import threading
     side = state.setdefault("side", torch.cuda.Stream())
+    dev = torch.cuda.current_device()
+
+    def work():
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(side):
+                state["next"] = model.prepare(fresh_batch(resident))
+        except BaseException as e:                      # surfaced by the training thread at join time
+            state["next_error"] = e
+
+    th = threading.Thread(target=work, name="irx-input-prep", daemon=True)
+    state["thread"] = th
+    th.start()
+
+
+def take_prepared(model, state):
+    th = state.pop("thread", None)
+    if th is None:
+        return None
+    th.join()
+    if "next_error" in state:
+        raise state.pop("next_error")
+    dd = state.pop("next")
     main = torch.cuda.current_stream()
-    with torch.cuda.stream(side):
-        nxt = model.prepare(fresh_batch(resident))
-    model.hand_over(nxt, main)
-    state["next"] = nxt
+    main.wait_stream(state["side"])                     # the prepared tensors are complete
+    model.hand_over(dd, main)
+    return dd
 
 
 def step_fn(model, resident, workload, reducer, opt, state=None):
     """One training step on the resident batch. Returns the loss tensor (no host sync)."""
     from instancerefer_amd.loss_helper import DatasetConfig, get_loss, ContrastiveLoss, compute_lang_classification_loss
-    if state is not None and state.get("next") is not None:
-        dd = state.pop("next")
-        torch.cuda.current_stream().wait_stream(state["side"])      # the prepared tensors are complete
-    else:
+    dd = take_prepared(model, state) if state is not None else None
+    if dd is None:
         dd = fresh_batch(resident)
+    if state is not None and state.get("pipeline"):
+        prepare_next(model, resident, state)             # batch N+1 is prepared while step N is issued and runs
     opt.zero_grad()
     dd = model(dd)
     if workload == "full":
@@ -111,8 +135,6 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
                 o += n
     loss.backward()
     opt.backward_step()          # one cat -> one all-reduce (N > 1) -> one fused Adam launch
-    if state is not None and state.get("pipeline"):
-        prepare_next(model, resident, state)
     return loss
 
 

@@ -89,11 +89,23 @@ bool irx_spconv2_enabled(char pass);
 int irx_spconv2_splits(int n_out, int K);
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
                        int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st);
-// irx_spconv_fwd with gradient accumulation (accumulate != 0: y += result; fast-path channel counts only)
+// irx_spconv_fwd with gradient accumulation (accumulate != 0: y += result; fast-path channel counts only) and an
+// optional prebuilt fragment-major weight image (wimg != NULL: the per-call permute launch is skipped)
 int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
-                        int flip_k, int trans_w, float* y, int accumulate, void* workspace, size_t workspace_bytes,
-                        void* stream);
+                        int flip_k, int trans_w, float* y, int accumulate, const float* wimg, void* workspace,
+                        size_t workspace_bytes, void* stream);
 int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st);
+// fragment images of up to 16 layers in one launch; dims are kernel-relative (cin = reduction, cout = outputs),
+// end4[j] = running total of float4 elements (K*cin*cout/4) up to and including job j
+struct IrxPermuteJobs {
+  const float* w[16];
+  float* dst[16];
+  int K[16], cin[16], cout[16];
+  size_t end4[16];
+  int n;
+};
+int irx_permute_w_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStream_t st);
+bool irx_spconv_fast_path(const void* x, const void* w, const void* y, int cin, int cout, int trans_w);
 int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
                              int cin, int cout, int splits, int rps, float* part, hipStream_t st);
 

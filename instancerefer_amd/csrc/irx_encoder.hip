@@ -46,9 +46,9 @@ bool pairs_path(const Layer& L) {
 }
 
 // workspace regions: [conv | wgrad | bn]
-struct Regions { size_t conv, wgrad, bn; };
+struct Regions { size_t conv, wgrad, bn, wimg; };
 Regions regions(const int64_t* desc, const double* fdesc, int n, bool backward) {
-  Regions r = {0, 0, 0};
+  Regions r = {0, 0, 0, 0};
   for (int i = 0; i < n; ++i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
     size_t c, b = irx_bn_workspace_bytes(L.n_out, L.cout), wg = 0;
@@ -59,6 +59,7 @@ Regions regions(const int64_t* desc, const double* fdesc, int n, bool backward) 
       wg = pairs_path(L) ? irx_spconv_wgrad_pairs_workspace_bytes(L.n_out, L.K, L.cin, L.cout)
                          : irx_spconv_wgrad_workspace_bytes(L.n_out, L.K, L.cin, L.cout);
     }
+    r.wimg += align256((size_t)L.K * L.cin * L.cout * sizeof(float));
     if (c > r.conv) r.conv = c;
     if (wg > r.wgrad) r.wgrad = wg;
     if (b > r.bn) r.bn = b;
@@ -71,21 +72,44 @@ Regions regions(const int64_t* desc, const double* fdesc, int n, bool backward) 
 extern "C" size_t irx_encoder_workspace_bytes(const int64_t* desc, const double* fdesc, int n_layers, int backward) {
   if (!desc || !fdesc || n_layers <= 0) return 0;
   const Regions r = regions(desc, fdesc, n_layers, backward != 0);
-  return r.conv + r.wgrad + r.bn + 256;
+  return r.conv + r.wgrad + r.bn + r.wimg + 256;
 }
 
 extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int n_layers, void* workspace,
                                    size_t workspace_bytes, void* stream) {
   IRX_REQUIRE(desc && fdesc && n_layers > 0, "irx_encoder_forward: empty descriptor table");
   const Regions r = regions(desc, fdesc, n_layers, false);
-  IRX_REQUIRE(workspace && workspace_bytes >= r.conv + r.bn, "irx_encoder_forward: workspace %zu < %zu", workspace_bytes,
-              r.conv + r.bn);
+  IRX_REQUIRE(workspace && workspace_bytes >= r.conv + r.bn + r.wimg + 255, "irx_encoder_forward: workspace %zu < %zu",
+              workspace_bytes, r.conv + r.bn + r.wimg + 255);
   char* ws_c = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   char* ws_b = ws_c + r.conv;
+  // fragment-major weight images of every fast-path layer: one launch
+  const float* wimg[64] = {nullptr};
+  IRX_REQUIRE(n_layers <= 16, "irx_encoder_forward: more than 16 layers");
+  {
+    IrxPermuteJobs J;
+    J.n = 0;
+    char* p = ws_b + r.bn;
+    size_t run = 0;
+    for (int i = 0; i < n_layers; ++i) {
+      const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
+      if (L.n_out > 0 && !irx_stem_supported(L.K, L.cin, L.cout) && irx_spconv_fast_path(L.x, L.w, L.c, L.cin, L.cout, 0)) {
+        const int j = J.n++;
+        J.w[j] = L.w; J.dst[j] = (float*)p; J.K[j] = L.K; J.cin[j] = L.cin; J.cout[j] = L.cout;
+        run += (size_t)L.K * L.cin * L.cout / 4;
+        J.end4[j] = run;
+        wimg[i] = (const float*)p;
+      }
+      p += align256((size_t)L.K * L.cin * L.cout * sizeof(float));
+    }
+    int rc = irx_permute_w_multi_launch(J, 0, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   for (int i = 0; i < n_layers; ++i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
     IRX_REQUIRE(L.res < i, "irx_encoder_forward: layer %d takes its residual from a later layer", i);
-    int rc = irx_spconv_fwd(L.x, L.w, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, 0, 0, L.c, ws_c, r.conv, stream);
+    int rc = irx_spconv_fwd_impl(L.x, L.w, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, 0, 0, L.c, 0, wimg[i], ws_c, r.conv,
+                                 stream);
     if (rc) return rc;
     rc = irx_bn_stats(L.c, L.n_out, L.cout, L.eps, L.momentum, L.mean, L.invstd, L.running_mean, L.running_var, ws_b,
                       r.bn, stream);
@@ -104,11 +128,34 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
                                     float* dx0, void* workspace, size_t workspace_bytes, void* stream) {
   IRX_REQUIRE(desc && fdesc && n_layers > 0 && dc_scratch, "irx_encoder_backward: bad arguments");
   const Regions r = regions(desc, fdesc, n_layers, true);
-  IRX_REQUIRE(workspace && workspace_bytes >= r.conv + r.wgrad + r.bn, "irx_encoder_backward: workspace %zu < %zu",
-              workspace_bytes, r.conv + r.wgrad + r.bn);
+  IRX_REQUIRE(workspace && workspace_bytes >= r.conv + r.wgrad + r.bn + r.wimg + 255,
+              "irx_encoder_backward: workspace %zu < %zu", workspace_bytes, r.conv + r.wgrad + r.bn + r.wimg + 255);
   char* ws_c = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   char* ws_w = ws_c + r.conv;
   char* ws_b = ws_w + r.wgrad;
+  // data-gradient weight images (kernel-relative: reduction = conv Cout, outputs = conv Cin): one launch
+  const float* wimg[64] = {nullptr};
+  IRX_REQUIRE(n_layers <= 16, "irx_encoder_backward: more than 16 layers");
+  {
+    IrxPermuteJobs J;
+    J.n = 0;
+    char* p = ws_b + r.bn;
+    size_t run = 0;
+    for (int i = 0; i < n_layers; ++i) {
+      const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
+      const float* dxp = (i > 0) ? (const float*)desc[(size_t)(i - 1) * IRX_ENC_NFIELDS + IRX_ENC_GY] : dx0;
+      if (dxp && L.n_in > 0 && irx_spconv_fast_path(dc_scratch, L.w, dxp, L.cout, L.cin, 1)) {
+        const int j = J.n++;
+        J.w[j] = L.w; J.dst[j] = (float*)p; J.K[j] = L.K; J.cin[j] = L.cout; J.cout[j] = L.cin;
+        run += (size_t)L.K * L.cin * L.cout / 4;
+        J.end4[j] = run;
+        wimg[i] = (const float*)p;
+      }
+      p += align256((size_t)L.K * L.cin * L.cout * sizeof(float));
+    }
+    int rc = irx_permute_w_multi_launch(J, 1, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   // a layer whose OUTPUT feeds a later layer's shortcut receives that share (dresidual) first; the main-path
   // gradient of the layer after it is then accumulated on top
   bool is_res_source[64] = {false};
@@ -133,8 +180,8 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
     float* dx = (i > 0) ? (float*)desc[(size_t)(i - 1) * IRX_ENC_NFIELDS + IRX_ENC_GY] : dx0;
     if (dx) {
       const int acc = (i > 0 && is_res_source[i - 1]) ? 1 : 0;
-      rc = irx_spconv_fwd_impl(dc_scratch, L.w, L.tbl_b, L.ld_b, L.n_in, L.K, L.cout, L.cin, L.flip_b, 1, dx, acc, ws_c,
-                               r.conv, stream);
+      rc = irx_spconv_fwd_impl(dc_scratch, L.w, L.tbl_b, L.ld_b, L.n_in, L.K, L.cout, L.cin, L.flip_b, 1, dx, acc, wimg[i],
+                               ws_c, r.conv, stream);
       if (rc) return rc;
     }
   }

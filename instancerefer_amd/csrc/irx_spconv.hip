@@ -297,13 +297,18 @@ extern "C" size_t irx_spconv_fwd_workspace_bytes(int n_out, int K, int cin, int 
 extern "C" int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr, int ld, int n_out,
                               int K, int cin, int cout, int flip_k, int trans_w, float* y,
                               void* workspace, size_t workspace_bytes, void* stream) {
-  return irx_spconv_fwd_impl(x, w, nbr, ld, n_out, K, cin, cout, flip_k, trans_w, y, 0, workspace, workspace_bytes,
-                             stream);
+  return irx_spconv_fwd_impl(x, w, nbr, ld, n_out, K, cin, cout, flip_k, trans_w, y, 0, nullptr, workspace,
+                             workspace_bytes, stream);
+}
+
+bool irx_spconv_fast_path(const void* x, const void* w, const void* y, int cin, int cout, int trans_w) {
+  const bool aligned = (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0;
+  return aligned && irx_spconv2_supported(cin, cout) && irx_spconv2_enabled(trans_w ? 'd' : 'f');
 }
 
 int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
-                        int flip_k, int trans_w, float* y, int accumulate, void* workspace, size_t workspace_bytes,
-                        void* stream) {
+                        int flip_k, int trans_w, float* y, int accumulate, const float* wimg, void* workspace,
+                        size_t workspace_bytes, void* stream) {
   IRX_REQUIRE(n_out >= 0 && K >= 1 && cin >= 1 && cout >= 1, "irx_spconv_fwd: bad sizes");
   if (n_out == 0) return IRX_OK;
   IRX_REQUIRE(x && w && nbr && y, "irx_spconv_fwd: null pointer");
@@ -319,9 +324,13 @@ int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int 
     }
     const int splits = irx_spconv2_splits(n_out, K);
     float* slabs = (float*)((char*)workspace + fwd_ws_weights(K, cin, cout));
-    int rc = irx_permute_w_launch(w, K, cin, cout, trans_w, (float*)workspace, S(stream));
-    if (rc) return rc;
-    rc = irx_spconv2_launch(x, (const float*)workspace, nbr, ld, n_out, K, cin, cout, flip_k,
+    int rc = IRX_OK;
+    if (!wimg) {
+      rc = irx_permute_w_launch(w, K, cin, cout, trans_w, (float*)workspace, S(stream));
+      if (rc) return rc;
+      wimg = (const float*)workspace;
+    }
+    rc = irx_spconv2_launch(x, wimg, nbr, ld, n_out, K, cin, cout, flip_k,
                             splits > 1 ? slabs : y, splits, accumulate, S(stream));
     if (rc) return rc;
     if (splits > 1) {

@@ -557,6 +557,43 @@ int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int 
   return IRX_OK;
 }
 
+// All layers of an encoder in ONE launch (the per-layer permutes were 54 launches of ~5 us per training step).
+__global__ void k_permute_w_multi(IrxPermuteJobs J, int trans_w) {
+  const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int j = 0;
+  while (j < J.n && f >= J.end4[j]) ++j;
+  if (j >= J.n) return;
+  const size_t fl = f - (j ? J.end4[j - 1] : 0);
+  const int K = J.K[j], cin = J.cin[j], cout = J.cout[j];
+  const float* __restrict__ w = J.w[j];
+  const int NT = cout >= 128 ? 2 : 1;
+  const int NCS = cout / (16 * NT);
+  const int NJ = cin / 16;
+  const int lane = (int)(fl & 63);
+  size_t r = fl >> 6;
+  const int t = (int)(r % NT); r /= NT;
+  const int jj = (int)(r % NJ); r /= NJ;
+  const int cs = (int)(r % NCS); r /= NCS;
+  const int k = (int)r;
+  (void)K;
+  const int n = cs * 16 * NT + 16 * t + (lane & 15);
+  const int c0 = 16 * jj + 4 * (lane >> 4);
+  float4 v;
+  float* pv = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    pv[i] = trans_w ? w[((size_t)k * cout + n) * cin + c0 + i] : w[((size_t)k * cin + c0 + i) * cout + n];
+  reinterpret_cast<float4*>(J.dst[j])[fl] = v;
+}
+
+int irx_permute_w_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStream_t st) {
+  if (jobs.n == 0) return IRX_OK;
+  const size_t total = jobs.end4[jobs.n - 1];
+  k_permute_w_multi<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(jobs, trans_w);
+  IRX_CHECK_LAUNCH("irx_encoder(permute)");
+  return IRX_OK;
+}
+
 int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st) {
   const size_t total = (size_t)K * cin * cout / 4;
   k_permute_w<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(w, K, cin, cout, trans_w, wf);
