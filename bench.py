@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--candidates", type=int, default=4)
     ap.add_argument("--tokens", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scenes", type=int, default=2)
+    ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-pipeline", action="store_true",

@@ -202,6 +202,12 @@ int irx_bn_backward(const float* x, const float* y, const float* dy, int n, int 
                     float* dx, float* dgamma, float* dbeta, float* dresidual, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* Measurement aid for bench.py's `roofline` object: the next dominant sparse-conv kernel launched by THIS host thread
+ * (the MFMA kernel of irx_spconv_fwd / irx_spconv_wgrad / irx_spconv_wgrad_pairs, not the weight-permute or
+ * split-reduce helpers that share the call) is bracketed with the two caller-owned HIP events on its launch stream.
+ * One-shot: cleared after that kernel. Pass NULL, NULL to cancel. */
+int irx_profile_next_kernel(void* ev_start, void* ev_stop);
+
 /* ---- whole-encoder executor ------------------------------------------------------------
  * SparseConvEncoder.forward / BEVEncoder.forward (models/basic_blocks.py:59-95,136-171) and their backward as ONE
  * call per direction: for every layer  c = conv(x);  (mean, invstd) = stats(c);  y = relu(bn(c) (+ y[res]))  — the

@@ -6,3 +6,21 @@ sparse/               : torchsparse-shaped host surface (SparseTensor, nn, utils
                         models/* and lib/loss_helper.py interfaces
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# Host-side dispatch cost of the small dense GEMMs of the language / matching heads (M <= a few hundred rows), measured on
+# MI355X with PyTorch 2.10: hipBLASLt 18 us per mm / 21 us per nn.Linear, rocBLAS 7 / 16 us (tools/micro/gemm_host.py).
+# With ~70 such calls per training step and the step host-bound, that is ~0.6 ms of 12.  The kernels themselves are
+# microseconds either way.  IRX_KEEP_BLAS=1 leaves PyTorch's defaults untouched.
+if _os.environ.get("IRX_KEEP_BLAS") != "1":
+    _os.environ.setdefault("DISABLE_ADDMM_CUDA_LT", "1")      # read once by ATen at the first addmm
+    try:
+        import torch as _torch
+        if _torch.cuda.is_available():
+            import warnings as _warnings
+            with _warnings.catch_warnings():
+                _warnings.simplefilter("ignore")
+                _torch.backends.cuda.preferred_blas_library("cublas")     # "cublas" is rocBLAS on ROCm
+    except Exception:                                          # pragma: no cover - plumbing only
+        pass

@@ -83,6 +83,12 @@ __device__ static inline int irx_hash_lookup(const uint64_t* __restrict__ tk,
   }
 }
 
+// ---- measurement aid (irx_profile_next_kernel, include/irx.h): brackets the next DOMINANT sparse-conv kernel of this
+// host thread (k_spconv2 / k_wgrad_pairs / k_spconv2_wgrad / k_stem_*) with two caller-owned events, excluding the small helper
+// launches (weight permute, split reduce) that share the C-ABI call.
+void irx_bracket_begin(hipStream_t st);
+void irx_bracket_end(hipStream_t st);
+
 // ---- second-generation sparse-conv launchers (irx_spconv2.hip) ---------------------------------
 bool irx_spconv2_supported(int cin, int cout);
 bool irx_spconv2_enabled(char pass);

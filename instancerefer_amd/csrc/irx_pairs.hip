@@ -244,9 +244,11 @@ extern "C" size_t irx_spconv_wgrad_pairs_workspace_bytes(int n_out, int K, int c
 template <int CIN>
 static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* il,
                       const int32_t* ol, int ldp, const int32_t* counts, int K, int ns, float* part) {
+  irx_bracket_begin(st);
   if (cout == 128) k_wgrad_pairs<CIN, 128><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, ns, part);
   else if (cout == 64) k_wgrad_pairs<CIN, 64><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, ns, part);
   else k_wgrad_pairs<CIN, 32><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, ns, part);
+  irx_bracket_end(st);
 }
 
 extern "C" int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int32_t* in_list,

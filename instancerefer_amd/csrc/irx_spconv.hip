@@ -268,18 +268,34 @@ __global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t ele
 }
 
 // ---------------------------------------------------------------------------- host side -----
+static thread_local hipEvent_t g_br_start = nullptr, g_br_stop = nullptr;
+extern "C" int irx_profile_next_kernel(void* ev_start, void* ev_stop) {
+  g_br_start = (hipEvent_t)ev_start;
+  g_br_stop = (hipEvent_t)ev_stop;
+  return IRX_OK;
+}
+void irx_bracket_begin(hipStream_t st) {
+  if (g_br_start) (void)hipEventRecord(g_br_start, st);
+}
+void irx_bracket_end(hipStream_t st) {
+  if (g_br_stop) (void)hipEventRecord(g_br_stop, st);
+  g_br_start = g_br_stop = nullptr;
+}
+
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
 template <bool TRANS_W, bool VEC>
 static void launch_fwd(int bn, dim3 grid, hipStream_t st, const float* x, const float* w,
                        const int32_t* nbr, int ld, int n_out, int K, int cin, int cout, int flip_k,
                        float* y) {
+  irx_bracket_begin(st);
   if (bn == 128)
     k_spconv_fwd<128, TRANS_W, VEC><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, cin, cout, flip_k, y);
   else if (bn == 64)
     k_spconv_fwd<64, TRANS_W, VEC><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, cin, cout, flip_k, y);
   else
     k_spconv_fwd<32, TRANS_W, VEC><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, cin, cout, flip_k, y);
+  irx_bracket_end(st);
 }
 
 static size_t fwd_ws_weights(int K, int cin, int cout) { return ((size_t)K * cin * cout * sizeof(float) + 255) & ~(size_t)255; }
@@ -408,10 +424,14 @@ extern "C" int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* 
   if (vec && irx_spconv2_supported(cin, cout) && irx_spconv2_enabled('w')) {
     int rc = irx_spconv2_wgrad_launch(x, dy, nbr, ld, n_out, K, cin, cout, s, rps, part, S(stream));
     if (rc) return rc;
-  } else if (vec)
-    k_spconv_wgrad<true><<<grid, 256, 0, S(stream)>>>(x, dy, nbr, ld, n_out, K, cin, cout, rps, nct_n, part);
-  else
-    k_spconv_wgrad<false><<<grid, 256, 0, S(stream)>>>(x, dy, nbr, ld, n_out, K, cin, cout, rps, nct_n, part);
+  } else {
+    irx_bracket_begin(S(stream));
+    if (vec)
+      k_spconv_wgrad<true><<<grid, 256, 0, S(stream)>>>(x, dy, nbr, ld, n_out, K, cin, cout, rps, nct_n, part);
+    else
+      k_spconv_wgrad<false><<<grid, 256, 0, S(stream)>>>(x, dy, nbr, ld, n_out, K, cin, cout, rps, nct_n, part);
+    irx_bracket_end(S(stream));
+  }
   IRX_CHECK_LAUNCH("irx_spconv_wgrad");
   if (s > 1) {
     k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(part, s, elems, dw);

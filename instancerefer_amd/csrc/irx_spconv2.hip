@@ -550,9 +550,11 @@ int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int 
   IRX_REQUIRE(K <= 27, "irx_spconv_fwd: K = %d > 27 unsupported by the fast path", K);
   dim3 grid(irx_cdiv(n_out, S2_TM), splits);
   const int kps = irx_cdiv(K, splits);
+  irx_bracket_begin(st);
   if (cin == 128) launch_fwd2<128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
   else if (cin == 64) launch_fwd2<64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
   else launch_fwd2<32>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(v2)");
   return IRX_OK;
 }
@@ -612,9 +614,11 @@ static void launch_wg2(int cout, dim3 grid, hipStream_t st, const float* x, cons
 int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
                              int cin, int cout, int splits, int rps, float* part, hipStream_t st) {
   dim3 grid(splits, K);
+  irx_bracket_begin(st);
   if (cin == 128) launch_wg2<128>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part);
   else if (cin == 64) launch_wg2<64>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part);
   else launch_wg2<32>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part);
+  irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad(v2)");
   return IRX_OK;
 }

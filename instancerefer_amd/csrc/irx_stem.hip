@@ -126,6 +126,7 @@ bool irx_stem_supported(int K, int cin, int cout) { return K == 27 && cout == ST
 int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin,
                         float* y, hipStream_t st) {
   const int grid = irx_cdiv(n_out, 32);
+  irx_bracket_begin(st);
   switch (cin) {
     case 1: k_stem_fwd<1><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
     case 2: k_stem_fwd<2><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
@@ -136,6 +137,7 @@ int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int 
     case 7: k_stem_fwd<7><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
     default: k_stem_fwd<8><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
   }
+  irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(stem)");
   return IRX_OK;
 }
@@ -151,6 +153,7 @@ int irx_stem_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, i
                           int blocks, float* part, hipStream_t st) {
   int rpb = irx_cdiv(n_out, blocks);
   rpb = irx_cdiv(rpb, 64) * 64;
+  irx_bracket_begin(st);
   switch (cin) {
     case 1: k_stem_wgrad<1><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
     case 2: k_stem_wgrad<2><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
@@ -161,6 +164,7 @@ int irx_stem_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, i
     case 7: k_stem_wgrad<7><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
     default: k_stem_wgrad<8><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
   }
+  irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad(stem)");
   return IRX_OK;
 }

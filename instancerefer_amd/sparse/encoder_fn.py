@@ -23,33 +23,40 @@ class _Layer:
     __slots__ = ("conv", "bn", "lv_in", "lv_out", "K", "cin", "cout", "tbl", "ld", "n_in", "n_out", "down", "res")
 
 
-def build_plan(encoder, level0):
-    """Resolve the coordinate levels / tables of every layer (all cached on the levels; the pyramid is already built)."""
-    layers = []
+def _skeleton(encoder):
+    """(conv, bn, down, res) of the 13 layers — static per encoder instance."""
+    sk = encoder.__dict__.get("_irx_skeleton")
+    if sk is None:
+        sk = [(encoder.stem[0].net[0], encoder.stem[0].net[1], False, -1)]
+        for stage in (encoder.stage1, encoder.stage2, encoder.stage3, encoder.stage4):
+            sk.append((stage[0].net[0], stage[0].net[1], True, -1))
+            d = len(sk) - 1
+            rb = stage[1]
+            if len(rb.downsample) != 0:
+                raise NotImplementedError("encoder executor: projection shortcuts are not part of the InstanceRefer encoders")
+            sk.append((rb.net[0], rb.net[1], False, -1))
+            sk.append((rb.net[3], rb.net[4], False, d))
+        encoder.__dict__["_irx_skeleton"] = sk
+    return sk
 
-    def add(block_conv, block_bn, lv_in, down, res):
+
+def build_plan(encoder, level0):
+    """Bind the coordinate levels / tables of this batch to the layer skeleton (the pyramid is already built)."""
+    layers = []
+    lv = level0
+    for conv, bn, down, res in _skeleton(encoder):
         L = _Layer()
-        L.conv, L.bn, L.lv_in, L.down, L.res = block_conv, block_bn, lv_in, down, res
-        L.K, L.cin, L.cout = block_conv.kernel.shape
+        L.conv, L.bn, L.lv_in, L.down, L.res = conv, bn, lv, down, res
+        L.K, L.cin, L.cout = conv.kernel.shape
         if down:
-            dm = lv_in.down()
+            dm = lv.down()
             L.lv_out, L.tbl, L.ld = dm.out_level, dm.child, dm.ld
         else:
-            L.lv_out = lv_in
-            L.tbl, L.ld = lv_in.nbr27()
-        L.n_in, L.n_out = lv_in.n, L.lv_out.n
+            L.lv_out = lv
+            L.tbl, L.ld = lv.nbr27()
+        L.n_in, L.n_out = lv.n, L.lv_out.n
         layers.append(L)
-        return L.lv_out
-
-    lv = add(encoder.stem[0].net[0], encoder.stem[0].net[1], level0, False, -1)
-    for stage in (encoder.stage1, encoder.stage2, encoder.stage3, encoder.stage4):
-        lv = add(stage[0].net[0], stage[0].net[1], lv, True, -1)
-        d = len(layers) - 1
-        rb = stage[1]
-        if len(rb.downsample) != 0:
-            raise NotImplementedError("encoder executor: projection shortcuts are not part of the InstanceRefer encoders")
-        lv = add(rb.net[0], rb.net[1], lv, False, -1)
-        lv = add(rb.net[3], rb.net[4], lv, False, d)
+        lv = L.lv_out
     return layers
 
 
@@ -199,9 +206,13 @@ def can_fuse(encoder):
     """The executor covers the training configuration of the reference (train-mode BatchNorm, fp32, no bias)."""
     if not (encoder.training and torch.is_grad_enabled()) or F_.PROFILE is not None:
         return False
-    for m in encoder.modules():
-        if isinstance(m, torch.nn.BatchNorm1d) and (not m.track_running_stats or m.weight is None):
-            return False
-        if hasattr(m, "kernel") and getattr(m, "bias", None) is not None:
-            return False
-    return True
+    ok = encoder.__dict__.get("_irx_fusable")          # structural part: decided once per encoder instance
+    if ok is None:
+        ok = True
+        for m in encoder.modules():
+            if isinstance(m, torch.nn.BatchNorm1d) and (not m.track_running_stats or m.weight is None):
+                ok = False
+            if hasattr(m, "kernel") and getattr(m, "bias", None) is not None:
+                ok = False
+        encoder.__dict__["_irx_fusable"] = ok
+    return ok

@@ -22,6 +22,17 @@ def _stream():
     return _lib.stream_ptr()
 
 
+def _bracket():
+    """Two timing events that the library records right around the next dominant sparse-conv kernel of this thread
+    (irx_profile_next_kernel): the measured span excludes the weight-permute / split-reduce helper launches."""
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()                                      # instantiates the HIP events; re-recorded by the library
+    e1.record()
+    _lib.call("irx_profile_next_kernel", e0.cuda_event, e1.cuda_event)
+    return e0, e1
+
+
 def _f32c(t):
     if t.dtype != _f32:
         t = t.float()
@@ -145,13 +156,10 @@ def spconv_gather_gemm(x, w, tbl, ld, n_out, K, cin, cout, flip_k, trans_w):
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     if PROFILE is not None:
         m = _pairs(tbl, K)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0, e1 = _bracket()
     _lib.call("irx_spconv_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(tbl), ld, n_out, K, cin, cout,
               int(flip_k), int(trans_w), _lib.ptr(y), _lib.ptr(ws), wsb, _stream())
     if PROFILE is not None:
-        e1.record()
         PROFILE.append(("dgrad" if trans_w else "fwd", n_out, K, cin, cout, m, e0, e1))
     return y
 
@@ -162,13 +170,10 @@ def spconv_wgrad(x, dy, tbl, ld, n_out, K, cin, cout):
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     if PROFILE is not None:
         m = _pairs(tbl, K)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0, e1 = _bracket()
     _lib.call("irx_spconv_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(tbl), ld, n_out, K, cin, cout,
               _lib.ptr(dw), _lib.ptr(ws), wsb, _stream())
     if PROFILE is not None:
-        e1.record()
         PROFILE.append(("wgrad", n_out, K, cin, cout, m, e0, e1))
     return dw
 
@@ -197,13 +202,10 @@ def spconv_wgrad_pairs(x, dy, pairs, n_out, K, cin, cout, m_for_profile=None):
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     if PROFILE is not None:
         m = int(counts.sum().item())
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0, e1 = _bracket()
     _lib.call("irx_spconv_wgrad_pairs", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_list), _lib.ptr(out_list), ldp,
               _lib.ptr(counts), n_out, K, cin, cout, _lib.ptr(dw), _lib.ptr(ws), wsb, _stream())
     if PROFILE is not None:
-        e1.record()
         PROFILE.append(("wgrad", n_out, K, cin, cout, m, e0, e1))
     return dw
 
