@@ -76,10 +76,11 @@ def fresh_batch(resident):
 
 def prepare_next(model, resident, state):
     """Input preparation of the NEXT step (candidate voxelisation, Morton sort, coordinate pyramids: the part of the
-    forward that needs host syncs) on an input-pipeline thread with its own HIP stream, so that neither its kernels
-    nor its ~9 host syncs sit on the training thread — the usual DataLoader-worker arrangement. Every step still does
-    exactly one preparation of a fresh batch; nothing is cached."""
-    import threading
+    forward that needs host syncs) on its own HIP stream. Single GPU: on an input-pipeline thread, so that neither its
+    kernels nor its ~9 host syncs sit on the training thread (the usual DataLoader-worker arrangement). Multi-rank:
+    inline on the training thread (a second host thread per rank next to the collective's progress is not worth the
+    risk; measured with 2 gloo ranks on one GPU it stalls). Every step still does exactly one preparation of a fresh
+    batch; nothing is cached."""
     side = state.setdefault("side", torch.cuda.Stream())
     dev = torch.cuda.current_device()
 
@@ -91,16 +92,22 @@ def prepare_next(model, resident, state):
         except BaseException as e:                      # surfaced by the training thread at join time
             state["next_error"] = e
 
-    th = threading.Thread(target=work, name="irx-input-prep", daemon=True)
-    state["thread"] = th
-    th.start()
+    if state.get("threaded", True):
+        import threading
+        th = threading.Thread(target=work, name="irx-input-prep", daemon=True)
+        state["thread"] = th
+        th.start()
+    else:
+        work()
+        state["thread"] = None
 
 
 def take_prepared(model, state):
-    th = state.pop("thread", None)
-    if th is None:
+    if "thread" not in state:
         return None
-    th.join()
+    th = state.pop("thread")
+    if th is not None:
+        th.join()
     if "next_error" in state:
         raise state.pop("next_error")
     dd = state.pop("next")
@@ -116,7 +123,7 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
     dd = take_prepared(model, state) if state is not None else None
     if dd is None:
         dd = fresh_batch(resident)
-    if state is not None and state.get("pipeline"):
+    if state is not None and state.get("pipeline") and state.get("threaded", True):
         prepare_next(model, resident, state)             # batch N+1 is prepared while step N is issued and runs
     opt.zero_grad()
     dd = model(dd)
@@ -135,6 +142,8 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
                 o += n
     loss.backward()
     opt.backward_step()          # one cat -> one all-reduce (N > 1) -> one fused Adam launch
+    if state is not None and state.get("pipeline") and not state.get("threaded", True):
+        prepare_next(model, resident, state)             # inline variant: issued behind the step, on the side stream
     return loss
 
 
@@ -301,7 +310,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    state = {"pipeline": not args.no_pipeline}
+    state = {"pipeline": not args.no_pipeline, "threaded": world == 1}
     for i in range(args.warmup):
         step_fn(model, resident, args.workload, reducer, opt, state)
         if i == 0:
