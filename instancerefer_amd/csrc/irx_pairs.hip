@@ -74,12 +74,28 @@ __global__ __launch_bounds__(256) void k_pairs_write(const int32_t* __restrict__
   }
 }
 
-// part[s][k][c][n] = sum over this split's share of list k:  x[in][c] * dy[out][n]
+// Work split proportional to the list lengths (they differ ~3x between the centre and the corner offsets and live in
+// device memory): with G workgroups for T = sum_k ceil(cnt_k / 64) stages, offset k is cut into
+// ceil(nst_k / ceil(T / G)) shares (1 .. smax), so every workgroup gets about the same number of 64-pair stages.
+// (Equal splits per offset made the centre offset's workgroups the critical path at ~2.8x the average work.)
+__device__ __forceinline__ int pairs_shares(const int32_t* __restrict__ counts, int K, int k, int G, int smax) {
+  int T = 0;
+  for (int j = 0; j < K; ++j) T += (counts[j] + 63) >> 6;
+  int tgt = (T + G - 1) / G;
+  if (tgt < 1) tgt = 1;
+  const int nst = (counts[k] + 63) >> 6;
+  int sp = (nst + tgt - 1) / tgt;
+  if (sp < 1) sp = 1;
+  if (sp > smax) sp = smax;
+  return sp;
+}
+
+// part[s][k][c][n] = sum over share s of list k:  x[in][c] * dy[out][n]   (s < pairs_shares(k); grid = (smax, K))
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const int32_t* __restrict__ in_list,
                                                         const int32_t* __restrict__ out_list, int ldp,
-                                                        const int32_t* __restrict__ counts, int K, int nsplit,
+                                                        const int32_t* __restrict__ counts, int K, int G, int smax,
                                                         float* __restrict__ part) {
   constexpr int TC = CIN / 16, TN = COUT / 16;
   constexpr int CW = (TC >= 4) ? TC / 4 : 1;             // c-tiles per wave
@@ -98,7 +114,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
   const int ct0 = (TC >= 4) ? wave * CW : (wave % TC);
   const int nt0 = (TC >= 4) ? 0 : (wave / TC) * NW;
   const int cnt = counts[k];
-  // equal shares, stage-aligned
+  const int nsplit = pairs_shares(counts, K, k, G, smax);
+  if (s >= nsplit) return;                               // block-uniform
+  // equal shares of this offset's stages
   const int nst = (cnt + 63) / 64;
   const int st0 = (int)(((long long)nst * s) / nsplit), st1 = (int)(((long long)nst * (s + 1)) / nsplit);
   const int32_t* il = in_list + (size_t)k * ldp;
@@ -190,11 +208,19 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
       }
 }
 
-__global__ void k_pairs_reduce(const float* __restrict__ part, int S, size_t elems, float* __restrict__ dw) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// dw[k] = sum of the shares of offset k in a fixed order (deterministic). One workgroup never straddles two offsets
+// (cin * cout is a multiple of 256 for the supported channel counts).
+__global__ __launch_bounds__(256) void k_pairs_reduce(const float* __restrict__ part, const int32_t* __restrict__ counts,
+                                                      int K, int G, int smax, size_t per_offset, size_t elems,
+                                                      float* __restrict__ dw) {
+  __shared__ int s_n;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x == 0) s_n = pairs_shares(counts, K, (int)(((size_t)blockIdx.x * blockDim.x) / per_offset), G, smax);
+  __syncthreads();
   if (i >= elems) return;
+  const int n = s_n;
   float s = 0.f;
-  for (int j = 0; j < S; ++j) s += part[(size_t)j * elems + i];
+  for (int j = 0; j < n; ++j) s += part[(size_t)j * elems + i];
   dw[i] = s;
 }
 
@@ -227,27 +253,29 @@ extern "C" int irx_pairs_build(const int32_t* nbr, int ld, int n_out, int K, int
   return IRX_OK;
 }
 
-static int pairs_splits(int n_out, int K) {
+// G = workgroup budget (~1024, fewer for small layers: >= ~8 stages of useful work per workgroup on average);
+// smax = shares cap per offset = 3x the average (the centre offset of a 3^3 kernel holds ~2.8x the average pairs).
+static int pairs_budget(int n_out, int K) {
   int s = irx_cdiv(1024, K);
-  const int max_s = irx_cdiv(n_out, 512);     // >= ~8 stages of useful work per workgroup on average
+  const int max_s = irx_cdiv(n_out, 512);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
-  return s;
+  return s * K;
 }
+static int pairs_smax(int n_out, int K) { return 3 * (pairs_budget(n_out, K) / K); }
 
 extern "C" size_t irx_spconv_wgrad_pairs_workspace_bytes(int n_out, int K, int cin, int cout) {
   if (n_out <= 0 || K <= 0 || cin <= 0 || cout <= 0) return 0;
-  const int s = pairs_splits(n_out, K);
-  return s <= 1 ? 0 : (size_t)s * K * cin * cout * sizeof(float);
+  return (size_t)pairs_smax(n_out, K) * K * cin * cout * sizeof(float);
 }
 
 template <int CIN>
 static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* il,
-                      const int32_t* ol, int ldp, const int32_t* counts, int K, int ns, float* part) {
+                      const int32_t* ol, int ldp, const int32_t* counts, int K, int G, int smax, float* part) {
   irx_bracket_begin(st);
-  if (cout == 128) k_wgrad_pairs<CIN, 128><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, ns, part);
-  else if (cout == 64) k_wgrad_pairs<CIN, 64><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, ns, part);
-  else k_wgrad_pairs<CIN, 32><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, ns, part);
+  if (cout == 128) k_wgrad_pairs<CIN, 128><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+  else if (cout == 64) k_wgrad_pairs<CIN, 64><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+  else k_wgrad_pairs<CIN, 32><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
   irx_bracket_end(st);
 }
 
@@ -264,21 +292,20 @@ extern "C" int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int
   }
   IRX_REQUIRE(x && dy && in_list && out_list && counts, "irx_spconv_wgrad_pairs: null pointer");
   IRX_REQUIRE(((((uintptr_t)x | (uintptr_t)dy)) & 15) == 0, "irx_spconv_wgrad_pairs: x / dy must be 16-byte aligned");
-  const int s = pairs_splits(n_out, K);
+  const int G = pairs_budget(n_out, K), smax = pairs_smax(n_out, K);
   const size_t need = irx_spconv_wgrad_pairs_workspace_bytes(n_out, K, cin, cout);
-  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+  if (workspace == nullptr || workspace_bytes < need) {
     irx_set_error("irx_spconv_wgrad_pairs: workspace %zu < %zu", workspace_bytes, need);
     return IRX_ERR_WORKSPACE;
   }
-  float* part = s > 1 ? (float*)workspace : dw;
-  dim3 grid(s, K);
-  if (cin == 128) launch_wp<128>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, s, part);
-  else if (cin == 64) launch_wp<64>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, s, part);
-  else launch_wp<32>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, s, part);
+  float* part = (float*)workspace;
+  dim3 grid(smax, K);
+  if (cin == 128) launch_wp<128>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part);
+  else if (cin == 64) launch_wp<64>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part);
+  else launch_wp<32>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad_pairs");
-  if (s > 1) {
-    k_pairs_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(part, s, elems, dw);
-    IRX_CHECK_LAUNCH("irx_spconv_wgrad_pairs(reduce)");
-  }
+  k_pairs_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(part, counts, K, G, smax, (size_t)cin * cout, elems,
+                                                                       dw);
+  IRX_CHECK_LAUNCH("irx_spconv_wgrad_pairs(reduce)");
   return IRX_OK;
 }

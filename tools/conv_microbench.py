@@ -31,5 +31,6 @@ for li, cin, cout in ((1, 64, 64), (2, 128, 128), (3, 128, 128), (4, 128, 128)):
     x = torch.randn(n, cin, device=dev); w = torch.randn(27, cin, cout, device=dev) * 0.05
     us = bench(lambda: F_.spconv_gather_gemm(x, w, tbl, ld, n, 27, cin, cout, 1, 1))
     dy = torch.randn(n, cout, device=dev)
-    usw = bench(lambda: F_.spconv_wgrad(x, dy, tbl, ld, n, 27, cin, cout))
-    print('stride %2d n=%7d M=%8d %3d->%3d  dgrad %7.1f us %6.2f TF | wgrad %7.1f us %6.2f TF' % (lv.stride, n, M, cin, cout, us, 2.0 * M * cin * cout / us / 1e6, usw, 2.0 * M * cin * cout / usw / 1e6))
+    pairs = lv.pairs27()
+    usw = bench(lambda: F_.spconv_wgrad_pairs(x, dy, pairs, n, 27, cin, cout))
+    print('stride %2d n=%7d M=%8d %3d->%3d  dgrad %7.1f us %6.2f TF | wgrad(pairs) %7.1f us %6.2f TF' % (lv.stride, n, M, cin, cout, us, 2.0 * M * cin * cout / us / 1e6, usw, 2.0 * M * cin * cout / usw / 1e6))
