@@ -310,7 +310,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    state = {"pipeline": not args.no_pipeline, "threaded": world == 1}
+    # Input-prep pipeline (thread + own stream) on single-GPU runs only: with two ranks time-sharing ONE GPU (the
+    # IRX_BENCH_SHARE_GPU test rig) a third stream per process made every host sync wait ~250 ms (2.2 s/step), and a real
+    # multi-GPU node is not available to this build to rule the effect out there, so N > 1 prepares inline.
+    state = {"pipeline": (not args.no_pipeline) and world == 1, "threaded": True}
     for i in range(args.warmup):
         step_fn(model, resident, args.workload, reducer, opt, state)
         if i == 0:
