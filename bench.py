@@ -88,7 +88,10 @@ def prepare_next(model, resident, state):
         try:
             torch.cuda.set_device(dev)
             with torch.cuda.stream(side):
-                state["next"] = model.prepare(fresh_batch(resident))
+                nxt = model.prepare(fresh_batch(resident))
+                if state.get("labels") is not None:          # host half of get_loss (IoU labelling) is input-only too
+                    nxt["_loss_prepared"] = state["labels"](nxt)
+                state["next"] = nxt
         except BaseException as e:                      # surfaced by the training thread at join time
             state["next_error"] = e
 
@@ -314,6 +317,9 @@ def main():
     # IRX_BENCH_SHARE_GPU test rig) a third stream per process made every host sync wait ~250 ms (2.2 s/step), and a real
     # multi-GPU node is not available to this build to rule the effect out there, so N > 1 prepares inline.
     state = {"pipeline": (not args.no_pipeline) and world == 1, "threaded": True}
+    if args.workload == "full":
+        from instancerefer_amd.loss_helper import prepare_labels
+        state["labels"] = lambda dd: prepare_labels(dd, step_fn.cfg, device) if "_attr_prepared" in dd else None
     for i in range(args.warmup):
         step_fn(model, resident, args.workload, reducer, opt, state)
         if i == 0:

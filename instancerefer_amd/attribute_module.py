@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .basic_blocks import SparseConvEncoder
-from .data import idx_tensor, upload_instances
+from .data import idx_tensor, selection_on_device, upload_instances
 from .sparse import nn as spnn
 from .sparse.utils import voxelize
 
@@ -42,10 +42,10 @@ class AttributeModule(nn.Module):
         pack = upload_instances(data_dict)
         sel = pack.select(lang_cls_pred)
         dev = pack.pts32.device
-        cand = idx_tensor(sel['cand'], dev)
         nc = len(sel['cand'])
         if nc == 0:
             return None, sel
+        cand = selection_on_device(sel, pack, dev)['cand']
         xyz = pack.xyz64.index_select(0, cand)                 # (Nc, P, 3) float64
         pts = pack.pts32.index_select(0, cand)                 # (Nc, P, C0) float32
         p = xyz.shape[1]
@@ -92,6 +92,8 @@ class AttributeModule(nn.Module):
         data_dict['obj_feats'] = feats
         feats = self.vis_emb_fc(feats)
         feats = nn.functional.normalize(feats, p=2, dim=1)
-        lang_flat = lang_feats.index_select(0, idx_tensor(sel['cand_scene'], dev))
+        sd = selection_on_device(sel, upload_instances(data_dict), dev)
+        data_dict['_sel_dev'] = sd                         # the scene head reuses cand_scene
+        lang_flat = lang_feats.index_select(0, sd['cand_scene'])
         data_dict['attribute_scores'] = torch.sum(feats * lang_flat, dim=1)
         return data_dict

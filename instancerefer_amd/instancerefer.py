@@ -41,7 +41,10 @@ class InstanceRefer(nn.Module):
         if self.args.attribute_module and self.args.use_gt_lang and hasattr(self.attribute, 'prepare'):
             cls = data_dict['object_cat']
             cls_list = data_dict['_host']['object_cat'] if 'object_cat' in data_dict.get('_host', {}) else cls.tolist()
-            data_dict = self.attribute.prepare(data_dict, [int(v) for v in cls_list])
+            cls_list = [int(v) for v in cls_list]
+            data_dict = self.attribute.prepare(data_dict, cls_list)
+            if self.args.relation_module and hasattr(self.relation, 'prepare'):
+                data_dict = self.relation.prepare(data_dict, cls_list)
         if self.args.scene_module and 'lidar' in data_dict:
             lidar = data_dict['lidar']
             if lidar._batch_size is None and 'point_min' in data_dict:
@@ -61,6 +64,18 @@ class InstanceRefer(nn.Module):
         prep = data_dict.get('_attr_prepared')
         if prep is not None and prep[0] is not None:
             prep[0].record_stream(stream)
+        if prep is not None and prep[1].get('_dev') is not None:
+            for t in prep[1]['_dev'].values():
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(stream)
+        rel = data_dict.get('_rel_prepared')
+        if rel is not None and rel[0] is not None:
+            for t in rel[0][2:]:
+                t.record_stream(stream)
+        lab = data_dict.get('_loss_prepared')
+        if lab is not None and lab.get('buf') is not None:
+            for t in (lab['buf'], lab['fbuf']):
+                t.record_stream(stream)
 
     def forward(self, data_dict):
         data_dict = self.prepare(data_dict)

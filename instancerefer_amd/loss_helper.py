@@ -128,62 +128,96 @@ def _host_np(data_dict, key):
     return data_dict[key].detach().cpu().numpy()
 
 
-def get_loss(data_dict, config):
-    """Same outputs as the reference (loss, ref_loss, lang_loss, seg_loss, seg_acc, cluster_label), but batched:
-    IoU labelling = one vectorised numpy pass over all candidates, ONE H2D copy of the labels, and the per-sample
-    ContrastiveLoss evaluated for all scenes at once on a (scenes x max_candidates) padded matrix (-inf padding for
-    the log-sum-exp) — ~10 launches instead of ~10 per sample."""
-    lang_loss = compute_lang_classification_loss(data_dict)
-    data_dict["lang_loss"] = lang_loss
-    seg_loss, seg_acc = compute_scene_mask_loss(data_dict)
-    dev = lang_loss.device
-
+def prepare_labels(data_dict, config, device=None):
+    """Host half of get_loss: IoU labelling of every candidate box against the GT box (float64 numpy, as the reference)
+    and ONE staged upload each of the integer / float label arrays. Depends only on the batch's inputs (GT labels +
+    the candidate boxes chosen by the class filter), so a training loop can run it in its input-preparation stage
+    (data_dict['_loss_prepared'] = prepare_labels(...)); get_loss does it itself otherwise."""
+    if 'pred_obb_batch' in data_dict:
+        pred_obb_batch = data_dict['pred_obb_batch']
+    else:
+        pred_obb_batch = data_dict['_attr_prepared'][1]['pred_obb_batch']
+    if device is None:
+        device = data_dict['point_min'].device if torch.is_tensor(data_dict.get('point_min')) else torch.device('cpu')
     ref_gt_obb = config.param2obb_batch(_host_np(data_dict, "ref_center_label"),
                                         _host_np(data_dict, "ref_heading_class_label"),
                                         _host_np(data_dict, "ref_heading_residual_label"),
                                         _host_np(data_dict, "ref_size_class_label"),
                                         _host_np(data_dict, "ref_size_residual_label"))
     ref_gt_bbox = get_3d_box_batch(ref_gt_obb[:, 3:6], ref_gt_obb[:, 6], ref_gt_obb[:, 0:3])   # (B, 8, 3)
-
-    pred_obb_batch = data_dict['pred_obb_batch']
     batch_size = len(pred_obb_batch)
     counts = [int(p.shape[0]) for p in pred_obb_batch]
     total = sum(counts)
+    out = dict(batch_size=batch_size, counts=counts, total=total, srow=0, lmax=0, buf=None, fbuf=None)
+    if total == 0:
+        return out
+    obbs = np.concatenate([p.reshape(-1, 7) for p in pred_obb_batch if p.shape[0]], 0)       # (total, 7)
+    scene_of = np.repeat(np.arange(batch_size), counts)
+    pred_bbox = get_3d_box_batch(obbs[:, 3:6], obbs[:, 6], obbs[:, 0:3])
+    ious = box3d_iou_batch(pred_bbox, ref_gt_bbox[scene_of])
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    label_all = np.zeros(total, np.float32)
+    keep, rows, cols = [], [], []
+    srow = 0
+    for i in range(batch_size):                       # B iterations of O(1) numpy on tiny slices
+        n = counts[i]
+        if n == 0:
+            continue
+        seg = ious[starts[i]:starts[i + 1]]
+        label_all[starts[i] + int(seg.argmax())] = 1.0  # the box with the highest IoU is the positive
+        if n >= 2:
+            rows.append(np.full(n, srow))
+            cols.append(np.arange(n))
+            keep.append(1.0 if seg.max() >= 0.2 else 0.0)
+            srow += 1
+    out.update(starts=starts, srow=srow)
+    device = torch.device(device)
+    pin = device.type == "cuda"
+    if srow:
+        scored = np.concatenate([np.arange(starts[i], starts[i + 1]) for i in range(batch_size) if counts[i] >= 2])
+        lmax = max(c for c in counts if c >= 2)
+        flat_h = np.concatenate(rows) * lmax + np.concatenate(cols)
+        lab_h = label_all[scored]
+    else:
+        lmax, flat_h, lab_h = 0, np.zeros(0, np.int64), np.zeros(0, np.float32)
+    fh = torch.empty(total + lab_h.size + srow, dtype=torch.float32, pin_memory=pin)
+    fv = fh.numpy()
+    fv[:total] = label_all
+    fv[total:total + lab_h.size] = lab_h
+    fv[total + lab_h.size:] = np.asarray(keep, np.float32)
+    ih = torch.empty(max(flat_h.size, 1), dtype=torch.int64, pin_memory=pin)
+    ih.numpy()[:flat_h.size] = flat_h
+    fbuf = fh.to(device, non_blocking=True)
+    buf = ih.to(device, non_blocking=True)
+    out.update(lmax=lmax, fbuf=fbuf, buf=buf, label_dev=fbuf[:total], lab=fbuf[total:total + lab_h.size],
+               keep_dev=fbuf[total + lab_h.size:], flat=buf[:flat_h.size])
+    return out
+
+
+def get_loss(data_dict, config):
+    """Same outputs as the reference (loss, ref_loss, lang_loss, seg_loss, seg_acc, cluster_label), but batched:
+    IoU labelling = one vectorised numpy pass over all candidates (prepare_labels), ONE H2D copy of the labels, and the
+    per-sample ContrastiveLoss evaluated for all scenes at once on a (scenes x max_candidates) padded matrix (-inf
+    padding for the log-sum-exp) — ~10 launches instead of ~10 per sample."""
+    lang_loss = compute_lang_classification_loss(data_dict)
+    data_dict["lang_loss"] = lang_loss
+    seg_loss, seg_acc = compute_scene_mask_loss(data_dict)
+    dev = lang_loss.device
+    lp = data_dict.pop('_loss_prepared', None)
+    if lp is None:
+        lp = prepare_labels(data_dict, config, dev)
+    batch_size, counts, total, srow, lmax = lp['batch_size'], lp['counts'], lp['total'], lp['srow'], lp['lmax']
     margin, gamma = 0.2, 5.0
     if total == 0:
         ref_loss = torch.zeros(1, device=dev)
         cluster_label = [[] for _ in range(batch_size)]
     else:
-        obbs = np.concatenate([p.reshape(-1, 7) for p in pred_obb_batch if p.shape[0]], 0)       # (total, 7)
-        scene_of = np.repeat(np.arange(batch_size), counts)
-        pred_bbox = get_3d_box_batch(obbs[:, 3:6], obbs[:, 6], obbs[:, 0:3])
-        ious = box3d_iou_batch(pred_bbox, ref_gt_bbox[scene_of])
-        starts = np.concatenate([[0], np.cumsum(counts)])
-        label_all = np.zeros(total, np.float32)
-        keep, rows, cols = [], [], []
-        srow = 0
-        for i in range(batch_size):                       # B iterations of O(1) numpy on tiny slices
-            n = counts[i]
-            if n == 0:
-                continue
-            seg = ious[starts[i]:starts[i + 1]]
-            label_all[starts[i] + int(seg.argmax())] = 1.0  # the box with the highest IoU is the positive
-            if n >= 2:
-                rows.append(np.full(n, srow))
-                cols.append(np.arange(n))
-                keep.append(1.0 if seg.max() >= 0.2 else 0.0)
-                srow += 1
-        from .data import idx_tensor
-        label_dev = idx_tensor(label_all, dev, torch.float32)
+        starts, label_dev = lp['starts'], lp['label_dev']
         cluster_label = [label_dev[starts[i]:starts[i + 1]] if counts[i] else [] for i in range(batch_size)]
         if srow == 0:
             ref_loss = torch.zeros(1, device=dev)
         else:
-            scored = np.concatenate([np.arange(starts[i], starts[i + 1]) for i in range(batch_size) if counts[i] >= 2])
-            lmax = max(c for c in counts if c >= 2)
-            flat = idx_tensor(np.concatenate(rows) * lmax + np.concatenate(cols), dev)
-            lab = label_dev.index_select(0, idx_tensor(scored, dev))
-            keep_dev = idx_tensor(np.asarray(keep, np.float32), dev, torch.float32)
+            flat, lab, keep_dev = lp['flat'], lp['lab'], lp['keep_dev']
             score = (data_dict['attribute_scores'] + data_dict['relation_scores'] + data_dict['scene_scores']) * gamma
             sim = torch.zeros(srow * lmax, dtype=score.dtype, device=dev).index_put((flat,), score * lab).view(srow, lmax).sum(1)
             neg = torch.full((srow * lmax,), float("-inf"), dtype=score.dtype, device=dev).index_put(

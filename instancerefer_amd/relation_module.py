@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .basic_blocks import DynamicEdgeConv
-from .data import idx_tensor, upload_instances
+from .data import idx_tensor, selection_on_device, upload_instances
 from .sparse import functional as F_
 
 
@@ -35,37 +35,47 @@ class RelationModule(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, data_dict):
-        lang_feats = self.lang_emb_fc(data_dict['lang_rel_feats'])           # (B, h_dim)
-        if not self.args.use_gt_lang:
-            lang_cls_pred = torch.argmax(data_dict["lang_scores"], dim=1)
-        else:
-            lang_cls_pred = data_dict['object_cat']
+    def node_features(self, data_dict, cls_list):
+        """Everything of this module that depends only on the inputs: candidate selection, its device index tensors
+        and the per-instance node features [box centre, mean colour/height, one-hot class]. -> (sel, sd, centres, feats)
+        or None when no scene has >= 2 candidates. Parameter-free, so a training loop can run it in its
+        input-preparation stage (InstanceRefer.prepare does when use_gt_lang)."""
         pack = upload_instances(data_dict)
-        cls_list = data_dict.get('_lang_cls_pred_list')
-        sel = pack.select(cls_list if cls_list is not None else lang_cls_pred.tolist())
-        dev = lang_feats.device
+        sel = pack.select(cls_list)
         if len(sel['cand']) == 0:
-            data_dict['relation_scores'] = lang_feats.new_zeros((0,))
-            return data_dict
-
-        support = idx_tensor(sel['support'], dev)
+            return None
+        dev = pack.pts32.device
+        sd = selection_on_device(sel, pack, dev)
+        support = sd['support']
         mean = F_.segment_mean(pack.pts32.index_select(0, support))          # (S, C0)
         centres = pack.centres.index_select(0, support)                     # (S, 3)
         mean = torch.cat([centres, mean[:, 3:]], 1)                         # xyz <- box centre
-        onehot = nn.functional.one_hot(idx_tensor([pack.classes[s] for s in sel['support']], dev),
-                                       self.args.num_classes).to(mean.dtype)
+        onehot = nn.functional.one_hot(sd['support_class'], self.args.num_classes).to(mean.dtype)
         feats = torch.cat([mean, onehot], 1)                                # (S, C0 + num_classes)
+        return sel, sd, centres, feats
 
-        # batch ids of the support rows, renumbered over the kept scenes (contiguous segments)
-        kept = sel['support_scene_offsets']
-        seg_of = np.repeat(np.arange(len(kept) - 1), np.diff(kept))
-        batch_index = idx_tensor(seg_of, dev)
-        filtered_index = idx_tensor(sel['query_in_support'], dev)
-        sup_off = idx_tensor(kept, dev, torch.int32)
+    def prepare(self, data_dict, cls_list):
+        data_dict['_rel_prepared'] = (self.node_features(data_dict, cls_list),)
+        return data_dict
 
-        feats = self.gcn(centres, batch_index, filtered_index, feats, support_offsets=sup_off)
+    def forward(self, data_dict):
+        lang_feats = self.lang_emb_fc(data_dict['lang_rel_feats'])           # (B, h_dim)
+        if '_rel_prepared' in data_dict:
+            prep = data_dict.pop('_rel_prepared')[0]
+        else:
+            cls_list = data_dict.get('_lang_cls_pred_list')
+            if cls_list is None:
+                lang_cls_pred = (data_dict['object_cat'] if self.args.use_gt_lang
+                                 else torch.argmax(data_dict["lang_scores"], dim=1))
+                cls_list = lang_cls_pred.tolist()
+            prep = self.node_features(data_dict, cls_list)
+        if prep is None:
+            data_dict['relation_scores'] = lang_feats.new_zeros((0,))
+            return data_dict
+        sel, sd, centres, feats = prep
+        # batch ids of the support rows are renumbered over the kept scenes (contiguous segments)
+        feats = self.gcn(centres, sd['support_seg'], sd['query_in_support'], feats, support_offsets=sd['support_offsets'])
         feats = self.vis_emb_fc(feats)
-        lang_flat = lang_feats.index_select(0, idx_tensor(sel['cand_scene'], dev))
+        lang_flat = lang_feats.index_select(0, sd['cand_scene'])
         data_dict['relation_scores'] = nn.functional.cosine_similarity(feats, lang_flat, dim=1)
         return data_dict

@@ -86,7 +86,8 @@ class SceneModule(nn.Module):
         if len(cand_scene) == 0:
             data_dict['scene_scores'] = scene_feats.new_zeros((0,))
             return data_dict
-        scene_flat = scene_feats.index_select(0, idx_tensor(cand_scene, scene_feats.device))
+        sd = data_dict.get('_sel_dev')
+        scene_flat = scene_feats.index_select(0, sd['cand_scene'] if sd is not None else idx_tensor(cand_scene, scene_feats.device))
         obj = self.vis_emb_fc1(obj_feats_flatten)
         data_dict['scene_scores'] = nn.functional.cosine_similarity(obj, scene_flat, dim=1)
         return data_dict
