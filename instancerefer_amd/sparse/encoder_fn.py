@@ -77,44 +77,73 @@ def _up(n):
     return (n + _ALIGN - 1) // _ALIGN * _ALIGN
 
 
+def _static_template(encoder, layers, params):
+    """Descriptor rows with everything that does not change from batch to batch (layer shapes, residual links, parameter
+    and running-stat pointers, relative stats offsets), cached per encoder; rebuilt when the parameters were re-homed
+    (FlatAdam moves them into its flat buffer once)."""
+    anchor = tuple(p.data_ptr() for p in params[:3])
+    cached = encoder.__dict__.get("_irx_template")
+    if cached is not None and cached[0] == anchor:
+        return cached[1:]
+    nl = len(layers)
+    t = np.zeros((nl, _NF), dtype=np.int64)
+    f = np.zeros((nl, 2), dtype=np.float64)
+    counters = []
+    for i, L in enumerate(layers):
+        bn = L.bn
+        t[i, _E["K"]], t[i, _E["CIN"]], t[i, _E["COUT"]], t[i, _E["RES"]] = L.K, L.cin, L.cout, L.res
+        t[i, _E["W"]] = params[3 * i].data_ptr()
+        t[i, _E["GAMMA"]], t[i, _E["BETA"]] = params[3 * i + 1].data_ptr(), params[3 * i + 2].data_ptr()
+        t[i, _E["RUNNING_MEAN"]], t[i, _E["RUNNING_VAR"]] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        t[i, _E["MEAN"]], t[i, _E["INVSTD"]] = 4 * (i * 256), 4 * (i * 256 + 128)       # relative to the stats tensor
+        f[i] = (bn.eps, 0.0 if bn.momentum is None else bn.momentum)
+        if bn.num_batches_tracked is not None:
+            counters.append(bn.num_batches_tracked)
+    cout = t[:, _E["COUT"]].copy()
+    wsize = t[:, _E["K"]] * t[:, _E["CIN"]] * cout
+    # parameter-gradient arena layout (kernel, gamma, beta per layer), 256 B aligned
+    sizes = np.stack([_up_np(wsize), _up_np(cout), _up_np(cout)], 1).reshape(-1)
+    poffs = (np.concatenate([[0], np.cumsum(sizes)[:-1]]) * 4).reshape(nl, 3)
+    ptotal = int(sizes.sum())
+    encoder.__dict__["_irx_template"] = (anchor, t, f, counters, cout, poffs, ptotal)
+    return t, f, counters, cout, poffs, ptotal
+
+
+def _up_np(a):
+    return (a + (_ALIGN - 1)) // _ALIGN * _ALIGN
+
+
 class EncoderFn(torch.autograd.Function):
     """forward / backward = one irx_encoder_forward / irx_encoder_backward call over a descriptor table; activations,
-    gradients-in-flight and parameter gradients live in three arenas allocated once per call."""
+    gradients-in-flight and parameter gradients live in three arenas allocated once per call. The table is a cached
+    static template plus a handful of vectorised numpy fills (level sizes, table pointers, arena offsets)."""
 
     @staticmethod
-    def forward(ctx, feats, layers, *params):
+    def forward(ctx, feats, encoder, layers, *params):
         lib = _lib.load()
         dev = feats.device
         x0 = feats.contiguous().float()
         nl = len(layers)
+        tmpl, fdesc, counters, cout, poffs, ptotal = _static_template(encoder, layers, params)
+        n_out = np.fromiter((L.n_out for L in layers), dtype=np.int64, count=nl)
+        desc = tmpl.copy()
+        desc[:, _E["N_IN"]] = np.fromiter((L.n_in for L in layers), dtype=np.int64, count=nl)
+        desc[:, _E["N_OUT"]] = n_out
+        desc[:, _E["TBL"]] = np.fromiter((L.tbl.data_ptr() for L in layers), dtype=np.int64, count=nl)
+        desc[:, _E["LD"]] = np.fromiter((L.ld for L in layers), dtype=np.int64, count=nl)
         # activation arena: conv output c_i and layer output y_i of every layer
-        offs, total = [], 0
-        for L in layers:
-            n = _up(L.n_out * L.cout)
-            offs.append((total, total + n))
-            total += 2 * n
+        sz = _up_np(n_out * cout)
+        start = np.concatenate([[0], np.cumsum(2 * sz)[:-1]])
+        total = int(2 * sz.sum())
         arena = torch.empty(total, dtype=_f32, device=dev)
         stats = torch.empty((nl, 2, 128), dtype=_f32, device=dev)       # mean / invstd rows (cout <= 128)
         base, sbase = arena.data_ptr(), stats.data_ptr()
-        rows, frows, counters = [], [], []
-        for i, L in enumerate(layers):
-            bn = L.bn
-            r = [0] * _NF
-            r[_E["K"]], r[_E["CIN"]], r[_E["COUT"]] = L.K, L.cin, L.cout
-            r[_E["N_IN"]], r[_E["N_OUT"]], r[_E["RES"]] = L.n_in, L.n_out, L.res
-            r[_E["TBL"]], r[_E["LD"]] = L.tbl.data_ptr(), L.ld
-            r[_E["W"]] = params[3 * i].data_ptr()
-            r[_E["GAMMA"]], r[_E["BETA"]] = params[3 * i + 1].data_ptr(), params[3 * i + 2].data_ptr()
-            r[_E["RUNNING_MEAN"]], r[_E["RUNNING_VAR"]] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-            r[_E["C"]], r[_E["Y"]] = base + 4 * offs[i][0], base + 4 * offs[i][1]
-            r[_E["X"]] = x0.data_ptr() if i == 0 else rows[i - 1][_E["Y"]]
-            r[_E["MEAN"]], r[_E["INVSTD"]] = sbase + 4 * (i * 256), sbase + 4 * (i * 256 + 128)
-            rows.append(r)
-            frows.append((bn.eps, 0.0 if bn.momentum is None else bn.momentum))
-            if bn.num_batches_tracked is not None:
-                counters.append(bn.num_batches_tracked)
-        desc = np.array(rows, dtype=np.int64)
-        fdesc = np.array(frows, dtype=np.float64)
+        desc[:, _E["C"]] = base + 4 * start
+        desc[:, _E["Y"]] = base + 4 * (start + sz)
+        desc[0, _E["X"]] = x0.data_ptr()
+        desc[1:, _E["X"]] = desc[:-1, _E["Y"]]
+        desc[:, _E["MEAN"]] += sbase
+        desc[:, _E["INVSTD"]] += sbase
         nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 0)
         ws = _ws(nbytes, dev)
         rc = lib.irx_encoder_forward(desc.ctypes.data, fdesc.ctypes.data, nl, ws.data_ptr(), nbytes, _lib.stream_ptr())
@@ -122,56 +151,45 @@ class EncoderFn(torch.autograd.Function):
             _lib.check(rc, "irx_encoder_forward")
         if counters:
             torch._foreach_add_(counters, 1)
-        ctx.layers, ctx.desc, ctx.fdesc = layers, desc, fdesc
+        ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = layers, desc, fdesc, (n_out, cout, poffs, ptotal)
         ctx.save_for_backward(x0, arena, stats, *params)
-        o0 = offs[-1][1]
+        o0 = int(start[-1] + sz[-1])
         return arena[o0:o0 + layers[-1].n_out * layers[-1].cout].view(layers[-1].n_out, layers[-1].cout)
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
         layers, nl = ctx.layers, len(ctx.layers)
-        x0, arena, stats = ctx.saved_tensors[:3]
+        n_out, cout, poffs, ptotal = ctx.extra
         dev = dout.device
         dout = dout.contiguous().float()
         # gradients in flight: gy_i for every layer but the last (that one IS dout) + the shared dc scratch
-        goffs, total, dc_max = [], 0, 0
-        for L in layers[:-1]:
-            goffs.append(total)
-            total += _up(L.n_out * L.cout)
-        for L in layers:
-            dc_max = max(dc_max, L.n_out * L.cout)
-        dc_off = total
-        total += _up(dc_max)
+        gsz = _up_np(n_out * cout)
+        goffs = np.concatenate([[0], np.cumsum(gsz[:-1])])              # nl entries; the last one = start of dc
+        dc_off = int(goffs[-1])
+        total = dc_off + int(gsz.max())
         garena = torch.empty(total, dtype=_f32, device=dev)
-        # parameter gradients, in parameter order (kernel, gamma, beta per layer)
-        poffs, ptotal = [], 0
-        for L in layers:
-            o = [ptotal]
-            ptotal += _up(L.K * L.cin * L.cout)
-            o.append(ptotal)
-            ptotal += _up(L.cout)
-            o.append(ptotal)
-            ptotal += _up(L.cout)
-            poffs.append(o)
-        pgrad = torch.empty(ptotal, dtype=_f32, device=dev)
+        pgrad = torch.empty(ptotal, dtype=_f32, device=dev)            # kernel, gamma, beta gradients of every layer
         gbase, pbase = garena.data_ptr(), pgrad.data_ptr()
         desc = ctx.desc.copy()
         need_dx0 = ctx.needs_input_grad[0]
-        for i, L in enumerate(layers):
-            r = desc[i]
+        tb, pr = [], []
+        for L in layers:
             if L.down:
                 tbl_b, ld_b = L.lv_in.down().child_t()
-                r[_E["TBL_B"]], r[_E["LD_B"]], r[_E["FLIP_B"]] = tbl_b.data_ptr(), ld_b, 0
+                tb.append((tbl_b.data_ptr(), ld_b, 0))
             else:
-                r[_E["TBL_B"]], r[_E["LD_B"]], r[_E["FLIP_B"]] = L.tbl.data_ptr(), L.ld, 1
+                tb.append((L.tbl.data_ptr(), L.ld, 1))
             if L.cin in _PAIR and L.cout in _PAIR:
                 il, ol, counts, ldp = L.lv_in.down().pairs() if L.down else L.lv_in.pairs27()
-                r[_E["PAIR_IN"]], r[_E["PAIR_OUT"]] = il.data_ptr(), ol.data_ptr()
-                r[_E["PAIR_COUNTS"]], r[_E["LD_PAIRS"]] = counts.data_ptr(), ldp
-            r[_E["DW"]], r[_E["DGAMMA"]], r[_E["DBETA"]] = (pbase + 4 * poffs[i][0], pbase + 4 * poffs[i][1],
-                                                          pbase + 4 * poffs[i][2])
-            r[_E["GY"]] = gbase + 4 * goffs[i] if i < nl - 1 else dout.data_ptr()
+                pr.append((il.data_ptr(), ol.data_ptr(), counts.data_ptr(), ldp))
+            else:
+                pr.append((0, 0, 0, 0))
+        desc[:, _E["TBL_B"]:_E["FLIP_B"] + 1] = np.array(tb, dtype=np.int64)
+        desc[:, _E["PAIR_IN"]:_E["LD_PAIRS"] + 1] = np.array(pr, dtype=np.int64)
+        desc[:, _E["DW"]:_E["DBETA"] + 1] = pbase + poffs
+        desc[:-1, _E["GY"]] = gbase + 4 * goffs[:-1]
+        desc[-1, _E["GY"]] = dout.data_ptr()
         dfeats = torch.empty((layers[0].n_in, layers[0].cin), dtype=_f32, device=dev) if need_dx0 else None
         fdesc = ctx.fdesc
         nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 1)
@@ -182,12 +200,13 @@ class EncoderFn(torch.autograd.Function):
         if rc:
             _lib.check(rc, "irx_encoder_backward")
         grads = []
+        po = poffs // 4
         for i, L in enumerate(layers):
-            o = poffs[i]
+            o = po[i]
             grads.append(pgrad[o[0]:o[0] + L.K * L.cin * L.cout].view(L.K, L.cin, L.cout))
             grads.append(pgrad[o[1]:o[1] + L.cout])
             grads.append(pgrad[o[2]:o[2] + L.cout])
-        return (dfeats, None) + tuple(grads)
+        return (dfeats, None, None) + tuple(grads)
 
 
 def run_encoder(encoder, st):
@@ -197,7 +216,7 @@ def run_encoder(encoder, st):
     params = []
     for L in layers:
         params += [L.conv.kernel, L.bn.weight, L.bn.bias]
-    y = EncoderFn.apply(st.F, layers, *params)
+    y = EncoderFn.apply(st.F, encoder, layers, *params)
     out = layers[-1].lv_out
     return SparseTensor(y, out.coords, out.stride, out.batch_size, out)
 
