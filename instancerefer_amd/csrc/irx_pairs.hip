@@ -213,12 +213,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
 __global__ __launch_bounds__(256) void k_pairs_reduce(const float* __restrict__ part, const int32_t* __restrict__ counts,
                                                       int K, int G, int smax, size_t per_offset, size_t elems,
                                                       float* __restrict__ dw) {
-  __shared__ int s_n;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (threadIdx.x == 0) s_n = pairs_shares(counts, K, (int)(((size_t)blockIdx.x * blockDim.x) / per_offset), G, smax);
-  __syncthreads();
+  // block-uniform offset index -> the share count is computed with scalar loads by every wave (no LDS round trip)
+  const int k = (int)(((size_t)blockIdx.x * blockDim.x) / per_offset);
+  const int n = pairs_shares(counts, K, k, G, smax);
   if (i >= elems) return;
-  const int n = s_n;
   float s = 0.f;
   for (int j = 0; j < n; ++j) s += part[(size_t)j * elems + i];
   dw[i] = s;
