@@ -110,7 +110,12 @@ def take_prepared(model, state):
         return None
     th = state.pop("thread")
     if th is not None:
-        th.join()
+        if "join_wait" in state:
+            t0 = time.perf_counter()
+            th.join()
+            state["join_wait"].append(time.perf_counter() - t0)
+        else:
+            th.join()
     if "next_error" in state:
         raise state.pop("next_error")
     dd = state.pop("next")

@@ -223,3 +223,39 @@ def test_solver_trains_and_writes_reference_style_checkpoints(lib, tmp_path):
     fresh.load_state_dict(sd)
     ck = torch.load(os.path.join(str(tmp_path), "checkpoint.tar"), map_location="cpu")
     assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict"}
+
+
+def test_pipelined_training_steps_equal_inline_steps(lib):
+    """bench.py's input pipeline (prepare() of batch N+1 on a helper thread + its own HIP stream, record_stream
+    hand-over, scene encoder on a second stream) must not change a single bit of the training trajectory compared
+    with fully inline steps: same seeds -> identical loss sequence and identical parameters after 4 steps."""
+    import argparse
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.loss_helper import DatasetConfig, prepare_labels
+    from instancerefer_amd.optim import FlatAdam
+    dev = torch.device("cuda")
+    bench.step_fn.cfg = DatasetConfig()
+    out = {}
+    for mode in ("inline", "pipelined"):
+        torch.manual_seed(99)
+        model = bench.build_model(argparse.Namespace(), "full", dev)
+        resident = S.to_device(S.make_batch(4, seed=11, num_points=6000, num_instances=6, num_candidates=3,
+                                            points_per_instance=256), dev)
+        lidar = resident.pop("lidar")
+        resident["lidar_F"], resident["lidar_C"], resident["B"] = lidar.F, lidar.C, 4
+        opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
+        state = {"pipeline": mode == "pipelined", "threaded": True}
+        if mode == "pipelined":
+            state["labels"] = lambda dd: prepare_labels(dd, bench.step_fn.cfg, dev) if "_attr_prepared" in dd else None
+        losses = [float(bench.step_fn(model, resident, "full", None, opt, state)) for _ in range(4)]
+        torch.cuda.synchronize()
+        th = state.pop("thread", None)
+        if th is not None:
+            th.join()
+        out[mode] = (losses, torch.cat([p.detach().flatten() for p in model.parameters()]).clone())
+    assert out["inline"][0] == out["pipelined"][0], (out["inline"][0], out["pipelined"][0])
+    assert torch.equal(out["inline"][1], out["pipelined"][1])

@@ -19,7 +19,7 @@ resident = S.to_device(S.make_batch(B, seed=123), dev)
 lidar = resident.pop("lidar"); perm = torch.randperm(lidar.F.shape[0], device=dev)
 resident["lidar_F"], resident["lidar_C"], resident["B"] = lidar.F[perm].contiguous(), lidar.C[perm].contiguous(), B
 opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
-state = {"pipeline": True}
+state = {"pipeline": True, "join_wait": []}
 try:
     from instancerefer_amd.loss_helper import prepare_labels
     state["labels"] = lambda dd: prepare_labels(dd, bench.step_fn.cfg, dev) if "_attr_prepared" in dd else None
@@ -39,5 +39,7 @@ for i in range(N):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
 issue.sort()
+jw = sorted(state["join_wait"][-N:])
+print("join wait on the input-prep thread: median %.2f ms, p90 %.2f ms" % (jw[len(jw)//2]*1e3, jw[9*len(jw)//10]*1e3))
 print("step %.2f ms | host issue per step: median %.2f ms, p10 %.2f, p90 %.2f | GPU already idle when the next step was issued: %d/%d steps"
       % (dt * 1e3, issue[N // 2] * 1e3, issue[N // 10] * 1e3, issue[9 * N // 10] * 1e3, dry, N - 1))
