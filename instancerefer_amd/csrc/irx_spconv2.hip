@@ -1,15 +1,14 @@
 // irx_spconv2.hip — second-generation sparse-conv kernels for the channel counts of the encoder
 // (Cin, Cout in {32, 64, 128}); irx_spconv.hip keeps the generic fallbacks (odd channel counts).
 //
-// Forward / data-gradient  k_spconv2<CIN, COUT>:
-//   * workgroup = 64 consecutive (Morton-ordered) output rows, 4 waves; the fp32 output tile lives in LDS.
-//   * per kernel offset k: ONE coalesced table read (lane == row), wave ballot -> the valid (input row,
-//     output row) pairs are COMPACTED in-register with ds_permute (rank = prefix popcount), so the MFMA only
-//     ever sees ceil(v/16) dense 16-row groups instead of every row of the tile (executed rows / useful pairs
-//     drop from 1.6-2.6x to ~1.2x on ScanNet-like surfaces);
-//   * weight-stationary: each wave owns a slice of output channels and keeps W[k][:, slice] in VGPRs
-//     (16-byte loads from an "n-major" weight image), so weights never pass through LDS and all four waves
-//     share one gathered A tile;
+// Forward / data-gradient  k_spconv2<CIN, COUT> (details at the kernel):
+//   * workgroup = 64 consecutive (Morton-ordered) output rows, 4 waves; the fp32 output tile lives in LDS;
+//   * setup: the tile's table columns are COMPACTED (lane == row, ballot + prefix popcount) into shared LDS pair
+//     lists, so the MFMA only ever sees ceil(v/16) dense 16-pair groups instead of every row of the tile (executed
+//     rows / useful pairs drop from 1.6-2.6x to ~1.2x on ScanNet-like surfaces);
+//   * weight-stationary: each wave owns a slice of output channels and keeps W[k][:, slice] in VGPRs (16-byte
+//     loads from a fragment-major weight image), so weights never pass through LDS and all four waves share one
+//     gathered A tile; the next item's weights and rows are requested from inside the current item's MFMA chain;
 //   * A rows are gathered with 16 B/lane coalesced loads (whole 128-512 B rows) into LDS, read back as
 //     ds_read_b128 fragments (the MFMA k index is permuted so a lane's 4 consecutive floats feed 4 MFMAs);
 //   * v_mfma_f32_16x16x4_f32 (exact fp32), results added into the LDS output tile (each wave owns its
@@ -58,28 +57,6 @@ __device__ static inline PairList compact_pairs(int my, int lane) {
   p.row_of_pair = __builtin_amdgcn_ds_permute(dst << 2, lane);
   p.v = v;
   return p;
-}
-
-// Per-wave compaction of one table column block (TM rows, TM/64 entries per lane) into LDS lists (wave-private
-// region: no barrier needed, only the wave's own lgkmcnt): list_in[p] = input row of pair p, list_row[p] = tile-local
-// output row, pairs in ascending row order. Returns v.
-template <int TM>
-__device__ static inline int compact_to_lds(const int* __restrict__ col, int lane, int* __restrict__ list_in,
-                                            int* __restrict__ list_row) {
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int base = 0;
-#pragma unroll
-  for (int h = 0; h < TM / 64; ++h) {
-    const int my = col[h * 64 + lane];
-    const unsigned long long valid = __ballot(my >= 0);
-    if (my >= 0) {
-      const int dst = base + __popcll(valid & lt);
-      list_in[dst] = my;
-      list_row[dst] = h * 64 + lane;
-    }
-    base += __popcll(valid);
-  }
-  return base;
 }
 
 // One 16-pair group of the current item for this wave's channel slice: A fragments from the LDS tile, weights from
