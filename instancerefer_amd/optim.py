@@ -1,5 +1,5 @@
 """Flat-buffer training state: every parameter is a view into ONE fp32 buffer, gradients are gathered into a
-second flat buffer with a single `torch.cat(out=)`, all-reduced once over RCCL/xGMI (ddp.py) and applied by
+second flat buffer with a single multi-tensor copy, all-reduced once over RCCL/xGMI (ddp.py) and applied by
 ONE fused Adam launch (csrc/irx_optim.hip). Semantics = torch.optim.Adam(lr, betas, eps, weight_decay), the
 optimizer of the reference (scripts/train.py:121)."""
 import torch
@@ -26,8 +26,8 @@ class FlatAdam:
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self._pads = [torch.zeros((p.numel() + 15) // 16 * 16 - p.numel(), dtype=torch.float32, device=dev)
-                      for p in self.params]
+        # gradient slots: views of flat_g with the parameters' shapes (same offsets as the parameters in flat_p)
+        self._slots = [self.flat_g[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
         with torch.no_grad():
             for p, off in zip(self.params, self.offsets):   # re-home every parameter inside the flat buffer
                 view = self.flat_p[off:off + p.numel()].view_as(p)
@@ -42,13 +42,12 @@ class FlatAdam:
             p.grad = None        # autograd then hands over freshly computed gradients without an add kernel
 
     def gather_grads(self):
-        """All .grad tensors -> flat_g with one concatenation launch (missing grads count as zero)."""
-        parts = []
-        for p, pad in zip(self.params, self._pads):
-            parts.append((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1))
-            if pad.numel():
-                parts.append(pad)
-        torch.cat(parts, out=self.flat_g)
+        """All .grad tensors -> their slots in flat_g with one multi-tensor copy (the padding between slots stays zero;
+        a missing grad counts as zero)."""
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            grads = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, self.params)]
+        torch._foreach_copy_(self._slots, grads)
 
     def all_reduce(self):
         if self.world_size > 1:
