@@ -288,6 +288,16 @@ int irx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 int irx_knn_batched(const float* sup_xyz, const int32_t* sup_offsets, const float* qry_xyz,
                     const int32_t* qry_batch, int nq, int k, int32_t* nbr_idx, void* stream);
 
+/* ---- language-instance matching scores ---------------------------------------------------
+ * models/attribute_module.py:122-126 (normalize + normalize + row dot), relation_module.py:104-105 and
+ * scene_module.py:104-106 (cosine_similarity): score[i] = <a_i, b_j> / (max(|a_i|, eps) * max(|b_j|, eps)) with
+ * j = idx[i] (idx NULL = identity), a [n][d], b [m][d]; norms [n][2] = (|a_i|, |b_j|) is kept for the backward.
+ * Backward: da [n][d] and db [m][d] (either may be NULL); db_j sums its candidates in ascending i (deterministic). */
+int irx_cosine_rows_fwd(const float* a, const float* b, const int64_t* idx, int n, int d, float eps, float* score,
+                        float* norms, void* stream);
+int irx_cosine_rows_bwd(const float* a, const float* b, const int64_t* idx, const float* score, const float* norms,
+                        const float* dscore, int n, int m, int d, float eps, float* da, float* db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

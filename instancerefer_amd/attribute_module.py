@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from .basic_blocks import SparseConvEncoder
 from .data import idx_tensor, selection_on_device, upload_instances
+from .dense import cosine_rows
 from .sparse import nn as spnn
 from .sparse.utils import voxelize
 
@@ -66,8 +67,7 @@ class AttributeModule(nn.Module):
 
     def forward(self, data_dict):
         lang_feats = data_dict['lang_attr_feats']
-        lang_feats = self.lang_emb_fc(lang_feats)
-        lang_feats = nn.functional.normalize(lang_feats, p=2, dim=1)          # (B, h_dim)
+        lang_feats = self.lang_emb_fc(lang_feats)                             # (B, h_dim)
 
         if '_attr_prepared' in data_dict:
             st, sel = data_dict.pop('_attr_prepared')
@@ -91,9 +91,8 @@ class AttributeModule(nn.Module):
         feats = self.pooling(feats)                       # (Nc, 128)
         data_dict['obj_feats'] = feats
         feats = self.vis_emb_fc(feats)
-        feats = nn.functional.normalize(feats, p=2, dim=1)
         sd = selection_on_device(sel, upload_instances(data_dict), dev)
         data_dict['_sel_dev'] = sd                         # the scene head reuses cand_scene
-        lang_flat = lang_feats.index_select(0, sd['cand_scene'])
-        data_dict['attribute_scores'] = torch.sum(feats * lang_flat, dim=1)
+        # normalize(vis) . normalize(lang)[scene of the candidate]  ==  a clamped cosine (F.normalize eps = 1e-12)
+        data_dict['attribute_scores'] = cosine_rows(feats, lang_feats, sd['cand_scene'], eps=1e-12)
         return data_dict

@@ -68,3 +68,44 @@ def gru_packed(gru: torch.nn.GRU, x, lengths, t_max):
         b_hh = torch.stack([getattr(gru, "bias_hh_l%d%s" % (layer, s)) for s in sfx], 0)
         h = GRULayerFn.apply(h, len32, w_ih, b_ih, w_hh, b_hh)
     return h
+
+
+class CosineRowsFn(torch.autograd.Function):
+    """score[i] = cos(a_i, b_{idx[i]}) with per-vector norm clamps (F.normalize / F.cosine_similarity semantics):
+    one launch forward, one backward pair (csrc/irx_match.hip) instead of ~27 ATen ops per matching head."""
+
+    @staticmethod
+    def forward(ctx, a, b, idx, eps):
+        a = a.contiguous().float()
+        b = b.contiguous().float()
+        n, d = a.shape
+        score = torch.empty(n, dtype=_f32, device=a.device)
+        norms = torch.empty((max(n, 1), 2), dtype=_f32, device=a.device)
+        _lib.call("irx_cosine_rows_fwd", _lib.ptr(a), _lib.ptr(b), _lib.ptr(idx) if idx is not None else None, n, d,
+                  float(eps), _lib.ptr(score), _lib.ptr(norms), _lib.stream_ptr())
+        ctx.save_for_backward(a, b, idx, score, norms)
+        ctx.eps = float(eps)
+        return score
+
+    @staticmethod
+    def backward(ctx, dscore):
+        a, b, idx, score, norms = ctx.saved_tensors
+        n, d = a.shape
+        m = b.shape[0]
+        dscore = dscore.contiguous().float()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        _lib.call("irx_cosine_rows_bwd", _lib.ptr(a), _lib.ptr(b), _lib.ptr(idx) if idx is not None else None,
+                  _lib.ptr(score), _lib.ptr(norms), _lib.ptr(dscore), n, m, d, ctx.eps, _lib.ptr(da), _lib.ptr(db),
+                  _lib.stream_ptr())
+        return da, db, None, None
+
+
+def cosine_rows(a, b, idx=None, eps=1e-8):
+    """Row-wise cosine of a (n, d) against b[idx] ((m, d), idx int64 (n,) or None). HIP tensors -> the fused kernels;
+    host tensors (CPU unit tests of the head logic) -> the PyTorch formulation."""
+    if a.is_cuda:
+        return CosineRowsFn.apply(a, b, idx, eps)
+    bb = b if idx is None else b.index_select(0, idx)
+    return torch.nn.functional.cosine_similarity(a, bb, dim=1, eps=eps)
+

@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from .basic_blocks import DynamicEdgeConv
 from .data import idx_tensor, selection_on_device, upload_instances
+from .dense import cosine_rows
 from .sparse import functional as F_
 
 
@@ -76,6 +77,5 @@ class RelationModule(nn.Module):
         # batch ids of the support rows are renumbered over the kept scenes (contiguous segments)
         feats = self.gcn(centres, sd['support_seg'], sd['query_in_support'], feats, support_offsets=sd['support_offsets'])
         feats = self.vis_emb_fc(feats)
-        lang_flat = lang_feats.index_select(0, sd['cand_scene'])
-        data_dict['relation_scores'] = nn.functional.cosine_similarity(feats, lang_flat, dim=1)
+        data_dict['relation_scores'] = cosine_rows(feats, lang_feats, sd['cand_scene'])      # F.cosine_similarity, eps 1e-8
         return data_dict

@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from .basic_blocks import BEVEncoder, SparseCrop, ToDenseBEVConvolution, batchnorm_rows, conv2d_rows
 from .data import idx_tensor
+from .dense import cosine_rows
 from .sparse import nn as spnn
 
 
@@ -87,7 +88,7 @@ class SceneModule(nn.Module):
             data_dict['scene_scores'] = scene_feats.new_zeros((0,))
             return data_dict
         sd = data_dict.get('_sel_dev')
-        scene_flat = scene_feats.index_select(0, sd['cand_scene'] if sd is not None else idx_tensor(cand_scene, scene_feats.device))
+        cs = sd['cand_scene'] if sd is not None else idx_tensor(cand_scene, scene_feats.device)
         obj = self.vis_emb_fc1(obj_feats_flatten)
-        data_dict['scene_scores'] = nn.functional.cosine_similarity(obj, scene_flat, dim=1)
+        data_dict['scene_scores'] = cosine_rows(obj, scene_feats, cs)                        # F.cosine_similarity, eps 1e-8
         return data_dict

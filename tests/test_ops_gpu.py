@@ -306,3 +306,31 @@ def test_pair_lists_and_dense_stage_wgrad(lib, clouds):
             ref = F_.spconv_wgrad(x, dy, tbl, ld, n_out, K, cin, cout)
             got = F_.spconv_wgrad_pairs(x, dy, (il, ol, counts, ldp), n_out, K, cin, cout)
             assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (K, cin, cout)
+
+
+@pytest.mark.parametrize("n,m,d,eps", [(64, 16, 128, 1e-8), (37, 5, 256, 1e-12), (3, 3, 20, 1e-8), (0, 4, 128, 1e-8)])
+def test_cosine_rows_matches_torch(lib, n, m, d, eps):
+    """Matching-score kernel vs F.normalize / F.cosine_similarity (forward 1e-6, gradients 1e-5 of their scale),
+    including a zero vector on either side (norm clamp) and candidates sharing one language row."""
+    from instancerefer_amd.dense import cosine_rows
+    g = torch.Generator().manual_seed(n * 1000 + d)
+    a = torch.randn(n, d, generator=g)
+    b = torch.randn(m, d, generator=g)
+    idx = torch.sort(torch.randint(0, m, (n,), generator=g))[0]
+    if n > 2:
+        a[1] = 0.0                                    # clamped norm on the candidate side
+        b[int(idx[2])] = 0.0                          # ... and on the language side
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.cosine_similarity(ar, br.index_select(0, idx), dim=1, eps=eps)
+    ad, bd = a.clone().cuda().requires_grad_(True), b.clone().cuda().requires_grad_(True)
+    got = cosine_rows(ad, bd, idx.cuda(), eps)
+    assert got.shape == ref.shape
+    if n == 0:
+        return
+    assert (got.detach().cpu() - ref.detach()).abs().max().item() <= 1e-6
+    w = torch.randn(n, generator=g)
+    (ref * w).sum().backward()
+    (got * w.cuda()).sum().backward()
+    for gd, gr in ((ad.grad, ar.grad), (bd.grad, br.grad)):
+        # rows behind a clamped norm have gradients of order 1/eps: compare relative to each tensor's own scale
+        assert (gd.cpu() - gr).abs().max().item() <= 1e-5 * max(gr.abs().max().item(), 1.0)
