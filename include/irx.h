@@ -298,6 +298,17 @@ int irx_cosine_rows_fwd(const float* a, const float* b, const int64_t* idx, int 
 int irx_cosine_rows_bwd(const float* a, const float* b, const int64_t* idx, const float* score, const float* norms,
                         const float* dscore, int n, int m, int d, float eps, float* da, float* db, void* stream);
 
+/* Batched ContrastiveLoss of the matching step (lib/loss_helper.py:93-107,248-258): for every scored scene s = rows
+ * [seg_off[s], seg_off[s+1]) of the candidate list, x = gamma*(s1+s2+s3), loss_s = keep_s * max(logsumexp(x*(1-lab)) -
+ * sum(x*lab) + margin, 0); out[0] = sum_s loss_s (fixed order). per / act / lse [nseg] are scratch kept for the backward,
+ * which writes ds [n] = d out / d s1 = d out / d s2 = d out / d s3 (scaled by dout[0]). */
+int irx_contrastive_fwd(const float* s1, const float* s2, const float* s3, const float* lab, const int64_t* seg_off,
+                        const float* keep, int nseg, float gamma, float margin, float* out, float* per, float* act,
+                        float* lse, void* stream);
+int irx_contrastive_bwd(const float* s1, const float* s2, const float* s3, const float* lab, const int64_t* seg_off,
+                        const float* act, const float* lse, const float* dout, int nseg, float gamma, float* ds,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

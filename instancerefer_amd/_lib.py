@@ -59,6 +59,8 @@ _SIGNATURES = {
     "irx_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P]),
     "irx_cosine_rows_fwd": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),
     "irx_cosine_rows_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "irx_contrastive_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P]),
+    "irx_contrastive_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P]),
     "irx_knn_batched": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
 }
 

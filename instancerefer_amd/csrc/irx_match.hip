@@ -109,3 +109,90 @@ extern "C" int irx_cosine_rows_bwd(const float* a, const float* b, const int64_t
   }
   return IRX_OK;
 }
+
+// ---- batched ContrastiveLoss (reference lib/loss_helper.py:93-107, called per sample at :248-258) ------------------
+// For every scored scene s (rows [off[s], off[s+1]) of the candidate list):  x = gamma * (s1 + s2 + s3);
+//   loss_s = keep_s * max( logsumexp_i( x_i * (1 - lab_i) ) - sum_i x_i * lab_i + margin, 0 );   out = sum_s loss_s.
+// (The positive slot enters the log-sum-exp as exp(0): reference quirk kept.)  One wave per scene, deterministic;
+// act[s] = keep_s if the hinge is active else 0 is kept for the backward, which recomputes the softmax weights.
+__global__ __launch_bounds__(64) void k_contrastive_fwd(const float* __restrict__ s1, const float* __restrict__ s2,
+                                                        const float* __restrict__ s3, const float* __restrict__ lab,
+                                                        const int64_t* __restrict__ off, const float* __restrict__ keep,
+                                                        int nseg, float gamma, float margin, float* __restrict__ per,
+                                                        float* __restrict__ act, float* __restrict__ lse) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int lo = (int)off[s], hi = (int)off[s + 1];
+  float mx = -INFINITY, sim = 0.f;
+  for (int i = lo + lane; i < hi; i += 64) {
+    const float x = gamma * (s1[i] + s2[i] + s3[i]);
+    const float l = lab[i];
+    sim += x * l;
+    mx = fmaxf(mx, x * (1.f - l));
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  sim = wave_sum(sim);
+  float se = 0.f;
+  for (int i = lo + lane; i < hi; i += 64) {
+    const float x = gamma * (s1[i] + s2[i] + s3[i]);
+    se += expf(x * (1.f - lab[i]) - mx);
+  }
+  se = wave_sum(se);
+  if (lane == 0) {
+    const float l = (hi > lo) ? mx + logf(se) : -INFINITY;
+    const float v = l - sim + margin;
+    per[s] = (v > 0.f) ? keep[s] * v : 0.f;
+    act[s] = (v > 0.f) ? keep[s] : 0.f;
+    lse[s] = l;
+  }
+}
+
+__global__ void k_contrastive_sum(const float* __restrict__ per, int nseg, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    for (int s = 0; s < nseg; ++s) t += per[s];      // fixed order
+    out[0] = t;
+  }
+}
+
+// d out / d s{1,2,3}[i] = dout * act_s * gamma * ( softmax_i * (1 - lab_i) - lab_i )
+__global__ __launch_bounds__(64) void k_contrastive_bwd(const float* __restrict__ s1, const float* __restrict__ s2,
+                                                        const float* __restrict__ s3, const float* __restrict__ lab,
+                                                        const int64_t* __restrict__ off, const float* __restrict__ act,
+                                                        const float* __restrict__ lse, const float* __restrict__ dout,
+                                                        float gamma, float* __restrict__ ds) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int lo = (int)off[s], hi = (int)off[s + 1];
+  const float k = dout[0] * act[s] * gamma, l = lse[s];
+  for (int i = lo + lane; i < hi; i += 64) {
+    const float x = gamma * (s1[i] + s2[i] + s3[i]);
+    const float lb = lab[i];
+    const float p = expf(x * (1.f - lb) - l);
+    ds[i] = k * (p * (1.f - lb) - lb);
+  }
+}
+
+extern "C" int irx_contrastive_fwd(const float* s1, const float* s2, const float* s3, const float* lab,
+                                   const int64_t* seg_off, const float* keep, int nseg, float gamma, float margin,
+                                   float* out, float* per, float* act, float* lse, void* stream) {
+  IRX_REQUIRE(nseg >= 0 && out, "irx_contrastive_fwd: bad arguments");
+  if (nseg > 0) {
+    IRX_REQUIRE(s1 && s2 && s3 && lab && seg_off && keep && per && act && lse, "irx_contrastive_fwd: null pointer");
+    k_contrastive_fwd<<<nseg, 64, 0, S(stream)>>>(s1, s2, s3, lab, seg_off, keep, nseg, gamma, margin, per, act, lse);
+    IRX_CHECK_LAUNCH("irx_contrastive_fwd");
+  }
+  k_contrastive_sum<<<1, 64, 0, S(stream)>>>(per, nseg, out);
+  IRX_CHECK_LAUNCH("irx_contrastive_fwd(sum)");
+  return IRX_OK;
+}
+
+extern "C" int irx_contrastive_bwd(const float* s1, const float* s2, const float* s3, const float* lab,
+                                   const int64_t* seg_off, const float* act, const float* lse, const float* dout,
+                                   int nseg, float gamma, float* ds, void* stream) {
+  IRX_REQUIRE(nseg >= 0, "irx_contrastive_bwd: bad arguments");
+  if (nseg == 0) return IRX_OK;
+  IRX_REQUIRE(s1 && s2 && s3 && lab && seg_off && act && lse && dout && ds, "irx_contrastive_bwd: null pointer");
+  k_contrastive_bwd<<<nseg, 64, 0, S(stream)>>>(s1, s2, s3, lab, seg_off, act, lse, dout, gamma, ds);
+  IRX_CHECK_LAUNCH("irx_contrastive_bwd");
+  return IRX_OK;
+}
+

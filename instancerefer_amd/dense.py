@@ -109,3 +109,33 @@ def cosine_rows(a, b, idx=None, eps=1e-8):
     bb = b if idx is None else b.index_select(0, idx)
     return torch.nn.functional.cosine_similarity(a, bb, dim=1, eps=eps)
 
+
+class ContrastiveFn(torch.autograd.Function):
+    """sum over scored scenes of keep_s * clamp(logsumexp(x * (1 - lab)) - sum(x * lab) + margin, 0), x = gamma*(s1+s2+s3):
+    the reference's per-sample ContrastiveLoss (lib/loss_helper.py:93-107) for all scenes in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, s1, s2, s3, lab, seg_off, keep, gamma, margin):
+        s1, s2, s3 = s1.contiguous().float(), s2.contiguous().float(), s3.contiguous().float()
+        nseg = keep.shape[0]
+        dev = s1.device
+        out = torch.empty(1, dtype=_f32, device=dev)
+        scratch = torch.empty((3, max(nseg, 1)), dtype=_f32, device=dev)
+        _lib.call("irx_contrastive_fwd", _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(s3), _lib.ptr(lab), _lib.ptr(seg_off),
+                  _lib.ptr(keep), nseg, float(gamma), float(margin), _lib.ptr(out), scratch[0].data_ptr(),
+                  scratch[1].data_ptr(), scratch[2].data_ptr(), _lib.stream_ptr())
+        ctx.save_for_backward(s1, s2, s3, lab, seg_off, scratch)
+        ctx.gamma = float(gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s1, s2, s3, lab, seg_off, scratch = ctx.saved_tensors
+        nseg = seg_off.shape[0] - 1
+        ds = torch.zeros_like(s1)
+        dout = dout.contiguous().float()
+        _lib.call("irx_contrastive_bwd", _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(s3), _lib.ptr(lab), _lib.ptr(seg_off),
+                  scratch[1].data_ptr(), scratch[2].data_ptr(), _lib.ptr(dout), nseg, ctx.gamma, _lib.ptr(ds),
+                  _lib.stream_ptr())
+        return ds, ds, ds, None, None, None, None, None
+

@@ -148,8 +148,19 @@ def prepare_labels(data_dict, config, device=None):
     batch_size = len(pred_obb_batch)
     counts = [int(p.shape[0]) for p in pred_obb_batch]
     total = sum(counts)
-    out = dict(batch_size=batch_size, counts=counts, total=total, srow=0, lmax=0, buf=None, fbuf=None)
+    out = dict(batch_size=batch_size, counts=counts, total=total, srow=0, lmax=0, buf=None, fbuf=None, area_label=None)
+    host = data_dict.get("_host") or {}
+    if "point_min" in host and "point_max" in host:
+        # 9-area label of the GT centre (compute_scene_mask_loss) from the host copies: same float64 comparisons
+        c = np.asarray(_host_np(data_dict, "ref_center_label"), dtype=np.float64)
+        pmin, pmax = np.asarray(host["point_min"], np.float64), np.asarray(host["point_max"], np.float64)
+        first = pmin + (pmax - pmin) / 3
+        second = pmin + (pmax - pmin) / 3 * 2
+        bx = (c[:, 0] > first[:, 0]).astype(np.int64) + (c[:, 0] > second[:, 0]).astype(np.int64)
+        by = (c[:, 1] > first[:, 1]).astype(np.int64) + (c[:, 1] > second[:, 1]).astype(np.int64)
+        out["area_label_host"] = by * 3 + bx
     if total == 0:
+        out.pop("area_label_host", None)
         return out
     obbs = np.concatenate([p.reshape(-1, 7) for p in pred_obb_batch if p.shape[0]], 0)       # (total, 7)
     scene_of = np.repeat(np.arange(batch_size), counts)
@@ -185,12 +196,19 @@ def prepare_labels(data_dict, config, device=None):
     fv[:total] = label_all
     fv[total:total + lab_h.size] = lab_h
     fv[total + lab_h.size:] = np.asarray(keep, np.float32)
-    ih = torch.empty(max(flat_h.size, 1), dtype=torch.int64, pin_memory=pin)
+    al = out.pop("area_label_host", None)
+    nal = 0 if al is None else al.size
+    seg_h = np.concatenate([[0], np.cumsum([c for c in counts if c >= 2])]).astype(np.int64)   # scored-scene offsets
+    ih = torch.empty(flat_h.size + nal + seg_h.size, dtype=torch.int64, pin_memory=pin)
     ih.numpy()[:flat_h.size] = flat_h
+    if nal:
+        ih.numpy()[flat_h.size:flat_h.size + nal] = al
+    ih.numpy()[flat_h.size + nal:] = seg_h
     fbuf = fh.to(device, non_blocking=True)
     buf = ih.to(device, non_blocking=True)
     out.update(lmax=lmax, fbuf=fbuf, buf=buf, label_dev=fbuf[:total], lab=fbuf[total:total + lab_h.size],
-               keep_dev=fbuf[total + lab_h.size:], flat=buf[:flat_h.size])
+               keep_dev=fbuf[total + lab_h.size:], flat=buf[:flat_h.size],
+               area_label=buf[flat_h.size:flat_h.size + nal] if nal else None, seg_off=buf[flat_h.size + nal:])
     return out
 
 
@@ -201,11 +219,16 @@ def get_loss(data_dict, config):
     padding for the log-sum-exp) — ~10 launches instead of ~10 per sample."""
     lang_loss = compute_lang_classification_loss(data_dict)
     data_dict["lang_loss"] = lang_loss
-    seg_loss, seg_acc = compute_scene_mask_loss(data_dict)
     dev = lang_loss.device
     lp = data_dict.pop('_loss_prepared', None)
     if lp is None:
         lp = prepare_labels(data_dict, config, dev)
+    if lp.get('area_label') is not None:             # label computed with the other labels on the host
+        pred, label = data_dict['seg_scores'], lp['area_label']
+        seg_loss = nn.functional.cross_entropy(pred, label)
+        seg_acc = (torch.argmax(pred, 1) == label).sum() / float(label.numel())
+    else:
+        seg_loss, seg_acc = compute_scene_mask_loss(data_dict)
     batch_size, counts, total, srow, lmax = lp['batch_size'], lp['counts'], lp['total'], lp['srow'], lp['lmax']
     margin, gamma = 0.2, 5.0
     if total == 0:
@@ -218,12 +241,18 @@ def get_loss(data_dict, config):
             ref_loss = torch.zeros(1, device=dev)
         else:
             flat, lab, keep_dev = lp['flat'], lp['lab'], lp['keep_dev']
-            score = (data_dict['attribute_scores'] + data_dict['relation_scores'] + data_dict['scene_scores']) * gamma
-            sim = torch.zeros(srow * lmax, dtype=score.dtype, device=dev).index_put((flat,), score * lab).view(srow, lmax).sum(1)
-            neg = torch.full((srow * lmax,), float("-inf"), dtype=score.dtype, device=dev).index_put(
-                (flat,), score * (1.0 - lab)).view(srow, lmax)
-            per_scene = torch.clamp(torch.logsumexp(neg, dim=1) - sim + margin, min=0)
-            ref_loss = (per_scene * keep_dev).sum().reshape(1)
+            if dev.type == 'cuda':                     # all scenes in one launch each way (csrc/irx_match.hip)
+                from .dense import ContrastiveFn
+                ref_loss = ContrastiveFn.apply(data_dict['attribute_scores'], data_dict['relation_scores'],
+                                               data_dict['scene_scores'], lab, lp['seg_off'], keep_dev, gamma, margin)
+            else:                                      # host tensors (CPU tests): padded-matrix formulation
+                score = (data_dict['attribute_scores'] + data_dict['relation_scores'] + data_dict['scene_scores']) * gamma
+                sim = torch.zeros(srow * lmax, dtype=score.dtype, device=dev).index_put((flat,), score * lab).view(
+                    srow, lmax).sum(1)
+                neg = torch.full((srow * lmax,), float("-inf"), dtype=score.dtype, device=dev).index_put(
+                    (flat,), score * (1.0 - lab)).view(srow, lmax)
+                per_scene = torch.clamp(torch.logsumexp(neg, dim=1) - sim + margin, min=0)
+                ref_loss = (per_scene * keep_dev).sum().reshape(1)
 
     ref_loss = ref_loss / batch_size
     data_dict['ref_loss'] = ref_loss

@@ -23,7 +23,8 @@ from .optim import FlatAdam
 GPU_KEYS = ("lang_feat", "lang_len", "object_cat", "lidar", "point_min", "point_max", "ref_center_label",
             "ref_size_residual_label")
 HOST_LABELS = ("ref_center_label", "ref_size_residual_label", "ref_heading_class_label",
-               "ref_heading_residual_label", "ref_size_class_label", "object_cat", "unique_multiple")
+               "ref_heading_residual_label", "ref_size_class_label", "object_cat", "unique_multiple", "point_min",
+               "point_max")
 
 
 def to_device(data_dict, device):

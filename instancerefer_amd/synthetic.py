@@ -114,7 +114,8 @@ def to_device(data_dict, device, voxel_size_glp=0.05):
     # labels originate on the host: keep numpy copies so get_loss needs no D2H round trip
     data_dict["_host"] = {k: data_dict[k].numpy() for k in ("ref_center_label", "ref_size_residual_label",
                                                             "ref_heading_class_label", "ref_heading_residual_label",
-                                                            "ref_size_class_label", "object_cat")}
+                                                            "ref_size_class_label", "object_cat", "point_min",
+                                                            "point_max")}
     data_dict["lang_len_max"] = int(data_dict["lang_len"].max())
     for k in ("lang_feat", "lang_len", "object_cat", "point_min", "point_max", "ref_center_label",
               "ref_size_residual_label"):

@@ -334,3 +334,31 @@ def test_cosine_rows_matches_torch(lib, n, m, d, eps):
     for gd, gr in ((ad.grad, ar.grad), (bd.grad, br.grad)):
         # rows behind a clamped norm have gradients of order 1/eps: compare relative to each tensor's own scale
         assert (gd.cpu() - gr).abs().max().item() <= 1e-5 * max(gr.abs().max().item(), 1.0)
+
+
+def test_contrastive_matches_reference_formulation(lib):
+    """Batched ContrastiveLoss kernel vs the per-sample formulation of the reference (loss_helper.ContrastiveLoss),
+    ragged scenes, a scene below the IoU threshold (keep = 0) and an inactive hinge; value 1e-6, gradients 1e-6."""
+    from instancerefer_amd.dense import ContrastiveFn
+    from instancerefer_amd.loss_helper import ContrastiveLoss
+    g = torch.Generator().manual_seed(3)
+    counts = [4, 2, 7, 3, 64]
+    n = sum(counts)
+    off = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int64)
+    s = [(torch.randn(n, generator=g) * 0.5).requires_grad_(True) for _ in range(3)]
+    lab = torch.zeros(n)
+    for i, c in enumerate(counts):
+        lab[int(off[i]) + int(torch.randint(0, c, (1,), generator=g))] = 1.0
+    with torch.no_grad():
+        s[0][off[3]:off[4]] = torch.where(lab[off[3]:off[4]] > 0, torch.tensor(3.0), torch.tensor(-3.0))   # hinge inactive
+    keep = torch.tensor([1.0, 0.0, 1.0, 1.0, 1.0])
+    crit = ContrastiveLoss(margin=0.2, gamma=5)
+    ref = sum(keep[i] * crit(s[0][off[i]:off[i + 1]] + s[1][off[i]:off[i + 1]] + s[2][off[i]:off[i + 1]],
+                             lab[off[i]:off[i + 1]]) for i in range(len(counts)))
+    ref.backward()
+    sd = [t.detach().clone().cuda().requires_grad_(True) for t in s]
+    got = ContrastiveFn.apply(sd[0], sd[1], sd[2], lab.cuda(), off.cuda(), keep.cuda(), 5.0, 0.2)
+    assert abs(float(got) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    (got * 1.0).sum().backward()
+    for a, b in zip(sd, s):
+        assert (a.grad.cpu() - b.grad).abs().max().item() <= 1e-5
