@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--prep-thread", action="store_true",
+                    help="run the input preparation on a helper thread instead of inline behind the step (same speed: "
+                         "the loop is GIL-bound, tools/micro/ab_thread.py)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do the input preparation of each step inline instead of on a side stream during the previous backward")
     return ap.parse_args()
@@ -75,11 +78,13 @@ def fresh_batch(resident):
 
 
 def prepare_next(model, resident, state):
-    """Input preparation of the NEXT step (candidate voxelisation, Morton sort, coordinate pyramids: the part of the
-    forward that needs host syncs) on its own HIP stream. Single GPU: on an input-pipeline thread, so that neither its
-    kernels nor its ~9 host syncs sit on the training thread (the usual DataLoader-worker arrangement). Multi-rank:
-    inline on the training thread (a second host thread per rank next to the collective's progress is not worth the
-    risk; measured with 2 gloo ranks on one GPU it stalls). Every step still does exactly one preparation of a fresh
+    """Input preparation of the NEXT step (candidate voxelisation, Morton sort, coordinate pyramids, relation node
+    features, IoU labels: everything that depends only on the inputs, including the part of the forward that needs host
+    syncs) on its own HIP stream, issued right behind step N so that its kernels overlap step N's backward on the GPU
+    and its syncs never wait behind a long queue. `--prep-thread` moves it to a helper thread (measured equal: the loop is
+    bound by Python/dispatch work under the GIL, not by the sync waits). Multi-rank runs prepare inline at the start of
+    the step (no extra stream: two gloo ranks time-sharing one GPU stalled with it, and a real multi-GPU node is not
+    available to this build to rule the effect out there). Every step still does exactly one preparation of a fresh
     batch; nothing is cached."""
     side = state.setdefault("side", torch.cuda.Stream())
     dev = torch.cuda.current_device()
@@ -321,7 +326,7 @@ def main():
     # Input-prep pipeline (thread + own stream) on single-GPU runs only: with two ranks time-sharing ONE GPU (the
     # IRX_BENCH_SHARE_GPU test rig) a third stream per process made every host sync wait ~250 ms (2.2 s/step), and a real
     # multi-GPU node is not available to this build to rule the effect out there, so N > 1 prepares inline.
-    state = {"pipeline": (not args.no_pipeline) and world == 1, "threaded": True}
+    state = {"pipeline": (not args.no_pipeline) and world == 1, "threaded": bool(args.prep_thread)}
     if args.workload == "full":
         from instancerefer_amd.loss_helper import prepare_labels
         state["labels"] = lambda dd: prepare_labels(dd, step_fn.cfg, device) if "_attr_prepared" in dd else None

@@ -226,8 +226,8 @@ def test_solver_trains_and_writes_reference_style_checkpoints(lib, tmp_path):
 
 
 def test_pipelined_training_steps_equal_inline_steps(lib):
-    """bench.py's input pipeline (prepare() of batch N+1 on a helper thread + its own HIP stream, record_stream
-    hand-over, scene encoder on a second stream) must not change a single bit of the training trajectory compared
+    """bench.py's input pipeline (prepare() of batch N+1 on its own HIP stream behind step N, inline or on a helper
+    thread, record_stream hand-over, scene encoder on a second stream) must not change a single bit of the training trajectory compared
     with fully inline steps: same seeds -> identical loss sequence and identical parameters after 4 steps."""
     import argparse
     import sys
@@ -240,7 +240,7 @@ def test_pipelined_training_steps_equal_inline_steps(lib):
     dev = torch.device("cuda")
     bench.step_fn.cfg = DatasetConfig()
     out = {}
-    for mode in ("inline", "pipelined"):
+    for mode in ("inline", "pipelined", "pipelined-thread"):
         torch.manual_seed(99)
         model = bench.build_model(argparse.Namespace(), "full", dev)
         resident = S.to_device(S.make_batch(4, seed=11, num_points=6000, num_instances=6, num_candidates=3,
@@ -248,8 +248,8 @@ def test_pipelined_training_steps_equal_inline_steps(lib):
         lidar = resident.pop("lidar")
         resident["lidar_F"], resident["lidar_C"], resident["B"] = lidar.F, lidar.C, 4
         opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
-        state = {"pipeline": mode == "pipelined", "threaded": True}
-        if mode == "pipelined":
+        state = {"pipeline": mode != "inline", "threaded": mode == "pipelined-thread"}
+        if mode != "inline":
             state["labels"] = lambda dd: prepare_labels(dd, bench.step_fn.cfg, dev) if "_attr_prepared" in dd else None
         losses = [float(bench.step_fn(model, resident, "full", None, opt, state)) for _ in range(4)]
         torch.cuda.synchronize()
@@ -257,5 +257,6 @@ def test_pipelined_training_steps_equal_inline_steps(lib):
         if th is not None:
             th.join()
         out[mode] = (losses, torch.cat([p.detach().flatten() for p in model.parameters()]).clone())
-    assert out["inline"][0] == out["pipelined"][0], (out["inline"][0], out["pipelined"][0])
-    assert torch.equal(out["inline"][1], out["pipelined"][1])
+    for mode in ("pipelined", "pipelined-thread"):
+        assert out["inline"][0] == out[mode][0], (mode, out["inline"][0], out[mode][0])
+        assert torch.equal(out["inline"][1], out[mode][1]), mode

@@ -17,7 +17,7 @@ resident = S.to_device(S.make_batch(B, seed=123), dev)
 lidar = resident.pop("lidar"); perm = torch.randperm(lidar.F.shape[0], device=dev)
 resident["lidar_F"], resident["lidar_C"], resident["B"] = lidar.F[perm].contiguous(), lidar.C[perm].contiguous(), B
 opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
-state = {"pipeline": True, "threaded": True}
+state = {"pipeline": True, "threaded": False}
 state["labels"] = lambda dd: prepare_labels(dd, bench.step_fn.cfg, dev) if "_attr_prepared" in dd else None
 import resource
 for blk in range(6):
