@@ -33,6 +33,16 @@ class FlatAdam:
                 view = self.flat_p[off:off + p.numel()].view_as(p)
                 view.copy_(p)
                 p.data = view
+        # Gradient sinks: a producer that computes ALL gradients of a parameter group in one native call (the sparse
+        # encoders' executor) may write them straight into the group's slots of flat_g and hand autograd `None` for those
+        # parameters: no AccumulateGrad node, no .grad tensor, no copy at gather time for ~half of the parameters.
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        for p, slot in zip(self.params, self._slots):
+            p._irx_sink = (self, slot)
+        self._direct = set()            # parameter indices whose slot already holds this step's gradient
+        self._direct_groups = set()     # producer keys that delivered since the last zero_grad()
+        self._gather_cache = {}
+        self._pending = []              # events of sink deliveries not yet waited for
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.world_size = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
@@ -40,14 +50,54 @@ class FlatAdam:
     def zero_grad(self):
         for p in self.params:
             p.grad = None        # autograd then hands over freshly computed gradients without an add kernel
+        self._direct.clear()
+        self._direct_groups.clear()
+
+    # ---- gradient-sink protocol (see __init__) ----
+    def sink_slots(self, key, params):
+        """-> list of slot tensors for `params` if the producer `key` may deliver directly now (every parameter is ours
+        and the producer has not delivered since the last zero_grad()), else None."""
+        if key in self._direct_groups:
+            return None                  # second backward before the step: fall back to ordinary accumulation
+        try:
+            return [self._slots[self._index[id(p)]] for p in params]
+        except KeyError:
+            return None
+
+    def sink_delivered(self, key, params):
+        """Called by the producer right after it enqueued the kernels that write the slots (on ITS current stream, which
+        for the scene encoder is not the optimizer's): an event makes gather_grads() wait for them. (Autograd only
+        synchronises the streams of AccumulateGrad nodes at the end of backward(), and these parameters have none now.)"""
+        self._direct_groups.add(key)
+        self._direct.update(self._index[id(p)] for p in params)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append(ev)
 
     def gather_grads(self):
         """All .grad tensors -> their slots in flat_g with one multi-tensor copy (the padding between slots stays zero;
-        a missing grad counts as zero)."""
-        grads = [p.grad for p in self.params]
-        if any(g is None for g in grads):
-            grads = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, self.params)]
-        torch._foreach_copy_(self._slots, grads)
+        a missing grad counts as zero); slots already filled through the sink protocol are left alone."""
+        if self._pending:
+            cur = torch.cuda.current_stream()
+            for ev in self._pending:
+                cur.wait_event(ev)
+            self._pending.clear()
+        key = frozenset(self._direct_groups)
+        todo = self._gather_cache.get(key)
+        if todo is None:
+            todo = [i for i in range(len(self.params)) if i not in self._direct]
+            self._gather_cache[key] = todo
+        slots, grads = [], []
+        for i in todo:
+            g = self.params[i].grad
+            slots.append(self._slots[i])
+            grads.append(g if g is not None else torch.zeros_like(self.params[i]))
+        if slots:
+            torch._foreach_copy_(slots, grads)
+        for i in self._direct:           # a producer delivered AND autograd accumulated (second backward): add it
+            g = self.params[i].grad
+            if g is not None:
+                self._slots[i].add_(g)
 
     def all_reduce(self):
         if self.world_size > 1:

@@ -152,6 +152,9 @@ class EncoderFn(torch.autograd.Function):
         if counters:
             torch._foreach_add_(counters, 1)
         ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = layers, desc, fdesc, (n_out, cout, poffs, ptotal)
+        # gradient sink (optim.FlatAdam): parameter gradients can go straight into the optimizer's flat buffer
+        sink = getattr(params[0], "_irx_sink", None)
+        ctx.sink = (sink[0], id(encoder), params) if sink is not None else None
         ctx.save_for_backward(x0, arena, stats, *params)
         o0 = int(start[-1] + sz[-1])
         return arena[o0:o0 + layers[-1].n_out * layers[-1].cout].view(layers[-1].n_out, layers[-1].cout)
@@ -169,8 +172,16 @@ class EncoderFn(torch.autograd.Function):
         dc_off = int(goffs[-1])
         total = dc_off + int(gsz.max())
         garena = torch.empty(total, dtype=_f32, device=dev)
-        pgrad = torch.empty(ptotal, dtype=_f32, device=dev)            # kernel, gamma, beta gradients of every layer
-        gbase, pbase = garena.data_ptr(), pgrad.data_ptr()
+        slots = None
+        if ctx.sink is not None:
+            owner, key, sparams = ctx.sink
+            slots = owner.sink_slots(key, sparams)
+        if slots is None:
+            pgrad = torch.empty(ptotal, dtype=_f32, device=dev)        # kernel, gamma, beta gradients of every layer
+            pptr = pgrad.data_ptr() + poffs
+        else:
+            pptr = np.fromiter((t.data_ptr() for t in slots), dtype=np.int64, count=3 * nl).reshape(nl, 3)
+        gbase = garena.data_ptr()
         desc = ctx.desc.copy()
         need_dx0 = ctx.needs_input_grad[0]
         tb, pr = [], []
@@ -187,7 +198,7 @@ class EncoderFn(torch.autograd.Function):
                 pr.append((0, 0, 0, 0))
         desc[:, _E["TBL_B"]:_E["FLIP_B"] + 1] = np.array(tb, dtype=np.int64)
         desc[:, _E["PAIR_IN"]:_E["LD_PAIRS"] + 1] = np.array(pr, dtype=np.int64)
-        desc[:, _E["DW"]:_E["DBETA"] + 1] = pbase + poffs
+        desc[:, _E["DW"]:_E["DBETA"] + 1] = pptr
         desc[:-1, _E["GY"]] = gbase + 4 * goffs[:-1]
         desc[-1, _E["GY"]] = dout.data_ptr()
         dfeats = torch.empty((layers[0].n_in, layers[0].cin), dtype=_f32, device=dev) if need_dx0 else None
@@ -199,6 +210,9 @@ class EncoderFn(torch.autograd.Function):
                                       _lib.stream_ptr())
         if rc:
             _lib.check(rc, "irx_encoder_backward")
+        if slots is not None:
+            owner.sink_delivered(key, sparams)
+            return (dfeats, None, None) + (None,) * (3 * nl)
         grads = []
         po = poffs // 4
         for i, L in enumerate(layers):
