@@ -149,8 +149,9 @@ __device__ static inline uint64_t parent_key(uint64_t key, int level) {
 
 // pass 1: per-tile count of segment heads (parent key differs from predecessor's).
 __global__ void k_ds_count(const uint64_t* __restrict__ keys, int n, int level,
-                           int32_t* __restrict__ tile_counts) {
+                           int32_t* __restrict__ tile_counts, const int32_t* __restrict__ n_dev) {
   __shared__ int s_wave[DS_BLOCK / 64];
+  if (n_dev) n = *n_dev;                           // row count produced on the device by the previous level
   int base = blockIdx.x * DS_TILE;
   int cnt = 0;
   for (int it = 0; it < DS_ITEMS; ++it) {
@@ -177,8 +178,10 @@ __global__ void k_ds_write(const uint64_t* __restrict__ keys, const int4* __rest
                            int level, int s2, const int32_t* __restrict__ tile_counts, int ntiles,
                            int32_t* __restrict__ parent, uint8_t* __restrict__ koff,
                            int4* __restrict__ out_coords, uint64_t* __restrict__ out_keys,
-                           int32_t* __restrict__ child, int ld, int32_t* __restrict__ n_out) {
+                           int32_t* __restrict__ child, int ld, int32_t* __restrict__ n_out,
+                           const int32_t* __restrict__ n_dev) {
   __shared__ int s_red[DS_BLOCK / 64];
+  if (n_dev) n = *n_dev;
   __shared__ int s_wave_base[DS_BLOCK / 64];
   __shared__ int s_tile_base;
   // exclusive prefix of tile counts for this tile
@@ -422,12 +425,67 @@ extern "C" int irx_downsample(const uint64_t* keys, const int32_t* coords, int n
   if (fb > 2048) fb = 2048;
   k_fill_i32<<<fb, 256, 0, S(stream)>>>(child, fill, -1);
   IRX_CHECK_LAUNCH("irx_downsample(fill)");
-  k_ds_count<<<ntiles, DS_BLOCK, 0, S(stream)>>>(keys, n, level, tile_counts);
+  k_ds_count<<<ntiles, DS_BLOCK, 0, S(stream)>>>(keys, n, level, tile_counts, nullptr);
   IRX_CHECK_LAUNCH("irx_downsample(count)");
   k_ds_write<<<ntiles, DS_BLOCK, 0, S(stream)>>>(keys, (const int4*)coords, n, level,
                                                 2 * tensor_stride, tile_counts, ntiles, parent, koff,
-                                                (int4*)out_coords, out_keys, child, ld, n_out);
+                                                (int4*)out_coords, out_keys, child, ld, n_out, nullptr);
   IRX_CHECK_LAUNCH("irx_downsample(write)");
+  return IRX_OK;
+}
+
+// child[k][p] = -1 for p < n (n on the device when n_dev != NULL): only the columns a level can use are touched
+__global__ void k_fill_child(int32_t* __restrict__ child, int ld, int n, const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = *n_dev;
+  const size_t total = (size_t)8 * n;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) child[(i / n) * ld + (i % n)] = -1;
+}
+
+// The whole `levels`-deep pyramid of one tensor in ONE call and with NO host sync in between: level l reads its row
+// count from counts[l-1] on the device (grids are sized for the upper bound n0; surplus workgroups find nothing to
+// do), so the caller needs a single D2H copy of counts[] instead of one per level (each cost ~0.12 ms of blocked
+// host time in the training loop). Every per-level buffer is caller-allocated for n0 rows; child tables have ld = ld.
+extern "C" int irx_pyramid_build(const uint64_t* keys0, const int32_t* coords0, int n0, int stride0, int levels,
+                                 int32_t* const* parent, uint8_t* const* koff, int32_t* const* out_coords,
+                                 uint64_t* const* out_keys, int32_t* const* child, int ld, int32_t* counts,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  IRX_REQUIRE(n0 >= 0 && levels >= 1 && levels <= 8 && counts, "irx_pyramid_build: bad arguments");
+  IRX_REQUIRE(stride0 >= 1 && (stride0 & (stride0 - 1)) == 0 && (stride0 << levels) <= 16384,
+              "irx_pyramid_build: tensor stride %d unsupported", stride0);
+  if (n0 == 0) {
+    IRX_CHECK_HIP(hipMemsetAsync(counts, 0, levels * sizeof(int32_t), S(stream)), "irx_pyramid_build(memset)");
+    return IRX_OK;
+  }
+  IRX_REQUIRE(keys0 && coords0 && parent && koff && out_coords && out_keys && child, "irx_pyramid_build: null pointer");
+  IRX_REQUIRE(ld >= n0, "irx_pyramid_build: ld %d < n0 %d", ld, n0);
+  if (workspace_bytes < irx_downsample_workspace_bytes(n0) || !workspace) {
+    irx_set_error("irx_pyramid_build: workspace %zu < %zu", workspace_bytes, irx_downsample_workspace_bytes(n0));
+    return IRX_ERR_WORKSPACE;
+  }
+  const int ntiles = irx_cdiv(n0, DS_TILE);
+  int32_t* tile_counts = (int32_t*)workspace;
+  const uint64_t* keys = keys0;
+  const int32_t* coords = coords0;
+  int stride = stride0;
+  for (int l = 0; l < levels; ++l) {
+    IRX_REQUIRE(parent[l] && koff[l] && out_coords[l] && out_keys[l] && child[l], "irx_pyramid_build: null level %d", l);
+    const int32_t* n_dev = l ? counts + (l - 1) : nullptr;
+    int fb = irx_cdiv((long long)8 * n0, 256);
+    if (fb > 2048) fb = 2048;
+    k_fill_child<<<fb, 256, 0, S(stream)>>>(child[l], ld, n0, n_dev);
+    IRX_CHECK_LAUNCH("irx_pyramid_build(fill)");
+    k_ds_count<<<ntiles, DS_BLOCK, 0, S(stream)>>>(keys, n0, ilog2(stride), tile_counts, n_dev);
+    IRX_CHECK_LAUNCH("irx_pyramid_build(count)");
+    k_ds_write<<<ntiles, DS_BLOCK, 0, S(stream)>>>(keys, (const int4*)coords, n0, ilog2(stride), 2 * stride, tile_counts,
+                                                  ntiles, parent[l], koff[l], (int4*)out_coords[l], out_keys[l],
+                                                  child[l], ld, counts + l, n_dev);
+    IRX_CHECK_LAUNCH("irx_pyramid_build(write)");
+    keys = out_keys[l];
+    coords = out_coords[l];
+    stride *= 2;
+  }
   return IRX_OK;
 }
 

@@ -113,6 +113,39 @@ def downsample(keys, coords, stride):
     return parent[:n], koff[:n], out_coords[:m], out_keys[:m], child, ld, m
 
 
+def pyramid_build(keys, coords, stride, levels):
+    """`levels` successive down-samplings in ONE library call and ONE host sync (irx_pyramid_build: each level reads
+    its row count from the device). -> list of (parent, koff, out_coords, out_keys, child, ld, n_out) per level, the same
+    tuples downsample() returns; all levels share five allocations sized for the finest level."""
+    import ctypes
+    n = coords.shape[0]
+    dev = coords.device
+    ld = max(n, 1)
+    parent = torch.empty((levels, ld), dtype=_i32, device=dev)
+    koff = torch.empty((levels, ld), dtype=torch.uint8, device=dev)
+    out_coords = torch.empty((levels, ld, 4), dtype=_i32, device=dev)
+    out_keys = torch.empty((levels, ld), dtype=_i64, device=dev)
+    child = torch.empty((levels, 8, ld), dtype=_i32, device=dev)
+    counts = torch.empty(levels, dtype=_i32, device=dev)
+    wsb = int(_lib.load().irx_downsample_workspace_bytes(n))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    arr = ctypes.c_void_p * levels
+
+    def ptrs(t):
+        step = t[0].numel() * t.element_size()
+        base = t.data_ptr()
+        return arr(*[base + l * step for l in range(levels)])
+
+    _lib.call("irx_pyramid_build", _lib.ptr(keys), _lib.ptr(coords), n, int(stride), levels, ptrs(parent), ptrs(koff),
+              ptrs(out_coords), ptrs(out_keys), ptrs(child), ld, _lib.ptr(counts), _lib.ptr(ws), wsb, _stream())
+    m = counts.tolist()                 # the ONE host sync of the pyramid
+    out, n_in = [], n
+    for l in range(levels):
+        out.append((parent[l, :n_in], koff[l, :n_in], out_coords[l, :m[l]], out_keys[l, :m[l]], child[l], ld, m[l]))
+        n_in = m[l]
+    return out
+
+
 def kmap_down_transpose(parent, koff):
     n = parent.shape[0]
     tbl = torch.empty((8, max(n, 1)), dtype=_i32, device=parent.device)

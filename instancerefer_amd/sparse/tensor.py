@@ -108,12 +108,18 @@ class Level:
         return out
 
     def build_pyramid(self, levels):
-        """Down-sample `levels` times now. Each level costs one tiny D2H (its row count); doing them back to back
-        BEFORE any convolution is queued keeps those syncs cheap (the queue is empty) and leaves the rest of the
-        forward pass free of host syncs."""
-        lv = self
-        for _ in range(levels):
-            lv = lv.down().out_level
+        """Down-sample `levels` times now, with ONE host sync for the whole pyramid (F_.pyramid_build: every level reads
+        its row count on the device) instead of one per level; done BEFORE any convolution is queued so that the sync
+        is cheap, which leaves the rest of the forward pass free of host syncs."""
+        lv, have = self, 0
+        while have < levels and lv._down is not None:      # levels already built (lazily or by an earlier call)
+            lv = lv._down.out_level
+            have += 1
+        if have < levels:
+            for parent, koff, oc, ok, child, ld, m in F_.pyramid_build(lv.keys, lv.coords, lv.stride, levels - have):
+                out = Level(oc, ok, lv.stride * 2, lv.batch_size)
+                lv._down = DownMap(parent, koff, child, ld, out)
+                lv = out
         return lv
 
     def offsets(self):
