@@ -77,26 +77,36 @@ def fresh_batch(resident):
     return dd
 
 
-def prepare_next(model, resident, state):
+def prepare_next(model, resident, state, phase="all"):
     """Input preparation of the NEXT step (candidate voxelisation, Morton sort, coordinate pyramids, relation node
     features, IoU labels: everything that depends only on the inputs, including the part of the forward that needs host
-    syncs) on its own HIP stream, issued right behind step N so that its kernels overlap step N's backward on the GPU
-    and its syncs never wait behind a long queue. `--prep-thread` moves it to a helper thread (measured equal: the loop is
-    bound by Python/dispatch work under the GIL, not by the sync waits). Multi-rank runs prepare inline at the start of
-    the step (no extra stream: two gloo ranks time-sharing one GPU stalled with it, and a real multi-GPU node is not
-    available to this build to rule the effect out there). Every step still does exactly one preparation of a fresh
-    batch; nothing is cached."""
+    syncs) on its own HIP stream. Inline mode (default) splits it around the issue of step N: the kernels are LAUNCHED
+    before step N's forward is issued (phase "launch": model.prepare_launch) and the level sizes are collected after
+    step N's optimizer launch (phase "finish"), by which time they have long arrived in pinned host memory — the syncs
+    cost nothing and the kernels overlap step N on the GPU. `--prep-thread` runs both phases on a helper thread instead
+    (measured equal: the loop is bound by Python/dispatch work under the GIL). Multi-rank runs prepare inline at the
+    start of the step (no extra stream: two gloo ranks time-sharing one GPU stalled with it, and a real multi-GPU node
+    is not available to this build to rule the effect out there). Every step still does exactly one preparation of a
+    fresh batch; nothing is cached."""
     side = state.setdefault("side", torch.cuda.Stream())
     dev = torch.cuda.current_device()
+
+    def launch():
+        with torch.cuda.stream(side):
+            nxt = model.prepare_launch(fresh_batch(resident))
+            if state.get("labels") is not None:          # host half of get_loss (IoU labelling) is input-only too
+                nxt["_loss_prepared"] = state["labels"](nxt)
+            state["launched"] = nxt
+
+    def finish():
+        with torch.cuda.stream(side):
+            state["next"] = model.prepare_finish(state.pop("launched"))
 
     def work():
         try:
             torch.cuda.set_device(dev)
-            with torch.cuda.stream(side):
-                nxt = model.prepare(fresh_batch(resident))
-                if state.get("labels") is not None:          # host half of get_loss (IoU labelling) is input-only too
-                    nxt["_loss_prepared"] = state["labels"](nxt)
-                state["next"] = nxt
+            launch()
+            finish()
         except BaseException as e:                      # surfaced by the training thread at join time
             state["next_error"] = e
 
@@ -105,8 +115,14 @@ def prepare_next(model, resident, state):
         th = threading.Thread(target=work, name="irx-input-prep", daemon=True)
         state["thread"] = th
         th.start()
+    elif phase == "launch":
+        launch()
+    elif phase == "finish":
+        finish()
+        state["thread"] = None
     else:
-        work()
+        launch()
+        finish()
         state["thread"] = None
 
 
@@ -136,8 +152,9 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
     dd = take_prepared(model, state) if state is not None else None
     if dd is None:
         dd = fresh_batch(resident)
-    if state is not None and state.get("pipeline") and state.get("threaded", True):
-        prepare_next(model, resident, state)             # batch N+1 is prepared while step N is issued and runs
+    if state is not None and state.get("pipeline"):
+        # batch N+1: threaded -> the whole preparation runs beside this step; inline -> only its launch phase now
+        prepare_next(model, resident, state, phase="launch")
     opt.zero_grad()
     dd = model(dd)
     if workload == "full":
@@ -156,7 +173,7 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
     loss.backward()
     opt.backward_step()          # one cat -> one all-reduce (N > 1) -> one fused Adam launch
     if state is not None and state.get("pipeline") and not state.get("threaded", True):
-        prepare_next(model, resident, state)             # inline variant: issued behind the step, on the side stream
+        prepare_next(model, resident, state, phase="finish")   # level sizes arrived during the step: no wait
     return loss
 
 

@@ -58,11 +58,20 @@ class AttributeModule(nn.Module):
         """Everything of this module that needs a host sync (class list -> candidate selection -> voxel count ->
         pyramid level sizes) and depends only on the inputs. InstanceRefer.forward runs it BEFORE queueing the heavy
         GPU work (when use_gt_lang), so these syncs never wait behind a long queue."""
+        return self.prepare_finish(self.prepare_launch(data_dict, lang_cls_pred))
+
+    def prepare_launch(self, data_dict, lang_cls_pred):
+        """prepare() up to (not including) the wait for the pyramid's level sizes."""
         st, sel = self.filter_candidates(data_dict, lang_cls_pred)
-        if st is not None:
-            st.level().build_pyramid(4)
+        data_dict['_attr_pending'] = st.level().build_pyramid_launch(4) if st is not None else None
         data_dict['_attr_prepared'] = (st, sel)
         data_dict['_lang_cls_pred_list'] = list(lang_cls_pred)
+        return data_dict
+
+    def prepare_finish(self, data_dict):
+        pending = data_dict.pop('_attr_pending', None)
+        if pending is not None:
+            data_dict['_attr_prepared'][0].level().build_pyramid_finish(pending)
         return data_dict
 
     def forward(self, data_dict):

@@ -32,17 +32,23 @@ class InstanceRefer(nn.Module):
 
     def prepare(self, data_dict):
         """Phase 0 — everything that needs a host sync and depends only on the inputs: candidate selection +
-        voxelisation + coordinate pyramid of the attribute path (needs the class list, i.e. GT classes), then Morton
-        sort + pyramid of the scene tensor. forward() calls it when the caller has not; a training loop can call it
-        for batch N+1 on a side stream while batch N's backward runs (bench.py does), after which forward() issues
-        its work without ever draining the GPU queue. Returns data_dict (marked prepared)."""
-        if data_dict.get('_prepared'):
+        voxelisation + coordinate pyramid of the attribute path (needs the class list, i.e. GT classes), the relation
+        node features, then Morton sort + pyramid of the scene tensor. forward() calls it when the caller has not; a
+        training loop can call it for batch N+1 on a side stream while batch N's backward runs (bench.py does), after
+        which forward() issues its work without ever draining the GPU queue. Returns data_dict (marked prepared)."""
+        return self.prepare_finish(self.prepare_launch(data_dict))
+
+    def prepare_launch(self, data_dict):
+        """prepare() up to the waits for the two pyramids' level sizes: every kernel is enqueued, the sizes are on their
+        way to pinned host memory. A loop that puts host work between prepare_launch() and prepare_finish() (bench.py:
+        the whole issue of step N) gets those syncs for free."""
+        if data_dict.get('_prepared') or data_dict.get('_prepare_launched'):
             return data_dict
-        if self.args.attribute_module and self.args.use_gt_lang and hasattr(self.attribute, 'prepare'):
+        if self.args.attribute_module and self.args.use_gt_lang and hasattr(self.attribute, 'prepare_launch'):
             cls = data_dict['object_cat']
             cls_list = data_dict['_host']['object_cat'] if 'object_cat' in data_dict.get('_host', {}) else cls.tolist()
             cls_list = [int(v) for v in cls_list]
-            data_dict = self.attribute.prepare(data_dict, cls_list)
+            data_dict = self.attribute.prepare_launch(data_dict, cls_list)
             if self.args.relation_module and hasattr(self.relation, 'prepare'):
                 data_dict = self.relation.prepare(data_dict, cls_list)
         if self.args.scene_module and 'lidar' in data_dict:
@@ -50,8 +56,21 @@ class InstanceRefer(nn.Module):
             if lidar._batch_size is None and 'point_min' in data_dict:
                 lidar._batch_size = data_dict['point_min'].shape[0]
             lidar = lidar.canonical()
-            lidar.level().build_pyramid(4)
+            data_dict['_scene_pending'] = lidar.level().build_pyramid_launch(4)
             data_dict['lidar'] = lidar
+        data_dict['_prepare_launched'] = True
+        return data_dict
+
+    def prepare_finish(self, data_dict):
+        if data_dict.get('_prepared'):
+            return data_dict
+        if not data_dict.get('_prepare_launched'):
+            data_dict = self.prepare_launch(data_dict)
+        if '_attr_pending' in data_dict:
+            data_dict = self.attribute.prepare_finish(data_dict)
+        pending = data_dict.pop('_scene_pending', None)
+        if pending is not None:
+            data_dict['lidar'].level().build_pyramid_finish(pending)
         data_dict['_prepared'] = True
         return data_dict
 

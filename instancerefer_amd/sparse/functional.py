@@ -113,10 +113,28 @@ def downsample(keys, coords, stride):
     return parent[:n], koff[:n], out_coords[:m], out_keys[:m], child, ld, m
 
 
-def pyramid_build(keys, coords, stride, levels):
-    """`levels` successive down-samplings in ONE library call and ONE host sync (irx_pyramid_build: each level reads
-    its row count from the device). -> list of (parent, koff, out_coords, out_keys, child, ld, n_out) per level, the same
-    tuples downsample() returns; all levels share five allocations sized for the finest level."""
+class PyramidPending:
+    """A pyramid whose kernels are enqueued (irx_pyramid_build) and whose level sizes are on their way to a pinned host
+    buffer; finish() waits for that copy (free if enough host work was done in between) and slices the levels."""
+
+    def __init__(self, bufs, counts_host, event, n, ld, levels):
+        self.bufs, self.counts_host, self.event, self.n, self.ld, self.levels = bufs, counts_host, event, n, ld, levels
+
+    def finish(self):
+        self.event.synchronize()            # the ONE host sync of the pyramid
+        m = self.counts_host.tolist()
+        parent, koff, out_coords, out_keys, child = self.bufs
+        out, n_in = [], self.n
+        for l in range(self.levels):
+            out.append((parent[l, :n_in], koff[l, :n_in], out_coords[l, :m[l]], out_keys[l, :m[l]], child[l], self.ld, m[l]))
+            n_in = m[l]
+        return out
+
+
+def pyramid_launch(keys, coords, stride, levels):
+    """Enqueue `levels` successive down-samplings as ONE library call (irx_pyramid_build: each level reads its row count
+    from the device) plus the async D2H copy of the level sizes. -> PyramidPending; all levels share five allocations
+    sized for the finest level."""
     import ctypes
     n = coords.shape[0]
     dev = coords.device
@@ -138,12 +156,16 @@ def pyramid_build(keys, coords, stride, levels):
 
     _lib.call("irx_pyramid_build", _lib.ptr(keys), _lib.ptr(coords), n, int(stride), levels, ptrs(parent), ptrs(koff),
               ptrs(out_coords), ptrs(out_keys), ptrs(child), ld, _lib.ptr(counts), _lib.ptr(ws), wsb, _stream())
-    m = counts.tolist()                 # the ONE host sync of the pyramid
-    out, n_in = [], n
-    for l in range(levels):
-        out.append((parent[l, :n_in], koff[l, :n_in], out_coords[l, :m[l]], out_keys[l, :m[l]], child[l], ld, m[l]))
-        n_in = m[l]
-    return out
+    counts_host = torch.empty(levels, dtype=_i32, pin_memory=True)
+    counts_host.copy_(counts, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return PyramidPending((parent, koff, out_coords, out_keys, child), counts_host, ev, n, ld, levels)
+
+
+def pyramid_build(keys, coords, stride, levels):
+    """-> list of (parent, koff, out_coords, out_keys, child, ld, n_out) per level, the tuples downsample() returns."""
+    return pyramid_launch(keys, coords, stride, levels).finish()
 
 
 def kmap_down_transpose(parent, koff):

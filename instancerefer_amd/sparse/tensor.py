@@ -111,12 +111,23 @@ class Level:
         """Down-sample `levels` times now, with ONE host sync for the whole pyramid (F_.pyramid_build: every level reads
         its row count on the device) instead of one per level; done BEFORE any convolution is queued so that the sync
         is cheap, which leaves the rest of the forward pass free of host syncs."""
+        return self.build_pyramid_finish(self.build_pyramid_launch(levels))
+
+    def build_pyramid_launch(self, levels):
+        """Enqueue the missing levels; -> opaque pending state for build_pyramid_finish(). Splitting the two lets an
+        input-preparation stage put useful host work between the launch and the (then free) sync."""
         lv, have = self, 0
         while have < levels and lv._down is not None:      # levels already built (lazily or by an earlier call)
             lv = lv._down.out_level
             have += 1
-        if have < levels:
-            for parent, koff, oc, ok, child, ld, m in F_.pyramid_build(lv.keys, lv.coords, lv.stride, levels - have):
+        if have == levels:
+            return (lv, None)
+        return (lv, F_.pyramid_launch(lv.keys, lv.coords, lv.stride, levels - have))
+
+    def build_pyramid_finish(self, pending):
+        lv, pend = pending
+        if pend is not None:
+            for parent, koff, oc, ok, child, ld, m in pend.finish():
                 out = Level(oc, ok, lv.stride * 2, lv.batch_size)
                 lv._down = DownMap(parent, koff, child, ld, out)
                 lv = out

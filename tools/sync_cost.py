@@ -24,16 +24,19 @@ acc = {"item": 0.0, "n": 0, "prep": 0.0}
 orig_item = torch.Tensor.item
 def timed_item(self):
     t0 = time.perf_counter(); r = orig_item(self); acc["item"] += time.perf_counter() - t0; acc["n"] += 1; return r
-orig_prep = model.prepare
-def timed_prep(dd):
-    t0 = time.perf_counter(); r = orig_prep(dd); acc["prep"] += time.perf_counter() - t0; return r
+orig_l, orig_f = model.prepare_launch, model.prepare_finish
+acc["fin"] = 0.0
+def timed_l(dd):
+    t0 = time.perf_counter(); r = orig_l(dd); acc["prep"] += time.perf_counter() - t0; return r
+def timed_f(dd):
+    t0 = time.perf_counter(); r = orig_f(dd); dt = time.perf_counter() - t0; acc["prep"] += dt; acc["fin"] += dt; return r
 for _ in range(10): bench.step_fn(model, resident, "full", None, opt, state)
 torch.cuda.synchronize()
-torch.Tensor.item = timed_item; model.prepare = timed_prep
+torch.Tensor.item = timed_item; model.prepare_launch = timed_l; model.prepare_finish = timed_f
 N = 50
 t0 = time.perf_counter()
 for _ in range(N): bench.step_fn(model, resident, "full", None, opt, state)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
-print("step %.2f ms | prepare() %.2f ms/step, of which blocked in .item(): %.2f ms (%.1f syncs/step, %.0f us each)"
-      % (dt * 1e3, acc["prep"] / N * 1e3, acc["item"] / N * 1e3, acc["n"] / N, acc["item"] / max(acc["n"], 1) * 1e6))
+print("step %.2f ms | prepare launch+finish %.2f ms/step (finish phase %.2f ms), of which blocked in .item(): %.2f ms (%.1f syncs/step, %.0f us each)"
+      % (dt * 1e3, acc["prep"] / N * 1e3, acc["fin"] / N * 1e3, acc["item"] / N * 1e3, acc["n"] / N, acc["item"] / max(acc["n"], 1) * 1e6))
