@@ -195,13 +195,15 @@ def batch_offsets(coords, nseg):
 
 
 # ------------------------------------------------------------------------------ sparse conv ---
-def _pairs(tbl, K):
-    """Number of valid (input, output) pairs M of a table (profiling only; cached per table storage)."""
-    key = (tbl.data_ptr(), tuple(tbl.shape), K)
+def _pairs(tbl, K, n_out):
+    """Number of valid (input, output) pairs M of a table (profiling only; cached per table storage). Only the first
+    n_out columns are meaningful: tables may be wider (ld > n_out, e.g. the shared pyramid buffers) and the rest is
+    uninitialised."""
+    key = (tbl.data_ptr(), tuple(tbl.shape), K, n_out)
     if key not in _PAIR_COUNT:
         if len(_PAIR_COUNT) > 4096:
             _PAIR_COUNT.clear()
-        _PAIR_COUNT[key] = int((tbl[:K] >= 0).sum().item())
+        _PAIR_COUNT[key] = int((tbl[:K, :n_out] >= 0).sum().item())
     return _PAIR_COUNT[key]
 
 
@@ -210,7 +212,7 @@ def spconv_gather_gemm(x, w, tbl, ld, n_out, K, cin, cout, flip_k, trans_w):
     wsb = int(_lib.load().irx_spconv_fwd_workspace_bytes(n_out, K, cin, cout, int(trans_w)))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     if PROFILE is not None:
-        m = _pairs(tbl, K)
+        m = _pairs(tbl, K, n_out)
         e0, e1 = _bracket()
     _lib.call("irx_spconv_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(tbl), ld, n_out, K, cin, cout,
               int(flip_k), int(trans_w), _lib.ptr(y), _lib.ptr(ws), wsb, _stream())
@@ -224,7 +226,7 @@ def spconv_wgrad(x, dy, tbl, ld, n_out, K, cin, cout):
     wsb = int(_lib.load().irx_spconv_wgrad_workspace_bytes(n_out, K, cin, cout))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     if PROFILE is not None:
-        m = _pairs(tbl, K)
+        m = _pairs(tbl, K, n_out)
         e0, e1 = _bracket()
     _lib.call("irx_spconv_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(tbl), ld, n_out, K, cin, cout,
               _lib.ptr(dw), _lib.ptr(ws), wsb, _stream())
