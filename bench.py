@@ -410,9 +410,9 @@ def summarise_roofline(recs):
     launch stream. The dominant HIP kernel is k_spconv2<128,128> (forward + data-gradient of every 128->128 layer:
     the largest total in the rocprofv3 kernel stats). Algorithmic figures per launch (SURVEY §8d formula A, e = 4):
         FLOPs = 2*M*Cin*Cout ;  Bytes_A = 4*(M*Cin + N_out*Cout + K*Cin*Cout) + 8*M      (wgrad: 4*(M*(Cin+Cout) + ...))
-    with M counted from the actual tables. achieved = sum(algorithmic flops or bytes of the binding resource) /
-    sum(measured time). The event bracket also covers the 4 us weight-permute launch and, for small layers, the
-    split-reduce launch that belong to the same C-ABI call."""
+    with M counted from the actual tables (valid columns only) and bounded by n_out*K — a pair count above that bound
+    would silently inflate the roofline figure, so it is an error. achieved = sum(algorithmic flops or bytes of the
+    binding resource) / sum(measured time); the events bracket the dominant kernel only (irx_profile_next_kernel)."""
     agg = {}
 
     def klass(kind, cin, cout):
@@ -427,6 +427,8 @@ def summarise_roofline(recs):
     tot = dict(ms=0.0, bound_ms=0.0)
     for kind, n_out, K, cin, cout, M, e0, e1 in recs:
         ms = e0.elapsed_time(e1)
+        if not 0 <= M <= n_out * K:
+            raise RuntimeError("roofline: pair count %d of a (%d rows, %d offsets) table is impossible" % (M, n_out, K))
         flops = 2.0 * M * cin * cout
         if kind == "wgrad":
             byts = 4.0 * (M * (cin + cout) + K * cin * cout) + 8.0 * M
