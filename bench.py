@@ -84,9 +84,8 @@ def prepare_next(model, resident, state, phase="all"):
     before step N's forward is issued (phase "launch": model.prepare_launch) and the level sizes are collected after
     step N's optimizer launch (phase "finish"), by which time they have long arrived in pinned host memory — the syncs
     cost nothing and the kernels overlap step N on the GPU. `--prep-thread` runs both phases on a helper thread instead
-    (measured equal: the loop is bound by Python/dispatch work under the GIL). Multi-rank runs prepare inline at the
-    start of the step (no extra stream: two gloo ranks time-sharing one GPU stalled with it, and a real multi-GPU node
-    is not available to this build to rule the effect out there). Every step still does exactly one preparation of a
+    (measured equal: the loop is bound by Python/dispatch work under the GIL). Multi-rank runs use the same two phases
+    on the main stream (see main()). Every step still does exactly one preparation of a
     fresh batch; nothing is cached."""
     side = state.setdefault("side", torch.cuda.Stream())
     dev = torch.cuda.current_device()
@@ -340,10 +339,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Input-prep pipeline (thread + own stream) on single-GPU runs only: with two ranks time-sharing ONE GPU (the
+    # Input-prep pipeline: launch phase before the step is issued, finish phase (level sizes) after it — the host never
+    # blocks in a sync. Single GPU: on its own stream, so the preparation kernels also overlap the step. Multi-rank: on
+    # the MAIN stream (they run ahead of the step's kernels, ~0.5 ms): with two gloo ranks time-sharing ONE GPU (the
     # IRX_BENCH_SHARE_GPU test rig) a third stream per process made every host sync wait ~250 ms (2.2 s/step), and a real
-    # multi-GPU node is not available to this build to rule the effect out there, so N > 1 prepares inline.
-    state = {"pipeline": (not args.no_pipeline) and world == 1, "threaded": bool(args.prep_thread)}
+    # multi-GPU node is not available to this build to rule the effect out there.
+    state = {"pipeline": not args.no_pipeline, "threaded": bool(args.prep_thread) and world == 1}
+    if world > 1 or os.environ.get("IRX_BENCH_PREP_MAIN") == "1":   # (env: emulate the N > 1 arrangement on one GPU)
+        state["side"] = torch.cuda.current_stream()
     if args.workload == "full":
         from instancerefer_amd.loss_helper import prepare_labels
         state["labels"] = lambda dd: prepare_labels(dd, step_fn.cfg, device) if "_attr_prepared" in dd else None

@@ -131,11 +131,12 @@ int irx_downsample(const uint64_t* keys, const int32_t* coords, int n, int tenso
  * without a host sync between levels: level l takes its row count from counts[l-1] ON THE DEVICE. Host arrays of
  * `levels` device pointers; every per-level buffer holds n0 rows (the upper bound), child tables int32 [8][ld], ld >= n0.
  * counts int32 [levels] (device): rows of each down-sampled level; one D2H copy of it replaces a sync per level.
+ * n0_dev (device, may be NULL): the input's actual row count when n0 is only an upper bound (un-synchronised voxeliser).
  * workspace: irx_downsample_workspace_bytes(n0). */
 int irx_pyramid_build(const uint64_t* keys0, const int32_t* coords0, int n0, int stride0, int levels,
                       int32_t* const* parent, uint8_t* const* koff, int32_t* const* out_coords,
-                      uint64_t* const* out_keys, int32_t* const* child, int ld, int32_t* counts, void* workspace,
-                      size_t workspace_bytes, void* stream);
+                      uint64_t* const* out_keys, int32_t* const* child, int ld, int32_t* counts,
+                      const int32_t* n0_dev, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Transposed table of a down-sampling map for its data-gradient: tbl[k][i] = parent[i] if
  * koff[i]==k else -1  (int32 [8][ld], ld >= n). */

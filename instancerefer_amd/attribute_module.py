@@ -14,7 +14,7 @@ from .basic_blocks import SparseConvEncoder
 from .data import idx_tensor, selection_on_device, upload_instances
 from .dense import cosine_rows
 from .sparse import nn as spnn
-from .sparse.utils import voxelize
+from .sparse.utils import voxelize, voxelize_launch
 
 
 class AttributeModule(nn.Module):
@@ -37,9 +37,10 @@ class AttributeModule(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    def filter_candidates(self, data_dict, lang_cls_pred):
+    def filter_candidates(self, data_dict, lang_cls_pred, launch_only=False):
         """-> (SparseTensor of all candidates' voxels, pred_obb_batch, num_filtered_objs); same selection
-        rule as the reference (class match; scenes with < 2 candidates contribute no voxels)."""
+        rule as the reference (class match; scenes with < 2 candidates contribute no voxels).
+        launch_only: -> (VoxelizePending, sel): voxeliser + 4-level pyramid enqueued, no host sync yet."""
         pack = upload_instances(data_dict)
         sel = pack.select(lang_cls_pred)
         dev = pack.pts32.device
@@ -51,6 +52,8 @@ class AttributeModule(nn.Module):
         pts = pack.pts32.index_select(0, cand)                 # (Nc, P, C0) float32
         p = xyz.shape[1]
         batch = torch.arange(nc, device=dev, dtype=torch.int32).repeat_interleave(p)
+        if launch_only:
+            return voxelize_launch(xyz.view(-1, 3), pts.view(nc * p, -1), batch, self.voxel_size, nc, 4), sel
         st = voxelize(xyz.view(-1, 3), pts.view(nc * p, -1), batch, self.voxel_size, nc)
         return st, sel
 
@@ -61,17 +64,18 @@ class AttributeModule(nn.Module):
         return self.prepare_finish(self.prepare_launch(data_dict, lang_cls_pred))
 
     def prepare_launch(self, data_dict, lang_cls_pred):
-        """prepare() up to (not including) the wait for the pyramid's level sizes."""
-        st, sel = self.filter_candidates(data_dict, lang_cls_pred)
-        data_dict['_attr_pending'] = st.level().build_pyramid_launch(4) if st is not None else None
-        data_dict['_attr_prepared'] = (st, sel)
+        """prepare() with every kernel enqueued and NO host sync: the voxel count and the pyramid level sizes are
+        collected by prepare_finish()."""
+        pending, sel = self.filter_candidates(data_dict, lang_cls_pred, launch_only=True)
+        data_dict['_attr_pending'] = pending
+        data_dict['_attr_prepared'] = (None, sel)
         data_dict['_lang_cls_pred_list'] = list(lang_cls_pred)
         return data_dict
 
     def prepare_finish(self, data_dict):
         pending = data_dict.pop('_attr_pending', None)
         if pending is not None:
-            data_dict['_attr_prepared'][0].level().build_pyramid_finish(pending)
+            data_dict['_attr_prepared'] = (pending.finish(), data_dict['_attr_prepared'][1])
         return data_dict
 
     def forward(self, data_dict):

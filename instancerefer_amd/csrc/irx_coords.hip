@@ -446,11 +446,12 @@ __global__ void k_fill_child(int32_t* __restrict__ child, int ld, int n, const i
 // The whole `levels`-deep pyramid of one tensor in ONE call and with NO host sync in between: level l reads its row
 // count from counts[l-1] on the device (grids are sized for the upper bound n0; surplus workgroups find nothing to
 // do), so the caller needs a single D2H copy of counts[] instead of one per level (each cost ~0.12 ms of blocked
-// host time in the training loop). Every per-level buffer is caller-allocated for n0 rows; child tables have ld = ld.
+// host time in the training loop). n0_dev != NULL: the finest level's own row count is on the device too (a voxeliser
+// that has not been synchronised yet) and n0 is only its upper bound. Every per-level buffer is caller-allocated for n0 rows; child tables have ld = ld.
 extern "C" int irx_pyramid_build(const uint64_t* keys0, const int32_t* coords0, int n0, int stride0, int levels,
                                  int32_t* const* parent, uint8_t* const* koff, int32_t* const* out_coords,
                                  uint64_t* const* out_keys, int32_t* const* child, int ld, int32_t* counts,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                 const int32_t* n0_dev, void* workspace, size_t workspace_bytes, void* stream) {
   IRX_REQUIRE(n0 >= 0 && levels >= 1 && levels <= 8 && counts, "irx_pyramid_build: bad arguments");
   IRX_REQUIRE(stride0 >= 1 && (stride0 & (stride0 - 1)) == 0 && (stride0 << levels) <= 16384,
               "irx_pyramid_build: tensor stride %d unsupported", stride0);
@@ -471,7 +472,7 @@ extern "C" int irx_pyramid_build(const uint64_t* keys0, const int32_t* coords0, 
   int stride = stride0;
   for (int l = 0; l < levels; ++l) {
     IRX_REQUIRE(parent[l] && koff[l] && out_coords[l] && out_keys[l] && child[l], "irx_pyramid_build: null level %d", l);
-    const int32_t* n_dev = l ? counts + (l - 1) : nullptr;
+    const int32_t* n_dev = l ? counts + (l - 1) : n0_dev;   // level 0: host n0, or (n0_dev != NULL) n0 = upper bound
     int fb = irx_cdiv((long long)8 * n0, 256);
     if (fb > 2048) fb = 2048;
     k_fill_child<<<fb, 256, 0, S(stream)>>>(child[l], ld, n0, n_dev);

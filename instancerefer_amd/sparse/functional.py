@@ -77,6 +77,19 @@ def voxel_unique(keys):
     return winners[:m].long()
 
 
+def voxel_unique_launch(keys):
+    """voxel_unique without the host sync: -> (winners int64 [n] with the m winning point indices first and zeros behind,
+    count int32 [1] on the device)."""
+    n = keys.shape[0]
+    tk, tv, cap = new_table(n, keys.device)
+    _lib.call("irx_voxel_insert", _lib.ptr(keys), n, _lib.ptr(tk), _lib.ptr(tv), cap, _stream())
+    winners = torch.zeros(max(n, 1), dtype=_i32, device=keys.device)
+    count = torch.empty(1, dtype=_i32, device=keys.device)
+    _lib.call("irx_voxel_select", _lib.ptr(keys), n, _lib.ptr(tk), _lib.ptr(tv), cap, _lib.ptr(winners),
+              _lib.ptr(count), _stream())
+    return winners[:n].long(), count
+
+
 def hash_build(keys):
     n = keys.shape[0]
     tk, tv, cap = new_table(n, keys.device)
@@ -115,26 +128,32 @@ def downsample(keys, coords, stride):
 
 class PyramidPending:
     """A pyramid whose kernels are enqueued (irx_pyramid_build) and whose level sizes are on their way to a pinned host
-    buffer; finish() waits for that copy (free if enough host work was done in between) and slices the levels."""
+    buffer; finish() waits for that copy (free if enough host work was done in between) and slices the levels.
+    n0 is None when the finest level's own row count was still on the device at launch (see pyramid_launch)."""
 
-    def __init__(self, bufs, counts_host, event, n, ld, levels):
+    def __init__(self, bufs, counts_host, event, n, ld, levels, n0_known):
         self.bufs, self.counts_host, self.event, self.n, self.ld, self.levels = bufs, counts_host, event, n, ld, levels
+        self.n0_known = n0_known
 
     def finish(self):
+        """-> (n0, [per-level tuples])"""
         self.event.synchronize()            # the ONE host sync of the pyramid
         m = self.counts_host.tolist()
+        n0 = self.n if self.n0_known else m[0]
+        m = m[1:]
         parent, koff, out_coords, out_keys, child = self.bufs
-        out, n_in = [], self.n
+        out, n_in = [], n0
         for l in range(self.levels):
             out.append((parent[l, :n_in], koff[l, :n_in], out_coords[l, :m[l]], out_keys[l, :m[l]], child[l], self.ld, m[l]))
             n_in = m[l]
-        return out
+        return n0, out
 
 
-def pyramid_launch(keys, coords, stride, levels):
+def pyramid_launch(keys, coords, stride, levels, n0_dev=None):
     """Enqueue `levels` successive down-samplings as ONE library call (irx_pyramid_build: each level reads its row count
     from the device) plus the async D2H copy of the level sizes. -> PyramidPending; all levels share five allocations
-    sized for the finest level."""
+    sized for the finest level. n0_dev (int32 device tensor of 1 element): the row count of keys / coords is still on
+    the device and their shape[0] is only its upper bound (sync-free voxeliser)."""
     import ctypes
     n = coords.shape[0]
     dev = coords.device
@@ -144,7 +163,9 @@ def pyramid_launch(keys, coords, stride, levels):
     out_coords = torch.empty((levels, ld, 4), dtype=_i32, device=dev)
     out_keys = torch.empty((levels, ld), dtype=_i64, device=dev)
     child = torch.empty((levels, 8, ld), dtype=_i32, device=dev)
-    counts = torch.empty(levels, dtype=_i32, device=dev)
+    counts = torch.zeros(levels + 1, dtype=_i32, device=dev)          # [n0, m_1 .. m_levels]
+    if n0_dev is not None:
+        counts[0:1].copy_(n0_dev)
     wsb = int(_lib.load().irx_downsample_workspace_bytes(n))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     arr = ctypes.c_void_p * levels
@@ -155,17 +176,18 @@ def pyramid_launch(keys, coords, stride, levels):
         return arr(*[base + l * step for l in range(levels)])
 
     _lib.call("irx_pyramid_build", _lib.ptr(keys), _lib.ptr(coords), n, int(stride), levels, ptrs(parent), ptrs(koff),
-              ptrs(out_coords), ptrs(out_keys), ptrs(child), ld, _lib.ptr(counts), _lib.ptr(ws), wsb, _stream())
-    counts_host = torch.empty(levels, dtype=_i32, pin_memory=True)
+              ptrs(out_coords), ptrs(out_keys), ptrs(child), ld, counts.data_ptr() + 4,
+              counts.data_ptr() if n0_dev is not None else None, _lib.ptr(ws), wsb, _stream())
+    counts_host = torch.empty(levels + 1, dtype=_i32, pin_memory=True)
     counts_host.copy_(counts, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    return PyramidPending((parent, koff, out_coords, out_keys, child), counts_host, ev, n, ld, levels)
+    return PyramidPending((parent, koff, out_coords, out_keys, child), counts_host, ev, n, ld, levels, n0_dev is None)
 
 
 def pyramid_build(keys, coords, stride, levels):
     """-> list of (parent, koff, out_coords, out_keys, child, ld, n_out) per level, the tuples downsample() returns."""
-    return pyramid_launch(keys, coords, stride, levels).finish()
+    return pyramid_launch(keys, coords, stride, levels).finish()[1]
 
 
 def kmap_down_transpose(parent, koff):

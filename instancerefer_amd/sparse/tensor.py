@@ -127,7 +127,7 @@ class Level:
     def build_pyramid_finish(self, pending):
         lv, pend = pending
         if pend is not None:
-            for parent, koff, oc, ok, child, ld, m in pend.finish():
+            for parent, koff, oc, ok, child, ld, m in pend.finish()[1]:
                 out = Level(oc, ok, lv.stride * 2, lv.batch_size)
                 lv._down = DownMap(parent, koff, child, ld, out)
                 lv = out

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import functional as F_
-from .tensor import Level, SparseTensor
+from .tensor import DownMap, Level, SparseTensor
 
 
 def _voxel3(quantization_size):
@@ -34,6 +34,44 @@ def voxelize(xyz, feats, batch, voxel_size, batch_size):
     Fv = feats.index_select(0, idx).float().contiguous()
     lv = Level(C, skeys, 1, batch_size)
     return SparseTensor(Fv, C, 1, batch_size, lv)
+
+
+class VoxelizePending:
+    """voxelize() + a `levels`-deep coordinate pyramid with every kernel enqueued and NO host sync yet: buffers are
+    sized for the upper bound (one voxel per point), the voxel count travels on the device into irx_pyramid_build and
+    arrives on the host together with the level sizes. finish() -> canonical SparseTensor with its pyramid built."""
+
+    def __init__(self, C, Fv, skeys, batch_size, pyramid):
+        self.C, self.Fv, self.skeys, self.batch_size, self.pyramid = C, Fv, skeys, batch_size, pyramid
+
+    def finish(self):
+        n0, levels = self.pyramid.finish()
+        C, Fv, skeys = self.C[:n0], self.Fv[:n0], self.skeys[:n0]
+        lv0 = Level(C, skeys, 1, self.batch_size)
+        lv = lv0
+        for parent, koff, oc, ok, child, ld, m in levels:
+            out = Level(oc, ok, lv.stride * 2, lv.batch_size)
+            lv._down = DownMap(parent, koff, child, ld, out)
+            lv = out
+        return SparseTensor(Fv, C, 1, self.batch_size, lv0)
+
+
+_KEY_PAD = (1 << 63) - 1        # sorts behind every real Morton key (batch index < 2^15)
+
+
+def voxelize_launch(xyz, feats, batch, voxel_size, batch_size, levels):
+    """Sync-free voxelize + pyramid (see VoxelizePending). Same result as voxelize() followed by build_pyramid()."""
+    coords, keys = F_.quantize(xyz, batch, _voxel3(voxel_size))
+    n = keys.shape[0]
+    win, count = F_.voxel_unique_launch(keys)                    # winners first, zeros behind; count on the device
+    valid = torch.arange(n, device=keys.device, dtype=torch.int32) < count
+    wkeys = torch.where(valid, keys.index_select(0, win), torch.full((), _KEY_PAD, dtype=keys.dtype, device=keys.device))
+    skeys, order = torch.sort(wkeys)                             # padding rows sort to the end
+    idx = win.index_select(0, order)
+    C = coords.index_select(0, idx).contiguous()
+    Fv = feats.index_select(0, idx).float().contiguous()
+    pyr = F_.pyramid_launch(skeys, C, 1, levels, n0_dev=count)
+    return VoxelizePending(C, Fv, skeys, batch_size, pyr)
 
 
 def sparse_quantize(coords, feats=None, labels=None, ignore_label=255, return_index=False,
