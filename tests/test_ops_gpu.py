@@ -362,3 +362,27 @@ def test_contrastive_matches_reference_formulation(lib):
     (got * 1.0).sum().backward()
     for a, b in zip(sd, s):
         assert (a.grad.cpu() - b.grad).abs().max().item() <= 1e-5
+
+
+def test_sync_free_voxelize_and_single_call_pyramid_equal_the_stepwise_path(lib, clouds):
+    """voxelize_launch (upper-bound buffers, voxel count on the device) + irx_pyramid_build (device-side level sizes) must
+    reproduce voxelize() + four irx_downsample calls bit for bit: coordinates, keys, features, parent / child maps."""
+    from instancerefer_amd.sparse import functional as F_
+    from instancerefer_amd.sparse.utils import voxelize, voxelize_launch
+    pts = [torch.from_numpy(c) for c in clouds]
+    allp = torch.cat(pts).cuda()
+    batch = torch.cat([torch.full((p.shape[0],), i, dtype=torch.int32) for i, p in enumerate(pts)]).cuda()
+    xyz, feats = allp[:, :3].double().contiguous(), allp.float()
+    ref = voxelize(xyz, feats, batch, [0.05] * 3, len(pts))
+    got = voxelize_launch(xyz, feats, batch, [0.05] * 3, len(pts), 4).finish()
+    assert torch.equal(got.C, ref.C) and torch.equal(got.F, ref.F)
+    a, b = ref.level(), got.level()
+    for _ in range(4):
+        parent, koff, oc, ok, child, ld, m = F_.downsample(a.keys, a.coords, a.stride)       # the stepwise reference
+        db = b._down
+        assert db is not None, "pyramid was not built by the launch"
+        assert torch.equal(db.parent, parent) and torch.equal(db.koff, koff)
+        assert torch.equal(db.out_level.coords, oc) and torch.equal(db.out_level.keys, ok)
+        assert torch.equal(db.child[:, :m], child[:, :m])
+        from instancerefer_amd.sparse.tensor import Level
+        a, b = Level(oc, ok, a.stride * 2, a.batch_size), db.out_level
