@@ -43,13 +43,20 @@ class FlatAdam:
         self._direct_groups = set()     # producer keys that delivered since the last zero_grad()
         self._gather_cache = {}
         self._pending = []              # events of sink deliveries not yet waited for
+        self._todo_last = list(range(len(self.params)))
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.world_size = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
 
     def zero_grad(self):
-        for p in self.params:
-            p.grad = None        # autograd then hands over freshly computed gradients without an add kernel
+        # autograd then hands over freshly computed gradients without an add kernel. Parameters whose gradient went
+        # through the sink never held a .grad tensor (gather_grads clears the rare exception), so they are skipped.
+        if self._direct:
+            for i in self._todo_last:
+                self.params[i].grad = None
+        else:
+            for p in self.params:
+                p.grad = None
         self._direct.clear()
         self._direct_groups.clear()
 
@@ -87,6 +94,7 @@ class FlatAdam:
         if todo is None:
             todo = [i for i in range(len(self.params)) if i not in self._direct]
             self._gather_cache[key] = todo
+        self._todo_last = todo
         slots, grads = [], []
         for i in todo:
             g = self.params[i].grad
@@ -98,6 +106,7 @@ class FlatAdam:
             g = self.params[i].grad
             if g is not None:
                 self._slots[i].add_(g)
+                self.params[i].grad = None
 
     def all_reduce(self):
         if self.world_size > 1:
