@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
   }
   for (int st = st0; st < st1; ++st) {
     __syncthreads();                                     // previous stage's fragment reads are done
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the rows requested during the previous chain
 #pragma unroll
     for (int i = 0; i < NX; ++i) *reinterpret_cast<float4*>(&sX[(xr + i * PX) * LDX + xc]) = rx[i];
 #pragma unroll
@@ -165,33 +166,54 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
       sOutRow[parn][tid] = p < cnt ? ol[p] : -1;
     }
     __syncthreads();
-    if (st + 1 < st1) {                                  // prefetch next stage's rows; they land during the MFMAs
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        const int idx = sIn[parn][xr + i * PX];
-        rx[i] = idx >= 0 ? *reinterpret_cast<const float4*>(x + (size_t)idx * CIN + xc) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < ND; ++i) {
-        const int idx = sOutRow[parn][dr + i * PD];
-        rd[i] = idx >= 0 ? *reinterpret_cast<const float4*>(dy + (size_t)idx * COUT + dc) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+    const bool has_next = st + 1 < st1;
     int npairs = cnt - st * 64;
     if (npairs > 64) npairs = 64;
     const int nks = (npairs + 3) >> 2;
-    for (int ks = 0; ks < nks; ++ks) {
-      const int pp = ks * 4 + g4;
-      float a[CW], b[NW];
+    if (has_next) {
+      // A stage that has a successor is a full one (16 k-steps): the next stage's rows are requested from INSIDE its
+      // MFMA chain, one x and one dy load per step, so the wave never queues at the vector-memory pipe with an idle
+      // MFMA pipe behind it (the lesson of k_spconv2). Loads are unconditional (missing pairs re-read row 0 and are
+      // zeroed by a select), so the chain has no branches.
 #pragma unroll
-      for (int i = 0; i < CW; ++i) a[i] = sX[pp * LDX + (ct0 + i) * 16 + m];   // A[m = c][kk = pair]
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks < NX) {
+          const int idx = sIn[parn][xr + ks * PX];
+          const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(idx < 0 ? 0 : idx) * CIN + xc);
+          rx[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (ks < ND) {
+          const int idx = sOutRow[parn][dr + ks * PD];
+          const float4 v = *reinterpret_cast<const float4*>(dy + (size_t)(idx < 0 ? 0 : idx) * COUT + dc);
+          rd[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int pp = ks * 4 + g4;
+        float a[CW], b[NW];
 #pragma unroll
-      for (int i = 0; i < NW; ++i) b[i] = sD[pp * LDD + (nt0 + i) * 16 + m];   // B[kk = pair][n]
+        for (int i = 0; i < CW; ++i) a[i] = sX[pp * LDX + (ct0 + i) * 16 + m];   // A[m = c][kk = pair]
 #pragma unroll
-      for (int i = 0; i < CW; ++i)
+        for (int i = 0; i < NW; ++i) b[i] = sD[pp * LDD + (nt0 + i) * 16 + m];   // B[kk = pair][n]
 #pragma unroll
-        for (int jn = 0; jn < NW; ++jn)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+        for (int i = 0; i < CW; ++i)
+#pragma unroll
+          for (int jn = 0; jn < NW; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      for (int ks = 0; ks < nks; ++ks) {
+        const int pp = ks * 4 + g4;
+        float a[CW], b[NW];
+#pragma unroll
+        for (int i = 0; i < CW; ++i) a[i] = sX[pp * LDX + (ct0 + i) * 16 + m];   // A[m = c][kk = pair]
+#pragma unroll
+        for (int i = 0; i < NW; ++i) b[i] = sD[pp * LDD + (nt0 + i) * 16 + m];   // B[kk = pair][n]
+#pragma unroll
+        for (int i = 0; i < CW; ++i)
+#pragma unroll
+          for (int jn = 0; jn < NW; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+      }
     }
     par = parn;
   }
