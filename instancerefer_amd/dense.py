@@ -1,5 +1,6 @@
 """Dense sequence ops of the language encoder on the irx kernels: a persistent GRU recurrence
-(csrc/irx_gru.hip) with the time-parallel projections as hipBLASLt GEMMs.
+(csrc/irx_gru.hip) with the time-parallel projections as GEMMs; plus the fused matching-score / contrastive-loss ops
+(csrc/irx_match.hip).
 
 `gru_packed(gru, x, lengths)` reproduces `pad_packed_sequence(gru(pack_padded_sequence(x, lengths)))` of an
 `nn.GRU(batch_first=True)` (reference models/lang_module.py:53-57) using that module's own parameters

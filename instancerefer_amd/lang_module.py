@@ -4,7 +4,7 @@ keys `gru.* word_projection.* fc_a fc_cls fc_rel fc_scene lang_cls.0`, and data_
 GloVe(300) -> MLP 300->256->256 -> 2-layer (bi)GRU(128) -> four attention heads that pool the
 *MLP-projected* embeddings (softmax over padded positions, then mask + renormalise; reference
 lang_module.py:61-83) -> 4 x 256-d sentence vectors + 18-way classifier. Dense work: PyTorch-ROCm
-(MIOpen GRU, hipBLASLt GEMMs run on MFMA); the four heads are evaluated as one batched GEMM.
+(own persistent GRU recurrence kernel on HIP devices, GEMMs on MFMA); the four heads are evaluated as one batched GEMM.
 """
 import torch
 import torch.nn as nn
