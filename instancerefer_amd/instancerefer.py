@@ -130,6 +130,8 @@ class InstanceRefer(nn.Module):
     def _encoder_stream(self, device):
         st = getattr(self, '_enc_stream', None)
         if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
+            # high priority: the scene encoder is the long pole of the step (its output gates the scene head, its
+            # backward is the last big thing to finish), so its kernels should win CUs over the main stream's
+            st = torch.cuda.Stream(device=device, priority=-1)
             object.__setattr__(self, '_enc_stream', st)      # not a module attribute: never pickled with the state
         return st
