@@ -115,27 +115,31 @@ __global__ void k_voxel_select(const uint64_t* __restrict__ keys, int n,
   }
 }
 
-// one thread per (offset k, voxel q): consecutive threads -> consecutive q (coalesced stores).
+// one thread per (offset k <= 13, voxel q): consecutive threads -> consecutive q (coalesced stores). The table is
+// symmetric -- nbr[k][q] = j  <=>  nbr[26-k][j] = q  (offset 26-k is the negated offset k) -- so only 13 of the 26
+// non-centre offsets are probed in the hash table (the probes are the cost: ~47 -> ~27 us at N = 490 k) and the mirror
+// entry is scattered; rows 14..26 are pre-filled with -1 for the voxels that receive no mirror entry.
 __global__ void k_kmap_s1(const int4* __restrict__ coords, int n, int s,
                           const uint64_t* __restrict__ tk, const int32_t* __restrict__ tv,
                           uint64_t mask, int32_t* __restrict__ nbr, int ld) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
-  int k = blockIdx.y;
+  int k = blockIdx.y;                               // 0..13
   if (q >= n) return;
+  if (k == 13) {
+    nbr[(size_t)13 * ld + q] = q;
+    return;
+  }
   int4 c = coords[q];
   int dx = (k % 3) - 1, dy = ((k / 3) % 3) - 1, dz = (k / 9) - 1;  // x fastest (odd kernel)
   int r;
-  if (k == 13) {
-    r = q;
-  } else {
-    int x = c.x + dx * s, y = c.y + dy * s, z = c.z + dz * s;
-    if (x < -IRX_COORD_BIAS || x >= IRX_COORD_BIAS || y < -IRX_COORD_BIAS || y >= IRX_COORD_BIAS ||
-        z < -IRX_COORD_BIAS || z >= IRX_COORD_BIAS)
-      r = -1;
-    else
-      r = irx_hash_lookup(tk, tv, mask, irx_make_key(x, y, z, c.w));
-  }
+  int x = c.x + dx * s, y = c.y + dy * s, z = c.z + dz * s;
+  if (x < -IRX_COORD_BIAS || x >= IRX_COORD_BIAS || y < -IRX_COORD_BIAS || y >= IRX_COORD_BIAS ||
+      z < -IRX_COORD_BIAS || z >= IRX_COORD_BIAS)
+    r = -1;
+  else
+    r = irx_hash_lookup(tk, tv, mask, irx_make_key(x, y, z, c.w));
   nbr[(size_t)k * ld + q] = r;
+  if (r >= 0) nbr[(size_t)(26 - k) * ld + r] = q;
 }
 
 // ---- down-sampling by segmented scan over Morton-sorted keys ----------------------------
@@ -387,7 +391,9 @@ extern "C" int irx_kmap_build_s1(const int32_t* coords, int n, int tensor_stride
   int rc = check_table("irx_kmap_build_s1", tk, tv, cap, n);
   if (rc) return rc;
   IRX_REQUIRE(coords && nbr, "irx_kmap_build_s1: null pointer");
-  dim3 grid(irx_cdiv(n, 256), 27);
+  IRX_CHECK_HIP(hipMemsetAsync(nbr + (size_t)14 * ld, 0xFF, (size_t)13 * ld * sizeof(int32_t), S(stream)),
+                "irx_kmap_build_s1(fill)");
+  dim3 grid(irx_cdiv(n, 256), 14);
   k_kmap_s1<<<grid, 256, 0, S(stream)>>>((const int4*)coords, n, tensor_stride, tk, tv,
                                         (uint64_t)cap - 1, nbr, ld);
   IRX_CHECK_LAUNCH("irx_kmap_build_s1");
