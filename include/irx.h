@@ -183,6 +183,11 @@ int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int ld
 size_t irx_pairs_workspace_bytes(int n_out, int K);
 int irx_pairs_build(const int32_t* nbr, int ld, int n_out, int K, int32_t* in_list, int32_t* out_list,
                     int ldp, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+/* irx_pairs_build for up to 16 tables in one call (two launches in total): host arrays of per-table arguments.
+ * workspace: the sum of irx_pairs_workspace_bytes(n_out[t], K[t]). */
+int irx_pairs_build_multi(int n_tables, const int32_t* const* nbr, const int* ld, const int* n_out, const int* K,
+                          int32_t* const* in_list, int32_t* const* out_list, const int* ldp, int32_t* const* counts,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* Weight-gradient over pair lists in DENSE 64-pair MFMA stages (cin, cout in {32,64,128}); same result as
  * irx_spconv_wgrad up to fp32 summation order; deterministic. */
 size_t irx_spconv_wgrad_pairs_workspace_bytes(int n_out, int K, int cin, int cout);

@@ -14,6 +14,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
 #define PB_TILE 2048   // rows per count/scatter workgroup (256 threads x 8)
+#define IRX_PAIRS_MAX_TABLES 16
 
 __global__ __launch_bounds__(256) void k_pairs_count(const int32_t* __restrict__ nbr, int ld, int n_out,
                                                      int32_t* __restrict__ tile_counts, int ntiles) {
@@ -276,6 +277,136 @@ extern "C" int irx_pairs_build(const int32_t* nbr, int ld, int n_out, int K, int
 
 // G = workgroup budget (~1024, fewer for small layers: >= ~8 stages of useful work per workgroup on average);
 // smax = shares cap per offset = 3x the average (the centre offset of a 3^3 kernel holds ~2.8x the average pairs).
+// ---- several tables in one call --------------------------------------------------------------------------------
+// The backward pass of one encoder needs the pair lists of eight tables (four 27-neighbour tables, four child tables):
+// built one by one that is 16 launches, ~32 allocations and 8 library calls per encoder and step, all on the host's
+// critical path.  Here: two launches for all of them; blockIdx.x runs over the concatenated tiles of every table.
+struct IrxPairJobs {
+  const int32_t* nbr[IRX_PAIRS_MAX_TABLES];
+  int32_t* in_list[IRX_PAIRS_MAX_TABLES];
+  int32_t* out_list[IRX_PAIRS_MAX_TABLES];
+  int32_t* counts[IRX_PAIRS_MAX_TABLES];
+  int32_t* tile_counts[IRX_PAIRS_MAX_TABLES];
+  int ld[IRX_PAIRS_MAX_TABLES], n_out[IRX_PAIRS_MAX_TABLES], K[IRX_PAIRS_MAX_TABLES], ldp[IRX_PAIRS_MAX_TABLES];
+  int tile_end[IRX_PAIRS_MAX_TABLES];       // running total of tiles up to and including table j
+  int n;
+};
+
+__device__ __forceinline__ int pair_job_of(const IrxPairJobs& J, int bx, int& tile) {
+  int j = 0;
+  while (j < J.n - 1 && bx >= J.tile_end[j]) ++j;
+  tile = bx - (j ? J.tile_end[j - 1] : 0);
+  return j;
+}
+
+__global__ __launch_bounds__(256) void k_pairs_count_multi(IrxPairJobs J) {
+  __shared__ int s_w[4];
+  int tile;
+  const int j = pair_job_of(J, blockIdx.x, tile), k = blockIdx.y;
+  if (k >= J.K[j]) return;
+  const int ntiles = J.tile_end[j] - (j ? J.tile_end[j - 1] : 0);
+  const int32_t* nbr = J.nbr[j];
+  int cnt = 0;
+  for (int it = 0; it < 8; ++it) {
+    const int q = tile * PB_TILE + it * 256 + threadIdx.x;
+    if (q < J.n_out[j] && nbr[(size_t)k * J.ld[j] + q] >= 0) ++cnt;
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) J.tile_counts[j][k * ntiles + tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void k_pairs_write_multi(IrxPairJobs J) {
+  __shared__ int s_red[4];
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  int tile;
+  const int j = pair_job_of(J, blockIdx.x, tile), k = blockIdx.y;
+  if (k >= J.K[j]) return;
+  const int ntiles = J.tile_end[j] - (j ? J.tile_end[j - 1] : 0);
+  const int32_t* nbr = J.nbr[j];
+  const int32_t* tile_counts = J.tile_counts[j];
+  const int ld = J.ld[j], n_out = J.n_out[j], ldp = J.ldp[j];
+  int acc = 0;
+  for (int t = threadIdx.x; t < tile; t += 256) acc += tile_counts[k * ntiles + t];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (tile == ntiles - 1) J.counts[j][k] = s_base + tile_counts[k * ntiles + tile];
+  }
+  __syncthreads();
+  int running = s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int it = 0; it < 8; ++it) {
+    const int q = tile * PB_TILE + it * 256 + threadIdx.x;
+    int idx = -1;
+    if (q < n_out) idx = nbr[(size_t)k * ld + q];
+    const unsigned long long b = __ballot(idx >= 0);
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+      const int c = s_wave[w];
+      if (w < wave) wbase += c;
+      total += c;
+    }
+    if (idx >= 0) {
+      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int pos = running + wbase + __popcll(b & lt);
+      J.in_list[j][(size_t)k * ldp + pos] = idx;
+      J.out_list[j][(size_t)k * ldp + pos] = q;
+    }
+    running += total;
+    __syncthreads();
+  }
+}
+
+// tables: n_tables <= IRX_PAIRS_MAX_TABLES; arrays of per-table arguments with irx_pairs_build's meaning. workspace:
+// sum over tables of irx_pairs_workspace_bytes(n_out, K).
+extern "C" int irx_pairs_build_multi(int n_tables, const int32_t* const* nbr, const int* ld, const int* n_out, const int* K,
+                                     int32_t* const* in_list, int32_t* const* out_list, const int* ldp,
+                                     int32_t* const* counts, void* workspace, size_t workspace_bytes, void* stream) {
+  IRX_REQUIRE(n_tables >= 0 && n_tables <= IRX_PAIRS_MAX_TABLES, "irx_pairs_build_multi: %d tables (max %d)", n_tables,
+              IRX_PAIRS_MAX_TABLES);
+  if (n_tables == 0) return IRX_OK;
+  IRX_REQUIRE(nbr && ld && n_out && K && in_list && out_list && ldp && counts, "irx_pairs_build_multi: null pointer");
+  IrxPairJobs J;
+  J.n = 0;
+  size_t need = 0;
+  int tiles = 0, kmax = 0;
+  for (int t = 0; t < n_tables; ++t) {
+    IRX_REQUIRE(n_out[t] >= 0 && K[t] >= 1 && K[t] <= 27 && counts[t], "irx_pairs_build_multi: bad table %d", t);
+    if (n_out[t] == 0) {
+      IRX_CHECK_HIP(hipMemsetAsync(counts[t], 0, K[t] * sizeof(int32_t), S(stream)), "irx_pairs_build_multi(memset)");
+      continue;
+    }
+    IRX_REQUIRE(nbr[t] && in_list[t] && out_list[t] && ld[t] >= n_out[t] && ldp[t] >= n_out[t],
+                "irx_pairs_build_multi: table %d: null pointer or ld / ldp < n_out", t);
+    const int j = J.n++;
+    J.nbr[j] = nbr[t]; J.in_list[j] = in_list[t]; J.out_list[j] = out_list[t]; J.counts[j] = counts[t];
+    J.ld[j] = ld[t]; J.n_out[j] = n_out[t]; J.K[j] = K[t]; J.ldp[j] = ldp[t];
+    J.tile_counts[j] = (int32_t*)((char*)workspace + need);
+    need += irx_pairs_workspace_bytes(n_out[t], K[t]);
+    tiles += irx_cdiv(n_out[t], PB_TILE);
+    J.tile_end[j] = tiles;
+    if (K[t] > kmax) kmax = K[t];
+  }
+  if (J.n == 0) return IRX_OK;
+  if (workspace == nullptr || workspace_bytes < need) {
+    irx_set_error("irx_pairs_build_multi: workspace %zu < %zu", workspace_bytes, need);
+    return IRX_ERR_WORKSPACE;
+  }
+  dim3 grid(tiles, kmax);
+  k_pairs_count_multi<<<grid, 256, 0, S(stream)>>>(J);
+  IRX_CHECK_LAUNCH("irx_pairs_build_multi(count)");
+  k_pairs_write_multi<<<grid, 256, 0, S(stream)>>>(J);
+  IRX_CHECK_LAUNCH("irx_pairs_build_multi(write)");
+  return IRX_OK;
+}
+
 static int pairs_budget(int n_out, int K) {
   int s = irx_cdiv(1024, K);
   const int max_s = irx_cdiv(n_out, 512);

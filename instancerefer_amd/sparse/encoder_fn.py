@@ -184,6 +184,25 @@ class EncoderFn(torch.autograd.Function):
         gbase = garena.data_ptr()
         desc = ctx.desc.copy()
         need_dx0 = ctx.needs_input_grad[0]
+        # pair lists still missing for this pyramid: all of them in one library call
+        missing, seen = [], set()
+        for L in layers:
+            if L.cin in _PAIR and L.cout in _PAIR:
+                if L.down:
+                    dm = L.lv_in.down()
+                    if dm._pairs is None and id(dm) not in seen:
+                        seen.add(id(dm))
+                        missing.append((dm, (dm.child, dm.ld, dm.out_level.n, 8)))
+                elif L.lv_in._pairs27 is None and id(L.lv_in) not in seen:
+                    seen.add(id(L.lv_in))
+                    tbl27, ld27 = L.lv_in.nbr27()
+                    missing.append((L.lv_in, (tbl27, ld27, L.lv_in.n, 27)))
+        if missing:
+            for (holder, _), built in zip(missing, F_.pairs_build_multi([m[1] for m in missing])):
+                if hasattr(holder, "_pairs27"):
+                    holder._pairs27 = built
+                else:
+                    holder._pairs = built
         tb, pr = [], []
         for L in layers:
             if L.down:

@@ -271,6 +271,38 @@ def pairs_build(tbl, ld, n_out, K):
     return in_list, out_list, counts, ldp
 
 
+def pairs_build_multi(tables):
+    """pairs_build for several tables [(tbl, ld, n_out, K), ...] in ONE library call (two launches) and three
+    allocations. -> [(in_list, out_list, counts, ldp), ...]"""
+    import ctypes
+    nt = len(tables)
+    if nt == 0:
+        return []
+    dev = tables[0][0].device
+    lib = _lib.load()
+    ldps = [max(n_out, 1) for _, _, n_out, _ in tables]
+    sizes = [K * ldp for (_, _, _, K), ldp in zip(tables, ldps)]
+    lists = torch.empty(2 * sum(sizes), dtype=_i32, device=dev)
+    counts = torch.empty(sum(K for _, _, _, K in tables), dtype=_i32, device=dev)
+    wsb = sum(int(lib.irx_pairs_workspace_bytes(n_out, K)) for _, _, n_out, K in tables)
+    ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
+    out, il_p, ol_p, cnt_p = [], [], [], []
+    lo, co = 0, 0
+    for (tbl, ld, n_out, K), ldp, sz in zip(tables, ldps, sizes):
+        il = lists[lo:lo + sz].view(K, ldp)
+        ol = lists[lo + sz:lo + 2 * sz].view(K, ldp)
+        cn = counts[co:co + K]
+        lo += 2 * sz
+        co += K
+        out.append((il, ol, cn, ldp))
+        il_p.append(il.data_ptr()); ol_p.append(ol.data_ptr()); cnt_p.append(cn.data_ptr())
+    P, I = ctypes.c_void_p * nt, ctypes.c_int * nt
+    _lib.call("irx_pairs_build_multi", nt, P(*[t[0].data_ptr() for t in tables]), I(*[t[1] for t in tables]),
+              I(*[t[2] for t in tables]), I(*[t[3] for t in tables]), P(*il_p), P(*ol_p), I(*ldps), P(*cnt_p),
+              _lib.ptr(ws), wsb, _stream())
+    return out
+
+
 _PAIR_CHANNELS = (32, 64, 128)
 
 

@@ -308,6 +308,26 @@ def test_pair_lists_and_dense_stage_wgrad(lib, clouds):
             assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (K, cin, cout)
 
 
+def test_batched_pair_list_build_equals_per_table_builds(lib, clouds):
+    """irx_pairs_build_multi over every table of a pyramid == irx_pairs_build table by table (bit-exact)."""
+    from instancerefer_amd.sparse import functional as F_
+    d = device_batch(clouds, 0.05)
+    tables, lv = [], d.level()
+    for _ in range(3):
+        tables.append((lv.nbr27()[0], lv.nbr27()[1], lv.n, 27))
+        dm = lv.down()
+        tables.append((dm.child, dm.ld, dm.out_level.n, 8))
+        lv = dm.out_level
+    multi = F_.pairs_build_multi(tables)
+    assert F_.pairs_build_multi([]) == []
+    for (tbl, ld, n_out, K), (il, ol, cnt, ldp) in zip(tables, multi):
+        il1, ol1, cnt1, ldp1 = F_.pairs_build(tbl, ld, n_out, K)
+        assert ldp == ldp1 and torch.equal(cnt, cnt1)
+        c = cnt.cpu().numpy()
+        for k in range(K):
+            assert torch.equal(il[k, :c[k]], il1[k, :c[k]]) and torch.equal(ol[k, :c[k]], ol1[k, :c[k]])
+
+
 @pytest.mark.parametrize("n,m,d,eps", [(64, 16, 128, 1e-8), (37, 5, 256, 1e-12), (3, 3, 20, 1e-8), (0, 4, 128, 1e-8)])
 def test_cosine_rows_matches_torch(lib, n, m, d, eps):
     """Matching-score kernel vs F.normalize / F.cosine_similarity (forward 1e-6, gradients 1e-5 of their scale),
