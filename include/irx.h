@@ -271,6 +271,24 @@ int irx_segment_mean(const float* x, int nseg, int len, int c, float* y, void* s
 /* offsets[b] = first row whose batch index >= b, for b in [0, nseg]  (rows sorted by batch). */
 int irx_batch_offsets(const int32_t* coords, int n, int nseg, int32_t* offsets, void* stream);
 
+/* ---- per-sample input pipeline on a resident scan (reference lib/dataset.py:124,154-181,207-232;
+ *      SURVEY.md 8(f) rank 1). elem_bytes = 4 (float32, the dtype of ScanNet's *_aligned_vert.npy) or 8. ------ */
+
+/* random_sampling + augmentation (lib/dataset.py:124,154-181, _translate :440-453): dst[r] = src[choices[r]] with
+ * the xyz columns flipped (x and/or y negated), rotated by n_rot (0..3) row-major 3x3 float64 matrices applied in
+ * order (new = R p == numpy dot(p, R.T), each result rounded to the storage type like the in-place numpy assignment),
+ * then shifted (shift may be NULL). The caller draws choices / angles / shift from the reference's RNG streams. */
+int irx_scene_sample(const void* src, int n_src, int c, const int32_t* choices, int n, int flip_x, int flip_y,
+                     const double* rot, int n_rot, const double* shift, void* dst, int elem_bytes, void* stream);
+/* The instance loop of lib/dataset.py:207-232 for one sampled cloud pts [n][c]: instance i owns the rows
+ * order[seg[i] .. seg[i+1]) (ascending point index = np.nonzero(labels == id)); obbs[i] = (0.5*(lo+hi), hi-lo, 0)
+ * computed in the storage type and widened to float64; inst_points[i][s] = pts[rows[i][s]] (the 1024-point resample,
+ * rows index the sampled cloud); extent (optional, 6 storage-type values) = min xyz, max xyz of the whole cloud
+ * (point_min / point_max, lib/dataset.py:267-268). Segments must not be empty. */
+int irx_instance_split(const void* pts, int n, int c, const int32_t* order, const int32_t* seg, int n_inst,
+                       const int32_t* rows, int n_sample, void* inst_points, double* obbs, void* extent,
+                       int elem_bytes, void* stream);
+
 /* ---- language encoder recurrence (nn.GRU on a packed sequence, reference models/lang_module.py:22-28,53-57) -- */
 
 /* One GRU layer, ndir (1|2) directions, hidden size H in {64,128}: the sequential part only.

@@ -56,6 +56,8 @@ _SIGNATURES = {
     "irx_segment_max_backward": (_I, [_P, _P, _I, _I, _P, _P]),
     "irx_segment_mean": (_I, [_P, _I, _I, _I, _P, _P]),
     "irx_batch_offsets": (_I, [_P, _I, _I, _P, _P]),
+    "irx_scene_sample": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P]),
+    "irx_instance_split": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
     "irx_gru_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "irx_gru_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "irx_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P]),

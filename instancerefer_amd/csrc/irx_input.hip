@@ -1,0 +1,169 @@
+// irx_input.hip — device side of the per-sample input pipeline (reference lib/dataset.py:124,154-181,207-232):
+// sub-sample a resident scan, apply the augmentation transform, split it into instances (bounding box + fixed-size
+// resample). All of it is row gathers and min/max reductions: HBM/latency-bound, no arithmetic beyond the 3x3
+// rotations. Element type follows the scan on disk (float32 for ScanNet `_aligned_vert.npy`; float64 supported).
+#include "irx_common.h"
+
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+struct IrxAug {
+  int flip_x, flip_y, n_rot, has_shift;
+  double rot[3][9];   // applied in order; row-major R, new = R * p (numpy: dot(p, R.T))
+  double shift[3];
+};
+
+// dst[r][:] = src[choices[r]][:], xyz (first three columns) transformed. Every assignment of the reference rounds
+// to the storage type (the numpy array is modified in place), so does this.
+template <typename T>
+__global__ __launch_bounds__(256) void k_scene_sample(const T* __restrict__ src, const int32_t* __restrict__ choices,
+                                                      int n, int c, IrxAug aug, T* __restrict__ dst) {
+#pragma clang fp contract(off)
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const T* s = src + (size_t)choices[r] * c;
+  T* d = dst + (size_t)r * c;
+  T x = s[0], y = s[1], z = s[2];
+  if (aug.flip_x) x = -x;
+  if (aug.flip_y) y = -y;
+  for (int m = 0; m < aug.n_rot; ++m) {
+    const double* R = aug.rot[m];
+    const double px = (double)x, py = (double)y, pz = (double)z;
+    x = (T)((px * R[0] + py * R[1]) + pz * R[2]);
+    y = (T)((px * R[3] + py * R[4]) + pz * R[5]);
+    z = (T)((px * R[6] + py * R[7]) + pz * R[8]);
+  }
+  if (aug.has_shift) {
+    x = (T)((double)x + aug.shift[0]);
+    y = (T)((double)y + aug.shift[1]);
+    z = (T)((double)z + aug.shift[2]);
+  }
+  d[0] = x;
+  d[1] = y;
+  d[2] = z;
+  for (int j = 3; j < c; ++j) d[j] = s[j];
+}
+
+// One workgroup per instance (blockIdx.x < n_inst) + one for the whole cloud (blockIdx.x == n_inst, if extent != 0):
+// min / max of xyz over the segment's rows (exact, order-free), then centre = 0.5 * (lo + hi) and size = hi - lo in
+// the storage type T like numpy does, widened to float64 (np.concatenate with an int array, lib/dataset.py:223).
+template <typename T>
+__global__ __launch_bounds__(256) void k_instance_box(const T* __restrict__ pts, int n, int c,
+                                                      const int32_t* __restrict__ order,
+                                                      const int32_t* __restrict__ seg, int n_inst,
+                                                      double* __restrict__ obbs, T* __restrict__ extent) {
+#pragma clang fp contract(off)
+  __shared__ T slo[3][256], shi[3][256];
+  const int i = blockIdx.x;
+  const bool whole = (i == n_inst);
+  const int beg = whole ? 0 : seg[i], end = whole ? n : seg[i + 1];
+  T lo[3], hi[3];
+  bool any = false;
+  for (int p = beg + threadIdx.x; p < end; p += 256) {
+    const T* row = pts + (size_t)(whole ? p : order[p]) * c;
+    for (int a = 0; a < 3; ++a) {
+      const T v = row[a];
+      lo[a] = any ? (v < lo[a] ? v : lo[a]) : v;
+      hi[a] = any ? (v > hi[a] ? v : hi[a]) : v;
+    }
+    any = true;
+  }
+  // threads without rows take the segment's first row (segments are never empty)
+  if (!any) {
+    const T* row = pts + (size_t)(whole ? beg : order[beg]) * c;
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = row[a];
+  }
+  for (int a = 0; a < 3; ++a) {
+    slo[a][threadIdx.x] = lo[a];
+    shi[a][threadIdx.x] = hi[a];
+  }
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w)
+      for (int a = 0; a < 3; ++a) {
+        const T l2 = slo[a][threadIdx.x + w], h2 = shi[a][threadIdx.x + w];
+        if (l2 < slo[a][threadIdx.x]) slo[a][threadIdx.x] = l2;
+        if (h2 > shi[a][threadIdx.x]) shi[a][threadIdx.x] = h2;
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    const T l = slo[a][0], h = shi[a][0];
+    if (whole) {
+      extent[a] = l;
+      extent[3 + a] = h;
+    } else {
+      obbs[(size_t)i * 7 + a] = (double)((T)0.5 * (T)(l + h));
+      obbs[(size_t)i * 7 + 3 + a] = (double)(T)(h - l);
+      if (a == 0) obbs[(size_t)i * 7 + 6] = 0.0;
+    }
+  }
+}
+
+// out[i][s][:] = pts[rows[i][s]][:]  (the 1024-point resample; rows index the sampled cloud)
+template <typename T>
+__global__ __launch_bounds__(256) void k_instance_gather(const T* __restrict__ pts, int c,
+                                                         const int32_t* __restrict__ rows, size_t total,
+                                                         T* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per output element
+  if (e >= total) return;
+  const size_t r = e / c;
+  const int j = (int)(e % c);
+  out[e] = pts[(size_t)rows[r] * c + j];
+}
+
+extern "C" int irx_scene_sample(const void* src, int n_src, int c, const int32_t* choices, int n, int flip_x,
+                                int flip_y, const double* rot, int n_rot, const double* shift, void* dst,
+                                int elem_bytes, void* stream) {
+  IRX_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "irx_scene_sample: elem_bytes must be 4 or 8 (got %d)", elem_bytes);
+  IRX_REQUIRE(c >= 3 && n >= 0 && n_src >= 0 && n_rot >= 0 && n_rot <= 3, "irx_scene_sample: bad sizes");
+  IRX_REQUIRE(n_rot == 0 || rot, "irx_scene_sample: rot is NULL");
+  if (n == 0) return 0;
+  IRX_REQUIRE(src && choices && dst && n_src > 0, "irx_scene_sample: NULL argument");
+  IrxAug aug;
+  aug.flip_x = flip_x;
+  aug.flip_y = flip_y;
+  aug.n_rot = n_rot;
+  aug.has_shift = shift != nullptr;
+  for (int m = 0; m < 3; ++m)
+    for (int k = 0; k < 9; ++k) aug.rot[m][k] = (m < n_rot) ? rot[m * 9 + k] : 0.0;
+  for (int k = 0; k < 3; ++k) aug.shift[k] = shift ? shift[k] : 0.0;
+  const int grid = (n + 255) / 256;
+  if (elem_bytes == 4)
+    k_scene_sample<float><<<grid, 256, 0, S(stream)>>>((const float*)src, choices, n, c, aug, (float*)dst);
+  else
+    k_scene_sample<double><<<grid, 256, 0, S(stream)>>>((const double*)src, choices, n, c, aug, (double*)dst);
+  IRX_CHECK_LAUNCH("k_scene_sample");
+  return 0;
+}
+
+extern "C" int irx_instance_split(const void* pts, int n, int c, const int32_t* order, const int32_t* seg, int n_inst,
+                                  const int32_t* rows, int n_sample, void* inst_points, double* obbs, void* extent,
+                                  int elem_bytes, void* stream) {
+  IRX_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "irx_instance_split: elem_bytes must be 4 or 8 (got %d)", elem_bytes);
+  IRX_REQUIRE(c >= 3 && n >= 0 && n_inst >= 0 && n_sample >= 0, "irx_instance_split: bad sizes");
+  if (n == 0) return 0;
+  IRX_REQUIRE(pts, "irx_instance_split: pts is NULL");
+  IRX_REQUIRE(n_inst == 0 || (order && seg && obbs), "irx_instance_split: NULL instance argument");
+  const int blocks = n_inst + (extent ? 1 : 0);
+  if (blocks > 0) {
+    if (elem_bytes == 4)
+      k_instance_box<float><<<blocks, 256, 0, S(stream)>>>((const float*)pts, n, c, order, seg, n_inst, obbs,
+                                                           (float*)extent);
+    else
+      k_instance_box<double><<<blocks, 256, 0, S(stream)>>>((const double*)pts, n, c, order, seg, n_inst, obbs,
+                                                            (double*)extent);
+    IRX_CHECK_LAUNCH("k_instance_box");
+  }
+  const size_t total = (size_t)n_inst * n_sample * c;
+  if (total > 0) {
+    IRX_REQUIRE(rows && inst_points, "irx_instance_split: rows / inst_points is NULL");
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (elem_bytes == 4)
+      k_instance_gather<float><<<grid, 256, 0, S(stream)>>>((const float*)pts, c, rows, total, (float*)inst_points);
+    else
+      k_instance_gather<double><<<grid, 256, 0, S(stream)>>>((const double*)pts, c, rows, total, (double*)inst_points);
+    IRX_CHECK_LAUNCH("k_instance_gather");
+  }
+  return 0;
+}

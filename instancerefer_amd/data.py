@@ -45,6 +45,26 @@ class InstancePack:
         self.centres = torch.from_numpy(self.obbs[:, :3].astype(np.float32)).to(device)
         self._sel_cache = {}
 
+    @classmethod
+    def from_device(cls, inst_points, obbs_host, obbs_dev, classes, scene_of, scene_start):
+        """Pack built by the device-side input pipeline (scene_input.build_batch): the instance points never existed
+        on the host. inst_points (S, P, C0) cuda f32/f64; obbs_host (S, 7) numpy; obbs_dev (S, 7) cuda f64."""
+        self = cls.__new__(cls)
+        self.batch_size = len(scene_start) - 1
+        self.classes, self.scene_of, self.scene_start = list(classes), list(scene_of), list(scene_start)
+        self.obbs = np.asarray(obbs_host, np.float64).reshape(-1, 7)
+        if inst_points.shape[0]:
+            self.xyz64 = inst_points[:, :, :3].double().contiguous()
+            self.pts32 = inst_points.float().contiguous()
+            self.centres = obbs_dev[:, :3].float().contiguous()
+        else:
+            dev = inst_points.device
+            self.xyz64 = torch.zeros((0, 1, 3), dtype=torch.float64, device=dev)
+            self.pts32 = torch.zeros((0, 1, 3), dtype=torch.float32, device=dev)
+            self.centres = torch.zeros((0, 3), dtype=torch.float32, device=dev)
+        self._sel_cache = {}
+        return self
+
     def select(self, lang_cls_pred):
         """Candidate filtering of AttributeModule.filter_candidates / RelationModule.filter_candidates
         (reference attribute_module.py:42-81, relation_module.py:38-78) on host integers only.

@@ -1,0 +1,285 @@
+"""Device-side per-sample input pipeline: what the reference does in numpy inside
+`ScannetReferenceDataset.__getitem__` (lib/dataset.py:93-298) + `collate_fn` (:456-469) for every sample of every step
+— scene sub-sampling, augmentation, the instance loop (box, 1024-point resample), both voxelisations — on a scan that
+stays RESIDENT in HBM (a ScanNet scan is ~2.4 MB of float32 features; all 562 training scans fit in 1.4 GB, and
+ScanRefer revisits each scan ~65 times per epoch).
+
+Split of work:
+  host  (`draw_sample`)  integer label logic on the (V,) label arrays and every random draw, consumed from the SAME
+                         generators in the SAME order as the reference (numpy global RandomState for the two
+                         `random_sampling` sites, torch's default generator for the augmentation), so a seeded run
+                         reproduces the reference sample for sample; box labels (<= 128 boxes) in numpy.
+  device (`build_batch`) irx_scene_sample (gather + flips / rotations / shift), irx_instance_split (boxes, resample,
+                         scene extent), the scene voxelisation; the candidate voxelisation happens in the model's
+                         prepare stage from the device-resident InstancePack as before. Only index arrays go up
+                         (~0.5 MB per sample instead of ~3 MB of float64 points) and 7 floats per instance come back.
+
+The CPU restatement used as the checker is oracle/dataset_ref.py (pinned to the reference's own __getitem__ by
+tests/golden/dataset.npz); this module never imports it.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .data import InstancePack
+
+MEAN_COLOR_RGB = np.array([109.8, 97.2, 83.8])     # lib/dataset.py:22
+MAX_NUM_OBJ = 128                                  # lib/dataset.py:21
+NUM_INSTANCE_POINTS = 1024                         # lib/dataset.py:224
+
+
+class ClassTables:
+    """The pieces of data/scannet/model_util_scannet.py:ScannetDatasetConfig this path reads: `nyu40ids` (the
+    nyu40 ids that are objects), `nyu40id2class` (array indexed by nyu40 id, -1 elsewhere), `mean_size_arr`."""
+
+    def __init__(self, nyu40ids, nyu40id2class, mean_size_arr):
+        self.nyu40ids = np.asarray(nyu40ids)
+        self.nyu40id2class = np.asarray(nyu40id2class)
+        self.mean_size_arr = np.asarray(mean_size_arr)
+        self._is_object = np.zeros(max(int(self.nyu40ids.max()) + 1, len(self.nyu40id2class)), bool)
+        self._is_object[self.nyu40ids] = True
+
+    def is_object(self, nyu):
+        nyu = int(nyu)
+        return 0 <= nyu < len(self._is_object) and bool(self._is_object[nyu])
+
+
+def point_features(mesh_vertices, use_color=True, use_normal=False, use_height=True, multiview=None):
+    """Static per scan (lib/dataset.py:99-122): normalised colours, optional normals / multiview features, height above
+    the 0.99-percentile floor. dtype follows `mesh_vertices` (the reference works in place on the loaded array)."""
+    v = np.array(mesh_vertices, copy=True)
+    cols = v[:, 0:6] if use_color else v[:, 0:3]
+    if use_color:
+        cols[:, 3:6] = (cols[:, 3:6] - MEAN_COLOR_RGB) / 256.0
+    if use_normal:
+        cols = np.concatenate([cols, v[:, 6:9]], 1)
+    if multiview is not None:
+        cols = np.concatenate([cols, multiview], 1)
+    if use_height:
+        floor = np.percentile(cols[:, 2], 0.99)
+        cols = np.concatenate([cols, np.expand_dims(cols[:, 2] - floor, 1)], 1)
+    return cols
+
+
+class ResidentScan:
+    """One scan with its point features in HBM and its label arrays on the host."""
+
+    def __init__(self, raw, device, use_color=True, use_normal=False, use_height=True, multiview=None):
+        pc = np.ascontiguousarray(point_features(raw["mesh_vertices"], use_color, use_normal, use_height, multiview))
+        if pc.dtype not in (np.float32, np.float64):
+            pc = pc.astype(np.float64)
+        self.points = torch.from_numpy(pc).to(device)
+        self.instance_labels = np.asarray(raw["instance_labels"])
+        self.semantic_labels = np.asarray(raw["semantic_labels"])
+        self.instance_bboxes = np.asarray(raw["instance_bboxes"])
+
+    @property
+    def num_vertices(self):
+        return self.points.shape[0]
+
+
+def _rotation(axis, t):
+    """utils/pc_utils.py rotx / roty / rotz."""
+    c, s = np.cos(t), np.sin(t)
+    if axis == 0:
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], np.float64)
+    if axis == 1:
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float64)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], np.float64)
+
+
+def _rotate_boxes(boxes, rot, axis):
+    """Axis-aligned boxes under a rotation about `axis` (model_util_scannet.py:51-83): centres rotate; the two
+    extents across the axis become those of the rotated rectangle's bounding rectangle."""
+    a, b = ((1, 2), (0, 2), (0, 1))[axis]
+    half = np.stack([boxes[:, 3 + a], boxes[:, 3 + b]], 1) / 2.0
+    ext = np.zeros((boxes.shape[0], 2, 4))
+    for k, (sa, sb) in enumerate(((-1, -1), (1, -1), (1, 1), (-1, 1))):
+        corner = np.zeros((boxes.shape[0], 3))
+        corner[:, 0], corner[:, 1] = sa * half[:, 0], sb * half[:, 1]
+        corner = np.dot(corner, rot.T)
+        ext[:, 0, k], ext[:, 1, k] = corner[:, 0], corner[:, 1]
+    out = np.concatenate([np.dot(boxes[:, 0:3], rot.T), boxes[:, 3:6]], 1)
+    out[:, 3 + a], out[:, 3 + b] = 2.0 * ext[:, 0].max(1), 2.0 * ext[:, 1].max(1)
+    return out
+
+
+class SampleDraw:
+    """Host half of one sample: every random draw + the integer bookkeeping the device kernels need."""
+    __slots__ = ("scan", "choices", "flip_x", "flip_y", "rot", "shift", "order", "seg", "rows", "classes", "labels",
+                 "instance_labels")
+
+
+def draw_sample(scan, object_id, tables, num_points=40000, augment=False):
+    """Consumes the RNG streams exactly like lib/dataset.py:124 (scene choice), :154-181 (flips, three angles, shift)
+    and :224 (one choice per object instance, ascending instance id)."""
+    d = SampleDraw()
+    d.scan = scan
+    V = scan.num_vertices
+    choices = np.random.choice(V, num_points, replace=V < num_points)
+    d.choices = choices.astype(np.int32)
+    ins = scan.instance_labels[choices]
+    sem = scan.semantic_labels[choices]
+    d.instance_labels = ins.astype(np.int64)
+
+    boxes = scan.instance_bboxes
+    nb = min(boxes.shape[0], MAX_NUM_OBJ)
+    target = np.zeros((MAX_NUM_OBJ, 6))
+    target[:nb] = boxes[:MAX_NUM_OBJ, 0:6]
+    d.flip_x = d.flip_y = False
+    d.rot, d.shift = [], None
+    if augment:
+        if torch.rand(1).item() > 0.5:
+            d.flip_x = True
+            target[:, 0] = -target[:, 0]
+        if torch.rand(1).item() > 0.5:
+            d.flip_y = True
+            target[:, 1] = -target[:, 1]
+        for axis in range(3):
+            rot = _rotation(axis, (torch.rand(1).item() * np.pi / 18) - np.pi / 36)
+            d.rot.append(rot)
+            target = _rotate_boxes(target, rot, axis)
+        d.shift = np.asarray((torch.rand(3) - 0.5).tolist(), np.float64)
+        target[:, :3] += d.shift
+    box_cls = [int(tables.nyu40id2class[int(x)]) for x in boxes[:nb, -2]]
+    size_cls = np.zeros((MAX_NUM_OBJ,))
+    size_res = np.zeros((MAX_NUM_OBJ, 3))
+    size_cls[:nb] = box_cls
+    size_res[:nb] = target[:nb, 3:6] - tables.mean_size_arr[box_cls]
+    ref_box = np.zeros(MAX_NUM_OBJ)
+    ref_center, ref_cls, ref_res = np.zeros(3), 0, np.zeros(3)
+    for i, gt in enumerate(boxes[:nb, -1]):
+        if gt == object_id:
+            ref_box[i] = 1
+            ref_center, ref_cls, ref_res = target[i, 0:3], size_cls[i], size_res[i]
+    d.labels = dict(center_label=target.astype(np.float32)[:, 0:3], size_class_label=size_cls.astype(np.int64),
+                    size_residual_label=size_res.astype(np.float32), num_bbox=np.array(nb).astype(np.int64),
+                    ref_box_label=ref_box.astype(np.int64), ref_center_label=ref_center.astype(np.float32),
+                    ref_size_class_label=np.array(int(ref_cls)).astype(np.int64),
+                    ref_size_residual_label=ref_res.astype(np.float32),
+                    ref_heading_class_label=np.array(0).astype(np.int64),
+                    ref_heading_residual_label=np.array(0).astype(np.int64))
+
+    # instance segments: stable sort by label == np.nonzero(labels == id) per ascending id (lib/dataset.py:207-210)
+    small = ins.size and ins.min() >= -32768 and ins.max() <= 32767      # int16 keys take numpy's radix sort (6x)
+    order = np.argsort(ins.astype(np.int16) if small else ins, kind="stable")
+    sl = ins[order]
+    starts = np.flatnonzero(np.concatenate(([True], sl[1:] != sl[:-1])))
+    ends = np.concatenate((starts[1:], [len(sl)]))
+    keep_order, seg, rows, classes = [], [0], [], []
+    for lo, hi in zip(starts, ends):
+        nyu = sem[order[lo]]
+        if not tables.is_object(nyu):
+            continue
+        classes.append(int(tables.nyu40id2class[int(nyu)]))
+        idx = order[lo:hi]
+        keep_order.append(idx)
+        seg.append(seg[-1] + (hi - lo))
+        n_i = hi - lo
+        rows.append(idx[np.random.choice(n_i, NUM_INSTANCE_POINTS, replace=n_i < NUM_INSTANCE_POINTS)])
+    d.order = (np.concatenate(keep_order) if keep_order else np.zeros(0)).astype(np.int32)
+    d.seg = np.asarray(seg, np.int32)
+    d.rows = (np.stack(rows, 0) if rows else np.zeros((0, NUM_INSTANCE_POINTS))).astype(np.int32)
+    d.classes = classes
+    return d
+
+
+class PendingBatch:
+    """Everything of a batch enqueued; `finish()` waits for the (tiny) box / extent read-back and assembles the
+    data_dict entries. Between build_batch() and finish() the host is free (e.g. to issue the previous step)."""
+
+    def __init__(self, draws, clouds, inst_points, obbs_dev, extent_dev, host_back, event, voxel_size, device, keep):
+        self.draws, self.clouds, self.inst_points = draws, clouds, inst_points
+        self.obbs_dev, self.extent_dev, self.host_back, self.event = obbs_dev, extent_dev, host_back, event
+        self.voxel_size, self.device, self._keep = voxel_size, device, keep
+
+    def finish(self, data_dict=None):
+        from .sparse.utils import voxelize
+        B = len(self.draws)
+        dd = {} if data_dict is None else data_dict
+        n, c = self.clouds.shape[1], self.clouds.shape[2]
+        flat = self.clouds.view(B * n, c)
+        batch = torch.arange(B, device=self.device, dtype=torch.int32).repeat_interleave(n)
+        dd["lidar"] = voxelize(flat[:, :3].contiguous(), flat, batch, [self.voxel_size] * 3, B)
+        self.event.synchronize()
+        S = self.inst_points.shape[0]
+        back = self.host_back.numpy()
+        obbs = back[:S * 7].reshape(S, 7).copy()
+        ext = back[S * 7:].reshape(B, 6).copy()
+        classes, scene_of, start = [], [], [0]
+        for i, d in enumerate(self.draws):
+            classes += d.classes
+            scene_of += [i] * len(d.classes)
+            start.append(len(classes))
+        dd["irx"] = InstancePack.from_device(self.inst_points, obbs, self.obbs_dev, classes, scene_of, start)
+        dtype = self.clouds.dtype
+        dd["point_min"] = self.extent_dev[:, :3].contiguous()
+        dd["point_max"] = self.extent_dev[:, 3:].contiguous()
+        np_dtype = np.float32 if dtype == torch.float32 else np.float64
+        host = dict(point_min=ext[:, :3].astype(np_dtype), point_max=ext[:, 3:].astype(np_dtype))
+        for k in ("ref_center_label", "ref_size_residual_label", "ref_size_class_label", "ref_heading_class_label",
+                  "ref_heading_residual_label", "ref_box_label", "center_label", "size_class_label",
+                  "size_residual_label", "num_bbox"):
+            host[k] = np.stack([d.labels[k] for d in self.draws], 0)
+        dd["_host"] = dict(dd.get("_host", {}), **host)
+        for k in ("ref_center_label", "ref_size_residual_label"):
+            dd[k] = torch.from_numpy(host[k]).to(self.device, non_blocking=True)
+        for k in ("ref_size_class_label", "ref_heading_class_label", "ref_heading_residual_label"):
+            dd[k] = torch.from_numpy(host[k])
+        dd["point_clouds"] = self.clouds
+        dd["instance_labels"] = [d.instance_labels for d in self.draws]
+        return dd
+
+
+def build_batch(draws, device, voxel_size_glp=0.05):
+    """Enqueue the device half for a list of SampleDraw (one per sample of the batch) on the current stream.
+    -> PendingBatch. All samples must share num_points and the scans' feature width / dtype."""
+    B = len(draws)
+    assert B > 0
+    pts0 = draws[0].scan.points
+    c, dtype = pts0.shape[1], pts0.dtype
+    eb = 4 if dtype == torch.float32 else 8
+    n = len(draws[0].choices)
+    for d in draws:
+        assert len(d.choices) == n and d.scan.points.shape[1] == c and d.scan.points.dtype == dtype
+    S = sum(len(d.classes) for d in draws)
+    # ONE pinned staging buffer + ONE H2D copy for every index array of the batch
+    sizes = [(len(d.choices), len(d.order), len(d.seg), d.rows.size) for d in draws]
+    total = sum(sum(s) for s in sizes)
+    stage = torch.empty(max(total, 1), dtype=torch.int32, pin_memory=True)
+    sv = stage.numpy()
+    o, offs = 0, []
+    for d, (a, b, s, r) in zip(draws, sizes):
+        sv[o:o + a] = d.choices
+        sv[o + a:o + a + b] = d.order
+        sv[o + a + b:o + a + b + s] = d.seg
+        sv[o + a + b + s:o + a + b + s + r] = d.rows.reshape(-1)
+        offs.append((o, o + a, o + a + b, o + a + b + s))
+        o += a + b + s + r
+    idx = stage.to(device, non_blocking=True)
+    clouds = torch.empty((B, n, c), dtype=dtype, device=device)
+    inst_points = torch.empty((S, NUM_INSTANCE_POINTS, c), dtype=dtype, device=device)
+    obbs_dev = torch.empty((max(S, 1), 7), dtype=torch.float64, device=device)
+    extent_dev = torch.empty((B, 6), dtype=dtype, device=device)
+    stream = _lib.stream_ptr()
+    base = idx.data_ptr()
+    s0 = 0
+    for i, (d, (oc, oo, os_, orow)) in enumerate(zip(draws, offs)):
+        ni = len(d.classes)
+        rot = np.ascontiguousarray(np.stack(d.rot, 0).reshape(-1)) if d.rot else None
+        _lib.call("irx_scene_sample", _lib.ptr(d.scan.points), d.scan.num_vertices, c, base + 4 * oc, n,
+                  int(d.flip_x), int(d.flip_y), rot.ctypes.data if rot is not None else None, len(d.rot),
+                  d.shift.ctypes.data if d.shift is not None else None, clouds[i].data_ptr(), eb, stream)
+        _lib.call("irx_instance_split", clouds[i].data_ptr(), n, c, base + 4 * oo, base + 4 * os_, ni,
+                  base + 4 * orow, NUM_INSTANCE_POINTS,
+                  inst_points[s0:].data_ptr() if ni else None, obbs_dev[s0:].data_ptr(), extent_dev[i].data_ptr(),
+                  eb, stream)
+        s0 += ni
+    # boxes + extents back to the host in one async copy
+    back_dev = torch.cat([obbs_dev[:S].reshape(-1), extent_dev.double().reshape(-1)])
+    host_back = torch.empty(back_dev.shape, dtype=torch.float64, pin_memory=True)
+    host_back.copy_(back_dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return PendingBatch(draws, clouds, inst_points, obbs_dev[:S], extent_dev, host_back, ev, voxel_size_glp, device,
+                        (idx, back_dev, stage))

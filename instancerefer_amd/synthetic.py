@@ -78,6 +78,45 @@ def make_scene(seed, num_points=50000, num_instances=8, num_candidates=4, target
         unique_multiple=np.array(0 if num_candidates == 1 else 1, np.int64), scan_idx=np.array(seed, np.int64))
 
 
+# nyu40 ids used by make_raw_scene: wall / floor for the background (not in DC.nyu40ids -> "scene_points"
+# branch of lib/dataset.py:246-247), then object ids cycling through real ScanNet categories
+_NYU40_OBJECT_IDS = (5, 5, 5, 7, 4, 3, 6, 14, 33, 34, 39, 24)
+
+
+def make_raw_scene(seed, num_vertices=60000, num_instances=8, same_class=3):
+    """What lib/dataset.py:94-97 loads from disk for one scan: `mesh_vertices` (V, 6) float32 [xyz, rgb 0..255],
+    `instance_labels` (V,) (0 = none, object_id + 1 otherwise), `semantic_labels` (V,) nyu40 ids,
+    `instance_bboxes` (I, 8) float64 [centre, size, nyu40 id, object id]. The first `same_class` objects share
+    nyu40 id 5 (chair)."""
+    rng = np.random.default_rng(seed)
+    room = np.array([8.0, 10.0, 3.0])
+    n_bg = num_vertices // 2
+    per = (num_vertices - n_bg) // num_instances
+    bg = rng.uniform(0, 1, (n_bg, 3)) * room
+    which = rng.integers(0, 5, n_bg)
+    bg[which == 0, 2] = 0.0
+    bg[which == 1, 1] = 0.0
+    bg[which == 2, 1] = room[1]
+    bg[which == 3, 0] = 0.0
+    bg[which == 4, 0] = room[0]
+    xyz, ins, sem, boxes = [bg], [np.zeros(n_bg, np.int64)], [np.where(which == 0, 2, 1)], []
+    for j in range(num_instances):
+        size = rng.uniform(0.4, 1.2, 3)
+        cxy = rng.uniform([0.8, 0.8], [room[0] - 0.8, room[1] - 0.8])
+        centre = np.array([cxy[0], cxy[1], size[2] / 2])
+        n_j = per if j < num_instances - 1 else num_vertices - n_bg - per * (num_instances - 1)
+        xyz.append(_box_surface(rng, n_j, centre, size))
+        ins.append(np.full(n_j, j + 1, np.int64))
+        nyu = 5 if j < same_class else _NYU40_OBJECT_IDS[j % len(_NYU40_OBJECT_IDS)]
+        sem.append(np.full(n_j, nyu, np.int64))
+        boxes.append(np.concatenate([centre, size, [nyu, j]]))
+    xyz = np.concatenate(xyz, 0)
+    perm = rng.permutation(num_vertices)                       # scans are not sorted by instance
+    verts = np.concatenate([xyz, rng.uniform(0, 255, (num_vertices, 3))], 1).astype(np.float32)[perm]
+    return dict(mesh_vertices=verts, instance_labels=np.concatenate(ins)[perm],
+                semantic_labels=np.concatenate(sem)[perm], instance_bboxes=np.asarray(boxes, np.float64))
+
+
 _STACK = ("lang_feat", "lang_len", "object_cat", "point_min", "point_max", "ref_center_label",
           "ref_size_residual_label", "ref_size_class_label", "ref_heading_class_label",
           "ref_heading_residual_label", "unique_multiple", "scan_idx")

@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -92,3 +93,38 @@ def test_flat_grad_allreduce_gloo_world2():
     model(x[0:4]).mean().backward()
     ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()]) / 2     # rank 1 contributed zeros
     assert torch.allclose(out[0], ref, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", ["plain", "augmented"])
+def test_input_pipeline_host_half_matches_reference_getitem(case):
+    """scene_input.draw_sample (labels, classes, RNG consumption) against the fixture made by the reference's own
+    ScannetReferenceDataset.__getitem__ (tests/golden/make_golden_dataset.py). The device half is a GPU test."""
+    import os
+    from instancerefer_amd import scene_input as SI
+
+    class HostScan:                      # ResidentScan without the upload
+        def __init__(self, raw):
+            self.instance_labels, self.semantic_labels = raw["instance_labels"], raw["semantic_labels"]
+            self.instance_bboxes = raw["instance_bboxes"]
+            self.num_vertices = raw["mesh_vertices"].shape[0]
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset.npz"))
+    nv, ni, sc, npts = (int(v) for v in g["raw"])
+    seed = int(g[case + "/seed"])
+    raw = S.make_raw_scene(seed, num_vertices=nv, num_instances=ni, same_class=sc)
+    tables = SI.ClassTables(g["nyu40ids"], g["nyu40id2class"], g["mean_size_arr"])
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    d = SI.draw_sample(HostScan(raw), int(g[case + "/object_id"]), tables, num_points=npts,
+                       augment=bool(g[case + "/augment"]))
+    for k, v in d.labels.items():
+        assert np.array_equal(v, g[case + "/" + k]) and v.dtype == g[case + "/" + k].dtype, k
+    assert np.array_equal(d.instance_labels, g[case + "/instance_labels"])
+    assert d.classes == list(g[case + "/instance_class"])
+    assert d.rows.shape == (len(d.classes), 1024) and d.seg[-1] == len(d.order)
+    # the features are static per scan: colour / height columns of the sampled cloud
+    pc = SI.point_features(raw["mesh_vertices"])[d.choices]
+    assert np.array_equal(pc[:, 3:], g[case + "/point_clouds"][:, 3:])
+    if case == "plain":
+        assert np.array_equal(pc, g[case + "/point_clouds"])
+        assert np.array_equal(pc[d.rows], g[case + "/instance_points"])

@@ -3,6 +3,7 @@ cross-check its sparse conv against an independent dense formulation (F.conv3d o
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from helpers import GOLDEN_CFG, WEIGHT_SEED, surface_cloud, oracle_batch
@@ -110,3 +111,43 @@ def test_c_openmp_port_matches_python_oracle():
             got = cgrads[off:off + ref.size]
             off += ref.size
             assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), name
+
+
+def _dataset_golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset.npz"))
+
+
+def _voxel_set(cf):
+    c = np.asarray(cf[0])[:, :3].astype(np.int64)
+    o = np.lexsort((c[:, 2], c[:, 1], c[:, 0]))
+    return c[o].astype(np.int32), np.asarray(cf[1])[o]
+
+
+@pytest.mark.parametrize("case", ["plain", "augmented"])
+def test_oracle_input_pipeline_matches_reference_getitem(case):
+    """oracle/dataset_ref.get_item == the reference's ScannetReferenceDataset.__getitem__ (fixture generated by
+    tests/golden/make_golden_dataset.py), bit for bit, same RNG streams."""
+    from oracle import dataset_ref as DR
+    from instancerefer_amd import synthetic as S
+    g = _dataset_golden()
+    nv, ni, sc, npts = (int(v) for v in g["raw"])
+    seed = int(g[case + "/seed"])
+    raw = S.make_raw_scene(seed, num_vertices=nv, num_instances=ni, same_class=sc)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    d = DR.get_item(raw, int(g[case + "/object_id"]), int(g[case + "/object_cat"]), g["nyu40ids"], g["nyu40id2class"],
+                    g["mean_size_arr"], num_points=npts, augment=bool(g[case + "/augment"]))
+    for k in ("point_clouds", "instance_labels", "point_min", "point_max", "center_label", "size_class_label",
+              "size_residual_label", "num_bbox", "ref_box_label", "ref_center_label", "ref_size_class_label",
+              "ref_size_residual_label"):
+        assert np.array_equal(np.asarray(d[k]), g[case + "/" + k]), k
+        assert np.asarray(d[k]).dtype == g[case + "/" + k].dtype, k
+    assert np.array_equal(np.stack(d["instance_points"]), g[case + "/instance_points"])
+    assert np.array_equal(np.stack(d["instance_obbs"]), g[case + "/instance_obbs"])
+    assert np.array_equal(np.asarray(d["instance_class"]), g[case + "/instance_class"])
+    assert np.array_equal(np.asarray(d["pred_obb_batch"]), g[case + "/pred_obb_batch"])
+    c, f = _voxel_set(d["lidar"])
+    assert np.array_equal(c, g[case + "/lidar_C"]) and np.array_equal(f, g[case + "/lidar_F"])
+    assert [len(t[0]) for t in d["pts_batch"]] == list(g[case + "/pts_batch_sizes"])
+    c, f = _voxel_set(d["pts_batch"][0])
+    assert np.array_equal(c, g[case + "/pts_batch0_C"]) and np.array_equal(f, g[case + "/pts_batch0_F"])
