@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3      # fp32 vector == fp32-input MFMA peak
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md; --dtype bf16 only)
 
 
 def parse():
@@ -42,6 +43,9 @@ def parse():
     ap.add_argument("--instances", type=int, default=8)
     ap.add_argument("--candidates", type=int, default=4)
     ap.add_argument("--tokens", type=int, default=30)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="compute dtype of the MFMA sparse-conv kernels: f32 (default: the reference's dtype, exact) or bf16 "
+                         "operands with fp32 accumulation (BASELINE configs[2]-[4]); tensors, BatchNorm, heads stay fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--cpu-timeout", type=int, default=150)
@@ -307,6 +311,8 @@ def main():
     from instancerefer_amd import _build, _lib
     _build.build_lib()
     _lib.load()
+    import instancerefer_amd as irx
+    irx.set_compute_dtype("bf16" if args.dtype == "bf16" else "fp32")
     from instancerefer_amd import synthetic as S
     from instancerefer_amd.ddp import FlatGradAllReduce
     from instancerefer_amd.loss_helper import DatasetConfig
@@ -380,17 +386,20 @@ def main():
         opt.world_size = saved_world
         recs = F_.PROFILE
         F_.PROFILE = None
-        roof = summarise_roofline(recs)
+        roof = summarise_roofline(recs, args.dtype == "bf16")
 
     if rank == 0:
         out = {
             "metric": "scenes/sec fwd+bwd (50k-pt synthetic ScanRefer)",
             "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("full InstanceRefer (lang+attribute+relation+scene) fwd+bwd+allreduce+Adam, "
-                                    "BASELINE configs[2]/[3] shape in fp32" if args.workload == "full" else
-                                    "BASELINE configs[1]: SparseConv3d + attribute_module only, fwd+bwd+Adam, fp32"),
+                                    "BASELINE configs[2]/[3] shape" if args.workload == "full" else
+                                    "BASELINE configs[1]: SparseConv3d + attribute_module only, fwd+bwd+Adam") +
+                                   (", fp32" if args.dtype == "f32" else
+                                    ", bf16 operands / fp32 accumulation in the 32/64/128-channel sparse convs "
+                                    "(fwd, dgrad, wgrad); fp32 tensors, BatchNorm, stem, heads"),
                        "scenes_per_gpu": B, "global_batch": world * B, "points_per_scene": args.points,
                        "instances": args.instances, "candidates": args.candidates, "tokens": args.tokens,
                        "scene_voxels_per_gpu": n_scene_vox, "parallelism": "dp%d" % world, "loss": final_loss,
@@ -408,7 +417,7 @@ def main():
         dist.destroy_process_group()
 
 
-def summarise_roofline(recs):
+def summarise_roofline(recs, bf16=False):
     """recs: (kind, n_out, K, cin, cout, M, start_event, end_event), one per C-ABI conv call, events recorded on the
     launch stream. The dominant HIP kernel is k_spconv2<128,128> (forward + data-gradient of every 128->128 layer:
     the largest total in the rocprofv3 kernel stats). Algorithmic figures per launch (SURVEY §8d formula A, e = 4):
@@ -437,12 +446,14 @@ def summarise_roofline(recs):
             byts = 4.0 * (M * (cin + cout) + K * cin * cout) + 8.0 * M
         else:
             byts = 4.0 * (M * cin + n_out * cout + K * cin * cout) + 8.0 * M
-        a = agg.setdefault(klass(kind, cin, cout), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, bound_ms=0.0))
+        kl = klass(kind, cin, cout)
+        a = agg.setdefault(kl, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, bound_ms=0.0))
         a["ms"] += ms
         a["flops"] += flops
         a["bytes"] += byts
         a["launches"] += 1
-        b_ms = max(byts / (PEAK_HBM_GBS * 1e9), flops / (PEAK_F32_TFLOPS * 1e12)) * 1e3
+        a["peak_tf"] = peak_tf = PEAK_BF16_TFLOPS if (bf16 and kl.startswith(("k_spconv2<", "k_wgrad_pairs<"))) else PEAK_F32_TFLOPS
+        b_ms = max(byts / (PEAK_HBM_GBS * 1e9), flops / (peak_tf * 1e12)) * 1e3
         a["bound_ms"] += b_ms
         tot["ms"] += ms
         tot["bound_ms"] += b_ms
@@ -464,7 +475,8 @@ def summarise_roofline(recs):
     a = agg[dom]
     tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
     gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
-    mfma_bound = a["flops"] / (PEAK_F32_TFLOPS * 1e12) >= a["bytes"] / (PEAK_HBM_GBS * 1e9)
+    peak_tf = a["peak_tf"]
+    mfma_bound = a["flops"] / (peak_tf * 1e12) >= a["bytes"] / (PEAK_HBM_GBS * 1e9)
     per_kernel = {k: {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                       "algo_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
@@ -473,14 +485,16 @@ def summarise_roofline(recs):
     try:   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json; see its _note)
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
         key = dom.replace(",", ", ")
+        if key.startswith(("k_spconv2<", "k_wgrad_pairs<")):       # template flag: bf16 operand mode
+            key = key[:-1] + (", true>" if bf16 else ", false>")
         if key in pmc:
             traffic = pmc[key]["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
     return {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm",
-            "achieved": tf if mfma_bound else gbs, "peak": PEAK_F32_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+            "achieved": tf if mfma_bound else gbs, "peak": peak_tf if mfma_bound else PEAK_HBM_GBS,
             "unit": "TFLOP/s" if mfma_bound else "GB/s",
-            "frac": (tf / PEAK_F32_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS),
+            "frac": (tf / peak_tf) if mfma_bound else (gbs / PEAK_HBM_GBS),
             "traffic": traffic, "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
             "algorithmic_flops_per_launch": a["flops"] / a["launches"],
             "avg_launch_us": 1e3 * a["ms"] / a["launches"], "launches": a["launches"],

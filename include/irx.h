@@ -155,6 +155,14 @@ int irx_bev_table(const int32_t* coords, int n, int tensor_stride, int batch_siz
 
 /* ---- sparse convolution (spnn.Conv3d fwd + bwd; models/basic_blocks.py:14-19,32-43) --- */
 
+/* Compute dtype of the MFMA sparse-conv kernels (channel counts 32/64/128; forward, data- and weight-gradient):
+ * 0 (default) = exact fp32 (v_mfma_f32_16x16x4_f32: the reference's dtype, the 1e-4 parity gate);
+ * 1 = bf16 operands with fp32 accumulation (BASELINE configs[2]-[4]: x, w, dy are rounded to bf16, round-to-nearest-
+ * even, as they enter the matrix core; every tensor in HBM, BatchNorm statistics and all other kernels stay fp32).
+ * Process-wide; set it before a step, not concurrently with running calls. */
+int irx_set_compute_dtype(int bf16);
+int irx_get_compute_dtype(void);
+
 /* y[q][:] = sum_k x[nbr[k'][q]][:] * W[k]    (k' = K-1-k when flip_k, else k)
  * with W[k] = w[k][cin][cout]               when !trans_w   (forward)
  *      W[k] = transpose(w[k][cout'][cin'])  when  trans_w   (data-gradient: pass x = dy,

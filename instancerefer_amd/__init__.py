@@ -24,3 +24,17 @@ if _os.environ.get("IRX_KEEP_BLAS") != "1":
                 _torch.backends.cuda.preferred_blas_library("cublas")     # "cublas" is rocBLAS on ROCm
     except Exception:                                          # pragma: no cover - plumbing only
         pass
+
+
+def set_compute_dtype(name):
+    """Compute dtype of the MFMA sparse-conv kernels (irx_set_compute_dtype, include/irx.h): "fp32" (default, exact;
+    the parity gate) or "bf16" (bf16 operands, fp32 accumulation — BASELINE configs[2]-[4]). Tensors stay fp32."""
+    from . import _lib
+    if name not in ("fp32", "f32", "bf16"):
+        raise ValueError("compute dtype must be 'fp32' or 'bf16', got %r" % (name,))
+    _lib.call("irx_set_compute_dtype", 1 if name == "bf16" else 0)
+
+
+def get_compute_dtype():
+    from . import _lib
+    return "bf16" if _lib.load().irx_get_compute_dtype() else "fp32"

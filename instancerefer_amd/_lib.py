@@ -35,6 +35,8 @@ _SIGNATURES = {
     "irx_pyramid_build": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _P]),
     "irx_kmap_down_transpose": (_I, [_P, _P, _I, _P, _I, _P]),
     "irx_bev_table": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _I, _P, _P, _P]),
+    "irx_set_compute_dtype": (_I, [_I]),
+    "irx_get_compute_dtype": (_I, []),
     "irx_spconv_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "irx_spconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "irx_spconv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I]),

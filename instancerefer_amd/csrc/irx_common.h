@@ -83,6 +83,22 @@ __device__ static inline int irx_hash_lookup(const uint64_t* __restrict__ tk,
   }
 }
 
+// ---- bf16 operand helpers of the MFMA conv kernels (irx_set_compute_dtype(1)) ---------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// two fp32 -> one dword of two bf16 (lo = a, hi = b), round-to-nearest-even
+// (compiler-native convert, NOT inline asm: the hazard recognizer has to see the VALU write to pad the wait states a
+// following MFMA operand read needs — an asm v_cvt_pk_bf16_f32 fed the matrix core stale registers)
+__device__ __forceinline__ unsigned irx_pk_bf16(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(((f32x2){a, b}), bf16x2));
+}
+__device__ __forceinline__ s16x4 irx_frag_bf16(unsigned lo, unsigned hi) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(s16x4, ((u32x2){lo, hi}));
+}
+
+
 // ---- measurement aid (irx_profile_next_kernel, include/irx.h): brackets the next DOMINANT sparse-conv kernel of this
 // host thread (k_spconv2 / k_wgrad_pairs / k_spconv2_wgrad / k_stem_*) with two caller-owned events, excluding the small helper
 // launches (weight permute, split reduce) that share the C-ABI call.
@@ -90,6 +106,7 @@ void irx_bracket_begin(hipStream_t st);
 void irx_bracket_end(hipStream_t st);
 
 // ---- second-generation sparse-conv launchers (irx_spconv2.hip) ---------------------------------
+bool irx_conv_bf16();   // irx_set_compute_dtype(1): bf16 operands / fp32 accumulation in the MFMA conv kernels
 bool irx_spconv2_supported(int cin, int cout);
 bool irx_spconv2_enabled(char pass);
 int irx_spconv2_splits(int n_out, int K);

@@ -92,7 +92,7 @@ __device__ __forceinline__ int pairs_shares(const int32_t* __restrict__ counts, 
 }
 
 // part[s][k][c][n] = sum over share s of list k:  x[in][c] * dy[out][n]   (s < pairs_shares(k); grid = (smax, K))
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool BF>
 __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const int32_t* __restrict__ in_list,
                                                         const int32_t* __restrict__ out_list, int ldp,
@@ -171,7 +171,50 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
     int npairs = cnt - st * 64;
     if (npairs > 64) npairs = 64;
     const int nks = (npairs + 3) >> 2;
-    if (has_next) {
+    if constexpr (BF) {
+      // bf16 operands (irx_set_compute_dtype(1)): a lane of the 16x16x16 MFMA holds FOUR consecutive pairs of its
+      // channel (A) / column (B): 4 LDS reads + 2 packed converts per fragment, one MFMA where fp32 issues four.
+      // Rows of missing pairs are zero in LDS, so partial stages just run fewer 16-pair steps.
+      const int n16 = has_next ? 4 : ((npairs + 15) >> 4);
+#pragma unroll
+      for (int k16 = 0; k16 < 4; ++k16) {
+        if (k16 < n16) {
+          float a[CW][4], b[NW][4];
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4) {
+            const int ks = k16 * 4 + i4;
+            if (has_next) {                                // next stage's rows, spread over the chain as in fp32
+              if (ks < NX) {
+                const int idx = sIn[parn][xr + ks * PX];
+                const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(idx < 0 ? 0 : idx) * CIN + xc);
+                rx[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+              }
+              if (ks < ND) {
+                const int idx = sOutRow[parn][dr + ks * PD];
+                const float4 v = *reinterpret_cast<const float4*>(dy + (size_t)(idx < 0 ? 0 : idx) * COUT + dc);
+                rd[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+              }
+            }
+            const int pp = 16 * k16 + 4 * g4 + i4;
+#pragma unroll
+            for (int i = 0; i < CW; ++i) a[i][i4] = sX[pp * LDX + (ct0 + i) * 16 + m];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) b[i][i4] = sD[pp * LDD + (nt0 + i) * 16 + m];
+          }
+          s16x4 pa[CW], pb[NW];
+#pragma unroll
+          for (int i = 0; i < CW; ++i) pa[i] = irx_frag_bf16(irx_pk_bf16(a[i][0], a[i][1]), irx_pk_bf16(a[i][2], a[i][3]));
+#pragma unroll
+          for (int i = 0; i < NW; ++i) pb[i] = irx_frag_bf16(irx_pk_bf16(b[i][0], b[i][1]), irx_pk_bf16(b[i][2], b[i][3]));
+#pragma unroll
+          for (int i = 0; i < CW; ++i)
+#pragma unroll
+            for (int jn = 0; jn < NW; ++jn)
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[i], pb[jn], acc[i][jn], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else if (has_next) {
       // A stage that has a successor is a full one (16 k-steps): the next stage's rows are requested from INSIDE its
       // MFMA chain, one x and one dy load per step, so the wave never queues at the vector-memory pipe with an idle
       // MFMA pipe behind it (the lesson of k_spconv2). Loads are unconditional (missing pairs re-read row 0 and are
@@ -425,9 +468,15 @@ template <int CIN>
 static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* il,
                       const int32_t* ol, int ldp, const int32_t* counts, int K, int G, int smax, float* part) {
   irx_bracket_begin(st);
-  if (cout == 128) k_wgrad_pairs<CIN, 128><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-  else if (cout == 64) k_wgrad_pairs<CIN, 64><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-  else k_wgrad_pairs<CIN, 32><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+  if (irx_conv_bf16()) {
+    if (cout == 128) k_wgrad_pairs<CIN, 128, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    else if (cout == 64) k_wgrad_pairs<CIN, 64, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    else k_wgrad_pairs<CIN, 32, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    return;
+  }
+  if (cout == 128) k_wgrad_pairs<CIN, 128, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+  else if (cout == 64) k_wgrad_pairs<CIN, 64, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+  else k_wgrad_pairs<CIN, 32, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
   irx_bracket_end(st);
 }
 

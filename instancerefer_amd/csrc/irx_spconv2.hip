@@ -22,6 +22,18 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Compute dtype of the fast sparse-conv kernels (irx_set_compute_dtype, include/irx.h): 0 = exact fp32 MFMA
+// (v_mfma_f32_16x16x4_f32), 1 = bf16 operands (round-to-nearest-even of x and w at use) with fp32 accumulation
+// (v_mfma_f32_16x16x16_bf16). Tensors in HBM stay fp32 in both modes.
+static int g_irx_conv_bf16 = 0;
+extern "C" int irx_set_compute_dtype(int bf16) {
+  IRX_REQUIRE(bf16 == 0 || bf16 == 1, "irx_set_compute_dtype: %d is not 0 (fp32) or 1 (bf16)", bf16);
+  g_irx_conv_bf16 = bf16;
+  return IRX_OK;
+}
+extern "C" int irx_get_compute_dtype(void) { return g_irx_conv_bf16; }
+bool irx_conv_bf16() { return g_irx_conv_bf16 != 0; }
+
 #define S2_TM 64
 
 // Dev-only per-phase cycle attribution of k_spconv2 (tools/conv_phase_prof.py builds a -DIRX_S2_PROF variant).
@@ -66,12 +78,14 @@ __device__ static inline PairList compact_pairs(int my, int lane) {
 // in that queue instead of feeding the MFMA pipe (measured: 34 % of all wave cycles).  The prefetch loads are
 // UNCONDITIONAL (padded pairs re-read row `nrow` = a valid row; their results go to the dump row), so every chain
 // issues exactly NJ * (NT + 1) loads and the consumer can wait with an exact s_waitcnt vmcnt(n).
-template <int CIN, int COUT, int NJ, int NT, int LDA, int LDO, bool PREFETCH>
+// Weights: fp32 mode  WT = float4, one per fragment f = j * NT + t (4 consecutive reduction channels of one column);
+//          bf16 mode  WT = uint4 = fragments 2p (.xy) and 2p + 1 (.zw) as 4 bf16 each, WN = NJ * NT / 2 per item.
+template <int CIN, int COUT, int NJ, int NT, int LDA, int LDO, bool PREFETCH, bool BF, typename WT, int WN>
 __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __restrict__ sOut,
                                          const unsigned char* __restrict__ lrow, int g, int vs, int m, int g4,
-                                         int n_base, const float4 (&wc)[NJ][NT], float4 (&wx)[NJ][NT],
+                                         int n_base, const WT (&wc)[WN], WT (&wx)[WN],
                                          float4 (&sx)[NJ], const int (&nrow)[NJ], const float* __restrict__ x, int c4,
-                                         const float* __restrict__ wnk) {
+                                         const WT* __restrict__ wnk) {
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -85,19 +99,32 @@ __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __
     const float4 a4 = a_nxt;                       // fragment j was requested one step ago
     if (j + 1 < NJ) a_nxt = *reinterpret_cast<const float4*>(pa + 16 * (j + 1));
     if (PREFETCH) {
+      // this step's share of the item's weight loads
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wx[j][t] = *reinterpret_cast<const float4*>(wnk + (size_t)(j * NT + t) * 256);
+      for (int i = (BF ? (j * NT) / 2 : j * NT); i < (BF ? ((j + 1) * NT) / 2 : (j + 1) * NT); ++i)
+        wx[i] = wnk[(size_t)i * 64];
       sx[j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
     }
-    // alternate the accumulators so consecutive MFMAs never depend on each other
+    if constexpr (BF) {
+      // a lane's 4 consecutive floats are exactly the 4 k-slots of the 16x16x16 bf16 MFMA: one MFMA replaces four
+      const s16x4 pa = irx_frag_bf16(irx_pk_bf16(a4.x, a4.y), irx_pk_bf16(a4.z, a4.w));
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wc[j][t].x, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) {
+        const int f = j * NT + t;
+        const s16x4 pb = (f & 1) ? irx_frag_bf16(wc[f >> 1].z, wc[f >> 1].w) : irx_frag_bf16(wc[f >> 1].x, wc[f >> 1].y);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pb, acc[t], 0, 0, 0);
+      }
+    } else {
+      // alternate the accumulators so consecutive MFMAs never depend on each other
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wc[j][t].y, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wc[j * NT + t].x, acc[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wc[j][t].z, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wc[j * NT + t].y, acc[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wc[j][t].w, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wc[j * NT + t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wc[j * NT + t].w, acc[t], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);             // keep this step's loads between the MFMA blocks
   }
   // D layout: col = lane&15, row = (lane>>4)*4 + r -> pair 16g + 4*g4 + r.  Branch-free, batched read-modify-write:
@@ -164,7 +191,7 @@ __device__ __forceinline__ void s2_wait_vmcnt() {
 //           is shorter than the L2 latency (measured before: 30 % of the 64->64 wave cycles waiting in vmcnt(0)).
 // Register discipline: the item loop is unrolled DEPTH + 1 times so that every register set is a compile-time name
 // (no copies), and the explicit exact vmcnt tells the compiler's waitcnt pass that nothing consumed is pending.
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool BF>
 __global__ __launch_bounds__(256, 2)
 void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const int32_t* __restrict__ nbr, int ld,
                int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate) {
@@ -188,7 +215,9 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   constexpr int KMAX = 27;
   constexpr int DEPTH = (CIN >= 128) ? 1 : 2;     // items of prefetch distance
   constexpr int NS = DEPTH + 1;                   // register sets
-  constexpr int LPC = NJ * (NT + 1);              // loads per prefetch chain (exact)
+  using WT = typename std::conditional<BF, uint4, float4>::type;   // one weight load (16 B / lane)
+  constexpr int WN = BF ? NJ * NT / 2 : NJ * NT;   // weight loads per item
+  constexpr int LPC = WN + NJ;                    // loads per prefetch chain (exact)
   static_assert(NCS * NGP == 4, "4 waves");
   static_assert(NIT == NJ, "one gather pass per MFMA k-step");
   __shared__ __attribute__((aligned(16))) float sOut[(TM + 1) * LDO];   // + dump row for padded pairs
@@ -245,7 +274,8 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
 
   // ---- register sets and the prologue.  Sets are only ever indexed by compile-time constants (integral_constant
   // arguments of the generic lambdas below): a run-time choice of set would demote the arrays to scratch memory. ----
-  float4 W[3][NJ][NT], S[3][NJ];
+  WT W[3][WN];
+  float4 S[3][NJ];
   int kk[3] = {-1, -1, -1}, vv[3] = {0, 0, 0};     // offset / pair count of the item living in each set
   // the item whose loads are issued next: offset kq, pair count vq (kq = -1: past the end -> dummy loads of offset kl)
   int kq, vq, kl = kb;
@@ -256,13 +286,11 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     vv[T] = vq;
     int nrow[NJ];
     s2_gather_rows<NIT, PPP>(sIn + kl * TM, pbase, vq, nrow);
-    const float* wnk = wn + ((((size_t)kl * NCS + cs) * NJ) * NT * 64 + lane) * 4;
+    const WT* wnk = reinterpret_cast<const WT*>(wn) + (((size_t)kl * NCS + cs) * WN) * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int i = 0; i < WN; ++i) W[T][i] = wnk[(size_t)i * 64];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) W[T][j][t] = *reinterpret_cast<const float4*>(wnk + (size_t)(j * NT + t) * 256);
-      S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
-    }
+    for (int j = 0; j < NJ; ++j) S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -300,24 +328,22 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     vv[T] = vq;
     int nrow[NJ];
     s2_gather_rows<NIT, PPP>(sIn + kl * TM, pbase, vq, nrow);
-    const float* wnk = wn + ((((size_t)kl * NCS + cs) * NJ) * NT * 64 + lane) * 4;
+    const WT* wnk = reinterpret_cast<const WT*>(wn) + (((size_t)kl * NCS + cs) * WN) * 64 + lane;
     S2_TICK(5);
     // ---- MFMA over dense 16-pair groups; this wave's channel slice ----
     const unsigned char* lrow = sRow + k * TM;
     int g = gp;
     if (NGP == 1 || g * 16 < vpad) {
-      s2_group<CIN, COUT, NJ, NT, LDA, LDO, true>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T], S[T], nrow, x, c4,
-                                                  wnk);
+      s2_group<CIN, COUT, NJ, NT, LDA, LDO, true, BF, WT, WN>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T], S[T],
+                                                              nrow, x, c4, wnk);
       for (g += NGP; g * 16 < vpad; g += NGP)
-        s2_group<CIN, COUT, NJ, NT, LDA, LDO, false>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T], S[T], nrow, x,
-                                                     c4, wnk);
+        s2_group<CIN, COUT, NJ, NT, LDA, LDO, false, BF, WT, WN>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
+                                                                 S[T], nrow, x, c4, wnk);
     } else {                                       // a wave without a group in this item still prefetches its share
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      for (int i = 0; i < WN; ++i) W[T][i] = wnk[(size_t)i * 64];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) W[T][j][t] = *reinterpret_cast<const float4*>(wnk + (size_t)(j * NT + t) * 256);
-        S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
-      }
+      for (int j = 0; j < NJ; ++j) S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
     }
     S2_TICK(6);
   };
@@ -452,7 +478,16 @@ __global__ __launch_bounds__(256, 2) void k_spconv2_wgrad(const float* __restric
 // Conv3d.kernel w -> fragment-major image for k_spconv2.  Kernel-relative dims (cin_k = reduction, cout_k = outputs):
 //   forward      : W[k][c][n] = w[(k*cin_k + c)*cout_k + n]
 //   data-gradient: W[k][c][n] = w[(k*cout_k + n)*cin_k + c]   (w is the forward [K][conv Cin][conv Cout] tensor)
-__global__ void k_permute_w(const float* __restrict__ w, int K, int cin, int cout, int trans_w, float* __restrict__ wf) {
+// bf16 image: fragments 2p and 2p + 1 of a lane share one 16-byte element -> [K*NCS][NF/2][64 lanes][2][4 bf16]
+__device__ __forceinline__ void s2_store_frag_bf16(float* wf, size_t kcs, int nf, int f, int lane, float4 v) {
+  uint2 o;
+  o.x = irx_pk_bf16(v.x, v.y);
+  o.y = irx_pk_bf16(v.z, v.w);
+  reinterpret_cast<uint2*>(wf)[((kcs * (nf / 2) + (f >> 1)) * 64 + lane) * 2 + (f & 1)] = o;
+}
+
+__global__ void k_permute_w(const float* __restrict__ w, int K, int cin, int cout, int trans_w, float* __restrict__ wf,
+                            int bf16) {
   const int NT = cout >= 128 ? 2 : 1;
   const int NCS = cout / (16 * NT);
   const int NJ = cin / 16;
@@ -472,7 +507,10 @@ __global__ void k_permute_w(const float* __restrict__ w, int K, int cin, int cou
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     pv[i] = trans_w ? w[((size_t)k * cout + n) * cin + c0 + i] : w[((size_t)k * cin + c0 + i) * cout + n];
-  reinterpret_cast<float4*>(wf)[f] = v;
+  if (bf16)
+    s2_store_frag_bf16(wf, (size_t)k * NCS + cs, NJ * NT, j * NT + t, lane, v);
+  else
+    reinterpret_cast<float4*>(wf)[f] = v;
 }
 
 // ---------------------------------------------------------------------------- host dispatch ---
@@ -491,12 +529,12 @@ bool irx_spconv2_supported(int cin, int cout) {
   return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128);
 }
 
-template <int CIN>
+template <int CIN, bool BF>
 static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
                         int ld, int n_out, int K, int flip_k, float* y, int kps, int acc) {
-  if (cout == 128) k_spconv2<CIN, 128><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
-  else if (cout == 64) k_spconv2<CIN, 64><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
-  else k_spconv2<CIN, 32><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  if (cout == 128) k_spconv2<CIN, 128, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  else if (cout == 64) k_spconv2<CIN, 64, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  else k_spconv2<CIN, 32, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
 }
 
 // Output rows per workgroup: 64.  (128-row tiles stream half the weight bytes per useful FLOP but MEASURED SLOWER on
@@ -528,16 +566,22 @@ int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int 
   dim3 grid(irx_cdiv(n_out, S2_TM), splits);
   const int kps = irx_cdiv(K, splits);
   irx_bracket_begin(st);
-  if (cin == 128) launch_fwd2<128>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
-  else if (cin == 64) launch_fwd2<64>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
-  else launch_fwd2<32>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  if (g_irx_conv_bf16) {
+    if (cin == 128) launch_fwd2<128, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+    else if (cin == 64) launch_fwd2<64, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+    else launch_fwd2<32, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  } else {
+    if (cin == 128) launch_fwd2<128, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+    else if (cin == 64) launch_fwd2<64, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+    else launch_fwd2<32, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+  }
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(v2)");
   return IRX_OK;
 }
 
 // All layers of an encoder in ONE launch (the per-layer permutes were 54 launches of ~5 us per training step).
-__global__ void k_permute_w_multi(IrxPermuteJobs J, int trans_w) {
+__global__ void k_permute_w_multi(IrxPermuteJobs J, int trans_w, int bf16) {
   const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int j = 0;
   while (j < J.n && f >= J.end4[j]) ++j;
@@ -562,20 +606,23 @@ __global__ void k_permute_w_multi(IrxPermuteJobs J, int trans_w) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     pv[i] = trans_w ? w[((size_t)k * cout + n) * cin + c0 + i] : w[((size_t)k * cin + c0 + i) * cout + n];
-  reinterpret_cast<float4*>(J.dst[j])[fl] = v;
+  if (bf16)
+    s2_store_frag_bf16(J.dst[j], (size_t)k * NCS + cs, NJ * NT, jj * NT + t, lane, v);
+  else
+    reinterpret_cast<float4*>(J.dst[j])[fl] = v;
 }
 
 int irx_permute_w_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStream_t st) {
   if (jobs.n == 0) return IRX_OK;
   const size_t total = jobs.end4[jobs.n - 1];
-  k_permute_w_multi<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(jobs, trans_w);
+  k_permute_w_multi<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(jobs, trans_w, g_irx_conv_bf16);
   IRX_CHECK_LAUNCH("irx_encoder(permute)");
   return IRX_OK;
 }
 
 int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st) {
   const size_t total = (size_t)K * cin * cout / 4;
-  k_permute_w<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(w, K, cin, cout, trans_w, wf);
+  k_permute_w<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(w, K, cin, cout, trans_w, wf, g_irx_conv_bf16);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(permute)");
   return IRX_OK;
 }

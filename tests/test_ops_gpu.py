@@ -143,6 +143,56 @@ def test_conv_fwd_bwd(lib, clouds, cin, cout, ks, stride):
     assert (dwd - dwo).abs().max().item() <= 2e-5 * max(dwo.abs().max().item(), 1.0), "wgrad"
 
 
+@pytest.mark.parametrize("cin,cout,ks,stride", [(32, 64, 2, 2), (64, 64, 3, 1), (64, 128, 2, 2), (128, 128, 3, 1),
+                                                (128, 64, 3, 1), (32, 32, 3, 1)])
+def test_conv_bf16_operand_mode(lib, clouds, cin, cout, ks, stride):
+    """irx_set_compute_dtype(1): forward, data- and weight-gradient equal the oracle evaluated on operands rounded to
+    bf16 (round-to-nearest-even) with fp32 accumulation — i.e. only the summation order differs (1e-5 relative)."""
+    import instancerefer_amd as irx
+    import oracle.torchsparse.nn as ospnn
+    from oracle.torchsparse import SparseTensor as OT
+    from instancerefer_amd.sparse import nn as spnn
+
+    def r(t):
+        return t.bfloat16().float()
+    torch.manual_seed(cin * 77 + cout)
+    o = oracle_batch(clouds, 0.05)
+    d = device_batch(clouds, 0.05)
+    ia, ib = align(d.C.cpu().numpy(), o.C.numpy())
+    n = len(ia)
+    feats = torch.randn(n, cin)
+    fo = torch.empty(n, cin); fo[ib] = r(feats)
+    fd = torch.empty(n, cin); fd[ia] = feats
+    oconv = ospnn.Conv3d(cin, cout, ks, stride=stride)
+    dconv = spnn.Conv3d(cin, cout, ks, stride=stride).cuda()
+    dconv.kernel.data.copy_(oconv.kernel.data)
+    oconv.kernel.data.copy_(r(oconv.kernel.data))
+    xo = fo.clone().requires_grad_(True)
+    xd = fd.clone().cuda().requires_grad_(True)
+    yo = oconv(OT(xo, o.C, 1))
+    irx.set_compute_dtype("bf16")
+    try:
+        assert irx.get_compute_dtype() == "bf16"
+        yd = dconv(d.with_feats(xd))
+        ja, jb = align(yd.C.cpu().numpy(), yo.C.numpy())
+        got, exp = yd.F.detach().cpu()[ja], yo.F.detach()[jb]
+        assert (got - exp).abs().max().item() <= 1e-5 * max(exp.abs().max().item(), 1.0), "forward"
+        g = torch.randn(len(ja), cout)
+        go = torch.empty_like(g); go[jb] = r(g)
+        gd = torch.empty_like(g); gd[ja] = g
+        yo.F.backward(go)
+        yd.F.backward(gd.cuda())
+    finally:
+        irx.set_compute_dtype("fp32")
+    dxo, dxd = xo.grad[ib], xd.grad.cpu()[ia]
+    assert (dxd - dxo).abs().max().item() <= 1e-5 * max(dxo.abs().max().item(), 1.0), "dgrad"
+    dwo, dwd = oconv.kernel.grad, dconv.kernel.grad.cpu()
+    assert (dwd - dwo).abs().max().item() <= 2e-5 * max(dwo.abs().max().item(), 1.0), "wgrad"
+    # and it is NOT the fp32 result (the mode really changes the arithmetic)
+    y32 = dconv(d.with_feats(xd.detach())).F.detach().cpu()[ja]
+    assert (y32 - exp).abs().max().item() > 1e-4 * max(exp.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize("n,c,relu,res", [(5000, 32, True, False), (777, 64, True, True), (3001, 128, False, True),
                                           (260, 128, True, False), (1500, 20, True, True)])
 def test_batchnorm_act(lib, n, c, relu, res):

@@ -5,6 +5,9 @@ from instancerefer_amd import synthetic as S
 from instancerefer_amd.sparse import functional as F_
 from instancerefer_amd.sparse.utils import voxelize
 dev = torch.device('cuda')
+import instancerefer_amd as irx
+if os.environ.get('IRX_DTYPE'): irx.set_compute_dtype(os.environ['IRX_DTYPE'])
+print('compute dtype', irx.get_compute_dtype())
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dd = S.make_batch(B, seed=123)
 pts = [torch.from_numpy(p) for p in dd['scene_points']]
