@@ -260,6 +260,16 @@ int irx_encoder_forward(const int64_t* desc, const double* fdesc, int n_layers, 
  * dx0 [n_in0][cin0]; GY of the other layers and dc_scratch [max n_out*cout] are scratch. */
 int irx_encoder_backward(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch, float* dx0,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Asynchronous issue of the two calls above: a lane (0..3) is a library thread that performs the call from a copy of
+ * the descriptor table while the caller's thread goes on issuing independent work (Python: the ctypes call returns at
+ * once). backward == 0: irx_encoder_forward (dc_scratch / dx0 ignored). Jobs of a lane run in submission order. The
+ * caller keeps every device buffer alive, and enqueues nothing that depends on the pass on its stream — nor records an
+ * event there — before irx_encoder_wait(lane) returned; that call blocks until the lane is idle and returns the first
+ * failing status since the previous wait (message in irx_last_error()). */
+int irx_encoder_submit(int lane, int backward, const int64_t* desc, const double* fdesc, int n_layers,
+                       float* dc_scratch, float* dx0, void* workspace, size_t workspace_bytes, void* stream);
+int irx_encoder_wait(int lane);
+
 
 /* ---- segmented reductions ------------------------------------------------------------- */
 

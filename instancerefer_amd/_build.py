@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("IRX_LIB_PATH") or os.path.join(CSRC, "libirx.so")   #
 SOURCES = ["irx_coords.hip", "irx_spconv.hip", "irx_spconv2.hip", "irx_pairs.hip", "irx_encoder.hip", "irx_stem.hip", "irx_norm.hip", "irx_pool.hip", "irx_match.hip", "irx_input.hip", "irx_gru.hip", "irx_optim.hip"]
 HEADERS = ["irx_common.h", os.path.join("..", "..", "include", "irx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-pthread"]
 
 
 def _stale() -> bool:
@@ -62,7 +62,7 @@ def _build_locked(objdir, verbose):
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

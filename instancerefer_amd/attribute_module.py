@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from .basic_blocks import SparseConvEncoder
 from .data import idx_tensor, selection_on_device, upload_instances
+from .sparse.encoder_fn import lane_of, lane_wait
 from .dense import cosine_rows
 from .sparse import nn as spnn
 from .sparse.utils import voxelize, voxelize_launch
@@ -78,6 +79,14 @@ class AttributeModule(nn.Module):
             data_dict['_attr_prepared'] = (pending.finish(), data_dict['_attr_prepared'][1])
         return data_dict
 
+    def encode(self, data_dict):
+        """Issue the candidate encoder now if the candidates are already known (prepare() ran: GT classes) — it needs
+        nothing from the language module. forward() picks the result up; identical to running it there."""
+        prep = data_dict.get('_attr_prepared')
+        if prep is not None and prep[0] is not None and '_attr_encoded' not in data_dict:
+            data_dict['_attr_encoded'] = self.net(prep[0])
+        return data_dict
+
     def forward(self, data_dict):
         lang_feats = data_dict['lang_attr_feats']
         lang_feats = self.lang_emb_fc(lang_feats)                             # (B, h_dim)
@@ -100,7 +109,10 @@ class AttributeModule(nn.Module):
             data_dict['attribute_scores'] = lang_feats.new_zeros((0,))
             return data_dict
 
-        feats = self.net(st)
+        feats = data_dict.pop('_attr_encoded', None)
+        if feats is None:
+            feats = self.net(st)
+        lane_wait(lane_of(self.net))                      # the encoder may be issued by a library thread
         feats = self.pooling(feats)                       # (Nc, 128)
         data_dict['obj_feats'] = feats
         feats = self.vis_emb_fc(feats)

@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 
 _PKG = __name__.rsplit('.', 1)[0]
+import os as _os
+_ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
 
 
 def _import(name):
@@ -29,6 +31,10 @@ class InstanceRefer(nn.Module):
             self.relation = _import(args.relation_module).RelationModule(input_feature_dim, args)
         if args.scene_module:
             self.scene = _import(args.scene_module).SceneModule(input_feature_dim, args)
+        # the two sparse encoders are issued by library threads (sparse/encoder_fn.py "asynchronous issue"): lanes 0 / 1
+        for lane, owner in enumerate((getattr(self, 'scene', None), getattr(self, 'attribute', None))):
+            if owner is not None and hasattr(owner, 'net'):
+                owner.net.__dict__['_irx_lane'] = lane
 
     def prepare(self, data_dict):
         """Phase 0 — everything that needs a host sync and depends only on the inputs: candidate selection +
@@ -114,18 +120,35 @@ class InstanceRefer(nn.Module):
                     data_dict = self.scene.encode(data_dict)
             else:
                 data_dict = self.scene.encode(data_dict)
+        if self.args.attribute_module and hasattr(self.attribute, 'encode') and self._attr_early():
+            # candidates already chosen (prepare()): their encoder does not need the language features either, and its
+            # launches are issued by a library thread while this one goes on with the language module (see _attr_early)
+            data_dict = self.attribute.encode(data_dict)
         data_dict = self.lang(data_dict)
         if self.args.attribute_module:
             data_dict = self.attribute(data_dict)
         if self.args.relation_module:
             data_dict = self.relation(data_dict)
         if side is not None:
+            from .sparse.encoder_fn import lane_of, lane_wait
+            lane_wait(lane_of(self.scene.net))               # every launch of the scene encoder is on `side` now
             main = torch.cuda.current_stream()
             main.wait_stream(side)
             data_dict['_scene_encoded'].record_stream(main)
         if self.args.scene_module:
             data_dict = self.scene(data_dict)
         return data_dict
+
+    @staticmethod
+    def _attr_early():
+        """Issue the candidate encoder BEFORE the language module? Measured on MI355X (B = 16): with bf16 conv operands
+        the step is host-bound and the early issue (a library thread launches the encoder while this thread issues
+        the language module) is worth +15 % (1620 -> 1874 scenes/s, 1981 with both encoders asynchronous); in fp32 the
+        step is GPU-bound and the early encoder takes CUs from the scene encoder on the critical path (-3 %)."""
+        if _ATTR_EARLY is not None:
+            return _ATTR_EARLY != '0'
+        from . import get_compute_dtype
+        return get_compute_dtype() == 'bf16'
 
     def _encoder_stream(self, device):
         st = getattr(self, '_enc_stream', None)

@@ -71,12 +71,17 @@ class FlatAdam:
         except KeyError:
             return None
 
-    def sink_delivered(self, key, params):
+    def sink_delivered(self, key, params, lane=None):
         """Called by the producer right after it enqueued the kernels that write the slots (on ITS current stream, which
         for the scene encoder is not the optimizer's): an event makes gather_grads() wait for them. (Autograd only
         synchronises the streams of AccumulateGrad nodes at the end of backward(), and these parameters have none now.)"""
         self._direct_groups.add(key)
         self._direct.update(self._index[id(p)] for p in params)
+        if lane is not None:
+            # the producer's launches are still being issued by a library thread (encoder_fn.lane_wait): the event is
+            # recorded on its stream by gather_grads(), after the lane went idle
+            self._pending.append((lane, torch.cuda.current_stream()))
+            return
         ev = torch.cuda.Event()
         ev.record()
         self._pending.append(ev)
@@ -87,7 +92,13 @@ class FlatAdam:
         if self._pending:
             cur = torch.cuda.current_stream()
             for ev in self._pending:
-                cur.wait_event(ev)
+                if isinstance(ev, tuple):
+                    from .sparse.encoder_fn import lane_wait
+                    lane_wait(ev[0])
+                    if ev[1] != cur:
+                        cur.wait_stream(ev[1])
+                else:
+                    cur.wait_event(ev)
             self._pending.clear()
         key = frozenset(self._direct_groups)
         todo = self._gather_cache.get(key)

@@ -12,6 +12,7 @@ import torch.nn as nn
 from .basic_blocks import BEVEncoder, SparseCrop, ToDenseBEVConvolution, batchnorm_rows, conv2d_rows
 from .data import idx_tensor
 from .dense import cosine_rows
+from .sparse.encoder_fn import lane_of, lane_wait
 from .sparse import nn as spnn
 
 
@@ -63,6 +64,7 @@ class SceneModule(nn.Module):
             if feats._batch_size is None:
                 feats._batch_size = batch_size   # known from the collate; avoids the reference's .item() sync
             feats = self.net(feats)
+        lane_wait(lane_of(self.net))             # the encoder may be issued by a library thread (encoder_fn.py)
         # SparseCrop (to_bev[0]) is folded into the BEV gather: only voxels inside the window are looked up.
         # The dense head runs on channels-last cell rows (cells, C) with the irx conv / BatchNorm kernels.
         nx, ny = self.to_bev[1].bev_shape

@@ -9,6 +9,8 @@ results); Python only fills the table and allocates three arenas.
 
 Layer list (index: conv, residual source): 0 stem | per stage s: 3s+1 down (2^3/2), 3s+2 res-a, 3s+3 res-b (+ out of 3s+1).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -113,6 +115,29 @@ def _up_np(a):
     return (a + (_ALIGN - 1)) // _ALIGN * _ALIGN
 
 
+# ---- asynchronous issue (irx_encoder_submit / irx_encoder_wait, include/irx.h) ---------------------------------------
+# An encoder with `_irx_lane` set (InstanceRefer does that for its two encoders) has its forward — and, when the
+# parameter gradients go to the optimizer's sink and no input gradient is wanted, its backward — issued by a library
+# thread, so ~0.2 ms of launch issue per pass leaves the Python thread. Whoever enqueues dependent work on that stream
+# (or records an event on it) calls lane_wait() first. IRX_ENCODER_ASYNC=0 switches it off.
+ASYNC = os.environ.get("IRX_ENCODER_ASYNC", "1") != "0"
+_HELD = {}            # lane -> device buffers that must outlive the queued jobs
+
+
+def lane_of(encoder):
+    return encoder.__dict__.get("_irx_lane") if ASYNC else None
+
+
+def lane_wait(lane):
+    """Block until the lane has enqueued everything submitted to it; raise if one of its passes failed."""
+    if lane is None:
+        return
+    rc = _lib.load().irx_encoder_wait(lane)
+    _HELD.pop(lane, None)
+    if rc:
+        _lib.check(rc, "irx_encoder (asynchronous pass)")
+
+
 class EncoderFn(torch.autograd.Function):
     """forward / backward = one irx_encoder_forward / irx_encoder_backward call over a descriptor table; activations,
     gradients-in-flight and parameter gradients live in three arenas allocated once per call. The table is a cached
@@ -146,9 +171,16 @@ class EncoderFn(torch.autograd.Function):
         desc[:, _E["INVSTD"]] += sbase
         nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 0)
         ws = _ws(nbytes, dev)
-        rc = lib.irx_encoder_forward(desc.ctypes.data, fdesc.ctypes.data, nl, ws.data_ptr(), nbytes, _lib.stream_ptr())
+        lane = lane_of(encoder)
+        if lane is not None:
+            rc = lib.irx_encoder_submit(lane, 0, desc.ctypes.data, fdesc.ctypes.data, nl, None, None, ws.data_ptr(),
+                                        nbytes, _lib.stream_ptr())
+            _HELD.setdefault(lane, []).append((ws, x0, arena, stats))
+        else:
+            rc = lib.irx_encoder_forward(desc.ctypes.data, fdesc.ctypes.data, nl, ws.data_ptr(), nbytes, _lib.stream_ptr())
         if rc:
             _lib.check(rc, "irx_encoder_forward")
+        ctx.lane = lane
         if counters:
             torch._foreach_add_(counters, 1)
         ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = layers, desc, fdesc, (n_out, cout, poffs, ptotal)
@@ -224,6 +256,17 @@ class EncoderFn(torch.autograd.Function):
         fdesc = ctx.fdesc
         nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 1)
         ws = _ws(nbytes, dev)
+        if ctx.lane is not None and slots is not None and not need_dx0:
+            # nothing autograd will touch depends on this pass: a library thread issues it; the optimizer waits for the
+            # lane before it records the delivery event (FlatAdam.gather_grads)
+            rc = lib.irx_encoder_submit(ctx.lane, 1, desc.ctypes.data, fdesc.ctypes.data, nl, gbase + 4 * dc_off, None,
+                                        ws.data_ptr(), nbytes, _lib.stream_ptr())
+            if rc:
+                _lib.check(rc, "irx_encoder_submit")
+            _HELD.setdefault(ctx.lane, []).append((ws, garena, dout, slots, ctx.saved_tensors))
+            owner.sink_delivered(key, sparams, lane=ctx.lane)
+            return (None, None, None) + (None,) * (3 * nl)
+        lane_wait(ctx.lane)                                  # same-stream order with the (possibly queued) forward
         rc = lib.irx_encoder_backward(desc.ctypes.data, fdesc.ctypes.data, nl, gbase + 4 * dc_off,
                                       dfeats.data_ptr() if need_dx0 else None, ws.data_ptr(), nbytes,
                                       _lib.stream_ptr())
