@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="compute dtype of the MFMA sparse-conv kernels: f32 (default: the reference's dtype, exact) or bf16 "
                          "operands with fp32 accumulation (BASELINE configs[2]-[4]); tensors, BatchNorm, heads stay fp32")
+    ap.add_argument("--no-alt-dtype", action="store_true",
+                    help="skip the extra bf16 leg (N = 1, --dtype f32 only) reported under 'alt_dtype'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--cpu-timeout", type=int, default=150)
@@ -388,6 +390,30 @@ def main():
         F_.PROFILE = None
         roof = summarise_roofline(recs, args.dtype == "bf16")
 
+    # ---- the same loop with bf16 conv operands (BASELINE configs[2]-[4] dtype), reported beside the fp32 headline ----
+    alt = None
+    if world == 1 and args.dtype == "f32" and not args.no_alt_dtype:
+        irx.set_compute_dtype("bf16")
+        try:
+            for _ in range(min(args.warmup, 10)):
+                step_fn(model, resident, args.workload, reducer, opt, state)
+            barrier()
+            ak = max(1, min(args.steps, 50))
+            t0 = time.perf_counter()
+            for _ in range(ak):
+                step_fn(model, resident, args.workload, reducer, opt, state)
+            barrier()
+            adt = time.perf_counter() - t0
+            alt = {"dtype": "bf16", "value": B * ak / adt, "unit": "scenes/s", "ms_per_step": 1000.0 * adt / ak,
+                   "steps": ak, "warmup": min(args.warmup, 10),
+                   "what": "same loop, irx_set_compute_dtype(1): bf16 operands / fp32 accumulation in the 32/64/128-channel "
+                           "sparse convs (fwd, dgrad, wgrad); tensors, BatchNorm, stem, heads fp32. Not the headline: the "
+                           "1e-4 parity gate is proven for fp32; bf16 tracks it within 4e-4 on the matching scores "
+                           "(tests/test_model_gpu.py) and equals the bf16-operand oracle to 1e-5 (tests/test_ops_gpu.py)"}
+        finally:
+            irx.set_compute_dtype("fp32")
+        log("bf16 leg done: %.1f ms/step" % alt["ms_per_step"])
+
     if rank == 0:
         out = {
             "metric": "scenes/sec fwd+bwd (50k-pt synthetic ScanRefer)",
@@ -406,6 +432,8 @@ def main():
                        "input_prep": "inline" if args.no_pipeline else "side-stream prefetch of step N+1 during step N"},
             "roofline": roof,
         }
+        if alt is not None:
+            out["alt_dtype"] = alt
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.workload)

@@ -195,6 +195,7 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
 // holding the GIL) goes on issuing the independent work of the other modules meanwhile. Jobs of a lane run in
 // submission order. The caller keeps every device buffer alive and enqueues nothing that depends on the pass (nor
 // records an event on its stream) before irx_encoder_wait(lane) returned.
+#include <stdlib.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -233,11 +234,13 @@ void lane_main(EncLane* L) {
   for (;;) {
     EncJob j;
     {
-      // The next job of a training loop arrives within one step (~10 ms): poll for a while before sleeping, a futex
-      // wake-up (plus a core leaving its idle state) costs 50-100 us, i.e. most of what the lane saves.
+      // Poll briefly before sleeping (IRX_LANE_POLL_US, default 200): back-to-back submissions skip the futex wake-up.
+      // Longer polling was measured equal (the caller only waits for the lane ~1 ms after submitting) and would burn
+      // CPU quota in multi-rank runs.
+      static const long poll_us = getenv("IRX_LANE_POLL_US") ? atol(getenv("IRX_LANE_POLL_US")) : 200;
       const auto t0 = std::chrono::steady_clock::now();
       while (L->queued.load(std::memory_order_acquire) == 0 &&
-             std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(30))
+             std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(poll_us))
         __builtin_ia32_pause();
       std::unique_lock<std::mutex> lk(L->mu);
       L->cv_job.wait(lk, [&] { return !L->q.empty(); });
