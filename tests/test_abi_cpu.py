@@ -61,6 +61,19 @@ def test_argument_validation_and_error_string(lib):
     assert lib.irx_device_props(0, out) in (0, -4)
 
 
+def test_mode_switch_and_lane_calls_validate_their_arguments(lib):
+    assert lib.irx_get_compute_dtype() == 0                      # fp32 (exact) is the default
+    assert lib.irx_set_compute_dtype(2) == -1 and b"irx_set_compute_dtype" in lib.irx_last_error()
+    assert lib.irx_set_compute_dtype(1) == 0 and lib.irx_get_compute_dtype() == 1
+    assert lib.irx_set_compute_dtype(0) == 0 and lib.irx_get_compute_dtype() == 0
+    assert lib.irx_encoder_wait(0) == 0                          # an idle lane returns at once
+    assert lib.irx_encoder_wait(7) == -1 and b"lane" in lib.irx_last_error()
+    assert lib.irx_encoder_submit(0, 0, None, None, 0, None, None, None, 0, None) == -1
+    assert lib.irx_scene_sample(None, 0, 7, None, 0, 0, 0, None, 0, None, None, 4, None) == 0    # empty sample
+    assert lib.irx_scene_sample(None, 0, 7, None, 0, 0, 0, None, 0, None, None, 2, None) == -1   # elem_bytes
+    assert lib.irx_instance_split(None, 0, 7, None, None, 0, None, 1024, None, None, None, 8, None) == 0
+
+
 def test_product_never_imports_oracle():
     """The product path must not route through the oracle or any CPU fallback."""
     pkg = os.path.join(ROOT, "instancerefer_amd")

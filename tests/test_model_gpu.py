@@ -326,3 +326,43 @@ def test_bf16_operand_mode_tracks_the_fp32_reference(lib):
     total = float(np.sqrt(sum(float(gold[k]) ** 2 for k in gold.files if k.startswith("grad_norm/"))))
     got = float(np.sqrt(sum(float(p.grad.double().norm()) ** 2 for p in model.parameters() if p.grad is not None)))
     assert np.isfinite(got) and abs(got - total) <= 5e-2 * total, (got, total)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_asynchronous_encoder_issue_changes_nothing(lib, dtype):
+    """Encoder passes issued by library threads (irx_encoder_submit / irx_encoder_wait; in bf16 mode the candidate
+    encoder is also issued ahead of the language module) vs the same passes issued inline by the Python thread: same
+    kernels on the same streams -> bit-identical losses and parameters after 3 training steps."""
+    import argparse
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import instancerefer_amd as irx
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.loss_helper import DatasetConfig
+    from instancerefer_amd.optim import FlatAdam
+    from instancerefer_amd.sparse import encoder_fn
+    dev = torch.device("cuda")
+    bench.step_fn.cfg = DatasetConfig()
+    out = {}
+    saved = encoder_fn.ASYNC
+    irx.set_compute_dtype(dtype)
+    try:
+        for mode in (True, False):
+            encoder_fn.ASYNC = mode
+            torch.manual_seed(11)
+            model = bench.build_model(argparse.Namespace(), "full", dev)
+            resident = S.to_device(S.make_batch(4, seed=33, num_points=6000, num_instances=6, num_candidates=3,
+                                                points_per_instance=256), dev)
+            lidar = resident.pop("lidar")
+            resident["lidar_F"], resident["lidar_C"], resident["B"] = lidar.F, lidar.C, 4
+            opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
+            losses = [float(bench.step_fn(model, resident, "full", None, opt, None).detach()) for _ in range(3)]
+            torch.cuda.synchronize()
+            out[mode] = (losses, opt.flat_p.clone())
+    finally:
+        encoder_fn.ASYNC = saved
+        irx.set_compute_dtype("fp32")
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])

@@ -22,6 +22,9 @@ for s in range(2 if cin == 128 else 1): lv = lv.down().out_level
 n = lv.n; tbl, ld = lv.nbr27()
 x = torch.randn(n, cin, device=dev); w = torch.randn(27, cin, cout, device=dev) * 0.05
 lib = _lib.load()
+import instancerefer_amd as irx
+if os.environ.get('IRX_DTYPE'): irx.set_compute_dtype(os.environ['IRX_DTYPE'])
+print('compute dtype', irx.get_compute_dtype())
 lib.irx_debug_s2_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
 F_.spconv_gather_gemm(x, w, tbl, ld, n, 27, cin, cout, 1, 1); torch.cuda.synchronize()
 lib.irx_debug_s2_prof(None, 1)
