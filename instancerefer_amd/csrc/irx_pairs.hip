@@ -8,6 +8,7 @@
 // pairs (the table-driven kernel gets only ~1/3 of a 64-row chunk filled): gather x[in] and dy[out] rows (16 B/lane)
 // -> LDS -> v_mfma_f32_16x16x4_f32 with the pairs as the reduction dimension; the next stage's indices and rows are
 // prefetched into registers before the current stage's MFMAs. Per-(split, offset) partial sums, deterministic reduce.
+#include <stdlib.h>
 #include "irx_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -451,7 +452,8 @@ extern "C" int irx_pairs_build_multi(int n_tables, const int32_t* const* nbr, co
 }
 
 static int pairs_budget(int n_out, int K) {
-  int s = irx_cdiv(1024, K);
+  static const int target = getenv("IRX_PAIRS_BUDGET") ? atoi(getenv("IRX_PAIRS_BUDGET")) : 1024;   // dev A/B knob
+  int s = irx_cdiv(target, K);
   const int max_s = irx_cdiv(n_out, 512);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
