@@ -298,11 +298,20 @@ int irx_batch_offsets(const int32_t* coords, int n, int nseg, int32_t* offsets, 
  * then shifted (shift may be NULL). The caller draws choices / angles / shift from the reference's RNG streams. */
 int irx_scene_sample(const void* src, int n_src, int c, const int32_t* choices, int n, int flip_x, int flip_y,
                      const double* rot, int n_rot, const double* shift, void* dst, int elem_bytes, void* stream);
+/* irx_scene_sample for a whole batch in one call (host arrays of per-sample arguments; choices are int64 device arrays,
+ * e.g. torch.randperm; flip_xy = 2 ints, rot = 27 doubles, shift = 3 doubles per sample): dst [n_samples][n][c]. When
+ * gslot != NULL it also gathers the sampled points' labels: gslot[b][r] = slot_src[b][choices[b][r]] + slot_base[b],
+ * sem[b][r] = sem_src[b][choices[b][r]] (int64, ready for bincount / sort on the device). */
+int irx_scene_sample_batch(int n_samples, const void* const* src, const int* n_src, int c, const int64_t* const* choices,
+                           int n, const int* flip_xy, const double* rot, const int* n_rot, const double* shift,
+                           const int* has_shift, void* dst, const int32_t* const* slot_src, const int32_t* const* sem_src,
+                           const int64_t* slot_base, int64_t* gslot, int64_t* sem, int elem_bytes, void* stream);
 /* The instance loop of lib/dataset.py:207-232 for one sampled cloud pts [n][c]: instance i owns the rows
  * order[seg[i] .. seg[i+1]) (ascending point index = np.nonzero(labels == id)); obbs[i] = (0.5*(lo+hi), hi-lo, 0)
  * computed in the storage type and widened to float64; inst_points[i][s] = pts[rows[i][s]] (the 1024-point resample,
  * rows index the sampled cloud); extent (optional, 6 storage-type values) = min xyz, max xyz of the whole cloud
- * (point_min / point_max, lib/dataset.py:267-268). Segments must not be empty. */
+ * (point_min / point_max, lib/dataset.py:267-268). An empty segment gets an all-zero box. order / seg / rows are device
+ * arrays, so the whole batch can go through ONE call (pts = all sampled clouds back to back, global row indices). */
 int irx_instance_split(const void* pts, int n, int c, const int32_t* order, const int32_t* seg, int n_inst,
                        const int32_t* rows, int n_sample, void* inst_points, double* obbs, void* extent,
                        int elem_bytes, void* stream);

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "irx_segment_mean": (_I, [_P, _I, _I, _I, _P, _P]),
     "irx_batch_offsets": (_I, [_P, _I, _I, _P, _P]),
     "irx_scene_sample": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P]),
+    "irx_scene_sample_batch": (_I, [_I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "irx_instance_split": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
     "irx_gru_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "irx_gru_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

@@ -56,6 +56,10 @@ __global__ __launch_bounds__(256) void k_instance_box(const T* __restrict__ pts,
   const int i = blockIdx.x;
   const bool whole = (i == n_inst);
   const int beg = whole ? 0 : seg[i], end = whole ? n : seg[i + 1];
+  if (end <= beg) {                                  // empty segment (an instance that lost all its points): zeros
+    if (!whole && threadIdx.x < 7) obbs[(size_t)i * 7 + threadIdx.x] = 0.0;
+    return;                                          // block-uniform
+  }
   T lo[3], hi[3];
   bool any = false;
   for (int p = beg + threadIdx.x; p < end; p += 256) {
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void k_instance_box(const T* __restrict__ pts,
     }
     any = true;
   }
-  // threads without rows take the segment's first row (segments are never empty)
+  // threads without rows take the segment's first row
   if (!any) {
     const T* row = pts + (size_t)(whole ? beg : order[beg]) * c;
     for (int a = 0; a < 3; ++a) lo[a] = hi[a] = row[a];
@@ -165,5 +169,86 @@ extern "C" int irx_instance_split(const void* pts, int n, int c, const int32_t* 
       k_instance_gather<double><<<grid, 256, 0, S(stream)>>>((const double*)pts, c, rows, total, (double*)inst_points);
     IRX_CHECK_LAUNCH("k_instance_gather");
   }
+  return 0;
+}
+
+// gslot[r] = slot_src[choices[r]] + slot_base, sem[r] = sem_src[choices[r]]  (labels of the sampled points, as int64
+// for torch's bincount / scatter_reduce / sort)
+__global__ __launch_bounds__(256) void k_sample_labels(const int32_t* __restrict__ slot_src,
+                                                       const int32_t* __restrict__ sem_src,
+                                                       const int64_t* __restrict__ choices, int n, int64_t slot_base,
+                                                       int64_t* __restrict__ gslot, int64_t* __restrict__ sem) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t v = choices[r];
+  gslot[r] = (int64_t)slot_src[v] + slot_base;
+  sem[r] = (int64_t)sem_src[v];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_scene_sample64(const T* __restrict__ src, const int64_t* __restrict__ choices,
+                                                        int n, int c, IrxAug aug, T* __restrict__ dst) {
+#pragma clang fp contract(off)
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const T* s = src + (size_t)choices[r] * c;
+  T* d = dst + (size_t)r * c;
+  T x = s[0], y = s[1], z = s[2];
+  if (aug.flip_x) x = -x;
+  if (aug.flip_y) y = -y;
+  for (int m = 0; m < aug.n_rot; ++m) {
+    const double* R = aug.rot[m];
+    const double px = (double)x, py = (double)y, pz = (double)z;
+    x = (T)((px * R[0] + py * R[1]) + pz * R[2]);
+    y = (T)((px * R[3] + py * R[4]) + pz * R[5]);
+    z = (T)((px * R[6] + py * R[7]) + pz * R[8]);
+  }
+  if (aug.has_shift) {
+    x = (T)((double)x + aug.shift[0]);
+    y = (T)((double)y + aug.shift[1]);
+    z = (T)((double)z + aug.shift[2]);
+  }
+  d[0] = x;
+  d[1] = y;
+  d[2] = z;
+  for (int j = 3; j < c; ++j) d[j] = s[j];
+}
+
+extern "C" int irx_scene_sample_batch(int n_samples, const void* const* src, const int* n_src, int c,
+                                      const int64_t* const* choices, int n, const int* flip_xy, const double* rot,
+                                      const int* n_rot, const double* shift, const int* has_shift, void* dst,
+                                      const int32_t* const* slot_src, const int32_t* const* sem_src,
+                                      const int64_t* slot_base, int64_t* gslot, int64_t* sem, int elem_bytes,
+                                      void* stream) {
+  IRX_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "irx_scene_sample_batch: elem_bytes must be 4 or 8 (got %d)", elem_bytes);
+  IRX_REQUIRE(n_samples >= 0 && c >= 3 && n >= 0, "irx_scene_sample_batch: bad sizes");
+  if (n_samples == 0 || n == 0) return 0;
+  IRX_REQUIRE(src && n_src && choices && flip_xy && n_rot && has_shift && dst, "irx_scene_sample_batch: NULL argument");
+  const int grid = (n + 255) / 256;
+  for (int b = 0; b < n_samples; ++b) {
+    IRX_REQUIRE(src[b] && choices[b] && n_src[b] > 0 && n_rot[b] >= 0 && n_rot[b] <= 3,
+                "irx_scene_sample_batch: sample %d: NULL pointer or bad sizes", b);
+    IRX_REQUIRE((n_rot[b] == 0 || rot) && (!has_shift[b] || shift), "irx_scene_sample_batch: rot / shift is NULL");
+    IrxAug aug;
+    aug.flip_x = flip_xy[2 * b];
+    aug.flip_y = flip_xy[2 * b + 1];
+    aug.n_rot = n_rot[b];
+    aug.has_shift = has_shift[b];
+    for (int m = 0; m < 3; ++m)
+      for (int k = 0; k < 9; ++k) aug.rot[m][k] = (m < n_rot[b]) ? rot[(size_t)b * 27 + m * 9 + k] : 0.0;
+    for (int k = 0; k < 3; ++k) aug.shift[k] = has_shift[b] ? shift[(size_t)b * 3 + k] : 0.0;
+    char* d = (char*)dst + (size_t)b * n * c * elem_bytes;
+    if (elem_bytes == 4)
+      k_scene_sample64<float><<<grid, 256, 0, S(stream)>>>((const float*)src[b], choices[b], n, c, aug, (float*)d);
+    else
+      k_scene_sample64<double><<<grid, 256, 0, S(stream)>>>((const double*)src[b], choices[b], n, c, aug, (double*)d);
+    if (gslot) {
+      IRX_REQUIRE(slot_src && sem_src && slot_base && sem && slot_src[b] && sem_src[b],
+                  "irx_scene_sample_batch: label arrays of sample %d are NULL", b);
+      k_sample_labels<<<grid, 256, 0, S(stream)>>>(slot_src[b], sem_src[b], choices[b], n, slot_base[b],
+                                                   gslot + (size_t)b * n, sem + (size_t)b * n);
+    }
+  }
+  IRX_CHECK_LAUNCH("irx_scene_sample_batch");
   return 0;
 }

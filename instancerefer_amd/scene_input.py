@@ -72,6 +72,11 @@ class ResidentScan:
         self.instance_labels = np.asarray(raw["instance_labels"])
         self.semantic_labels = np.asarray(raw["semantic_labels"])
         self.instance_bboxes = np.asarray(raw["instance_bboxes"])
+        # for the fully device-side mode (build_batch_device): every distinct instance label of the scan is a slot
+        # (ascending label = the order np.unique gives the reference); labels as slot ids + semantic ids in HBM
+        self.slots, slot_of_vertex = np.unique(self.instance_labels, return_inverse=True)
+        self.slot_of_vertex = torch.from_numpy(slot_of_vertex.astype(np.int32)).to(device)
+        self.semantic_dev = torch.from_numpy(self.semantic_labels.astype(np.int32)).to(device)
 
     @property
     def num_vertices(self):
@@ -104,24 +109,9 @@ def _rotate_boxes(boxes, rot, axis):
     return out
 
 
-class SampleDraw:
-    """Host half of one sample: every random draw + the integer bookkeeping the device kernels need."""
-    __slots__ = ("scan", "choices", "flip_x", "flip_y", "rot", "shift", "order", "seg", "rows", "classes", "labels",
-                 "instance_labels")
-
-
-def draw_sample(scan, object_id, tables, num_points=40000, augment=False):
-    """Consumes the RNG streams exactly like lib/dataset.py:124 (scene choice), :154-181 (flips, three angles, shift)
-    and :224 (one choice per object instance, ascending instance id)."""
-    d = SampleDraw()
-    d.scan = scan
-    V = scan.num_vertices
-    choices = np.random.choice(V, num_points, replace=V < num_points)
-    d.choices = choices.astype(np.int32)
-    ins = scan.instance_labels[choices]
-    sem = scan.semantic_labels[choices]
-    d.instance_labels = ins.astype(np.int64)
-
+def _augment_and_box_labels(d, scan, object_id, tables, augment):
+    """lib/dataset.py:145-198 on the (<= 128) boxes: augmentation draws from torch's default generator in the
+    reference's order (stored on `d` for the device kernel) and the box / reference-target labels."""
     boxes = scan.instance_bboxes
     nb = min(boxes.shape[0], MAX_NUM_OBJ)
     target = np.zeros((MAX_NUM_OBJ, 6))
@@ -160,6 +150,28 @@ def draw_sample(scan, object_id, tables, num_points=40000, augment=False):
                     ref_heading_class_label=np.array(0).astype(np.int64),
                     ref_heading_residual_label=np.array(0).astype(np.int64))
 
+
+
+class SampleDraw:
+    """Host half of one sample: every random draw + the integer bookkeeping the device kernels need."""
+    __slots__ = ("scan", "choices", "flip_x", "flip_y", "rot", "shift", "order", "seg", "rows", "classes", "labels",
+                 "instance_labels")
+
+
+def draw_sample(scan, object_id, tables, num_points=40000, augment=False):
+    """Consumes the RNG streams exactly like lib/dataset.py:124 (scene choice), :154-181 (flips, three angles, shift)
+    and :224 (one choice per object instance, ascending instance id)."""
+    d = SampleDraw()
+    d.scan = scan
+    V = scan.num_vertices
+    choices = np.random.choice(V, num_points, replace=V < num_points)
+    d.choices = choices.astype(np.int32)
+    ins = scan.instance_labels[choices]
+    sem = scan.semantic_labels[choices]
+    d.instance_labels = ins.astype(np.int64)
+
+    _augment_and_box_labels(d, scan, object_id, tables, augment)
+
     # instance segments: stable sort by label == np.nonzero(labels == id) per ascending id (lib/dataset.py:207-210)
     small = ins.size and ins.min() >= -32768 and ins.max() <= 32767      # int16 keys take numpy's radix sort (6x)
     order = np.argsort(ins.astype(np.int16) if small else ins, kind="stable")
@@ -194,6 +206,12 @@ class PendingBatch:
         self.voxel_size, self.device, self._keep = voxel_size, device, keep
 
     def finish(self, data_dict=None):
+        self.event.synchronize()
+        B, S = len(self.draws), self.inst_points.shape[0]
+        back = self.host_back.numpy()
+        return self._assemble(data_dict, back[:S * 7].reshape(S, 7).copy(), back[S * 7:].reshape(B, 6).copy())
+
+    def _assemble(self, data_dict, obbs, ext):
         from .sparse.utils import voxelize
         B = len(self.draws)
         dd = {} if data_dict is None else data_dict
@@ -201,11 +219,6 @@ class PendingBatch:
         flat = self.clouds.view(B * n, c)
         batch = torch.arange(B, device=self.device, dtype=torch.int32).repeat_interleave(n)
         dd["lidar"] = voxelize(flat[:, :3].contiguous(), flat, batch, [self.voxel_size] * 3, B)
-        self.event.synchronize()
-        S = self.inst_points.shape[0]
-        back = self.host_back.numpy()
-        obbs = back[:S * 7].reshape(S, 7).copy()
-        ext = back[S * 7:].reshape(B, 6).copy()
         classes, scene_of, start = [], [], [0]
         for i, d in enumerate(self.draws):
             classes += d.classes
@@ -283,3 +296,121 @@ def build_batch(draws, device, voxel_size_glp=0.05):
     ev.record()
     return PendingBatch(draws, clouds, inst_points, obbs_dev[:S], extent_dev, host_back, ev, voxel_size_glp, device,
                         (idx, back_dev, stage))
+
+
+# ---- fully device-side mode: no per-point work on the host at all ----------------------------------------------------
+class _Draw:
+    """The host part that remains in device mode: augmentation draws + box labels (<= 128 boxes)."""
+    __slots__ = ("scan", "flip_x", "flip_y", "rot", "shift", "labels", "classes", "instance_labels")
+
+
+class PendingDeviceBatch:
+    def __init__(self, draws, clouds, inst_points, obbs_dev, extent_dev, host_back, event, slot_base, voxel_size, device,
+                 keep):
+        self.draws, self.clouds, self.inst_points, self.obbs_dev = draws, clouds, inst_points, obbs_dev
+        self.extent_dev, self.host_back, self.event, self.slot_base = extent_dev, host_back, event, slot_base
+        self.voxel_size, self.device, self._keep = voxel_size, device, keep
+
+    def finish(self, data_dict=None):
+        """Collect (count, class) per slot + boxes + extents (one async copy, already under way), drop the slots that
+        are not object instances of this sample, assemble the data_dict entries."""
+        self.event.synchronize()
+        B, S = len(self.draws), self.inst_points.shape[0]
+        back = self.host_back.numpy()
+        counts, cls = back[:S].astype(np.int64), back[S:2 * S].astype(np.int64)
+        obbs = back[2 * S:2 * S + 7 * S].reshape(S, 7)
+        ext = back[9 * S:].reshape(B, 6).copy()
+        keep = np.flatnonzero((counts > 0) & (cls >= 0))
+        kept_dev = torch.from_numpy(keep).to(self.device, non_blocking=True)
+        inst_points = self.inst_points.index_select(0, kept_dev)
+        obbs_dev = self.obbs_dev.index_select(0, kept_dev)
+        for i, d in enumerate(self.draws):
+            mine = keep[(keep >= self.slot_base[i]) & (keep < self.slot_base[i + 1])]
+            d.classes = [int(c) for c in cls[mine]]
+            d.instance_labels = None
+        shim = PendingBatch(self.draws, self.clouds, inst_points, obbs_dev, self.extent_dev, None, None, self.voxel_size,
+                            self.device, None)
+        return shim._assemble(data_dict, obbs[keep].copy(), ext)
+
+
+def build_batch_device(scans, object_ids, tables, device, num_points=40000, augment=False, voxel_size_glp=0.05,
+                       generator=None):
+    """SURVEY §8(f) rank 1 as written: everything per-point on the GPU from the resident scan + its label arrays.
+    Scene sub-sampling, instance membership, boxes and the 1024-point resample use the DEVICE generator: the same
+    distributions as the reference (uniform subset without replacement; per instance a uniform 1024-subset, or 1024
+    uniform draws with replacement when it has fewer points) but not numpy's random stream — use draw_sample() +
+    build_batch() when a run must reproduce the reference sample for sample. Host work per sample: the augmentation
+    draws and the (<= 128) box labels only. -> PendingDeviceBatch (finish() as in build_batch)."""
+    B = len(scans)
+    pts0 = scans[0].points
+    c, dtype = pts0.shape[1], pts0.dtype
+    eb = 4 if dtype == torch.float32 else 8
+    n = num_points
+    draws = []
+    for sc, oid in zip(scans, object_ids):
+        d = _Draw()
+        d.scan = sc
+        _augment_and_box_labels(d, sc, oid, tables, augment)
+        draws.append(d)
+    stream = _lib.stream_ptr()
+    clouds = torch.empty((B, n, c), dtype=dtype, device=device)
+    slot_base = np.concatenate([[0], np.cumsum([len(sc.slots) for sc in scans])]).astype(np.int64)
+    S = int(slot_base[-1])
+    gslot = torch.empty((B, n), dtype=torch.int64, device=device)       # global slot id of every sampled point
+    sem = torch.empty((B, n), dtype=torch.int64, device=device)
+    choices = []
+    for sc in scans:
+        V = sc.num_vertices
+        choices.append(torch.randperm(V, device=device, generator=generator)[:n] if V >= n else
+                       torch.randint(0, V, (n,), device=device, generator=generator))
+    import ctypes
+    P, I, D, L = ctypes.c_void_p * B, ctypes.c_int * B, ctypes.c_double, ctypes.c_int64 * B
+    rots = np.zeros((B, 27))
+    shifts = np.zeros((B, 3))
+    for i, d in enumerate(draws):
+        if d.rot:
+            rots[i, :9 * len(d.rot)] = np.stack(d.rot, 0).reshape(-1)
+        if d.shift is not None:
+            shifts[i] = d.shift
+    flips = (ctypes.c_int * (2 * B))(*[int(v) for d in draws for v in (d.flip_x, d.flip_y)])
+    _lib.call("irx_scene_sample_batch", B, P(*[sc.points.data_ptr() for sc in scans]),
+              I(*[sc.num_vertices for sc in scans]), c, P(*[ch.data_ptr() for ch in choices]), n, flips,
+              rots.ctypes.data, I(*[len(d.rot) for d in draws]), shifts.ctypes.data,
+              I(*[int(d.shift is not None) for d in draws]), clouds.data_ptr(),
+              P(*[sc.slot_of_vertex.data_ptr() for sc in scans]), P(*[sc.semantic_dev.data_ptr() for sc in scans]),
+              L(*[int(v) for v in slot_base[:-1]]), gslot.data_ptr(), sem.data_ptr(), eb, stream)
+    gs = gslot.view(-1)
+    counts = torch.bincount(gs, minlength=S)
+    # semantic id of each instance's FIRST sampled point (lib/dataset.py:213: semantic_labels[ind[0]])
+    pidx = torch.arange(B * n, device=device)
+    first = torch.full((S,), B * n, dtype=torch.int64, device=device).scatter_reduce_(0, gs, pidx, "amin")
+    nyu = sem.view(-1).index_select(0, first.clamp_(max=B * n - 1))
+    lut = torch.from_numpy(np.where(tables._is_object[:len(tables.nyu40id2class)], tables.nyu40id2class, -1)
+                           .astype(np.int64)).to(device, non_blocking=True)
+    cls = torch.where((nyu >= 0) & (nyu < lut.shape[0]), lut[nyu.clamp(0, lut.shape[0] - 1)], torch.full_like(nyu, -1))
+    # random order inside every instance: one sort of (slot, random key) for the whole batch
+    rnd = torch.randint(0, 1 << 31, (B * n,), device=device, generator=generator)
+    order = torch.sort((gs << 32) | rnd).indices
+    seg = torch.zeros(S + 1, dtype=torch.int64, device=device)
+    torch.cumsum(counts, 0, out=seg[1:])
+    ar = torch.arange(NUM_INSTANCE_POINTS, device=device)
+    u = torch.rand((S, NUM_INSTANCE_POINTS), device=device, generator=generator)
+    cn = counts.unsqueeze(1)
+    within = torch.where(cn >= NUM_INSTANCE_POINTS, ar.unsqueeze(0).expand(S, -1),
+                         (u * cn).long().clamp_(max=(cn - 1).clamp_(min=0)))
+    rows = order.index_select(0, (seg[:-1].unsqueeze(1) + within).clamp_(max=B * n - 1).view(-1))
+    rows32, order32, seg32 = rows.to(torch.int32), order.to(torch.int32), seg.to(torch.int32)
+    inst_points = torch.empty((S, NUM_INSTANCE_POINTS, c), dtype=dtype, device=device)
+    obbs_dev = torch.empty((max(S, 1), 7), dtype=torch.float64, device=device)
+    _lib.call("irx_instance_split", clouds.data_ptr(), B * n, c, _lib.ptr(order32), _lib.ptr(seg32), S,
+              _lib.ptr(rows32), NUM_INSTANCE_POINTS, inst_points.data_ptr() if S else None, obbs_dev.data_ptr(), None,
+              eb, stream)
+    xyz = clouds[:, :, :3]
+    extent = torch.cat([xyz.amin(1), xyz.amax(1)], 1)
+    back_dev = torch.cat([counts.double(), cls.double(), obbs_dev[:S].reshape(-1), extent.double().reshape(-1)])
+    host_back = torch.empty(back_dev.shape, dtype=torch.float64, pin_memory=True)
+    host_back.copy_(back_dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return PendingDeviceBatch(draws, clouds, inst_points, obbs_dev[:S], extent, host_back, ev, slot_base, voxel_size_glp, device,
+                              (back_dev, rows32, order32, seg32, gslot, sem))

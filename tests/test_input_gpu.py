@@ -145,3 +145,64 @@ def test_model_trains_on_a_device_built_batch(lib):
     out["loss"].backward()
     assert torch.isfinite(out["loss"]).item()
     assert all(torch.isfinite(p.grad).all().item() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("augment", [False, True])
+def test_fully_device_side_mode_invariants(lib, augment):
+    """build_batch_device draws from the device generator, so it cannot be compared value for value with numpy's
+    stream; what must hold for every sample (checked here against numpy on the returned tensors):
+    the sampled cloud is a subset of the scan's rows WITHOUT replacement (feature columns identify the vertex); the kept
+    instances are exactly the object instances that still have points, in ascending label order, with the reference's
+    classes; every instance's 1024 rows belong to that instance and are distinct when it has >= 1024 points; its box is
+    0.5*(lo+hi), hi-lo over ALL of its sampled points in the storage dtype; extents, lidar voxel set and labels agree
+    with a numpy evaluation of the same sampled cloud."""
+    from instancerefer_amd import scene_input as SI
+    g = np.load(G)
+    tables = SI.ClassTables(g["nyu40ids"], g["nyu40id2class"], g["mean_size_arr"])
+    dev = torch.device("cuda")
+    raws = [S.make_raw_scene(800 + i, num_vertices=30000 + 5000 * i, num_instances=5 + 2 * i, same_class=3) for i in range(3)]
+    raws[2]["instance_labels"] = np.where(raws[2]["instance_labels"] == 2, 1, raws[2]["instance_labels"])   # a missing id
+    scans = [SI.ResidentScan(r, dev) for r in raws]
+    npts = 20000
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    torch.manual_seed(5)
+    dd = SI.build_batch_device(scans, [0, 1, 2], tables, dev, num_points=npts, augment=augment, generator=gen).finish()
+    pack = dd["irx"]
+    clouds = dd["point_clouds"].cpu().numpy()
+    for b, (raw, sc) in enumerate(zip(raws, scans)):
+        feats = SI.point_features(raw["mesh_vertices"])
+        # vertex identity through the (random, continuous) colour columns
+        key = {tuple(row): i for i, row in enumerate(feats[:, 3:6].tolist())}
+        vid = np.asarray([key[tuple(row)] for row in clouds[b][:, 3:6].tolist()])
+        assert len(np.unique(vid)) == npts                                     # without replacement
+        if not augment:
+            assert np.array_equal(clouds[b], feats[vid])
+        ins, sem = raw["instance_labels"][vid], raw["semantic_labels"][vid]
+        lo, hi = pack.scene_start[b], pack.scene_start[b + 1]
+        want_ids = [lab for lab in np.unique(ins) if sem[np.nonzero(ins == lab)[0][0]] in g["nyu40ids"]]
+        assert hi - lo == len(want_ids)
+        for j, lab in enumerate(want_ids):
+            ind = np.nonzero(ins == lab)[0]
+            assert pack.classes[lo + j] == int(g["nyu40id2class"][sem[ind[0]]])
+            x = clouds[b][ind]
+            got = pack.pts32[lo + j].cpu().numpy()
+            rowset = {tuple(r) for r in x[:, 3:6].tolist()}
+            assert all(tuple(r) in rowset for r in got[:, 3:6].tolist())       # rows of this instance only
+            if len(ind) >= 1024:
+                assert len({tuple(r) for r in got[:, 3:6].tolist()}) == 1024   # distinct
+            p, q = x[:, :3].min(0), x[:, :3].max(0)
+            assert np.array_equal(pack.obbs[lo + j], np.concatenate((0.5 * (p + q), q - p, np.array([0]))))
+        assert np.array_equal(dd["_host"]["point_min"][b], clouds[b].min(0)[:3])
+        assert np.array_equal(dd["_host"]["point_max"][b], clouds[b].max(0)[:3])
+        c, f = _scene_voxels(dd["lidar"], b)
+        from oracle.torchsparse.utils import sparse_quantize
+        oc, of = _rows_sorted(*sparse_quantize(clouds[b][:, :3], clouds[b], quantization_size=np.array([0.05] * 3)))
+        assert np.array_equal(c, oc) and np.array_equal(f, of)
+    # two calls with the same generator state give the same batch; a different state a different sample
+    gen.manual_seed(5)
+    torch.manual_seed(5)
+    dd2 = SI.build_batch_device(scans, [0, 1, 2], tables, dev, num_points=npts, augment=augment, generator=gen).finish()
+    assert torch.equal(dd2["point_clouds"], dd["point_clouds"]) and torch.equal(dd2["irx"].pts32, pack.pts32)
+    dd3 = SI.build_batch_device(scans, [0, 1, 2], tables, dev, num_points=npts, augment=augment, generator=gen).finish()
+    assert not torch.equal(dd3["point_clouds"], dd["point_clouds"])

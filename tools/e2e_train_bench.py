@@ -1,0 +1,102 @@
+"""Dev tool: END-TO-END training throughput — every step builds its batch from scans resident in HBM with the fully
+device-side input pipeline (scene_input.build_batch_device: sub-sampling, augmentation, instance split, boxes, resample,
+both voxelisations), then runs the full model forward + loss + backward + Adam. Nothing is cached between steps.
+  python tools/e2e_train_bench.py [--dtype bf16] [--batch 16] [--steps 60]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import instancerefer_amd as irx
+from instancerefer_amd import _lib, synthetic as S, scene_input as SI
+from instancerefer_amd.instancerefer import InstanceRefer
+from instancerefer_amd.loss_helper import DatasetConfig, get_loss
+from instancerefer_amd.optim import FlatAdam
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--steps", type=int, default=60)
+ap.add_argument("--warmup", type=int, default=10)
+ap.add_argument("--scans", type=int, default=32)
+ap.add_argument("--vertices", type=int, default=120000)
+ap.add_argument("--points", type=int, default=50000)
+ap.add_argument("--instances", type=int, default=8)
+ap.add_argument("--augment", action="store_true")
+a = ap.parse_args()
+_lib.load()
+irx.set_compute_dtype("bf16" if a.dtype == "bf16" else "fp32")
+dev = torch.device("cuda")
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dataset.npz"))
+tables = SI.ClassTables(g["nyu40ids"], g["nyu40id2class"], g["mean_size_arr"])
+scans = [SI.ResidentScan(S.make_raw_scene(3000 + i, num_vertices=a.vertices, num_instances=a.instances, same_class=4), dev)
+         for i in range(a.scans)]
+torch.manual_seed(0)
+model = InstanceRefer(7, S.default_args()).to(dev).train()
+opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
+cfg = DatasetConfig(mean_size_arr=g["mean_size_arr"])
+B = a.batch
+rng = np.random.default_rng(0)
+lang = np.zeros((B, 126, 300), np.float32); lang[:, :30] = rng.standard_normal((B, 30, 300)) * 0.4
+lang_dev = torch.from_numpy(lang).to(dev)
+lang_len = torch.full((B,), 30, dtype=torch.int64, device=dev)
+obj_cat = torch.full((B,), 2, dtype=torch.int64, device=dev)
+
+
+def make_pending(step):
+    pick = [(step * B + i) % len(scans) for i in range(B)]
+    return SI.build_batch_device([scans[j] for j in pick], [0] * B, tables, dev, num_points=a.points, augment=a.augment)
+
+
+def finish(p):
+    dd = p.finish()
+    dd["lang_feat"], dd["lang_len"], dd["lang_len_max"], dd["object_cat"] = lang_dev, lang_len, 30, obj_cat
+    dd["_host"]["object_cat"] = np.full(B, 2, np.int64)
+    dd["unique_multiple"] = torch.ones(B, dtype=torch.int64)
+    return dd
+
+
+from instancerefer_amd.loss_helper import prepare_labels
+side = torch.cuda.Stream()
+main = torch.cuda.current_stream()
+
+
+def stage_launch(step):
+    """On the side stream: collect batch step+1's input (enqueued one step ago: its read-back has long arrived), enqueue
+    its model-side preparation (candidate voxelisation, pyramids, labels), then enqueue the input pipeline of batch
+    step+2. Nothing here waits for the GPU."""
+    global pend
+    with torch.cuda.stream(side):
+        dd = finish(pend)
+        dd = model.prepare_launch(dd)
+        dd["_loss_prepared"] = prepare_labels(dd, cfg, dev) if "_attr_prepared" in dd else None
+        pend = make_pending(step + 2)
+    return dd
+
+
+def stage_finish(dd):
+    with torch.cuda.stream(side):
+        return model.prepare_finish(dd)
+
+
+with torch.cuda.stream(side):
+    pend = make_pending(0)
+    cur = model.prepare(finish(pend))
+    pend = make_pending(1)
+t0 = None
+for step in range(a.warmup + a.steps):
+    if step == a.warmup:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+    main.wait_stream(side)
+    model.hand_over(cur, main)
+    for t in list(cur.values()) + [cur["irx"].xyz64, cur["irx"].pts32, cur["irx"].centres]:   # made on the side stream
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(main)
+    launched = stage_launch(step)
+    opt.zero_grad()
+    out = get_loss(model(cur), cfg)
+    out["loss"].backward()
+    opt.backward_step()
+    cur = stage_finish(launched)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("end to end (%s, B=%d, %d pts from %d-vertex scans, input pipeline in the loop): %.1f scenes/s, %.2f ms/step, loss %.4f"
+      % (a.dtype, B, a.points, a.vertices, B * a.steps / dt, 1e3 * dt / a.steps, float(out["loss"])))

@@ -35,6 +35,15 @@ for rep in range(a.reps + 2):
     if rep >= 2:
         t_draw.append(t1 - t0); t_dev.append(e0.elapsed_time(e1) * 1e-3); t_total.append(t2 - t0)
 B = a.batch
+# fully device-side mode (device generator)
+t_dev2 = []
+for rep in range(a.reps + 2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dd = SI.build_batch_device(scans, [0] * a.batch, tables, dev, num_points=a.points, augment=a.augment).finish()
+    torch.cuda.synchronize()
+    if rep >= 2: t_dev2.append(time.perf_counter() - t0)
+print("fully device-side mode (device RNG): wall %.3f ms/sample -> %.0f samples/s" % (1e3 * np.mean(t_dev2) / a.batch, a.batch / np.mean(t_dev2)))
 print("device pipeline: host draws %.2f ms/sample, device work %.3f ms/sample (GPU events), wall %.2f ms/sample -> %.0f samples/s"
       % (1e3 * np.mean(t_draw) / B, 1e3 * np.mean(t_dev) / B, 1e3 * np.mean(t_total) / B, B / np.mean(t_total)))
 from oracle import dataset_ref as DR
