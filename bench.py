@@ -395,7 +395,7 @@ def main():
     if world == 1 and args.dtype == "f32" and not args.no_alt_dtype:
         irx.set_compute_dtype("bf16")
         try:
-            for _ in range(min(args.warmup, 10)):
+            for _ in range(max(3, min(args.warmup, 10))):
                 step_fn(model, resident, args.workload, reducer, opt, state)
             barrier()
             ak = max(1, min(args.steps, 50))
@@ -405,7 +405,7 @@ def main():
             barrier()
             adt = time.perf_counter() - t0
             alt = {"dtype": "bf16", "value": B * ak / adt, "unit": "scenes/s", "ms_per_step": 1000.0 * adt / ak,
-                   "steps": ak, "warmup": min(args.warmup, 10),
+                   "steps": ak, "warmup": max(3, min(args.warmup, 10)),
                    "what": "same loop, irx_set_compute_dtype(1): bf16 operands / fp32 accumulation in the 32/64/128-channel "
                            "sparse convs (fwd, dgrad, wgrad); tensors, BatchNorm, stem, heads fp32. Not the headline: the "
                            "1e-4 parity gate is proven for fp32; bf16 tracks it within 4e-4 on the matching scores "
