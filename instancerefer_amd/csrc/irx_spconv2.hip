@@ -544,13 +544,17 @@ int irx_spconv2_tile(int n_out) {
   return S2_TM;
 }
 
+// (Threshold: a layer with >= 256 tiles is left whole. In the training step the other encoder's stream fills the CUs
+// a 256..768-tile launch leaves idle, so splitting those only added slab traffic and a reduce launch: 768 -> 256
+// measured +1 % end to end, 128 equal, 64 worse.)
 // Offset splits for latency-bound (small) layers: a tile's 27 offsets form a serial chain of ~4 us each, so
 // when there are too few tiles to fill the chip the offsets are spread over `splits` workgroups per tile.
 int irx_spconv2_splits(int n_out, int K) {
   static const char* e = getenv("IRX_SPCONV_KSPLIT");
   if (e) { int s = atoi(e); return s < 1 ? 1 : (s > K ? K : s); }
   const int tiles = irx_cdiv(n_out, irx_spconv2_tile(n_out));
-  if (tiles >= 768 || K < 4) return 1;
+  static const int full = getenv("IRX_SPCONV_SPLIT_BELOW") ? atoi(getenv("IRX_SPCONV_SPLIT_BELOW")) : 256;
+  if (tiles >= full || K < 4) return 1;
   int s = irx_cdiv(1024, tiles);
   if (s > 9) s = 9;
   if (s > K) s = K;
