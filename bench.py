@@ -348,12 +348,13 @@ def main():
         torch.cuda.synchronize()
 
     # Input-prep pipeline: launch phase before the step is issued, finish phase (level sizes) after it — the host never
-    # blocks in a sync. Single GPU: on its own stream, so the preparation kernels also overlap the step. Multi-rank: on
-    # the MAIN stream (they run ahead of the step's kernels, ~0.5 ms): with two gloo ranks time-sharing ONE GPU (the
-    # IRX_BENCH_SHARE_GPU test rig) a third stream per process made every host sync wait ~250 ms (2.2 s/step), and a real
-    # multi-GPU node is not available to this build to rule the effect out there.
+    # blocks in a sync — on its own stream, so the preparation kernels also overlap the step; the same at every N (one
+    # process per GPU). History: with blocking syncs in the preparation, two gloo ranks time-sharing ONE GPU (the
+    # IRX_BENCH_SHARE_GPU test rig) stalled ~250 ms per sync behind a third stream, so N > 1 used the main stream; since
+    # the preparation is sync-free that rig runs the side stream faster than the main one (1054-1090 vs 1019-1038
+    # scenes/s for 2 ranks on one GPU), and the main-stream variant costs 5 % on a GPU of its own.
     state = {"pipeline": not args.no_pipeline, "threaded": bool(args.prep_thread) and world == 1}
-    if world > 1 or os.environ.get("IRX_BENCH_PREP_MAIN") == "1":   # (env: emulate the N > 1 arrangement on one GPU)
+    if os.environ.get("IRX_BENCH_PREP_MAIN") == "1":   # dev A/B: the preparation on the main stream
         state["side"] = torch.cuda.current_stream()
     if args.workload == "full":
         from instancerefer_amd.loss_helper import prepare_labels
