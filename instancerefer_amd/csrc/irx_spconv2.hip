@@ -89,15 +89,20 @@ __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float* pa = &sA[(16 * g + m) * LDA + 4 * g4];
+  // A tile: fp32 rows (stride LDA floats); bf16 mode: rows already rounded to bf16 by the writer (stride LDAB halves),
+  // so a fragment is one ds_read_b64 and no convert sits in the MFMA chain
+  using AT = typename std::conditional<BF, uint2, float4>::type;
+  constexpr int LDAB = CIN + 8;
+  const AT* pa = BF ? reinterpret_cast<const AT*>(reinterpret_cast<const unsigned short*>(sA) + (16 * g + m) * LDAB + 4 * g4)
+                    : reinterpret_cast<const AT*>(&sA[(16 * g + m) * LDA + 4 * g4]);
   int orow[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) orow[r] = lrow[(16 * g + 4 * g4 + r) & 63];
-  float4 a_nxt = *reinterpret_cast<const float4*>(pa);
+  AT a_nxt = pa[0];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const float4 a4 = a_nxt;                       // fragment j was requested one step ago
-    if (j + 1 < NJ) a_nxt = *reinterpret_cast<const float4*>(pa + 16 * (j + 1));
+    const AT a4 = a_nxt;                           // fragment j was requested one step ago
+    if (j + 1 < NJ) a_nxt = pa[4 * (j + 1)];       // 16 channels further: 4 elements of either type
     if (PREFETCH) {
       // this step's share of the item's weight loads
 #pragma unroll
@@ -107,7 +112,7 @@ __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __
     }
     if constexpr (BF) {
       // a lane's 4 consecutive floats are exactly the 4 k-slots of the 16x16x16 bf16 MFMA: one MFMA replaces four
-      const s16x4 pa = irx_frag_bf16(irx_pk_bf16(a4.x, a4.y), irx_pk_bf16(a4.z, a4.w));
+      const s16x4 pa = irx_frag_bf16(a4.x, a4.y);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int f = j * NT + t;
@@ -213,7 +218,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   constexpr int NIT = 64 / PPP;                   // gather passes for a full 64-pair item
   constexpr int NJ = CIN / 16;
   constexpr int KMAX = 27;
-  constexpr int DEPTH = (CIN >= 128) ? 1 : 2;     // items of prefetch distance
+  constexpr int DEPTH = (CIN >= 128) ? 1 : 2;     // items of prefetch distance (bf16, Cin 128: depth 2 fits in VGPRs but measured equal)
   constexpr int NS = DEPTH + 1;                   // register sets
   using WT = typename std::conditional<BF, uint4, float4>::type;   // one weight load (16 B / lane)
   constexpr int WN = BF ? NJ * NT / 2 : NJ * NT;   // weight loads per item
@@ -317,8 +322,12 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
       if (it < npass)                              // (component-wise: a struct copy out of S[][] keeps the sets in scratch)
-        *reinterpret_cast<float4*>(&sA[(pbase + it * PPP) * LDA + c4]) =
-            make_float4(S[C][it].x, S[C][it].y, S[C][it].z, S[C][it].w);
+        if constexpr (BF)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(sA) + (pbase + it * PPP) * (CIN + 8) + c4) =
+              make_uint2(irx_pk_bf16(S[C][it].x, S[C][it].y), irx_pk_bf16(S[C][it].z, S[C][it].w));
+        else
+          *reinterpret_cast<float4*>(&sA[(pbase + it * PPP) * LDA + c4]) =
+              make_float4(S[C][it].x, S[C][it].y, S[C][it].z, S[C][it].w);
     S2_TICK(3);
     __syncthreads();
     S2_TICK(4);
