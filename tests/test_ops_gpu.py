@@ -456,3 +456,59 @@ def test_sync_free_voxelize_and_single_call_pyramid_equal_the_stepwise_path(lib,
         assert torch.equal(db.child[:, :m], child[:, :m])
         from instancerefer_amd.sparse.tensor import Level
         a, b = Level(oc, ok, a.stride * 2, a.batch_size), db.out_level
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104])
+def test_coordinate_ops_on_random_ragged_batches(lib, seed):
+    """Randomised shapes the fixed fixture does not reach: ragged batches (one cloud of a single point, one heavily
+    duplicated), dense volumetric blobs (every one of the 27 neighbours present) next to thin surfaces, clouds far from
+    the origin on both sides, odd voxel sizes. Voxel set, 27-neighbour table, one down-sampling with its 8-offset map,
+    pair lists: bit-exact against the oracle."""
+    from instancerefer_amd.sparse import functional as F_
+    rng = np.random.default_rng(seed)
+    voxel = float(rng.choice([0.02, 0.05, 0.0375, 0.11]))
+    clouds = []
+    for i in range(int(rng.integers(2, 6))):
+        kind = rng.integers(0, 4)
+        ctr = rng.uniform(-40.0, 40.0, 3)
+        if kind == 0:
+            pc = surface_cloud(rng, int(rng.integers(200, 3000)), ctr, rng.uniform(0.3, 1.5, 3))
+        elif kind == 1:                                   # dense blob: full neighbourhoods
+            pc = np.concatenate([rng.uniform(-0.4, 0.4, (4000, 3)) + ctr, rng.uniform(-1, 1, (4000, 4))], 1)
+        elif kind == 2:                                   # heavy duplication: few voxels, many points
+            base = rng.uniform(-0.1, 0.1, (30, 3)) + ctr
+            pc = np.concatenate([base[rng.integers(0, 30, 2000)], rng.uniform(-1, 1, (2000, 4))], 1)
+        else:                                             # a single point
+            pc = np.concatenate([ctr[None], rng.uniform(-1, 1, (1, 4))], 1)
+        clouds.append(pc)
+    o = oracle_batch(clouds, voxel)
+    d = device_batch(clouds, voxel)
+    ia, ib = align(d.C.cpu().numpy(), o.C.numpy())          # asserts the same voxel set
+    assert np.array_equal(d.F.cpu().numpy()[ia], o.F.numpy()[ib].astype(np.float32))   # first point of every voxel
+    _, maps = _oracle_maps(o, 3, 1)
+    lv = d.level()
+    nbr, ld = lv.nbr27()
+    nbr_h = nbr.cpu().numpy()
+    o2d = np.empty(len(ib), np.int64)
+    o2d[ib] = ia
+    for k, (i_idx, o_idx) in enumerate(maps):
+        exp = np.full(len(ia), -1, np.int64)
+        exp[o2d[o_idx.numpy()]] = o2d[i_idx.numpy()]
+        assert np.array_equal(nbr_h[k, :len(ia)], exp), "offset %d" % k
+    newc, dmaps = _oracle_maps(o, 2, 2)
+    dm = lv.down()
+    out = dm.out_level
+    ja, jb = align(out.coords.cpu().numpy(), newc.numpy())
+    o2d_out = np.empty(len(jb), np.int64)
+    o2d_out[jb] = ja
+    child = dm.child.cpu().numpy()
+    for k, (i_idx, o_idx) in enumerate(dmaps):
+        exp = np.full(out.n, -1, np.int64)
+        exp[o2d_out[o_idx.numpy()]] = o2d[i_idx.numpy()]
+        assert np.array_equal(child[k, :out.n], exp), "down offset %d" % k
+    il, ol, cnt, ldp = F_.pairs_build(nbr, ld, lv.n, 27)
+    c = cnt.cpu().numpy()
+    for k in range(27):
+        rows = np.nonzero(nbr_h[k, :lv.n] >= 0)[0]
+        assert c[k] == len(rows) and np.array_equal(ol[k, :c[k]].cpu().numpy(), rows)
+        assert np.array_equal(il[k, :c[k]].cpu().numpy(), nbr_h[k, :lv.n][rows])
