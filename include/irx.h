@@ -306,6 +306,15 @@ int irx_scene_sample_batch(int n_samples, const void* const* src, const int* n_s
                            int n, const int* flip_xy, const double* rot, const int* n_rot, const double* shift,
                            const int* has_shift, void* dst, const int32_t* const* slot_src, const int32_t* const* sem_src,
                            const int64_t* slot_base, int64_t* gslot, int64_t* sem, int elem_bytes, void* stream);
+/* Counter-based random draws for the fully device-side mode (no generator state, no sort). irx_random_subset:
+ * out[b][r] (int64, [n_samples <= 64][n]) = a size-n subset of [0, n_src[b]) WITHOUT replacement when n_src[b] >= n —
+ * the first n values of a keyed pseudo-random permutation (4-round Feistel network, cycle-walked) — else n hashed
+ * uniform draws with replacement: the two cases of random_sampling (utils/pc_utils.py:32-40), same distribution family,
+ * not numpy's stream. irx_resample_rows: rows[i][s] = order[seg[i] + j] with j drawn the same way among the
+ * seg[i+1]-seg[i] rows of slot i (distinct when the slot has >= n_sample rows); an empty slot gets 0. */
+int irx_random_subset(int n_samples, const int* n_src, int n, const uint64_t* seeds, int64_t* out, void* stream);
+int irx_resample_rows(const int32_t* order, const int32_t* seg, int n_slots, int n_sample, uint64_t seed, int32_t* rows,
+                      void* stream);
 /* The instance loop of lib/dataset.py:207-232 for one sampled cloud pts [n][c]: instance i owns the rows
  * order[seg[i] .. seg[i+1]) (ascending point index = np.nonzero(labels == id)); obbs[i] = (0.5*(lo+hi), hi-lo, 0)
  * computed in the storage type and widened to float64; inst_points[i][s] = pts[rows[i][s]] (the 1024-point resample,

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "irx_batch_offsets": (_I, [_P, _I, _I, _P, _P]),
     "irx_scene_sample": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P]),
     "irx_scene_sample_batch": (_I, [_I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "irx_random_subset": (_I, [_I, _P, _I, _P, _P, _P]),
+    "irx_resample_rows": (_I, [_P, _P, _I, _I, _c.c_uint64, _P, _P]),
     "irx_instance_split": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
     "irx_gru_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "irx_gru_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

@@ -252,3 +252,99 @@ extern "C" int irx_scene_sample_batch(int n_samples, const void* const* src, con
   IRX_CHECK_LAUNCH("irx_scene_sample_batch");
   return 0;
 }
+
+// ---- counter-based randomness for the fully device-side mode: no sort, no generator state ---------------------------
+__device__ __forceinline__ uint32_t irx_mix32(uint32_t x) {   // murmur3 finaliser
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+// Pseudo-random PERMUTATION of [0, N): 4-round Feistel network on the smallest even-bit domain >= N, cycle-walked back
+// into range (a bijection of the domain restricted to [0, N) stays a bijection; < 4 walks expected). perm(0..n-1) is
+// therefore a size-n subset WITHOUT replacement, computed per element with no sort and no state.
+__device__ __forceinline__ uint32_t irx_prp(uint32_t x, uint32_t N, uint64_t key) {
+  if (N <= 1) return 0;
+  const int bits = 32 - __clz(N - 1);
+  const int h = (bits + 1) >> 1;
+  const uint32_t mask = (h >= 32) ? 0xFFFFFFFFu : ((1u << h) - 1u);
+  do {
+    uint32_t L = x >> h, R = x & mask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t F = irx_mix32(R ^ (uint32_t)(key >> (16 * r)) ^ (0x9E3779B9u * (uint32_t)(r + 1))) & mask;
+      const uint32_t t = L ^ F;
+      L = R;
+      R = t;
+    }
+    x = (L << h) | R;
+  } while (x >= N);
+  return x;
+}
+
+struct IrxSubsetJobs {
+  int n_src[64];
+  unsigned long long seed[64];
+};
+// out[b][r]: V >= n -> prp_b(r) (subset without replacement); V < n -> a hashed uniform draw (with replacement)
+__global__ __launch_bounds__(256) void k_random_subset(IrxSubsetJobs J, int n, int64_t* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t V = (uint32_t)J.n_src[b];
+  const uint64_t key = J.seed[b];
+  uint32_t v;
+  if (V >= (uint32_t)n) {
+    v = irx_prp((uint32_t)r, V, key);
+  } else {
+    const uint64_t hsh = ((uint64_t)irx_mix32((uint32_t)r ^ (uint32_t)key) << 32) | irx_mix32((uint32_t)r * 0x9E3779B9u ^ (uint32_t)(key >> 32));
+    v = (uint32_t)(hsh % V);
+  }
+  out[(size_t)b * n + r] = (int64_t)v;
+}
+
+// rows[i][s] = order[seg[i] + j]: j = prp_i(s) when the instance has >= n_sample points (distinct rows), a hashed
+// uniform draw otherwise (with replacement), 0 for an empty slot (its rows are dropped by the caller)
+__global__ __launch_bounds__(256) void k_resample_rows(const int32_t* __restrict__ order, const int32_t* __restrict__ seg,
+                                                       int n_slots, int n_sample, unsigned long long seed,
+                                                       int32_t* __restrict__ rows) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n_slots * n_sample) return;
+  const int i = (int)(e / n_sample), s = (int)(e % n_sample);
+  const int beg = seg[i], cnt = seg[i + 1] - beg;
+  if (cnt <= 0) { rows[e] = 0; return; }
+  const uint64_t key = seed ^ (0xD6E8FEB86659FD93ull * (uint64_t)(i + 1));
+  uint32_t j;
+  if (cnt >= n_sample) {
+    j = irx_prp((uint32_t)s, (uint32_t)cnt, key);
+  } else {
+    const uint64_t hsh = ((uint64_t)irx_mix32((uint32_t)s ^ (uint32_t)key) << 32) | irx_mix32((uint32_t)s * 0x9E3779B9u ^ (uint32_t)(key >> 32));
+    j = (uint32_t)(hsh % (uint32_t)cnt);
+  }
+  rows[e] = order[beg + (int)j];
+}
+
+extern "C" int irx_random_subset(int n_samples, const int* n_src, int n, const uint64_t* seeds, int64_t* out, void* stream) {
+  IRX_REQUIRE(n_samples >= 0 && n_samples <= 64 && n >= 0, "irx_random_subset: n_samples %d outside [0, 64] or n < 0", n_samples);
+  if (n_samples == 0 || n == 0) return 0;
+  IRX_REQUIRE(n_src && seeds && out, "irx_random_subset: NULL argument");
+  IrxSubsetJobs J;
+  for (int b = 0; b < n_samples; ++b) {
+    IRX_REQUIRE(n_src[b] > 0, "irx_random_subset: sample %d has no vertices", b);
+    J.n_src[b] = n_src[b];
+    J.seed[b] = seeds[b];
+  }
+  dim3 grid((n + 255) / 256, n_samples);
+  k_random_subset<<<grid, 256, 0, S(stream)>>>(J, n, out);
+  IRX_CHECK_LAUNCH("irx_random_subset");
+  return 0;
+}
+
+extern "C" int irx_resample_rows(const int32_t* order, const int32_t* seg, int n_slots, int n_sample, uint64_t seed,
+                                 int32_t* rows, void* stream) {
+  IRX_REQUIRE(n_slots >= 0 && n_sample >= 0, "irx_resample_rows: bad sizes");
+  const size_t total = (size_t)n_slots * n_sample;
+  if (total == 0) return 0;
+  IRX_REQUIRE(order && seg && rows, "irx_resample_rows: NULL argument");
+  k_resample_rows<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(order, seg, n_slots, n_sample, seed, rows);
+  IRX_CHECK_LAUNCH("irx_resample_rows");
+  return 0;
+}

@@ -128,3 +128,41 @@ def test_input_pipeline_host_half_matches_reference_getitem(case):
     if case == "plain":
         assert np.array_equal(pc, g[case + "/point_clouds"])
         assert np.array_equal(pc[d.rows], g[case + "/instance_points"])
+
+
+@pytest.mark.parametrize("augment", [False, True])
+def test_batched_box_labels_equal_the_per_sample_reference_order_code(augment):
+    """Device mode computes the augmentation parameters + box labels of a whole batch with vectorised numpy
+    (scene_input._augment_and_box_labels_batch); fed the same random numbers it must equal the per-sample code that is
+    pinned to the reference's __getitem__ (flips, three rotations of the axis-aligned boxes, shift, size residuals,
+    reference-target lookup)."""
+    from instancerefer_amd import scene_input as SI
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset.npz"))
+    tables = SI.ClassTables(g["nyu40ids"], g["nyu40id2class"], g["mean_size_arr"])
+
+    class HostScan:
+        def __init__(self, raw):
+            self.instance_bboxes = raw["instance_bboxes"]
+    scans = [HostScan(S.make_raw_scene(40 + i, num_vertices=3000, num_instances=4 + i, same_class=2)) for i in range(3)]
+    oids = [0, 1, 2]
+    torch.manual_seed(3)
+    batch = [SI._Draw() for _ in scans]
+    SI._augment_and_box_labels_batch(batch, scans, oids, tables, augment)
+    torch.manual_seed(3)
+    r = torch.rand((3, 8))
+    orig = torch.rand
+    try:
+        for i, (sc, oid) in enumerate(zip(scans, oids)):
+            feed = iter([r[i, 0:1], r[i, 1:2], r[i, 2:3], r[i, 3:4], r[i, 4:5], r[i, 5:8]])
+            torch.rand = lambda *a, **k: next(feed)
+            d = SI._Draw()
+            SI._augment_and_box_labels(d, sc, oid, tables, augment)
+            for k in d.labels:
+                assert np.allclose(d.labels[k], batch[i].labels[k], atol=1e-6), (i, k)
+                assert d.labels[k].dtype == batch[i].labels[k].dtype, k
+            assert (d.flip_x, d.flip_y) == (batch[i].flip_x, batch[i].flip_y)
+            if augment:
+                assert np.allclose(np.stack(d.rot), np.stack(batch[i].rot), atol=1e-7)
+                assert np.allclose(d.shift, batch[i].shift)
+    finally:
+        torch.rand = orig
