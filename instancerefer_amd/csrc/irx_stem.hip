@@ -9,6 +9,9 @@
 
 #define ST_COUT 32
 
+// Rows per thread: the kernel is bound by its LDS weight reads (one ds_read_b128 per (offset, channel) per wave costs 8
+// LDS cycles whether or not the lanes read the same address), so every weight fragment read is reused for ST_R rows.
+#define ST_R 4
 template <int CIN>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const int32_t* __restrict__ nbr, int ld, int n_out, int K,
@@ -16,25 +19,45 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, c
   __shared__ __attribute__((aligned(16))) float sW[27 * CIN * ST_COUT];
   for (int i = threadIdx.x; i < K * CIN * ST_COUT; i += 256) sW[i] = w[i];
   __syncthreads();
-  const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int row0 = blockIdx.x * (32 * ST_R) + (threadIdx.x >> 3);     // rows row0 + 32 j
   const int c4 = (threadIdx.x & 7) * 4;
-  if (row >= n_out) return;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc[ST_R];
+#pragma unroll
+  for (int j = 0; j < ST_R; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int k = 0; k < K; ++k) {
-    const int idx = nbr[(size_t)k * ld + row];
-    if (idx < 0) continue;
-    const float* xr = x + (size_t)idx * CIN;
+    int idx[ST_R];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < ST_R; ++j) {
+      const int row = row0 + 32 * j;
+      idx[j] = (row < n_out) ? nbr[(size_t)k * ld + row] : -1;
+      any |= idx[j] >= 0;
+    }
+    if (!__any(any)) continue;                                        // wave-uniform skip
+    float xv[ST_R][CIN];
+#pragma unroll
+    for (int j = 0; j < ST_R; ++j) {
+      const float* xr = x + (size_t)(idx[j] < 0 ? 0 : idx[j]) * CIN;  // missing neighbour: row 0, masked below
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) xv[j][c] = idx[j] >= 0 ? xr[c] : 0.f;
+    }
 #pragma unroll
     for (int c = 0; c < CIN; ++c) {
-      const float xv = xr[c];
       const float4 wv = *reinterpret_cast<const float4*>(&sW[(k * CIN + c) * ST_COUT + c4]);
-      acc.x = fmaf(xv, wv.x, acc.x);
-      acc.y = fmaf(xv, wv.y, acc.y);
-      acc.z = fmaf(xv, wv.z, acc.z);
-      acc.w = fmaf(xv, wv.w, acc.w);
+#pragma unroll
+      for (int j = 0; j < ST_R; ++j) {
+        acc[j].x = fmaf(xv[j][c], wv.x, acc[j].x);
+        acc[j].y = fmaf(xv[j][c], wv.y, acc[j].y);
+        acc[j].z = fmaf(xv[j][c], wv.z, acc[j].z);
+        acc[j].w = fmaf(xv[j][c], wv.w, acc[j].w);
+      }
     }
   }
-  *reinterpret_cast<float4*>(y + (size_t)row * ST_COUT + c4) = acc;
+#pragma unroll
+  for (int j = 0; j < ST_R; ++j) {
+    const int row = row0 + 32 * j;
+    if (row < n_out) *reinterpret_cast<float4*>(y + (size_t)row * ST_COUT + c4) = acc[j];
+  }
 }
 
 // part[blk][k*CIN + c][n].  Per 64-row chunk the dense im2col tile X[row][k*CIN + c] (zeros where the neighbour is
@@ -125,7 +148,7 @@ bool irx_stem_supported(int K, int cin, int cout) { return K == 27 && cout == ST
 
 int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin,
                         float* y, hipStream_t st) {
-  const int grid = irx_cdiv(n_out, 32);
+  const int grid = irx_cdiv(n_out, 32 * ST_R);
   irx_bracket_begin(st);
   switch (cin) {
     case 1: k_stem_fwd<1><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
