@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad(const float* __restrict__
   constexpr int MREAL = K * CIN;                 // 189 for CIN = 7
   constexpr int MT = (MREAL + 15) / 16;          // 12
   constexpr int MPW = (MT + 3) / 4;              // M-tiles per wave (3)
-  constexpr int LDX = MT * 16 + 16;              // 208: consecutive rows 16 banks apart
+  // Row stride 209 = 17 (mod 64): the im2col WRITES have lane == row at a fixed column — with the former stride 208
+  // (16 mod 64) they hit 4 banks (16-way conflict, the kernel's bound); 17 is coprime to 64 (conflict-free writes) and
+  // still keeps the four rows of an MFMA fragment read >= 16 banks apart (a 2-way conflict on 3 banks of 64).
+  constexpr int LDX = MT * 16 + 17;
   constexpr int LDD = ST_COUT + 16;              // 48
   __shared__ __attribute__((aligned(16))) float sX[64 * LDX];
   __shared__ __attribute__((aligned(16))) float sD[64 * LDD];
