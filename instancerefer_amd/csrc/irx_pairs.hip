@@ -285,8 +285,16 @@ __global__ __launch_bounds__(256) void k_pairs_reduce(const float* __restrict__ 
   const int k = (int)(((size_t)blockIdx.x * blockDim.x) / per_offset);
   const int n = pairs_shares(counts, K, k, G, smax);
   if (i >= elems) return;
-  float s = 0.f;
-  for (int j = 0; j < n; ++j) s += part[(size_t)j * elems + i];
+  float s = 0.f;                                  // loads in batches of 8, adds in the original order (bit-identical)
+  int j = 0;
+  for (; j + 8 <= n; j += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(j + u) * elems + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; j < n; ++j) s += part[(size_t)j * elems + i];
   dw[i] = s;
 }
 

@@ -262,8 +262,18 @@ __global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t ele
                                float* __restrict__ dw, int accumulate) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= elems) return;
+  // loads in batches of 8 (memory-level parallelism: one load per add left the kernel latency-bound), adds in the
+  // original order (bit-identical)
   float s = 0.f;
-  for (int j = 0; j < S; ++j) s += part[(size_t)j * elems + i];
+  int j = 0;
+  for (; j + 8 <= S; j += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(j + u) * elems + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; j < S; ++j) s += part[(size_t)j * elems + i];
   dw[i] = accumulate ? dw[i] + s : s;            // (old + sum), the order of the unfused `old.add_(sum)`
 }
 
