@@ -47,9 +47,11 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
         is[j] = invstd[qd * V + j];
       }
     }
-    for (int r = r0 + rg; r < r1; r += nrg) {
+    // U rows per trip: all their loads are issued before the first add (memory-level parallelism; a load per add left
+    // the kernel latency-bound), the adds keep the row order (bit-identical to the one-row loop)
+    constexpr int U = 4;
+    auto load_row = [&](int r, float (&xv)[V], float (&yv)[V], float (&dv)[V]) __attribute__((always_inline)) {
       const size_t off = (size_t)r * c + (size_t)qd * V;
-      float xv[V], yv[V], dv[V];
       if (V == 4) {
         *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + off);
         if (MODE == 1) {
@@ -63,6 +65,8 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
           if (relu) yv[0] = y[off];
         }
       }
+    };
+    auto add_row = [&](const float (&xv)[V], const float (&yv)[V], const float (&dv)[V]) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         if (MODE == 0) {
@@ -75,6 +79,19 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
           a1[j] += gval * ((xv[j] - mu[j]) * is[j]);
         }
       }
+    };
+    int r = r0 + rg;
+    for (; r + (U - 1) * nrg < r1; r += U * nrg) {
+      float xv[U][V], yv[U][V], dv[U][V];
+#pragma unroll
+      for (int u = 0; u < U; ++u) load_row(r + u * nrg, xv[u], yv[u], dv[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) add_row(xv[u], yv[u], dv[u]);
+    }
+    for (; r < r1; r += nrg) {
+      float xv[V], yv[V], dv[V];
+      load_row(r, xv, yv, dv);
+      add_row(xv, yv, dv);
     }
   }
 #pragma unroll
