@@ -34,13 +34,17 @@ class LangModule(nn.Module):
             self.lang_cls = nn.Sequential(nn.Linear(256, num_text_classes))
 
     def rnn_encoding(self, embed, length, data_dict):
-        embed = self.word_projection(embed)
         if embed.is_cuda:
             # HIP path: persistent GRU recurrence kernel (csrc/irx_gru.hip) + GEMM projections; one D2H of max(len)
             t_max = int(length.max().item()) if "lang_len_max" not in data_dict else int(data_dict["lang_len_max"])
+            # Only the first max(len) token positions reach the GRU and the attention pooling (the reference projects
+            # all 126 padded rows, lang_module.py:100-102, and drops the rest when it packs the sequence): projecting
+            # just those is the same function with the same gradients and a quarter of the MLP's GEMM work at 30 tokens.
+            embed = self.word_projection(embed[:, :t_max])
             feats = gru_packed(self.gru, embed, length, t_max)     # (B, T_max, o_dim), zeros at t >= len
         else:
             # host tensors (CPU unit tests of the head logic): the reference's own formulation
+            embed = self.word_projection(embed)
             len_cpu = length.detach().to("cpu", torch.int64)
             feats = pack_padded_sequence(embed, len_cpu, batch_first=True, enforce_sorted=False)
             feats, _ = self.gru(feats)
