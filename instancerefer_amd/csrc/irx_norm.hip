@@ -131,21 +131,7 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
   const int slice = threadIdx.x >> 5;
   double t0 = 0.0, t1 = 0.0;
   if (ch < c) {
-    int b = slice;
-    for (; b + 3 * BN_FIN_SLICES < nblk; b += 4 * BN_FIN_SLICES) {   // 8 loads in flight, adds in the original order
-      float p0[4], p1[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        p0[u] = part[((size_t)(b + u * BN_FIN_SLICES) * 2 + 0) * c + ch];
-        p1[u] = part[((size_t)(b + u * BN_FIN_SLICES) * 2 + 1) * c + ch];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        t0 += (double)p0[u];
-        t1 += (double)p1[u];
-      }
-    }
-    for (; b < nblk; b += BN_FIN_SLICES) {
+    for (int b = slice; b < nblk; b += BN_FIN_SLICES) {
       t0 += (double)part[((size_t)b * 2 + 0) * c + ch];
       t1 += (double)part[((size_t)b * 2 + 1) * c + ch];
     }
