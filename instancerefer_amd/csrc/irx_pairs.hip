@@ -220,6 +220,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
       // MFMA chain, one x and one dy load per step, so the wave never queues at the vector-memory pipe with an idle
       // MFMA pipe behind it (the lesson of k_spconv2). Loads are unconditional (missing pairs re-read row 0 and are
       // zeroed by a select), so the chain has no branches.
+      // fragments of step ks + 1 are read from LDS BEFORE the MFMAs of step ks (the sched_barrier that pins the global
+      // loads into the chain would otherwise make every step wait out its own LDS latency)
+      float a[CW], b[NW];
+#pragma unroll
+      for (int i = 0; i < CW; ++i) a[i] = sX[g4 * LDX + (ct0 + i) * 16 + m];     // A[m = c][kk = pair]
+#pragma unroll
+      for (int i = 0; i < NW; ++i) b[i] = sD[g4 * LDD + (nt0 + i) * 16 + m];     // B[kk = pair][n]
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         if (ks < NX) {
@@ -232,18 +239,26 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
           const float4 v = *reinterpret_cast<const float4*>(dy + (size_t)(idx < 0 ? 0 : idx) * COUT + dc);
           rd[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const int pp = ks * 4 + g4;
-        float a[CW], b[NW];
+        float an[CW], bn[NW];
+        if (ks + 1 < 16) {
+          const int pp = (ks + 1) * 4 + g4;
 #pragma unroll
-        for (int i = 0; i < CW; ++i) a[i] = sX[pp * LDX + (ct0 + i) * 16 + m];   // A[m = c][kk = pair]
+          for (int i = 0; i < CW; ++i) an[i] = sX[pp * LDX + (ct0 + i) * 16 + m];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) b[i] = sD[pp * LDD + (nt0 + i) * 16 + m];   // B[kk = pair][n]
+          for (int i = 0; i < NW; ++i) bn[i] = sD[pp * LDD + (nt0 + i) * 16 + m];
+        }
 #pragma unroll
         for (int i = 0; i < CW; ++i)
 #pragma unroll
           for (int jn = 0; jn < NW; ++jn)
             acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < 16) {
+#pragma unroll
+          for (int i = 0; i < CW; ++i) a[i] = an[i];
+#pragma unroll
+          for (int i = 0; i < NW; ++i) b[i] = bn[i];
+        }
       }
     } else {
       for (int ks = 0; ks < nks; ++ks) {
