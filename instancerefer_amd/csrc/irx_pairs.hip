@@ -177,14 +177,26 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
       // channel (A) / column (B): 4 LDS reads + 2 packed converts per fragment, one MFMA where fp32 issues four.
       // Rows of missing pairs are zero in LDS, so partial stages just run fewer 16-pair steps.
       const int n16 = has_next ? 4 : ((npairs + 15) >> 4);
+      // raw fp32 fragments of 16-pair step k16 + 1 are read from LDS before the MFMAs of step k16
+      float a[CW][4], b[NW][4];
+      auto read16 = [&](int k16, float (&ra)[CW][4], float (&rb)[NW][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const int pp = 16 * k16 + 4 * g4 + i4;
+#pragma unroll
+          for (int i = 0; i < CW; ++i) ra[i][i4] = sX[pp * LDX + (ct0 + i) * 16 + m];
+#pragma unroll
+          for (int i = 0; i < NW; ++i) rb[i][i4] = sD[pp * LDD + (nt0 + i) * 16 + m];
+        }
+      };
+      read16(0, a, b);
 #pragma unroll
       for (int k16 = 0; k16 < 4; ++k16) {
         if (k16 < n16) {
-          float a[CW][4], b[NW][4];
+          if (has_next) {                                  // next stage's rows, spread over the chain as in fp32
 #pragma unroll
-          for (int i4 = 0; i4 < 4; ++i4) {
-            const int ks = k16 * 4 + i4;
-            if (has_next) {                                // next stage's rows, spread over the chain as in fp32
+            for (int i4 = 0; i4 < 4; ++i4) {
+              const int ks = k16 * 4 + i4;
               if (ks < NX) {
                 const int idx = sIn[parn][xr + ks * PX];
                 const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(idx < 0 ? 0 : idx) * CIN + xc);
@@ -196,17 +208,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
                 rd[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
               }
             }
-            const int pp = 16 * k16 + 4 * g4 + i4;
-#pragma unroll
-            for (int i = 0; i < CW; ++i) a[i][i4] = sX[pp * LDX + (ct0 + i) * 16 + m];
-#pragma unroll
-            for (int i = 0; i < NW; ++i) b[i][i4] = sD[pp * LDD + (nt0 + i) * 16 + m];
           }
           s16x4 pa[CW], pb[NW];
 #pragma unroll
           for (int i = 0; i < CW; ++i) pa[i] = irx_frag_bf16(irx_pk_bf16(a[i][0], a[i][1]), irx_pk_bf16(a[i][2], a[i][3]));
 #pragma unroll
           for (int i = 0; i < NW; ++i) pb[i] = irx_frag_bf16(irx_pk_bf16(b[i][0], b[i][1]), irx_pk_bf16(b[i][2], b[i][3]));
+          if (k16 + 1 < 4 && k16 + 1 < n16) read16(k16 + 1, a, b);   // (a, b are free again: packed above)
 #pragma unroll
           for (int i = 0; i < CW; ++i)
 #pragma unroll
