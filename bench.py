@@ -153,7 +153,7 @@ def take_prepared(model, state):
 
 def step_fn(model, resident, workload, reducer, opt, state=None):
     """One training step on the resident batch. Returns the loss tensor (no host sync)."""
-    from instancerefer_amd.loss_helper import DatasetConfig, get_loss, ContrastiveLoss, compute_lang_classification_loss
+    from instancerefer_amd.loss_helper import DatasetConfig, get_loss, compute_lang_classification_loss
     dd = take_prepared(model, state) if state is not None else None
     if dd is None:
         dd = fresh_batch(resident)
@@ -166,15 +166,16 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
         loss = get_loss(dd, step_fn.cfg)["loss"]
     else:
         # configs[1]: attribute path only — contrastive loss on the attribute scores + language CE
-        crit = ContrastiveLoss()
+        # (the reference's per-sample ContrastiveLoss, lib/loss_helper.py:93-107,248-258, for all scenes in one fused launch
+        # each way, IoU labels as in get_loss; the relation / scene scores of the full model are absent here)
+        from instancerefer_amd.dense import ContrastiveFn
+        from instancerefer_amd.loss_helper import prepare_labels
         loss = compute_lang_classification_loss(dd)
-        o = 0
-        for i, n in enumerate(dd["num_filtered_objs"]):
-            if n >= 2:
-                lab = torch.zeros(n, device=loss.device)
-                lab[0] = 1.0
-                loss = loss + 10.0 * crit(dd["attribute_scores"][o:o + n], lab) / len(dd["num_filtered_objs"])
-                o += n
+        lp = dd.pop("_loss_prepared", None) or prepare_labels(dd, step_fn.cfg, loss.device)
+        if lp["total"] and lp["srow"]:
+            zero = torch.zeros_like(dd["attribute_scores"])
+            ref = ContrastiveFn.apply(dd["attribute_scores"], zero, zero, lp["lab"], lp["seg_off"], lp["keep_dev"], 5.0, 0.2)
+            loss = loss + 10.0 * ref / lp["batch_size"]
     loss.backward()
     opt.backward_step()          # one cat -> one all-reduce (N > 1) -> one fused Adam launch
     if state is not None and state.get("pipeline") and not state.get("threaded", True):
@@ -356,9 +357,8 @@ def main():
     state = {"pipeline": not args.no_pipeline, "threaded": bool(args.prep_thread) and world == 1}
     if os.environ.get("IRX_BENCH_PREP_MAIN") == "1":   # dev A/B: the preparation on the main stream
         state["side"] = torch.cuda.current_stream()
-    if args.workload == "full":
-        from instancerefer_amd.loss_helper import prepare_labels
-        state["labels"] = lambda dd: prepare_labels(dd, step_fn.cfg, device) if "_attr_prepared" in dd else None
+    from instancerefer_amd.loss_helper import prepare_labels
+    state["labels"] = lambda dd: prepare_labels(dd, step_fn.cfg, device) if "_attr_prepared" in dd else None
     for i in range(args.warmup):
         step_fn(model, resident, args.workload, reducer, opt, state)
         if i == 0:
