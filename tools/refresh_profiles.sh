@@ -1,6 +1,6 @@
 set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01l
+O=gpurun_out/r01m
 mkdir -p $O
 timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -2 > $O/pytest.txt
 timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
