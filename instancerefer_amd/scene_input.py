@@ -62,7 +62,8 @@ def point_features(mesh_vertices, use_color=True, use_normal=False, use_height=T
 
 
 class ResidentScan:
-    """One scan with its point features in HBM and its label arrays on the host."""
+    """One scan with its point features in HBM; the label arrays are kept on the host (host-RNG mode) and, as slot ids
+    + semantic ids, in HBM too (fully device-side mode)."""
 
     def __init__(self, raw, device, use_color=True, use_normal=False, use_height=True, multiview=None):
         pc = np.ascontiguousarray(point_features(raw["mesh_vertices"], use_color, use_normal, use_height, multiview))
@@ -410,8 +411,11 @@ def build_batch_device(scans, object_ids, tables, device, num_points=40000, augm
     Host work per sample: the augmentation draws and the (<= 128) box labels only; no host sync anywhere.
     -> PendingDeviceBatch (finish() as in build_batch)."""
     B = len(scans)
+    assert 0 < B <= 64, "build_batch_device: 1..64 samples per call (irx_random_subset)"
     pts0 = scans[0].points
     c, dtype = pts0.shape[1], pts0.dtype
+    for sc in scans:
+        assert sc.points.shape[1] == c and sc.points.dtype == dtype, "scans of a batch share feature width and dtype"
     eb = 4 if dtype == torch.float32 else 8
     n = num_points
     draws = []
