@@ -435,7 +435,7 @@ def main():
         }
         if alt is not None:
             out["alt_dtype"] = alt
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # contract: the CPU leg runs on rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.workload)
             except Exception as e:  # the baseline must never take the GPU number down with it
