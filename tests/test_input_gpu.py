@@ -162,6 +162,12 @@ def test_fully_device_side_mode_invariants(lib, augment):
     dev = torch.device("cuda")
     raws = [S.make_raw_scene(800 + i, num_vertices=30000 + 5000 * i, num_instances=5 + 2 * i, same_class=3) for i in range(3)]
     raws[2]["instance_labels"] = np.where(raws[2]["instance_labels"] == 2, 1, raws[2]["instance_labels"])   # a missing id
+    # two tiny instances in scan 1 (3 and 40 vertices of 35 000, 20 000 sampled): the first usually loses all its points
+    # (an empty slot that must be dropped), the second is resampled with replacement from a handful of points
+    for lab, cnt in ((97, 3), (98, 40)):
+        idx = np.flatnonzero(raws[1]["instance_labels"] == 0)[lab:lab + cnt * 7:7]
+        raws[1]["instance_labels"][idx] = lab
+        raws[1]["semantic_labels"][idx] = 5
     scans = [SI.ResidentScan(r, dev) for r in raws]
     npts = 20000
     torch.manual_seed(5)
