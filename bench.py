@@ -411,9 +411,11 @@ def main():
                            "sparse convs (fwd, dgrad, wgrad); tensors, BatchNorm, stem, heads fp32. Not the headline: the "
                            "1e-4 parity gate is proven for fp32; bf16 tracks it within 4e-4 on the matching scores "
                            "(tests/test_model_gpu.py) and equals the bf16-operand oracle to 1e-5 (tests/test_ops_gpu.py)"}
+        except Exception as e:                         # the extra leg must never take the headline down with it
+            alt = {"dtype": "bf16", "error": repr(e)}
         finally:
             irx.set_compute_dtype("fp32")
-        log("bf16 leg done: %.1f ms/step" % alt["ms_per_step"])
+        log("bf16 leg done: %s" % (alt.get("ms_per_step", alt.get("error")),))
 
     if rank == 0:
         out = {
