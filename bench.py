@@ -380,16 +380,21 @@ def main():
 
     # ---- instrumented steps: per-launch events on the launch stream for the sparse-conv kernels ----
     roof = None
+    roof_error = None
     if rank == 0:
-        F_.PROFILE = []
-        saved_world, opt.world_size = opt.world_size, 1     # rank-0-only steps: no collective (others are not in it)
-        for _ in range(max(1, args.profile_steps)):
-            step_fn(model, resident, args.workload, reducer, opt)
-        torch.cuda.synchronize()
-        opt.world_size = saved_world
-        recs = F_.PROFILE
-        F_.PROFILE = None
-        roof = summarise_roofline(recs, args.dtype == "bf16")
+        try:
+            F_.PROFILE = []
+            saved_world, opt.world_size = opt.world_size, 1     # rank-0-only steps: no collective (others are not in it)
+            for _ in range(max(1, args.profile_steps)):
+                step_fn(model, resident, args.workload, reducer, opt)
+            torch.cuda.synchronize()
+            opt.world_size = saved_world
+            recs = F_.PROFILE
+            F_.PROFILE = None
+            roof = summarise_roofline(recs, args.dtype == "bf16")
+        except Exception as e:                           # never lose the throughput line to the instrumented steps
+            F_.PROFILE = None
+            roof_error = repr(e)
 
     # ---- the same loop with bf16 conv operands (BASELINE configs[2]-[4] dtype), reported beside the fp32 headline ----
     alt = None
@@ -433,7 +438,7 @@ def main():
                        "instances": args.instances, "candidates": args.candidates, "tokens": args.tokens,
                        "scene_voxels_per_gpu": n_scene_vox, "parallelism": "dp%d" % world, "loss": final_loss,
                        "input_prep": "inline" if args.no_pipeline else "side-stream prefetch of step N+1 during step N"},
-            "roofline": roof,
+            "roofline": roof if roof_error is None else {"error": roof_error},
         }
         if alt is not None:
             out["alt_dtype"] = alt
