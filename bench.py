@@ -378,24 +378,6 @@ def main():
     final_loss = float(loss.item())
     log("timed region done: %.1f ms/step" % (1000.0 * dt / args.steps))
 
-    # ---- instrumented steps: per-launch events on the launch stream for the sparse-conv kernels ----
-    roof = None
-    roof_error = None
-    if rank == 0:
-        try:
-            F_.PROFILE = []
-            saved_world, opt.world_size = opt.world_size, 1     # rank-0-only steps: no collective (others are not in it)
-            for _ in range(max(1, args.profile_steps)):
-                step_fn(model, resident, args.workload, reducer, opt)
-            torch.cuda.synchronize()
-            opt.world_size = saved_world
-            recs = F_.PROFILE
-            F_.PROFILE = None
-            roof = summarise_roofline(recs, args.dtype == "bf16")
-        except Exception as e:                           # never lose the throughput line to the instrumented steps
-            F_.PROFILE = None
-            roof_error = repr(e)
-
     # ---- the same loop with bf16 conv operands (BASELINE configs[2]-[4] dtype), reported beside the fp32 headline ----
     alt = None
     if world == 1 and args.dtype == "f32" and not args.no_alt_dtype:
@@ -421,6 +403,24 @@ def main():
         finally:
             irx.set_compute_dtype("fp32")
         log("bf16 leg done: %s" % (alt.get("ms_per_step", alt.get("error")),))
+
+    # ---- instrumented steps: per-launch events on the launch stream for the sparse-conv kernels ----
+    roof = None
+    roof_error = None
+    if rank == 0:
+        try:
+            F_.PROFILE = []
+            saved_world, opt.world_size = opt.world_size, 1     # rank-0-only steps: no collective (others are not in it)
+            for _ in range(max(1, args.profile_steps)):
+                step_fn(model, resident, args.workload, reducer, opt)
+            torch.cuda.synchronize()
+            opt.world_size = saved_world
+            recs = F_.PROFILE
+            F_.PROFILE = None
+            roof = summarise_roofline(recs, args.dtype == "bf16")
+        except Exception as e:                           # never lose the throughput line to the instrumented steps
+            F_.PROFILE = None
+            roof_error = repr(e)
 
     if rank == 0:
         out = {
