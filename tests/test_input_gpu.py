@@ -214,3 +214,30 @@ def test_fully_device_side_mode_invariants(lib, augment):
     vid = np.asarray([key[tuple(r)] for r in clouds[0][:, 3:6].tolist()])
     hist = np.histogram(vid, bins=10, range=(0, raws[0]["mesh_vertices"].shape[0]))[0]
     assert hist.min() > 0.9 * npts / 10 and hist.max() < 1.1 * npts / 10, hist
+
+
+def test_scans_without_object_instances_give_an_empty_pack(lib):
+    """A batch whose scans hold only wall / floor points: both input modes return zero instances, valid clouds, extents
+    and voxels, and the model's candidate selection sees 'no candidates' (the reference crashes on torch.cat([]))."""
+    from instancerefer_amd import scene_input as SI
+    g = np.load(G)
+    tables = SI.ClassTables(g["nyu40ids"], g["nyu40id2class"], g["mean_size_arr"])
+    dev = torch.device("cuda")
+    raws = []
+    for i in range(2):
+        r = S.make_raw_scene(900 + i, num_vertices=8000, num_instances=3, same_class=1)
+        r["instance_labels"][:] = 0
+        r["semantic_labels"][:] = np.where(np.arange(8000) % 2 == 0, 1, 2)      # wall / floor: not in nyu40ids
+        raws.append(r)
+    scans = [SI.ResidentScan(r, dev) for r in raws]
+    np.random.seed(3)
+    torch.manual_seed(3)
+    draws = [SI.draw_sample(sc, 0, tables, num_points=5000) for sc in scans]
+    for dd in (SI.build_batch(draws, dev).finish(), SI.build_batch_device(scans, [0, 0], tables, dev, num_points=5000, seed=9).finish()):
+        pack = dd["irx"]
+        assert pack.pts32.shape[0] == 0 and pack.classes == [] and pack.scene_start == [0, 0, 0]
+        assert dd["point_clouds"].shape == (2, 5000, 7) and torch.isfinite(dd["point_clouds"]).all()
+        assert (dd["_host"]["point_max"] >= dd["_host"]["point_min"]).all()
+        assert dd["lidar"].F.shape[0] > 100
+        sel = pack.select([2, 2])
+        assert sel["cand"] == [] and sel["num_filtered_objs"] == [0, 0]
