@@ -9,6 +9,9 @@ from instancerefer_amd import _lib, synthetic as S
 from instancerefer_amd.loss_helper import DatasetConfig, prepare_labels
 from instancerefer_amd.optim import FlatAdam
 _lib.load()
+import instancerefer_amd as irx
+irx.set_compute_dtype('bf16' if args.dtype == 'bf16' else 'fp32')
+BLOCKS = int(os.environ.get('SOAK_BLOCKS', '6'))
 B = 16
 torch.manual_seed(1234)
 model = bench.build_model(args, "full", dev)
@@ -20,7 +23,7 @@ opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
 state = {"pipeline": True, "threaded": False}
 state["labels"] = lambda dd: prepare_labels(dd, bench.step_fn.cfg, dev) if "_attr_prepared" in dd else None
 import resource
-for blk in range(6):
+for blk in range(BLOCKS):
     t0 = time.perf_counter()
     for _ in range(100): loss = bench.step_fn(model, resident, "full", None, opt, state)
     torch.cuda.synchronize()
