@@ -564,7 +564,8 @@ int irx_spconv2_splits(int n_out, int K) {
   const int tiles = irx_cdiv(n_out, irx_spconv2_tile(n_out));
   static const int full = getenv("IRX_SPCONV_SPLIT_BELOW") ? atoi(getenv("IRX_SPCONV_SPLIT_BELOW")) : 256;
   if (tiles >= full || K < 4) return 1;
-  int s = irx_cdiv(1024, tiles);
+  static const int target = getenv("IRX_SPCONV_SPLIT_TARGET") ? atoi(getenv("IRX_SPCONV_SPLIT_TARGET")) : 1024;   // dev A/B knob
+  int s = irx_cdiv(target, tiles);
   if (s > 9) s = 9;
   if (s > K) s = K;
   const int kps = irx_cdiv(K, s);
