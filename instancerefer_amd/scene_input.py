@@ -486,3 +486,59 @@ def build_batch_device(scans, object_ids, tables, device, num_points=40000, augm
     ev.record()
     return PendingDeviceBatch(draws, clouds, inst_points, obbs_dev[:S], extent, host_back, ev, slot_base, voxel_size_glp, device,
                               (back_dev, rows32, order32, seg32, gslot, sem, choices_all))
+
+
+class ResidentLoader:
+    """Iterable of training batches built on the device from resident scans (build_batch_device), in the role of the
+    reference's DataLoader(ScannetReferenceDataset, collate_fn) for lib/solver.py-style loops (instancerefer_amd.solver.
+    Solver accepts it as dataloader["train"]). `samples`: list of dicts with `scan` (key into `scans`), `object_id`,
+    `object_cat`, `lang_feat` (126, 300) float32, `lang_len`, optional `unique_multiple`. The input pipeline of batch
+    i + 1 is enqueued before batch i is handed out, so its kernels overlap the training step; no host sync besides the
+    small read-back collected in finish()."""
+
+    def __init__(self, scans, samples, tables, batch_size, device, num_points=40000, augment=False, shuffle=True,
+                 seed=0, drop_last=True, voxel_size_glp=0.05):
+        self.scans, self.samples, self.tables, self.batch_size, self.device = scans, samples, tables, batch_size, device
+        self.num_points, self.augment, self.shuffle, self.seed, self.drop_last = num_points, augment, shuffle, seed, drop_last
+        self.voxel_size_glp = voxel_size_glp
+        self.epoch = 0
+
+    def __len__(self):
+        n = len(self.samples)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _launch(self, idx, seed):
+        batch = [self.samples[i] for i in idx]
+        pend = build_batch_device([self.scans[b["scan"]] for b in batch], [b["object_id"] for b in batch], self.tables,
+                                  self.device, self.num_points, self.augment, self.voxel_size_glp, seed=seed)
+        return pend, batch
+
+    def _finish(self, pend, batch):
+        dd = pend.finish()
+        B = len(batch)
+        lang = np.stack([np.asarray(b["lang_feat"], np.float32) for b in batch], 0)
+        lens = np.asarray([int(b["lang_len"]) for b in batch], np.int64)
+        cats = np.asarray([int(b["object_cat"]) for b in batch], np.int64)
+        dd["lang_feat"] = torch.from_numpy(lang).to(self.device, non_blocking=True)
+        dd["lang_len"] = torch.from_numpy(lens).to(self.device, non_blocking=True)
+        dd["lang_len_max"] = int(lens.max())
+        dd["object_cat"] = torch.from_numpy(cats).to(self.device, non_blocking=True)
+        dd["unique_multiple"] = torch.from_numpy(np.asarray([int(b.get("unique_multiple", 0)) for b in batch], np.int64))
+        dd["_host"].update(object_cat=cats, unique_multiple=dd["unique_multiple"].numpy())
+        assert dd["point_clouds"].shape[0] == B
+        return dd
+
+    def __iter__(self):
+        order = np.arange(len(self.samples))
+        if self.shuffle:
+            np.random.default_rng(self.seed + self.epoch).shuffle(order)
+        self.epoch += 1
+        chunks = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        if self.drop_last and chunks and len(chunks[-1]) < self.batch_size:
+            chunks.pop()
+        base = (self.seed * 1000003 + self.epoch) * 4099
+        pending = self._launch(chunks[0], base) if chunks else None
+        for ci in range(len(chunks)):
+            cur = pending
+            pending = self._launch(chunks[ci + 1], base + ci + 1) if ci + 1 < len(chunks) else None
+            yield self._finish(*cur)

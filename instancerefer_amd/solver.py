@@ -29,8 +29,11 @@ HOST_LABELS = ("ref_center_label", "ref_size_residual_label", "ref_heading_class
 
 def to_device(data_dict, device):
     """lib/solver.py:242-245 + host copies of the label tensors (they originate on the host) for get_loss / get_eval."""
-    data_dict["_host"] = {k: data_dict[k].detach().cpu().numpy() for k in HOST_LABELS
-                          if k in data_dict and isinstance(data_dict[k], torch.Tensor)}
+    host = dict(data_dict.get("_host") or {})      # a device-side loader (scene_input.ResidentLoader) brings its own
+    for k in HOST_LABELS:
+        if k not in host and isinstance(data_dict.get(k), torch.Tensor):
+            host[k] = data_dict[k].detach().cpu().numpy()
+    data_dict["_host"] = host
     if "lang_len" in data_dict:
         data_dict["lang_len_max"] = int(data_dict["lang_len"].max())
     for k in GPU_KEYS:
@@ -88,8 +91,9 @@ class Solver:
                     ev = get_eval(data_dict, self.config)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
-                rec = dict(epoch=epoch, iter=self.global_iter, loss=float(data_dict["loss"]), ref_loss=float(data_dict["ref_loss"]),
-                           lang_loss=float(data_dict["lang_loss"]), seg_loss=float(data_dict["seg_loss"]),
+                rec = dict(epoch=epoch, iter=self.global_iter, loss=float(data_dict["loss"].detach()),
+                           ref_loss=float(data_dict["ref_loss"].detach()),
+                           lang_loss=float(data_dict["lang_loss"].detach()), seg_loss=float(data_dict["seg_loss"].detach()),
                            lang_acc=float(ev["lang_acc"]), ref_acc=float(np.mean(ev["ref_acc"])),
                            iou_rate_25=ev["ref_iou_rate_0.25"], iou_rate_5=ev["ref_iou_rate_0.5"],
                            scenes_per_sec=self.world * seen / dt)
