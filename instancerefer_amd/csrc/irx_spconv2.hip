@@ -226,7 +226,15 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   static_assert(NCS * NGP == 4, "4 waves");
   static_assert(NIT == NJ, "one gather pass per MFMA k-step");
   __shared__ __attribute__((aligned(16))) float sOut[(TM + 1) * LDO];   // + dump row for padded pairs
-  __shared__ __attribute__((aligned(16))) float sA[64 * LDA];
+  // A tile, DOUBLE-buffered in bf16 mode (half-size tiles: no resident workgroup is lost): item i + 1 is then written
+  // while slower waves still read item i, and the barrier that protected the single buffer goes away (one barrier per
+  // item instead of two; barrier 2 of item i + 1 already orders the reads of item i before the writes of item i + 2):
+  // 64->64 151 -> 146 us, 128->128 129 -> 128 us. In fp32 the second buffer costs the 64-channel kernels their third
+  // resident workgroup per CU and that is worth more than the barrier (299 -> 337 us): single buffer there.
+  constexpr bool DB = BF;
+  constexpr int ABUF = BF ? 64 * (CIN + 8) / 2 : 64 * LDA;    // floats per buffer
+  __shared__ __attribute__((aligned(16))) float sA_all[(DB ? 2 : 1) * ABUF];
+  int abuf = 0;
   __shared__ int sIn[KMAX * TM];
   __shared__ unsigned char sRow[KMAX * TM];
   __shared__ int sCnt[32];
@@ -315,7 +323,9 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     const int k = kk[C], vs = vv[C];
     const int vpad = (vs + 15) & ~15;
     const int npass = (vpad + PPP - 1) / PPP;      // block-uniform
-    __syncthreads();                               // previous item's fragment reads are done
+    float* sA = sA_all + (DB ? abuf * ABUF : 0);
+    if (DB) abuf ^= 1;
+    else __syncthreads();                          // previous item's fragment reads are done
     S2_TICK(1);
     s2_wait_vmcnt<(DEPTH - 1) * LPC>();            // this item's rows + weights have landed (later items may be in flight)
     S2_TICK(2);
