@@ -36,14 +36,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="full", choices=["full", "attr"],
-                    help="full = whole InstanceRefer (BASELINE configs[2]/[3] shape); attr = configs[1]")
-    ap.add_argument("--batch", type=int, default=0, help="scenes per GPU (default 16 full / 8 attr)")
-    ap.add_argument("--points", type=int, default=50000)
-    ap.add_argument("--instances", type=int, default=8)
-    ap.add_argument("--candidates", type=int, default=4)
+    ap.add_argument("--workload", default="full", choices=["full", "attr", "stress"],
+                    help="full = whole InstanceRefer (BASELINE configs[2]/[3] shape); attr = configs[1]; stress = configs[4] "
+                         "(200k points, 64 instances, 16 candidates, multiview C0 = 135, bf16)")
+    ap.add_argument("--batch", type=int, default=0, help="scenes per GPU (default 16 full / 8 attr / 8 stress)")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--instances", type=int, default=None)
+    ap.add_argument("--candidates", type=int, default=None)
+    ap.add_argument("--multiview", type=int, default=None, help="extra ENet feature channels per point (128 in the stress config)")
     ap.add_argument("--tokens", type=int, default=30)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="compute dtype of the MFMA sparse-conv kernels: f32 (default: the reference's dtype, exact) or bf16 "
                          "operands with fp32 accumulation (BASELINE configs[2]-[4]); tensors, BatchNorm, heads stay fp32")
     ap.add_argument("--no-alt-dtype", action="store_true",
@@ -57,7 +59,15 @@ def parse():
                          "the loop is GIL-bound, tools/micro/ab_thread.py)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do the input preparation of each step inline instead of on a side stream during the previous backward")
-    return ap.parse_args()
+    args = ap.parse_args()
+    stress = args.workload == "stress"
+    for k, full, st in (("points", 50000, 200000), ("instances", 8, 64), ("candidates", 4, 16), ("multiview", 0, 128),
+                        ("dtype", "f32", "bf16")):
+        if getattr(args, k) is None:
+            setattr(args, k, st if stress else full)
+    if stress and args.cpu_scenes == 16:
+        args.cpu_scenes = 2                      # bounded CPU sample: these scenes are 4x the size
+    return args
 
 
 def build_model(args_ns, workload, device):
@@ -67,7 +77,7 @@ def build_model(args_ns, workload, device):
     if workload == "attr":
         margs.relation_module = None
         margs.scene_module = None
-    model = InstanceRefer(7, margs)
+    model = InstanceRefer(7 + int(getattr(args_ns, "multiview", 0) or 0), margs)
     model.load_state_dict(S.seeded_state_dict(model, 2024))
     return model.to(device).train()
 
@@ -162,7 +172,7 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
         prepare_next(model, resident, state, phase="launch")
     opt.zero_grad()
     dd = model(dd)
-    if workload == "full":
+    if workload in ("full", "stress"):
         loss = get_loss(dd, step_fn.cfg)["loss"]
     else:
         # configs[1]: attribute path only — contrastive loss on the attribute scores + language CE
@@ -199,7 +209,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline_worker(points, instances, candidates, tokens, n_scenes, threads):
+def cpu_baseline_worker(points, instances, candidates, tokens, n_scenes, threads, multiview=0):
     """Runs in a child process: the oracle (CPU restatement of the reference path; kind 'port') on a
     bounded sample of the workload. Prints one JSON line."""
     torch.set_num_threads(threads)
@@ -207,11 +217,11 @@ def cpu_baseline_worker(points, instances, candidates, tokens, n_scenes, threads
     from instancerefer_amd.loss_helper import DatasetConfig, get_loss
     from oracle.model_ref import InstanceRefer as OracleModel, oracle_data_dict
     n = max(2, n_scenes)      # BatchNorm1d heads need >= 2 samples
-    model = OracleModel(7, S.default_args())
+    model = OracleModel(7 + multiview, S.default_args())
     model.load_state_dict(S.seeded_state_dict(model, 2024))
     model.train()
     host = S.make_batch(n, seed=123, num_points=points, num_instances=instances,
-                        num_candidates=candidates, tokens=tokens)
+                        num_candidates=candidates, tokens=tokens, multiview=multiview)
     t0 = time.perf_counter()
     dd = oracle_data_dict(host)          # scene sparse_quantize: done by the dataloader in the reference
     t_prep = time.perf_counter() - t0
@@ -269,8 +279,8 @@ def cpu_baseline(args, workload):
     """Bounded, sandboxed: child process with a hard timeout so the baseline can never stall the bench."""
     import subprocess
     threads = min(usable_cores(), 64)
-    code = ("import sys; sys.path.insert(0, %r); import bench; bench.cpu_baseline_worker(%d, %d, %d, %d, %d, %d)"
-            % (ROOT, args.points, args.instances, args.candidates, args.tokens, args.cpu_scenes, threads))
+    code = ("import sys; sys.path.insert(0, %r); import bench; bench.cpu_baseline_worker(%d, %d, %d, %d, %d, %d, %d)"
+            % (ROOT, args.points, args.instances, args.candidates, args.tokens, args.cpu_scenes, threads, args.multiview))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
@@ -317,17 +327,18 @@ def main():
     import instancerefer_amd as irx
     irx.set_compute_dtype("bf16" if args.dtype == "bf16" else "fp32")
     from instancerefer_amd import synthetic as S
-    from instancerefer_amd.ddp import FlatGradAllReduce
     from instancerefer_amd.loss_helper import DatasetConfig
     from instancerefer_amd.sparse import functional as F_
 
     B = args.batch or (16 if args.workload == "full" else 8)
-    torch.manual_seed(1234 + rank)                       # dropout masks reproducible run to run
-    model = build_model(args, args.workload, device)
+    model_workload = "attr" if args.workload == "attr" else "full"     # stress = the full model on bigger inputs
+    torch.manual_seed(1234)                              # identical replicas: the same initial weights on every rank
+    model = build_model(args, model_workload, device)    # (FlatAdam broadcasts rank 0's parameters / buffers anyway)
+    torch.manual_seed(1234 + rank)                       # dropout masks: per rank, reproducible run to run
     step_fn.cfg = DatasetConfig()
     # weak scaling: every rank owns B distinct scenes (seeds offset by rank)
     host = S.make_batch(B, seed=123 + rank * B, num_points=args.points, num_instances=args.instances,
-                        num_candidates=args.candidates, tokens=args.tokens)
+                        num_candidates=args.candidates, tokens=args.tokens, multiview=args.multiview)
     log("host batch made")
     resident = S.to_device(host, device)
     torch.cuda.synchronize()
@@ -340,7 +351,7 @@ def main():
     n_scene_vox = int(lidar.F.shape[0])
     from instancerefer_amd.optim import FlatAdam
     reducer = None
-    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=world)
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=world, module=model)
 
     def barrier():
         torch.cuda.synchronize()
@@ -428,14 +439,17 @@ def main():
             "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("full InstanceRefer (lang+attribute+relation+scene) fwd+bwd+allreduce+Adam, "
-                                    "BASELINE configs[2]/[3] shape" if args.workload == "full" else
-                                    "BASELINE configs[1]: SparseConv3d + attribute_module only, fwd+bwd+Adam") +
+            "config": {"workload": ({"full": "full InstanceRefer (lang+attribute+relation+scene) fwd+bwd+allreduce+Adam, "
+                                             "BASELINE configs[2]/[3] shape",
+                                     "attr": "BASELINE configs[1]: SparseConv3d + attribute_module only, fwd+bwd+Adam",
+                                     "stress": "BASELINE configs[4]: dense-scene stress (200k pts, 64 instances, multiview "
+                                               "C0 = 135), full InstanceRefer fwd+bwd+allreduce+Adam"}[args.workload]) +
                                    (", fp32" if args.dtype == "f32" else
                                     ", bf16 operands / fp32 accumulation in the 32/64/128-channel sparse convs "
                                     "(fwd, dgrad, wgrad); fp32 tensors, BatchNorm, stem, heads"),
                        "scenes_per_gpu": B, "global_batch": world * B, "points_per_scene": args.points,
                        "instances": args.instances, "candidates": args.candidates, "tokens": args.tokens,
+                       "input_channels": 7 + args.multiview,
                        "scene_voxels_per_gpu": n_scene_vox, "parallelism": "dp%d" % world, "loss": final_loss,
                        "input_prep": "inline" if args.no_pipeline else "side-stream prefetch of step N+1 during step N"},
             "roofline": roof if roof_error is None else {"error": roof_error},

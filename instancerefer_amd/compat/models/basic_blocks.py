@@ -1,0 +1,4 @@
+"""`models.basic_blocks` of the reference (scripts/train.py:18, models/instancerefer.py:20-34 plug-in names) -> the irx drop-in."""
+from instancerefer_amd.basic_blocks import *  # noqa: F401,F403
+from instancerefer_amd import basic_blocks as _impl
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

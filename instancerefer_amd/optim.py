@@ -1,19 +1,63 @@
-"""Flat-buffer training state: every parameter is a view into ONE fp32 buffer, gradients are gathered into a
-second flat buffer with a single multi-tensor copy, all-reduced once over RCCL/xGMI (ddp.py) and applied by
-ONE fused Adam launch (csrc/irx_optim.hip). Semantics = torch.optim.Adam(lr, betas, eps, weight_decay), the
-optimizer of the reference (scripts/train.py:121)."""
+"""Flat-buffer training state — optimizer AND gradient reducer of the data-parallel path.
+
+Every parameter is a view into ONE fp32 buffer; gradients are gathered into a second flat buffer (the sparse encoders
+write theirs straight into it: "gradient sink"), all-reduced over RCCL/xGMI (torch.distributed backend "nccl" is RCCL
+on ROCm; "gloo" in the CPU tests) and applied by ONE fused Adam launch (csrc/irx_optim.hip). Semantics =
+torch.optim.Adam(lr, betas, eps, weight_decay), the optimizer of the reference (scripts/train.py:121), including its
+rule that a parameter without a gradient is left alone (no weight decay, no moment decay, no step count).
+
+The reference is single-GPU (lib/solver.py:200-205 is a plain backward(); step()), so the multi-rank behaviour is this
+build's own: one process per GPU, scenes sharded by rank (`shard_range`), parameters and buffers broadcast from rank 0
+at construction, gradients summed over ranks (ranks whose shard produced no gradient for a parameter contribute
+zeros) and divided by the world size inside the Adam kernel. The two encoders' gradient ranges (80 % of the 32 MB) are
+reduced as soon as their backward passes are enqueued, on the encoder's own stream, while the rest of the backward still
+runs (`overlap=True`).
+
+Buffer management, gather, all-reduce, broadcast and the state dict work on any device (the world-size-2 gloo test
+runs them on CPU tensors); `step()` is the HIP kernel and raises without a HIP device — there is no CPU optimizer."""
 import torch
 import torch.distributed as dist
 
 from . import _lib
 
 
+def shard_range(n_items, rank, world_size):
+    """Contiguous shard [lo, hi) of n_items for `rank` (DistributedSampler-like, equal sizes required
+    for loss parity with a single-process global batch: each rank divides by its local batch size)."""
+    per = n_items // world_size
+    return rank * per, (rank + 1) * per
+
+
+def broadcast_buffers(module, src=0):
+    """BatchNorm running statistics (and any other buffer) of rank `src` to every rank, one flat collective."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    bufs = [b for b in module.buffers() if b.numel()]
+    if not bufs:
+        return
+    by_dtype = {}
+    for b in bufs:
+        by_dtype.setdefault(b.dtype, []).append(b)
+    for group in by_dtype.values():
+        flat = torch.cat([b.detach().reshape(-1) for b in group])
+        dist.broadcast(flat, src)
+        off = 0
+        with torch.no_grad():
+            for b in group:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+
+
 class FlatAdam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=None, module=None,
+                 broadcast=True, overlap=True):
+        """params: iterable of parameters. module (optional): its buffers are broadcast from rank 0 together with the
+        parameters when world_size > 1 (broadcast=False: the caller guarantees identical replicas)."""
         self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        if dev.type != "cuda":
-            raise RuntimeError("FlatAdam needs parameters on a HIP device")
+        self.device = dev
         # every parameter starts on a 64-byte boundary of the flat buffer (the conv kernels need 16-byte aligned
         # weight pointers for their 16 B/lane loads); the padding elements stay zero in all four buffers
         self.offsets, off = [], 0
@@ -23,7 +67,11 @@ class FlatAdam:
         n = off
         self.n = n
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        # flat_g carries one activity flag per parameter behind the gradients, so that the flags travel inside the
+        # gradient all-reduce (no extra collective): flag > 0 after the reduce <=> some rank produced a gradient
+        self.n_total = n + (len(self.params) + 15) // 16 * 16
+        self.flat_g = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self._flags = self.flat_g[n:n + len(self.params)]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         # gradient slots: views of flat_g with the parameters' shapes (same offsets as the parameters in flat_p)
@@ -42,11 +90,24 @@ class FlatAdam:
         self._direct = set()            # parameter indices whose slot already holds this step's gradient
         self._direct_groups = set()     # producer keys that delivered since the last zero_grad()
         self._gather_cache = {}
-        self._pending = []              # events of sink deliveries not yet waited for
+        self._pending = []              # sink deliveries not yet waited for: (event | (lane, stream), parameter indices)
         self._todo_last = list(range(len(self.params)))
+        self._early = []                # flat ranges already all-reduced this step (encoder slots, overlap mode)
+        self._works = []                # async collectives in flight
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.step_count = 0
+        self.steps = [0] * len(self.params)           # torch.optim.Adam keeps `step` per parameter
+        self._inactive = frozenset()                  # parameters without a gradient this step
+        self._runs_cache = {}
         self.world_size = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.overlap = bool(overlap)
+        if broadcast and self.world_size > 1 and dist.is_initialized():
+            dist.broadcast(self.flat_p, 0)            # replicas start from rank 0's weights whatever the local seeds
+            if module is not None:
+                broadcast_buffers(module, 0)
+
+    @property
+    def step_count(self):
+        return max(self.steps) if self.steps else 0
 
     def zero_grad(self):
         # autograd then hands over freshly computed gradients without an add kernel. Parameters whose gradient went
@@ -59,6 +120,7 @@ class FlatAdam:
                 p.grad = None
         self._direct.clear()
         self._direct_groups.clear()
+        self._early = []
 
     # ---- gradient-sink protocol (see __init__) ----
     def sink_slots(self, key, params):
@@ -76,29 +138,50 @@ class FlatAdam:
         for the scene encoder is not the optimizer's): an event makes gather_grads() wait for them. (Autograd only
         synchronises the streams of AccumulateGrad nodes at the end of backward(), and these parameters have none now.)"""
         self._direct_groups.add(key)
-        self._direct.update(self._index[id(p)] for p in params)
+        idx = [self._index[id(p)] for p in params]
+        self._direct.update(idx)
         if lane is not None:
             # the producer's launches are still being issued by a library thread (encoder_fn.lane_wait): the event is
             # recorded on its stream by gather_grads(), after the lane went idle
-            self._pending.append((lane, torch.cuda.current_stream()))
+            self._pending.append(((lane, torch.cuda.current_stream()), idx))
             return
         ev = torch.cuda.Event()
         ev.record()
-        self._pending.append(ev)
+        self._pending.append(((ev, torch.cuda.current_stream()), idx))
+
+    def _range_of(self, idx):
+        """[lo, hi) of flat elements if the parameters `idx` are one contiguous run of the flat buffer, else None."""
+        idx = sorted(idx)
+        if idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        lo = self.offsets[idx[0]]
+        hi = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.offsets) else self.n
+        return lo, hi
 
     def gather_grads(self):
         """All .grad tensors -> their slots in flat_g with one multi-tensor copy (the padding between slots stays zero;
-        a missing grad counts as zero); slots already filled through the sink protocol are left alone."""
+        a missing grad leaves a zero slot and marks the parameter inactive for this step); slots already filled through
+        the sink protocol are left alone. In overlap mode with world_size > 1, each delivered group that is one
+        contiguous range of flat_g is all-reduced right here, on the producer's stream, before the copy of the remaining
+        gradients is even enqueued."""
         if self._pending:
             cur = torch.cuda.current_stream()
-            for ev in self._pending:
-                if isinstance(ev, tuple):
+            for (ev, stream), idx in self._pending:
+                if not isinstance(ev, torch.cuda.Event):
                     from .sparse.encoder_fn import lane_wait
-                    lane_wait(ev[0])
-                    if ev[1] != cur:
-                        cur.wait_stream(ev[1])
-                else:
+                    lane_wait(ev)
+                rng = self._range_of(idx) if (self.overlap and self.world_size > 1 and dist.is_initialized()) else None
+                if rng is not None:
+                    with torch.cuda.stream(stream):          # ordered behind the producer's kernels, nothing else
+                        if isinstance(ev, torch.cuda.Event):
+                            stream.wait_event(ev)
+                        w = dist.all_reduce(self.flat_g[rng[0]:rng[1]], op=dist.ReduceOp.SUM, async_op=True)
+                    self._works.append(w)
+                    self._early.append(rng)
+                if isinstance(ev, torch.cuda.Event):
                     cur.wait_event(ev)
+                elif stream != cur:
+                    cur.wait_stream(stream)
             self._pending.clear()
         key = frozenset(self._direct_groups)
         todo = self._gather_cache.get(key)
@@ -106,13 +189,20 @@ class FlatAdam:
             todo = [i for i in range(len(self.params)) if i not in self._direct]
             self._gather_cache[key] = todo
         self._todo_last = todo
-        slots, grads = [], []
+        slots, grads, zero, inactive = [], [], [], []
         for i in todo:
             g = self.params[i].grad
-            slots.append(self._slots[i])
-            grads.append(g if g is not None else torch.zeros_like(self.params[i]))
+            if g is None:
+                zero.append(self._slots[i])
+                inactive.append(i)
+            else:
+                slots.append(self._slots[i])
+                grads.append(g)
         if slots:
             torch._foreach_copy_(slots, grads)
+        if zero:
+            torch._foreach_zero_(zero)
+        self._inactive = frozenset(inactive)
         for i in self._direct:           # a producer delivered AND autograd accumulated (second backward): add it
             g = self.params[i].grad
             if g is not None:
@@ -120,18 +210,110 @@ class FlatAdam:
                 self.params[i].grad = None
 
     def all_reduce(self):
-        if self.world_size > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+        """Sum flat_g over the ranks (the division by world_size happens in the Adam kernel). Ranges reduced early
+        (overlap mode) are skipped; the activity flags travel with the gradients so that every rank skips the same
+        parameters (a parameter is inactive only when NO rank produced a gradient for it)."""
+        if self.world_size <= 1 or not dist.is_initialized():
+            return
+        self._flags.fill_(1.0)
+        if self._inactive:
+            self._flags[torch.as_tensor(sorted(self._inactive), device=self.device)] = 0.0
+        rest, lo = [], 0
+        for a, b in sorted(self._early):
+            if a > lo:
+                rest.append((lo, a))
+            lo = max(lo, b)
+        if lo < self.n_total:
+            rest.append((lo, self.n_total))
+        for a, b in rest:
+            self._works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        for w in self._works:
+            w.wait()                     # NCCL: the current stream waits for the collective; gloo: the host does
+        self._works = []
+        self._early = []
+        if self._inactive:
+            # A rank with gradients for everything knows every flag is > 0 and reads nothing back (the common case);
+            # only a rank that skipped something has to learn whether another rank did not (one small D2H, rare)
+            self._inactive = frozenset(i for i, f in enumerate(self._flags.tolist()) if f == 0.0)
+
+    def _runs(self):
+        """Contiguous runs of the flat buffer whose parameters are active and share one step count:
+        [(lo, hi, step)], one fused launch each (one run in all but the steps after a skipped gradient)."""
+        for i in range(len(self.params)):
+            if i not in self._inactive:
+                self.steps[i] += 1
+        key = (self._inactive, tuple(self.steps)) if (self._inactive or len(set(self.steps)) > 1) else None
+        if key is None:
+            return [(0, self.n, self.steps[0])]
+        runs = self._runs_cache.get(key)
+        if runs is None:
+            runs = []
+            for i in range(len(self.params)):
+                if i in self._inactive:
+                    continue
+                lo = self.offsets[i]
+                hi = self.offsets[i + 1] if i + 1 < len(self.offsets) else self.n
+                if runs and runs[-1][1] == lo and runs[-1][2] == self.steps[i]:
+                    runs[-1] = (runs[-1][0], hi, self.steps[i])
+                else:
+                    runs.append((lo, hi, self.steps[i]))
+            if len(self._runs_cache) > 64:
+                self._runs_cache.clear()
+            self._runs_cache[key] = runs
+        return runs
 
     def step(self):
-        self.step_count += 1
-        _lib.call("irx_adam_step", _lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.exp_avg),
-                  _lib.ptr(self.exp_avg_sq), self.n, float(self.lr), float(self.betas[0]), float(self.betas[1]),
-                  float(self.eps), float(self.weight_decay), self.step_count, 1.0 / self.world_size,
-                  _lib.stream_ptr())
+        for lo, hi, step in self._runs():
+            _lib.call("irx_adam_step", _lib.ptr(self.flat_p[lo:hi]), _lib.ptr(self.flat_g[lo:hi]),
+                      _lib.ptr(self.exp_avg[lo:hi]), _lib.ptr(self.exp_avg_sq[lo:hi]), hi - lo, float(self.lr),
+                      float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay), step,
+                      1.0 / self.world_size, _lib.stream_ptr())
 
     def backward_step(self):
         """After loss.backward(): gather -> all-reduce -> Adam."""
         self.gather_grads()
         self.all_reduce()
         self.step()
+
+    # ---- torch.optim.Adam-compatible state (reference scripts/train.py:114-119 calls optimizer.load_state_dict) ----
+    def state_dict(self):
+        """The layout torch.optim.Adam.state_dict() produces for the same parameter list: per-parameter `step`,
+        `exp_avg`, `exp_avg_sq` (own storage, parameter-shaped) and ONE param group."""
+        state = {}
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+            if self.steps[i] == 0:
+                continue                  # torch creates a parameter's state at its first step
+            state[i] = {"step": torch.tensor(float(self.steps[i])),
+                        "exp_avg": self.exp_avg[off:off + p.numel()].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + p.numel()].view_as(p).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Accepts what torch.optim.Adam.state_dict() (any torch since 1.6: `step` int or tensor) or state_dict() above
+        wrote for the same parameter list."""
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if len(ids) != len(self.params):
+            raise ValueError("optimizer state has %d parameters, this model %d" % (len(ids), len(self.params)))
+        g0 = groups[0]
+        self.lr, self.betas = float(g0["lr"]), tuple(float(b) for b in g0["betas"])
+        self.eps, self.weight_decay = float(g0["eps"]), float(g0["weight_decay"])
+        if g0.get("amsgrad"):
+            raise ValueError("amsgrad state is not supported")
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.steps = [0] * len(self.params)
+        with torch.no_grad():
+            for pos, pid in enumerate(ids):
+                st = sd["state"].get(pid)
+                if st is None:
+                    continue
+                p, off = self.params[pos], self.offsets[pos]
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError("optimizer state %d has shape %s, parameter %s" % (pid, tuple(st["exp_avg"].shape), tuple(p.shape)))
+                self.steps[pos] = int(float(st["step"]))
+                self.exp_avg[off:off + p.numel()].view_as(p).copy_(st["exp_avg"])
+                self.exp_avg_sq[off:off + p.numel()].view_as(p).copy_(st["exp_avg_sq"])

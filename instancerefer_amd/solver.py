@@ -3,8 +3,13 @@
 Same contract: iterate dataloaders that yield reference-format `data_dict`s (lib/dataset.py collate), move the tensor
 keys to the GPU (lib/solver.py:242-245), forward -> get_loss -> backward -> step, get_eval for the metrics, log every
 `verbose` iterations, save `model_last.pth` every epoch, `model.pth` on the best Acc@0.25 and `checkpoint.tar`
-({epoch, model_state_dict, optimizer_state_dict}) at the end — the reference's file names and state-dict keys, so
-checkpoints are interchangeable with scripts/eval.py:54-55 / scripts/train.py:114-119.
+({epoch, model_state_dict, optimizer_state_dict}) at the end — the reference's file names and state-dict keys;
+`optimizer_state_dict` is in torch.optim.Adam.state_dict() layout (optim.FlatAdam.state_dict), so the reference's
+`optimizer.load_state_dict(checkpoint["optimizer_state_dict"])` (scripts/train.py:114-119) reads it and
+`Solver(use_checkpoint=...)` / `Solver.load_checkpoint` resumes from either side's file. The scalars the reference
+sends to tensorboardX (lib/solver.py:344-366: loss/{loss,ref_loss,lang_loss,seg_loss}, score/{lang_acc,ref_acc,seg_acc,
+iou_rate_0.25,iou_rate_0.5}) go to `scalars.jsonl` under the same tags (and to a SummaryWriter when tensorboard is
+importable; it is not in this image).
 
 Differences, all below the API: one process per GPU with a single flat-gradient RCCL all-reduce and one fused Adam
 launch per step (optim.FlatAdam); rank 0 alone logs and writes files; timers are taken around device syncs only at
@@ -47,14 +52,17 @@ def to_device(data_dict, device):
 
 class Solver:
     def __init__(self, model, config, dataloader, lr=1e-3, weight_decay=1e-5, lr_decay_step=(15, 20), lr_decay_rate=0.1,
-                 out_dir=None, verbose=20, device=None):
+                 out_dir=None, verbose=20, device=None, use_checkpoint=None):
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.model = model.to(self.device)
         self.config = config
         self.dataloader = dataloader               # {"train": iterable, "val": iterable (optional)}
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.optimizer = FlatAdam(self.model.parameters(), lr=lr, weight_decay=weight_decay, world_size=self.world)
+        # world > 1: rank 0's parameters and buffers are broadcast, so per-rank seeds cannot make the replicas diverge
+        self.optimizer = FlatAdam(self.model.parameters(), lr=lr, weight_decay=weight_decay, world_size=self.world,
+                                  module=self.model)
+        self.start_epoch = 0
         self.base_lr, self.lr_decay_step, self.lr_decay_rate = lr, tuple(lr_decay_step or ()), lr_decay_rate
         self.out_dir = out_dir
         self.verbose = verbose
@@ -63,6 +71,15 @@ class Solver:
         self.global_iter = 0
         if self.rank == 0 and out_dir:
             os.makedirs(out_dir, exist_ok=True)
+        self._writer = None
+        if self.rank == 0 and out_dir:
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                self._writer = SummaryWriter(os.path.join(out_dir, "tensorboard"))
+            except Exception:                      # tensorboard is absent in this image: scalars.jsonl only
+                self._writer = None
+        if use_checkpoint:
+            self.load_checkpoint(use_checkpoint)
 
     # ------------------------------------------------------------------------------------------
     def _say(self, msg):
@@ -71,6 +88,35 @@ class Solver:
             if self.out_dir:
                 with open(os.path.join(self.out_dir, "log.txt"), "a") as f:
                     f.write(msg + "\n")
+
+    def _scalars(self, phase, rec):
+        """lib/solver.py:344-366 (_dump_log): the same tags, one JSON line per logging point."""
+        if self.rank != 0 or not self.out_dir:
+            return
+        tags = {}
+        for k in ("loss", "ref_loss", "lang_loss", "seg_loss"):
+            if k in rec:
+                tags["loss/" + k] = rec[k]
+        for k, src in (("lang_acc", "lang_acc"), ("ref_acc", "ref_acc"), ("seg_acc", "seg_acc"),
+                       ("iou_rate_0.25", "iou_rate_25"), ("iou_rate_0.5", "iou_rate_5")):
+            v = rec.get(src, rec.get(k))
+            if v is not None:
+                tags["score/" + k] = float(v)
+        import json
+        with open(os.path.join(self.out_dir, "scalars.jsonl"), "a") as f:
+            f.write(json.dumps({"phase": phase, "iter": self.global_iter, **tags}) + "\n")
+        if self._writer is not None:
+            for t, v in tags.items():
+                self._writer.add_scalar("%s/%s" % (phase, t), v, self.global_iter)
+
+    def load_checkpoint(self, path):
+        """Resume (reference scripts/train.py:114-119): checkpoint.tar written by this Solver OR by the reference's."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(ck["model_state_dict"])      # in place: parameters stay views of the flat buffer
+        self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        self.base_lr = self.optimizer.lr
+        self.start_epoch = int(ck.get("epoch", 0))
+        return ck
 
     def _forward(self, data_dict):
         return get_loss(self.model(to_device(data_dict, self.device)), self.config)
@@ -97,7 +143,9 @@ class Solver:
                            lang_acc=float(ev["lang_acc"]), ref_acc=float(np.mean(ev["ref_acc"])),
                            iou_rate_25=ev["ref_iou_rate_0.25"], iou_rate_5=ev["ref_iou_rate_0.5"],
                            scenes_per_sec=self.world * seen / dt)
+                rec["seg_acc"] = float(data_dict["seg_acc"].detach()) if "seg_acc" in data_dict else None
                 self.log["train"].append(rec)
+                self._scalars("train", rec)
                 self._say("[train] epoch %d iter %d loss %.4f (ref %.4f lang %.4f seg %.4f) ref_acc %.3f Acc@.25 %.3f "
                           "%.1f scenes/s" % (epoch, rec["iter"], rec["loss"], rec["ref_loss"], rec["lang_loss"],
                                              rec["seg_loss"], rec["ref_acc"], rec["iou_rate_25"], rec["scenes_per_sec"]))
@@ -121,12 +169,13 @@ class Solver:
         rec = {"epoch": epoch, "ref_acc": s[0] / max(s[1], 1), "iou_rate_0.25": s[2] / max(s[4], 1),
                "iou_rate_0.5": s[3] / max(s[4], 1)}
         self.log["val"].append(rec)
+        self._scalars("val", rec)
         self._say("[val] epoch %d ref_acc %.4f Acc@0.25 %.4f Acc@0.5 %.4f" % (epoch, rec["ref_acc"], rec["iou_rate_0.25"],
                                                                            rec["iou_rate_0.5"]))
         return rec
 
     def __call__(self, epochs):
-        for epoch in range(epochs):
+        for epoch in range(self.start_epoch, epochs):
             self.train_epoch(epoch)
             self.save("model_last.pth")
             rec = self.validate(epoch)
@@ -142,10 +191,8 @@ class Solver:
 
     def finish(self, epoch):
         if self.rank == 0 and self.out_dir:
-            o = self.optimizer
             torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(),
-                        "optimizer_state_dict": {"flat_exp_avg": o.exp_avg, "flat_exp_avg_sq": o.exp_avg_sq,
-                                                 "step": o.step_count, "lr": o.lr}},
+                        "optimizer_state_dict": self.optimizer.state_dict()},
                        os.path.join(self.out_dir, "checkpoint.tar"))
             with open(os.path.join(self.out_dir, "best.txt"), "w") as f:
                 for k, v in self.best.items():

@@ -7,6 +7,8 @@ centred on the origin with variant='centred', to exercise negative voxel coordin
 points on floor + walls, the rest on the faces of I axis-aligned boxes resting on the floor; features
 xyz + normalised rgb + height (C0 = 7); every instance resampled to 1024 points; class = id mod 18 except
 that the first `c` instances share the target class; a T-token utterance of N(0, 0.4) GloVe-like rows.
+`multiview=128` inserts the ENet multiview features of the stress config (lib/dataset.py:112-118: concatenated after the
+colours, before the height -> C0 = 135; synthetic: N(0,1) clipped at 0, like post-ReLU activations).
 """
 import numpy as np
 import torch
@@ -23,7 +25,7 @@ def _box_surface(rng, n, centre, size):
 
 
 def make_scene(seed, num_points=50000, num_instances=8, num_candidates=4, target_class=4, tokens=30,
-               points_per_instance=1024, variant="corner", num_classes=18):
+               points_per_instance=1024, variant="corner", num_classes=18, multiview=0):
     rng = np.random.default_rng(seed)
     room = np.array([8.0, 10.0, 3.0])
     n_bg = num_points // 2
@@ -55,7 +57,10 @@ def make_scene(seed, num_points=50000, num_instances=8, num_candidates=4, target
     rgb = (rng.uniform(0, 255, (num_points, 3)) - MEAN_COLOR_RGB) / 256.0
     floor = np.percentile(xyz[:, 2], 0.99)
     height = xyz[:, 2:3] - floor
-    pc = np.concatenate([xyz, rgb, height], 1)                            # (P, 7) float64
+    cols = [xyz, rgb]
+    if multiview:
+        cols.append(np.maximum(rng.standard_normal((num_points, multiview)), 0.0))
+    pc = np.concatenate(cols + [height], 1)                               # (P, 7 [+ multiview]) float64
 
     instance_points, instance_obbs, instance_class = [], [], []
     for j in range(num_instances):

@@ -113,3 +113,58 @@ def test_conv_linearity_and_adjoints_full_size(lib, scene, level, cin, cout):
     ref = max(abs(a), 1.0)
     # the three numbers are sums of ~1e9 fp32 products each computed in a different order
     assert abs(a - b) <= 2e-5 * ref + 1e-2 and abs(a - c) <= 2e-5 * ref + 1e-2, (a, b, c)
+
+
+@pytest.mark.parametrize("which", ["scene", "candidates"])
+def test_encoder_fwd_bwd_equals_c_port_at_full_size(lib, which):
+    """BASELINE.json's FULL sizes against the C/OpenMP port (oracle/csrc/spconv_cpu.c — itself pinned to the Python oracle
+    in tests/test_oracle_cpu.py; restates torchsparse's gather-GEMM-scatter conv behind reference
+    models/basic_blocks.py:59-95): the scene encoder on 16 scenes x 50 k points (~490 k voxels at 5 cm) and the candidate
+    encoder on 64 candidates x 1024 points at 2 cm; train-mode BatchNorm over the whole batch, global max-pool, loss =
+    <pooled, g>. Pooled features <= 1e-4 absolute; each of the 39 parameter gradients <= 1e-3 of its own max-norm
+    (floor: 1e-3 of the largest gradient, for the vanishing ones)."""
+    from oracle import cpu_port
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.basic_blocks import SparseConvEncoder
+    from instancerefer_amd.sparse import nn as spnn
+    from instancerefer_amd.sparse.utils import voxelize
+    dev = torch.device("cuda")
+    if which == "scene":
+        dd = S.make_batch(16, seed=321)
+        pts = [torch.from_numpy(p) for p in dd["scene_points"]]
+        voxel, nb = 0.05, 16
+    else:
+        dd = S.make_batch(16, seed=321, num_points=20000)
+        pts = [torch.from_numpy(p) for ps in dd["instance_points"] for p in ps[:4]]
+        voxel, nb = 0.02, 64
+    allp = torch.cat(pts).to(dev)
+    batch = torch.cat([torch.full((p.shape[0],), i, dtype=torch.int32) for i, p in enumerate(pts)]).to(dev)
+    st = voxelize(allp[:, :3].contiguous(), allp.float(), batch, [voxel] * 3, nb)
+    assert st.F.shape[0] > (300_000 if which == "scene" else 40_000)
+    enc = SparseConvEncoder(7)
+    enc.load_state_dict(S.seeded_state_dict(enc, 4242))
+    enc = enc.to(dev).train()
+    g = torch.from_numpy(np.random.default_rng(5).standard_normal((nb, 128)).astype(np.float32))
+    pooled = spnn.GlobalMaxPooling()(enc(st))
+    (pooled * g.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    params, order = cpu_port.pack_encoder_params({k: v.detach().cpu() for k, v in enc.state_dict().items()}, "")
+    closs, cpooled, cgrads = cpu_port.encoder_fwd_bwd(st.C.cpu().numpy(), st.F.detach().cpu().numpy(), nb, params, g.numpy())
+    err = float(np.abs(pooled.detach().cpu().numpy() - cpooled).max())
+    assert err <= 1e-4, ("pooled", err)
+    named = dict(enc.named_parameters())
+    refs, off = {}, 0
+    for conv, bn in order:
+        for name in (conv + ".kernel", bn + ".weight", bn + ".bias"):
+            n = named[name].numel()
+            refs[name] = cgrads[off:off + n]
+            off += n
+    assert off == cgrads.size and len(refs) == 39
+    top = max(float(np.abs(r).max()) for r in refs.values())
+    bad = {}
+    for name, ref in refs.items():
+        got = named[name].grad.detach().cpu().numpy().reshape(-1)
+        e = float(np.abs(got - ref).max())
+        if e > 1e-3 * max(float(np.abs(ref).max()), 1e-3 * top):
+            bad[name] = (e, float(np.abs(ref).max()))
+    assert not bad, bad

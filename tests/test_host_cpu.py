@@ -59,40 +59,120 @@ def test_synthetic_is_deterministic_and_shaped():
     assert c["scene_points"][0][:, 0].min() < 0
 
 
+def _toy():
+    return torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 1),
+                               torch.nn.Linear(1, 3))          # [4] never receives a gradient on any rank
+
+
 def _ddp_worker(rank, world, port, out):
+    """The PRODUCT reducer (optim.FlatAdam: what bench.py and solver.Solver use) on CPU tensors over gloo: broadcast of
+    parameters + buffers at construction, gather (with a gradient-sink delivery), flat all-reduce, activity flags."""
     import torch.distributed as dist
-    from instancerefer_amd.ddp import FlatGradAllReduce, shard_range
+    from instancerefer_amd.optim import FlatAdam, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)             # replicas start DIFFERENT: the constructor must make them equal
+    model = _toy()
+    with torch.no_grad():
+        model[1].running_mean.add_(rank + 1.0)
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, module=model)
+    out["p0_%d" % rank] = opt.flat_p.clone()
+    out["rm_%d" % rank] = model[1].running_mean.clone()
     torch.manual_seed(0)
-    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1))
     x = torch.randn(8, 8)
-    red = FlatGradAllReduce(model.parameters())
     lo, hi = shard_range(8, rank, world)
-    red.zero_grad()
+    opt.zero_grad()
     if rank == 1:
-        pass                                  # a rank with an empty shard still joins with zero grads
+        pass                                  # a rank whose shard yields no gradient still joins, with zeros
     else:
-        model(x[lo:hi]).mean().backward()
-    red.all_reduce()
-    out[rank] = red.flat.clone()
+        # parameters 0 and 1 (first Linear) arrive through the gradient-sink protocol, the rest through autograd
+        y = model[3](model[2](model[1](model[0](x[lo:hi])))).mean()
+        g = torch.autograd.grad(y, list(model.parameters())[:4] + list(model[3].parameters()))
+        slots = opt.sink_slots("toy", list(model[0].parameters()))
+        for s, gg in zip(slots, g[:2]):
+            s.copy_(gg)
+        opt._direct_groups.add("toy")
+        opt._direct.update([0, 1])
+        for p, gg in zip(list(model[1].parameters()) + list(model[3].parameters()), g[2:]):
+            p.grad = gg
+    opt.gather_grads()
+    out["inactive_local_%d" % rank] = sorted(opt._inactive)
+    opt.all_reduce()
+    out["g_%d" % rank] = opt.flat_g[:opt.n].clone()
+    out["inactive_%d" % rank] = sorted(opt._inactive)
+    try:
+        opt.step()
+        out["step_%d" % rank] = "ran"
+    except RuntimeError as e:                 # the optimizer kernel is HIP-only: it must fail loudly on CPU tensors
+        out["step_%d" % rank] = str(e)
     dist.destroy_process_group()
 
 
-def test_flat_grad_allreduce_gloo_world2():
+def test_flat_adam_reducer_gloo_world2():
     mp.set_start_method("spawn", force=True)
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29000 + os.getpid() % 2000
     mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
-    assert torch.equal(out[0], out[1])
+    # identical replicas after construction, equal to rank 0's initialisation
+    assert torch.equal(out["p0_0"], out["p0_1"]) and torch.equal(out["rm_0"], out["rm_1"])
+    torch.manual_seed(100)
+    ref_model = _toy()
+    ref_flat = torch.cat([torch.nn.functional.pad(p.detach().reshape(-1), (0, -p.numel() % 16)) for p in ref_model.parameters()])
+    assert torch.equal(out["p0_0"], ref_flat)
+    assert torch.equal(out["rm_0"], ref_model[1].running_mean + 1.0)
+    # summed gradients: rank 1 contributed zeros; both ranks hold the same buffer
+    assert torch.equal(out["g_0"], out["g_1"])
+    ref_model.train()
     torch.manual_seed(0)
-    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1))
     x = torch.randn(8, 8)
-    model(x[0:4]).mean().backward()
-    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()]) / 2     # rank 1 contributed zeros
-    assert torch.allclose(out[0], ref, atol=1e-7)
+    ref_model[3](ref_model[2](ref_model[1](ref_model[0](x[0:4])))).mean().backward()
+    ref = torch.cat([torch.nn.functional.pad((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1),
+                                             (0, -p.numel() % 16)) for p in ref_model.parameters()])
+    assert torch.allclose(out["g_0"], ref, atol=1e-7)
+    # rank 1 produced nothing locally but learns that rank 0 did; the unused Linear is inactive everywhere
+    assert out["inactive_local_1"] == list(range(8)) and out["inactive_local_0"] == [6, 7]
+    assert out["inactive_0"] == out["inactive_1"] == [6, 7]
+    assert "HIP device" in out["step_0"] and "HIP device" in out["step_1"]
+
+
+def test_flat_adam_state_dict_is_torch_adam_layout():
+    """checkpoint.tar["optimizer_state_dict"] (reference scripts/train.py:114-119 feeds it to
+    torch.optim.Adam.load_state_dict): FlatAdam.state_dict() loads into torch.optim.Adam over the same parameter list
+    and torch.optim.Adam.state_dict() loads into FlatAdam, values preserved."""
+    from instancerefer_amd.optim import FlatAdam
+    torch.manual_seed(1)
+    model = _toy()
+    opt = FlatAdam(model.parameters(), lr=2e-3, weight_decay=1e-5)
+    opt.exp_avg.uniform_(-1, 1)
+    opt.exp_avg_sq.uniform_(0, 1)
+    opt.steps = [3, 3, 3, 3, 3, 3, 0, 0]
+    sd = opt.state_dict()
+    twin = _toy()
+    ta = torch.optim.Adam(twin.parameters(), lr=1.0)
+    ta.load_state_dict(sd)
+    assert ta.param_groups[0]["lr"] == 2e-3 and ta.param_groups[0]["weight_decay"] == 1e-5
+    tp = list(twin.parameters())
+    for i, (p, off) in enumerate(zip(opt.params, opt.offsets)):
+        if i >= 6:
+            assert tp[i] not in ta.state
+            continue
+        st = ta.state[tp[i]]
+        assert float(st["step"]) == 3.0
+        assert torch.equal(st["exp_avg"], opt.exp_avg[off:off + p.numel()].view_as(p))
+        assert torch.equal(st["exp_avg_sq"], opt.exp_avg_sq[off:off + p.numel()].view_as(p))
+    # and back: a real torch.optim.Adam state (after two steps) into a fresh FlatAdam
+    for _ in range(2):
+        ta.zero_grad()
+        twin[3](twin[2](twin[1](twin[0](torch.randn(4, 8))))).mean().backward()
+        ta.step()
+    fresh = FlatAdam(_toy().parameters())
+    fresh.load_state_dict(ta.state_dict())
+    assert fresh.steps == [5, 5, 5, 5, 5, 5, 0, 0] and fresh.lr == 2e-3
+    for i, (p, off) in enumerate(zip(fresh.params, fresh.offsets)):
+        if i < 6:
+            assert torch.equal(fresh.exp_avg[off:off + p.numel()].view_as(p), ta.state[tp[i]]["exp_avg"])
 
 
 @pytest.mark.parametrize("case", ["plain", "augmented"])

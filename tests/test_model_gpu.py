@@ -123,16 +123,16 @@ def test_encoder_executor_equals_per_layer_path(lib):
         assert torch.equal(res["fused"][3][n], res["layers"][3][n]), n
 
 
-def _oracle_and_product(cfg, seed):
+def _oracle_and_product(cfg, seed, c0=7):
     from instancerefer_amd import synthetic as S
     from instancerefer_amd.instancerefer import InstanceRefer
     from instancerefer_amd.loss_helper import DatasetConfig, get_loss
     from oracle.model_ref import InstanceRefer as OracleModel, oracle_data_dict
     dev = torch.device("cuda")
-    model = InstanceRefer(7, S.default_args())
+    model = InstanceRefer(c0, S.default_args())
     sd = S.seeded_state_dict(model, seed)
     model.load_state_dict(sd)
-    oracle = OracleModel(7, S.default_args())
+    oracle = OracleModel(c0, S.default_args())
     oracle.load_state_dict(sd)
     for m in list(model.modules()) + list(oracle.modules()):
         if isinstance(m, torch.nn.Dropout):
@@ -169,6 +169,83 @@ def test_full_model_vs_cpu_oracle_negative_coords_and_ragged(lib, variant):
             continue
         exp = float(p.grad.double().norm())
         got = float(gp[n].grad.double().norm())
+        assert abs(got - exp) <= 2e-3 * max(exp, 1e-3 * total), (n, got, exp)
+
+
+def test_full_model_multiview_c135_vs_cpu_oracle(lib):
+    """BASELINE configs[4]'s input: use_multiview adds 128 ENet channels (reference scripts/train.py:74-75,
+    lib/dataset.py:112-118) -> C0 = 135 for both sparse stems, the relation node features (135 + 18) and the edge MLPs.
+    HIP path vs the CPU oracle at that width: forward 1e-4 absolute, gradient norms 2e-3."""
+    cfg = dict(batch_size=2, seed=950, num_points=4000, num_instances=5, num_candidates=[3, 2], tokens=[20, 11],
+               points_per_instance=200, multiview=128)
+    model, oracle, dd, od = _oracle_and_product(cfg, 78, c0=135)
+    assert model.scene.net.stem[0].net[0].kernel.shape == (27, 135, 32)
+    assert list(dd["num_filtered_objs"]) == list(od["num_filtered_objs"]) == [3, 2]
+    for k in ("lang_scores", "obj_feats", "attribute_scores", "relation_scores", "scene_scores", "seg_scores",
+              "vis_atten", "loss", "ref_loss", "lang_loss", "seg_loss"):
+        err = float((dd[k].detach().cpu() - od[k].detach()).abs().max())
+        assert err <= 1e-4, (k, err)
+    dd["loss"].backward()
+    od["loss"].backward()
+    gp = dict(model.named_parameters())
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in oracle.parameters() if p.grad is not None)))
+    for n, p in oracle.named_parameters():
+        if p.grad is None:
+            continue
+        exp = float(p.grad.double().norm())
+        got = float(gp[n].grad.double().norm())
+        assert abs(got - exp) <= 2e-3 * max(exp, 1e-3 * total), (n, got, exp)
+
+
+def test_use_gt_lang_false_takes_the_argmax_branch(lib):
+    """`use_gt_lang: False` (reference models/attribute_module.py:93-95, relation_module.py:86-88): the candidates are the
+    instances of the class the language classifier PREDICTS, so nothing can be prepared ahead of the language module.
+    The instances are relabelled so that the predicted class of each utterance has 3 / 2 / 1 members; HIP path vs the
+    CPU oracle: same selection, forward 1e-4, gradient norms 2e-3."""
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.instancerefer import InstanceRefer
+    from instancerefer_amd.loss_helper import DatasetConfig, get_loss
+    from oracle.model_ref import InstanceRefer as OracleModel, oracle_data_dict
+    dev = torch.device("cuda")
+    args = S.default_args(use_gt_lang=False)
+    model = InstanceRefer(7, args)
+    sd = S.seeded_state_dict(model, 91)
+    model.load_state_dict(sd)
+    oracle = OracleModel(7, S.default_args(use_gt_lang=False))
+    oracle.load_state_dict(sd)
+    for m in list(model.modules()) + list(oracle.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.to(dev).train()
+    oracle.train()
+    cfg = dict(batch_size=3, seed=1200, num_points=4000, num_instances=5, num_candidates=[3, 2, 1], tokens=[12, 30, 7],
+               points_per_instance=200)
+    oracle.eval()
+    with torch.no_grad():
+        pred = oracle.lang(oracle_data_dict(S.make_batch(**dict(cfg))))["lang_scores"].argmax(1).tolist()
+    oracle.train()
+    assert pred != [4, 4, 4], "the classifier must disagree with the ground-truth class somewhere"
+
+    def batch():
+        host = S.make_batch(**dict(cfg))
+        for i, c in enumerate(cfg["num_candidates"]):
+            host["instance_class"][i] = [pred[i] if j < c else (pred[i] + 1 + j) % 18 for j in range(cfg["num_instances"])]
+        return host
+    dd = get_loss(model(S.to_device(batch(), dev)), DatasetConfig())
+    od = get_loss(oracle(oracle_data_dict(batch())), DatasetConfig())
+    assert list(dd["num_filtered_objs"]) == list(od["num_filtered_objs"]) == [3, 2, 1]
+    for k in ("lang_scores", "obj_feats", "attribute_scores", "relation_scores", "scene_scores", "seg_scores", "loss",
+              "ref_loss"):
+        err = float((dd[k].detach().cpu() - od[k].detach()).abs().max())
+        assert err <= 1e-4, (k, err)
+    dd["loss"].backward()
+    od["loss"].backward()
+    gp = dict(model.named_parameters())
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in oracle.parameters() if p.grad is not None)))
+    for n, p in oracle.named_parameters():
+        if p.grad is None:
+            continue
+        exp, got = float(p.grad.double().norm()), float(gp[n].grad.double().norm())
         assert abs(got - exp) <= 2e-3 * max(exp, 1e-3 * total), (n, got, exp)
 
 
@@ -221,8 +298,25 @@ def test_solver_trains_and_writes_reference_style_checkpoints(lib, tmp_path):
     assert "attribute.net.stem.0.net.0.kernel" in sd and "scene.to_bev.1.kernel" in sd and "lang.gru.weight_ih_l0" in sd
     fresh = InstanceRefer(7, S.default_args())
     fresh.load_state_dict(sd)
-    ck = torch.load(os.path.join(str(tmp_path), "checkpoint.tar"), map_location="cpu")
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint.tar"), map_location="cpu", weights_only=False)
     assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict"}
+    # the reference resumes with torch.optim.Adam(model.parameters()).load_state_dict(...) (scripts/train.py:114-119)
+    ta = torch.optim.Adam(fresh.parameters(), lr=1.0)
+    ta.load_state_dict(ck["optimizer_state_dict"])
+    assert ta.param_groups[0]["lr"] == 1e-3 and len(ta.state) == len(list(fresh.parameters()))
+    assert all(float(s["step"]) == 6.0 for s in ta.state.values())
+    assert os.path.exists(os.path.join(str(tmp_path), "scalars.jsonl"))
+    # and this Solver resumes from it: same moments, same step counts, next epoch
+    again = InstanceRefer(7, S.default_args())
+    s2 = Solver(again, DatasetConfig(), {"train": Repeat(2, 3, seed=40, **kw)}, lr=1e-3, out_dir=str(tmp_path / "resumed"),
+                verbose=1, use_checkpoint=os.path.join(str(tmp_path), "checkpoint.tar"))
+    assert s2.start_epoch == 1 and s2.optimizer.steps == solver.optimizer.steps
+    assert torch.equal(s2.optimizer.exp_avg, solver.optimizer.exp_avg) and torch.equal(s2.optimizer.flat_p, solver.optimizer.flat_p)
+    for m in again.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    s2(2)
+    assert len(s2.log["train"]) == 2 and s2.log["train"][0]["loss"] < losses[0]
 
 
 def test_pipelined_training_steps_equal_inline_steps(lib):

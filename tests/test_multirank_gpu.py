@@ -1,0 +1,138 @@
+"""BASELINE configs[3] (data-parallel training) on ONE GPU: two ranks share cuda:0 and exchange over gloo (RCCL needs one
+device per rank), driving the PRODUCT path — optim.FlatAdam.backward_step with the encoders' gradient sinks, the
+asynchronous library lanes, the early all-reduce of the encoder ranges and the rank-0 broadcast at construction.
+
+The reference has no multi-GPU path (lib/solver.py:200-205 is a plain backward(); step()), so the oracle here is the
+single-rank run of the same code on the concatenated batch."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(num_points=5000, num_instances=5, points_per_instance=160)
+
+
+def _model(seed, dev):
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.instancerefer import InstanceRefer
+    torch.manual_seed(seed)
+    model = InstanceRefer(7, S.default_args())
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return model.to(dev)
+
+
+def _step(model, opt, batch, dev):
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.loss_helper import DatasetConfig, get_loss
+    opt.zero_grad()
+    dd = get_loss(model(S.to_device(batch, dev)), DatasetConfig())
+    dd["loss"].backward()
+    opt.gather_grads()
+    opt.all_reduce()
+    g = opt.flat_g[:opt.n].clone()
+    opt.step()
+    return float(dd["loss"].detach()), g
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from instancerefer_amd import _build, _lib, synthetic as S
+    from instancerefer_amd.optim import FlatAdam
+    from instancerefer_amd.sparse import encoder_fn
+    _build.build_lib()
+    _lib.load()
+    res = {}
+    # ---- A: train mode, per-rank seeds (the constructor must equalise the replicas), one rank without candidates ----
+    model = _model(500 + rank, dev).train()
+    with torch.no_grad():
+        model.scene.net.stem[0].net[1].running_mean.add_(float(rank))
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, module=model)
+    res["p_init"] = opt.flat_p.clone().cpu()
+    res["rm_init"] = model.scene.net.stem[0].net[1].running_mean.clone().cpu()
+    cands = [[3, 2], [1, 0]][rank]          # rank 1: no scene with >= 2 candidates -> empty score tensors, still joins
+    losses = []
+    for it in range(3):
+        batch = S.make_batch(2, seed=700 + 10 * it + 2 * rank, num_candidates=cands, **KW)
+        loss, g = _step(model, opt, batch, dev)
+        losses.append(loss)
+        if it == 0:
+            res["g_first"] = g.cpu()
+            res["delivered"] = len(opt._direct)
+    torch.cuda.synchronize()
+    res["losses"] = losses
+    res["p_final"] = opt.flat_p.clone().cpu()
+    res["steps"] = list(opt.steps)
+    index = {id(p): n for n, p in model.named_parameters()}
+    res["skipped"] = [index[id(p)] for p, s in zip(opt.params, opt.steps) if s != 3]
+    res["async"] = bool(encoder_fn.ASYNC)
+    # ---- B: BatchNorm in eval mode -> every quantity is per scene: 2 ranks x 2 scenes == 1 rank x 4 scenes ----
+    model2 = _model(900, dev).eval()
+    opt2 = FlatAdam(model2.parameters(), lr=1e-3, weight_decay=1e-5, module=model2)
+    sd0 = {k: v.clone() for k, v in model2.state_dict().items()}
+    batch = S.make_batch(2, seed=800 + 2 * rank, num_candidates=[[3, 2], [2, 4]][rank], **KW)
+    _, g2 = _step(model2, opt2, batch, dev)
+    res["g_eval_2rank"] = (g2 / world).cpu()
+    res["p_eval_2rank"] = opt2.flat_p.clone().cpu()
+    dist.barrier()
+    if rank == 0:
+        model1 = _model(901, dev).eval()
+        model1.load_state_dict(sd0)
+        opt1 = FlatAdam(model1.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1, broadcast=False)
+        batch = S.make_batch(4, seed=800, num_candidates=[3, 2, 2, 4], **KW)
+        _, g1 = _step(model1, opt1, batch, dev)
+        res["g_eval_1rank"] = g1.cpu()
+    torch.cuda.synchronize()
+    torch.save(res, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_two_ranks(tmp_path, timeout=420):
+    mp.set_start_method("spawn", force=True)
+    port = 29000 + (os.getpid() * 7 + int(time.time())) % 2000
+    ctx = mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=False, start_method="spawn")
+    deadline = time.time() + timeout
+    try:
+        while not ctx.join(timeout=5):
+            if time.time() > deadline:
+                raise TimeoutError("two-rank run exceeded %d s" % timeout)
+    finally:
+        for p in ctx.processes:              # exact PIDs we started, never a pattern
+            if p.is_alive():
+                p.kill()
+    return [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(2)]
+
+
+def test_two_ranks_share_one_gpu_product_path(lib, tmp_path):
+    r0, r1 = _run_two_ranks(tmp_path)
+    # construction: rank 0's parameters AND buffers everywhere, whatever the local seeds were
+    assert torch.equal(r0["p_init"], r1["p_init"]) and torch.equal(r0["rm_init"], r1["rm_init"])
+    # training: the summed gradient is the same buffer on both ranks -> bit-identical parameters after 3 steps
+    assert torch.equal(r0["g_first"], r1["g_first"])
+    assert torch.equal(r0["p_final"], r1["p_final"])
+    assert not torch.equal(r0["p_final"], r0["p_init"]) and bool(torch.isfinite(r0["p_final"]).all())
+    assert all(np.isfinite(r0["losses"] + r1["losses"]))
+    assert r0["async"] and r0["delivered"] == 78      # both encoders delivered through the sink (lanes on)
+    assert r1["delivered"] == 39                      # rank 1 never ran its candidate encoder: scene encoder only
+    # rank 1 had no gradient for the attribute / relation parameters but rank 0 did: nobody skips them
+    assert r0["steps"] == r1["steps"] and r0["skipped"] == r1["skipped"]
+    assert not [n for n in r0["skipped"] if n.startswith(("attribute.", "relation.", "scene.", "lang."))], r0["skipped"]
+    # 2 ranks x 2 scenes == 1 rank x 4 scenes when BatchNorm does not couple the scenes (fp32 summation order differs)
+    g2, g1 = r0["g_eval_2rank"], r0["g_eval_1rank"]
+    assert torch.equal(r0["g_eval_2rank"], r1["g_eval_2rank"]) and torch.equal(r0["p_eval_2rank"], r1["p_eval_2rank"])
+    scale = float(g1.abs().max())
+    assert scale > 0 and float((g2 - g1).abs().max()) <= 2e-4 * scale, (float((g2 - g1).abs().max()), scale)
+    assert abs(float(g2.double().norm()) - float(g1.double().norm())) <= 1e-4 * float(g1.double().norm())

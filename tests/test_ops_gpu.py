@@ -107,7 +107,8 @@ def test_downsample_bit_exact(lib, clouds):
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride", [(7, 32, 3, 1), (32, 64, 2, 2), (64, 64, 3, 1),
-                                                (64, 128, 2, 2), (128, 128, 3, 1), (20, 48, 3, 1)])
+                                                (64, 128, 2, 2), (128, 128, 3, 1), (20, 48, 3, 1),
+                                                (135, 32, 3, 1)])     # 135 = multiview stem (scripts/train.py:74-75)
 def test_conv_fwd_bwd(lib, clouds, cin, cout, ks, stride):
     import oracle.torchsparse.nn as ospnn
     from oracle.torchsparse import SparseTensor as OT
@@ -512,3 +513,70 @@ def test_coordinate_ops_on_random_ragged_batches(lib, seed):
         rows = np.nonzero(nbr_h[k, :lv.n] >= 0)[0]
         assert c[k] == len(rows) and np.array_equal(ol[k, :c[k]].cpu().numpy(), rows)
         assert np.array_equal(il[k, :c[k]].cpu().numpy(), nbr_h[k, :lv.n][rows])
+
+
+def test_pyg_surface_knn_and_message_passing(lib):
+    """instancerefer_amd.graph (the torch_geometric-shaped surface, reference models/basic_blocks.py:7,98-133):
+    knn -> the oracle's [2, E] edge list exactly; a reference-style MessagePassing(aggr='max') subclass == the oracle's
+    propagate (forward 1e-6, gradients 1e-5) == the drop-in DynamicEdgeConv on its fixed (query, k) grid."""
+    from instancerefer_amd.basic_blocks import DynamicEdgeConv
+    from instancerefer_amd.graph import nn as gnn
+    from oracle.torch_geometric import nn as ognn
+    rng = np.random.default_rng(31)
+    counts = [5, 12, 40, 1, 9]                   # two batch items with fewer than k support rows
+    nc, f_in, f_out, k = 18, 7 + 18, 128, 8
+    sup = rng.uniform(0, 8, (sum(counts), 3)).astype(np.float32)
+    bidx = np.concatenate([np.full(c, i) for i, c in enumerate(counts)])
+    qsel = np.sort(rng.choice(len(sup), 30, replace=False))
+    x, bx = torch.from_numpy(sup), torch.from_numpy(bidx)
+    y, by = x[qsel], bx[qsel]
+    e_ref = ognn.knn(x, y, k, bx, by)
+    e_dev = gnn.knn(x.cuda(), y.cuda(), k, bx.cuda(), by.cuda())
+    assert e_dev.dtype == torch.long and torch.equal(e_dev.cpu(), e_ref)
+
+    def build(base):
+        class Conv(base):                        # written the way the reference writes its DynamicEdgeConv
+            def __init__(self):
+                super().__init__(aggr='max')
+                self.mlp = torch.nn.Sequential(torch.nn.Linear(3 * f_in, f_out), torch.nn.ReLU(), torch.nn.Linear(f_out, f_out))
+                self.weight = torch.nn.Sequential(torch.nn.Linear(3 + 2 * nc, 64), torch.nn.ReLU(), torch.nn.Linear(64, f_in))
+
+            def forward(self, pos, batch, qidx, feats):
+                qp, qb, qf = pos.index_select(0, qidx), batch.index_select(0, qidx), feats.index_select(0, qidx)
+                row, col = self.knn(pos, qp, k, batch, qb)
+                return self.propagate(torch.stack([col, row], 0), x=(feats, qf), pos=(pos, qp))
+
+            def message(self, x_i, x_j, pos_i, pos_j):
+                w = self.weight(torch.cat([pos_j - pos_i, x_i[:, -nc:], x_j[:, -nc:]], -1))
+                return self.mlp(torch.cat([x_i, w, x_j], 1))
+        return Conv()
+
+    torch.manual_seed(4)
+    ref = build(ognn.MessagePassing)
+    ref.knn = ognn.knn
+    dev = build(gnn.MessagePassing)
+    dev.knn = gnn.knn
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.cuda()
+    drop = DynamicEdgeConv(f_in, f_out, k=k, num_classes=nc)
+    drop.load_state_dict(ref.state_dict())
+    drop = drop.cuda()
+    feats = torch.from_numpy(rng.standard_normal((len(sup), f_in)).astype(np.float32))
+    qidx = torch.from_numpy(qsel)
+    fr = feats.clone().requires_grad_(True)
+    fd = feats.clone().cuda().requires_grad_(True)
+    fp = feats.clone().cuda().requires_grad_(True)
+    out_r = ref(x, bx, qidx, fr)
+    out_d = dev(x.cuda(), bx.cuda(), qidx.cuda(), fd)
+    out_p = drop(x.cuda(), bx.cuda(), qidx.cuda(), fp)
+    assert (out_d.cpu() - out_r).abs().max().item() <= 1e-5 and (out_p.cpu() - out_r).abs().max().item() <= 1e-5
+    g = torch.from_numpy(rng.standard_normal(tuple(out_r.shape)).astype(np.float32))
+    out_r.backward(g); out_d.backward(g.cuda()); out_p.backward(g.cuda())
+    assert (fd.grad.cpu() - fr.grad).abs().max().item() <= 1e-5 and (fp.grad.cpu() - fr.grad).abs().max().item() <= 1e-5
+    for (n, pr), pd in zip(ref.named_parameters(), dev.parameters()):
+        assert (pd.grad.cpu() - pr.grad).abs().max().item() <= 1e-4 * max(1.0, pr.grad.abs().max().item()), n
+    # an unsorted target index and rows without any edge (fill = 0, torch_scatter's rule)
+    mp_ = gnn.MessagePassing(aggr='max')
+    msg = torch.tensor([[1.0, -2.0], [3.0, -5.0], [-1.0, -1.0]]).cuda()
+    out = mp_.aggregate(msg, torch.tensor([2, 0, 2]).cuda(), 4).cpu()
+    assert torch.equal(out, torch.tensor([[3.0, -5.0], [0.0, 0.0], [1.0, -1.0], [0.0, 0.0]]))

@@ -6,7 +6,6 @@ import torch, bench
 args = bench.parse()
 device = torch.device("cuda", 0)
 from instancerefer_amd import _lib, synthetic as S
-from instancerefer_amd.ddp import FlatGradAllReduce
 from instancerefer_amd.loss_helper import DatasetConfig
 _lib.load()
 B = args.batch or 16
