@@ -76,7 +76,9 @@ int irx_coords_to_keys(const int32_t* coords, int n, uint64_t* keys, void* strea
  * kept) — replaces the `np.floor(coords / quantization_size)` step reached from
  * models/attribute_module.py:65-69 and lib/dataset.py:229-233,256-260.
  * xyz: [n][3] (float64 when xyz_is_f64 else float32), batch: int32 [n] or NULL (=0).
- * Writes coords int32 [n][4] and keys uint64 [n]. */
+ * Writes coords int32 [n][4] and keys uint64 [n]. A point whose voxel coordinate falls outside [-32768, 32768) (or
+ * whose batch index is outside [0, 32768), or that is NaN) cannot be keyed: it receives a poison key, and
+ * irx_voxel_select reports it by returning a NEGATIVE count (sign bit set) — callers must treat that as an error. */
 int irx_quantize(const void* xyz, int xyz_is_f64, const int32_t* batch, int n,
                  double voxel_x, double voxel_y, double voxel_z,
                  int32_t* coords, uint64_t* keys, void* stream);
@@ -338,6 +340,48 @@ int irx_gru_forward(const float* gi, const int32_t* lengths, const float* w_hh, 
 int irx_gru_backward(const float* dout, const float* out, const float* gates, const int32_t* lengths,
                      const float* w_hh, int B, int T, int ndir, int H, float* dgi, float* dgh,
                      void* stream);
+
+/* ---- box labels of get_loss / get_eval --------------------------------------- */
+
+/* lib/loss_helper.py:233-258 without the per-sample host loop: IoU (float64, axis-aligned: utils/box_util.py:154-175,
+ * 310-333 with heading 0) of every same-class candidate box against its scene's ground-truth box, and the one-hot label
+ * of the best candidate (np.argmax: first maximum). obbs [S][7] double = (centre, size, heading) of every instance;
+ * filtered int64 [total] = rows of obbs, scene-major; starts int64 [n_scenes + 1]; gt_obb [n_scenes][7] double.
+ * Outputs: labels float [total] (cluster_label of every scene); for scenes with scored_pos[i] >= 0 (>= 2 candidates)
+ * the same labels at lab[scored_pos[i] + j] (aligned with the score vectors) and keep[scored_row[i]] = (max IoU >= 0.2);
+ * best_iou double [n_scenes] (optional). Bit-identical to the numpy evaluation. scored_pos / scored_row may be NULL. */
+int irx_iou_labels(const double* obbs, const int64_t* filtered, const int64_t* starts, const double* gt_obb,
+                   int n_scenes, const int64_t* scored_pos, const int64_t* scored_row, float* labels, float* lab,
+                   float* keep, double* best_iou, void* stream);
+
+/* lib/eval_helper.py:52-100 on the device: per scene the arg-max of the summed scores (s1 + s2) + s3 over its
+ * candidates (scenes with >= 2), the arg-max of its labels, the chosen box (the only candidate / a zero box for 1 / 0
+ * candidates) and its IoU against the ground-truth box. out [n_scenes][10] double = (pred, tgt, iou, chosen obb[7]);
+ * pred = tgt = -1 for scenes with < 2 candidates. */
+int irx_eval_select(const float* s1, const float* s2, const float* s3, const float* labels, const double* obbs,
+                    const int64_t* filtered, const int64_t* starts, const int64_t* scored_pos, const double* gt_obb,
+                    int n_scenes, double* out, void* stream);
+
+/* ---- multiview back-projection (lib/projection.py:191-279) ----------------------------- */
+
+/* ProjectionHelper.compute_projection for one frame: which of the n_points world points (float [n][3]) fall on which
+ * pixel of the depth frame (float [height][width]): inside the viewing frustum (six rounded plane tests), projected by
+ * world_to_camera + intrinsics onto a pixel inside the image whose depth lies in [depth_min, depth_max] and within
+ * `accuracy` of the point's camera depth. ind3d / ind2d: int64 [n_points + 1], the reference's format — [0] = number of
+ * correspondences m (it stays on the device: no host sync), [1 .. m] = point indices ascending / their pixel indices
+ * (y * width + x), zeros behind. params: HOST array of IRX_PROJ_NPARAMS floats = 6 inward plane normals [6][3],
+ * corner_coords[2][:3], corner_coords[4][:3], world_to_camera [4][4] row-major, fx, fy, cx, cy, depth_min, depth_max,
+ * accuracy (the 8-corner algebra of projection.py:49-122 is tiny host work). */
+#define IRX_PROJ_NPARAMS 47
+size_t irx_project_workspace_bytes(int n_points);
+int irx_project_points(const float* points, int n_points, const float* depth, int width, int height,
+                       const float* params, int64_t* ind3d, int64_t* ind2d, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ProjectionHelper.project / Projection.forward (lib/projection.py:255-279,285-305): out float [channels][n_points] =
+ * label[:, ind2d[1..m]] scattered to columns ind3d[1..m], zero elsewhere; m is read on the device. */
+int irx_project_features(const float* label, int channels, int n_pixels, const int64_t* ind3d, const int64_t* ind2d,
+                         int n_points, float* out, void* stream);
 
 /* ---- optimizer -------------------------------------------------------------------------------------- */
 

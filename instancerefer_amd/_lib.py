@@ -73,6 +73,11 @@ _SIGNATURES = {
     "irx_contrastive_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P]),
     "irx_contrastive_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P]),
     "irx_knn_batched": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "irx_project_workspace_bytes": (_Z, [_I]),
+    "irx_project_points": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    "irx_project_features": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
+    "irx_iou_labels": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "irx_eval_select": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -8,6 +8,7 @@
 #define IRX_WAVE 64
 #define IRX_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define IRX_COORD_BIAS 32768
+#define IRX_POISON_KEY 0xFFFFFFFFFFFFFFFEull   // k_quantize: a point outside the 16-bit voxel range / 15-bit batch range
 
 // ---- error plumbing (thread-local message; functions never throw) -----------------------
 void irx_set_error(const char* fmt, ...);

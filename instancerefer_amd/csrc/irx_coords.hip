@@ -61,10 +61,17 @@ __global__ void k_quantize(const T* __restrict__ xyz, const int32_t* __restrict_
   // float64 division then floor — bit-identical to numpy's `np.floor(coords / voxel)`.
   double x = (double)xyz[3 * (size_t)i + 0], y = (double)xyz[3 * (size_t)i + 1],
          z = (double)xyz[3 * (size_t)i + 2];
-  int cx = (int)floor(x / vx), cy = (int)floor(y / vy), cz = (int)floor(z / vz);
+  const double fx = floor(x / vx), fy = floor(y / vy), fz = floor(z / vz);
   int b = batch ? batch[i] : 0;
+  // A key holds 16 biased bits per coordinate and 15 bits of batch index: anything outside would alias onto another
+  // voxel's key (silently merged voxels, wrong kernel maps). Such a point gets the poison key instead; k_voxel_select
+  // turns it into a NEGATIVE voxel count, which every consumer treats as empty and the host raises on.
+  const bool ok = fx >= -(double)IRX_COORD_BIAS && fx < (double)IRX_COORD_BIAS && fy >= -(double)IRX_COORD_BIAS &&
+                  fy < (double)IRX_COORD_BIAS && fz >= -(double)IRX_COORD_BIAS && fz < (double)IRX_COORD_BIAS &&
+                  b >= 0 && b < 32768;          // (NaN coordinates fail the comparisons too)
+  int cx = ok ? (int)fx : 0, cy = ok ? (int)fy : 0, cz = ok ? (int)fz : 0;
   coords[i] = make_int4(cx, cy, cz, b);
-  keys[i] = irx_make_key(cx, cy, cz, b);
+  keys[i] = ok ? irx_make_key(cx, cy, cz, b) : IRX_POISON_KEY;
 }
 
 __global__ void k_fill_table(uint64_t* __restrict__ tk, int32_t* __restrict__ tv, size_t cap) {
@@ -102,7 +109,11 @@ __global__ void k_voxel_select(const uint64_t* __restrict__ keys, int n,
                                uint64_t mask, int32_t* __restrict__ winners, int32_t* count) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool win = false;
-  if (i < n) win = (irx_hash_lookup(tk, tv, mask, keys[i]) == i);
+  if (i < n) {
+    const uint64_t key = keys[i];
+    if (key == IRX_POISON_KEY) atomicOr(count, (int32_t)0x80000000);   // out-of-range point (k_quantize): count < 0
+    else win = (irx_hash_lookup(tk, tv, mask, key) == i);
+  }
   unsigned long long ballot = __ballot(win);
   if (ballot == 0ull) return;
   int lane = threadIdx.x & 63;

@@ -43,6 +43,9 @@ class InstancePack:
             self.xyz64 = torch.zeros((0, 1, 3), dtype=torch.float64, device=device)
             self.pts32 = torch.zeros((0, 1, 3), dtype=torch.float32, device=device)
         self.centres = torch.from_numpy(self.obbs[:, :3].astype(np.float32)).to(device)
+        # (S, 7) float64 boxes for the device-side IoU labelling / evaluation (irx_iou_labels, irx_eval_select)
+        self.obbs_dev = torch.from_numpy(np.ascontiguousarray(self.obbs)).to(device, non_blocking=True) if flat else \
+            torch.zeros((0, 7), dtype=torch.float64, device=device)
         self._sel_cache = {}
 
     @classmethod
@@ -53,6 +56,7 @@ class InstancePack:
         self.batch_size = len(scene_start) - 1
         self.classes, self.scene_of, self.scene_start = list(classes), list(scene_of), list(scene_start)
         self.obbs = np.asarray(obbs_host, np.float64).reshape(-1, 7)
+        self.obbs_dev = obbs_dev.double().contiguous()
         if inst_points.shape[0]:
             self.xyz64 = inst_points[:, :, :3].double().contiguous()
             self.pts32 = inst_points.float().contiguous()
@@ -80,12 +84,13 @@ class InstancePack:
         key = tuple(int(v) for v in lang_cls_pred)
         if key in self._sel_cache:
             return self._sel_cache[key]
-        cand, cand_scene, pred_obb_batch, nfo = [], [], [], []
+        cand, cand_scene, pred_obb_batch, nfo, filtered = [], [], [], [], []
         support, support_batch, query_in_support, sup_off = [], [], [], [0]
         for i in range(self.batch_size):
             lo, hi = self.scene_start[i], self.scene_start[i + 1]
             mine = [s for s in range(lo, hi) if self.classes[s] == key[i]]
             nfo.append(len(mine))
+            filtered += mine
             pred_obb_batch.append(np.asarray([self.obbs[s] for s in mine]))
             if len(mine) < 2:
                 continue
@@ -98,7 +103,7 @@ class InstancePack:
             sup_off.append(len(support))
         sel = dict(cand=cand, cand_scene=cand_scene, pred_obb_batch=pred_obb_batch, num_filtered_objs=nfo,
                    support=support, support_batch=support_batch, query_in_support=query_in_support,
-                   support_scene_offsets=sup_off)
+                   support_scene_offsets=sup_off, filtered=filtered)
         self._sel_cache[key] = sel
         return sel
 

@@ -2,7 +2,9 @@
 summed score (the only candidate / a zero box when a scene has 1 / 0 candidates), IoU against the GT box, `ref_acc`
 (arg-max hit for >= 2 candidates, IoU > 0.25 otherwise), Acc@0.25 / Acc@0.5 rates and the unique/multiple, "others"
 masks. Same keys and list/array types as the reference; the per-sample device round trips (`.item()`, tensor slicing and
-arg-max per scene) are replaced by one padded arg-max on the device and ONE D2H copy."""
+arg-max per scene) are replaced by ONE launch (irx_eval_select: per-scene arg-max of the summed scores and of the labels,
+the chosen box and its float64 IoU, bit-identical to the numpy evaluation) and ONE D2H copy of B x 10 doubles when get_loss
+left its resident label tensors behind; on host tensors (CPU tests) one padded arg-max + numpy."""
 import numpy as np
 import torch
 
@@ -27,6 +29,18 @@ def get_eval(data_dict, config):
     pred_obb_batch = data_dict['pred_obb_batch']
     counts = [int(p.shape[0]) for p in pred_obb_batch]
     scored = [i for i in range(batch_size) if counts[i] >= 2]
+    lp = data_dict.get('_labels')
+    on_device = None
+    if lp is not None and lp.get('dev') is not None and lp['counts'] == counts and data_dict['attribute_scores'].is_cuda:
+        from . import _lib
+        d = lp['dev']
+        res = torch.empty((batch_size, 10), dtype=torch.float64, device=d['gt'].device)
+        sc = [data_dict[k].detach().float().contiguous() for k in ('attribute_scores', 'relation_scores', 'scene_scores')]
+        _lib.call("irx_eval_select", _lib.ptr(sc[0]), _lib.ptr(sc[1]), _lib.ptr(sc[2]), _lib.ptr(lp['label_dev']),
+                  _lib.ptr(d['obbs']), _lib.ptr(d['filtered']), _lib.ptr(d['starts']), _lib.ptr(d['scored_pos']),
+                  _lib.ptr(d['gt']), batch_size, _lib.ptr(res), _lib.stream_ptr())
+        on_device = res.cpu().numpy()                  # the ONE D2H copy of the evaluation
+        scored = []
     # arg-max of the summed scores and of the cluster label for every scored scene: one padded matrix, one D2H
     pred_idx, tgt_idx = {}, {}
     if scored:
@@ -49,14 +63,20 @@ def get_eval(data_dict, config):
                                         _host_np(data_dict, "ref_heading_residual_label"),
                                         _host_np(data_dict, "ref_size_class_label"),
                                         _host_np(data_dict, "ref_size_residual_label"))
-    chosen = np.zeros((batch_size, 7))
-    for i in range(batch_size):
-        if counts[i] == 1:
-            chosen[i] = pred_obb_batch[i][0]
-        elif counts[i] >= 2:
-            chosen[i] = pred_obb_batch[i][pred_idx[i]]
-    ious = box3d_iou_batch(get_3d_box_batch(chosen[:, 3:6], chosen[:, 6], chosen[:, 0:3]),
-                           get_3d_box_batch(ref_gt_obb[:, 3:6], ref_gt_obb[:, 6], ref_gt_obb[:, 0:3]))
+    if on_device is not None:
+        for i in range(batch_size):
+            if counts[i] >= 2:
+                pred_idx[i], tgt_idx[i] = int(on_device[i, 0]), int(on_device[i, 1])
+        ious, chosen = on_device[:, 2].copy(), on_device[:, 3:10].copy()
+    else:
+        chosen = np.zeros((batch_size, 7))
+        for i in range(batch_size):
+            if counts[i] == 1:
+                chosen[i] = pred_obb_batch[i][0]
+            elif counts[i] >= 2:
+                chosen[i] = pred_obb_batch[i][pred_idx[i]]
+        ious = box3d_iou_batch(get_3d_box_batch(chosen[:, 3:6], chosen[:, 6], chosen[:, 0:3]),
+                               get_3d_box_batch(ref_gt_obb[:, 3:6], ref_gt_obb[:, 6], ref_gt_obb[:, 0:3]))
     um = _host_np(data_dict, "unique_multiple") if "unique_multiple" in data_dict else np.zeros(batch_size, np.int64)
     cat = _host_np(data_dict, "object_cat")
     ref_acc, pred_bboxes, gt_bboxes, multiple, others = [], [], [], [], []

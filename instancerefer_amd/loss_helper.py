@@ -3,8 +3,9 @@ compute_scene_mask_loss :131-161, compute_lang_classification_loss :189-193).
 
 loss = 10 * ref_loss + lang_loss + seg_loss.  ref_loss: per sample with >= 2 candidates and max IoU >= 0.2,
 ContrastiveLoss(margin .2, gamma 5) between the summed scores and the one-hot of the candidate with the
-highest IoU against the GT box, divided by the FULL batch size. IoU labelling is float64 numpy on the
-host exactly as in the reference (axis-aligned IoU of box corners, utils/box_util.py:154-175,310-333).
+highest IoU against the GT box, divided by the FULL batch size. IoU labelling (axis-aligned IoU of box corners,
+utils/box_util.py:154-175,310-333, float64): ONE device launch over all candidates of the batch (irx_iou_labels,
+bit-identical to numpy) when the instance boxes are resident, float64 numpy on the host otherwise (CPU tensors).
 `config` is duck-typed: anything with `param2obb_batch` (the reference's ScannetDatasetConfig works).
 """
 import numpy as np
@@ -128,6 +129,58 @@ def _host_np(data_dict, key):
     return data_dict[key].detach().cpu().numpy()
 
 
+def _selection(data_dict):
+    """The candidate selection of this batch (data.InstancePack.select) if the instance pack is attached."""
+    prep = data_dict.get('_attr_prepared')
+    if prep is not None:
+        return prep[1]
+    pack, cls = data_dict.get('irx'), data_dict.get('_lang_cls_pred_list')
+    if pack is not None and cls is not None:
+        return pack.select(cls)
+    return None
+
+
+def _prepare_labels_device(data_dict, out, ref_gt_obb, area_label, sel, pack, device):
+    """Device half: counts / offsets are host integers of the selection; the IoUs, the arg-max labels and the IoU >= 0.2
+    gate are ONE launch (csrc/irx_labels.hip) over boxes that are already resident (InstancePack.obbs_dev). One pinned
+    staging buffer, one H2D copy (indices + the B ground-truth boxes as raw float64 bits), no D2H."""
+    from . import _lib
+    counts, batch_size, total = out['counts'], out['batch_size'], out['total']
+    starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    scored_pos = np.full(batch_size, -1, np.int64)
+    scored_row = np.full(batch_size, -1, np.int64)
+    pos = row = 0
+    for i, c in enumerate(counts):
+        if c >= 2:
+            scored_pos[i], scored_row[i] = pos, row
+            pos += c
+            row += 1
+    nlab, srow = pos, row
+    seg_off = np.concatenate([[0], np.cumsum([c for c in counts if c >= 2])]).astype(np.int64)
+    nal = 0 if area_label is None else area_label.size
+    parts = [np.asarray(sel['filtered'], np.int64), starts, scored_pos, scored_row,
+             np.zeros(0, np.int64) if area_label is None else area_label.astype(np.int64), seg_off,
+             np.ascontiguousarray(ref_gt_obb, dtype=np.float64).reshape(-1).view(np.int64)]
+    ih = torch.empty(sum(a.size for a in parts), dtype=torch.int64, pin_memory=True)
+    hv, offs, o = ih.numpy(), [], 0
+    for a in parts:
+        hv[o:o + a.size] = a
+        offs.append((o, a.size))
+        o += a.size
+    buf = ih.to(device, non_blocking=True)
+    v = [buf[a:a + n] for a, n in offs]
+    gt_dev = v[6].view(torch.float64)
+    fbuf = torch.empty(total + nlab + srow, dtype=torch.float32, device=device)
+    labels, lab, keep = fbuf[:total], fbuf[total:total + nlab], fbuf[total + nlab:]
+    _lib.call("irx_iou_labels", _lib.ptr(pack.obbs_dev), _lib.ptr(v[0]), _lib.ptr(v[1]), _lib.ptr(gt_dev), batch_size,
+              _lib.ptr(v[2]) if srow else None, _lib.ptr(v[3]) if srow else None, _lib.ptr(labels),
+              _lib.ptr(lab) if srow else None, _lib.ptr(keep) if srow else None, None, _lib.stream_ptr())
+    out.update(starts=starts, srow=srow, lmax=0, fbuf=fbuf, buf=buf, label_dev=labels, lab=lab, keep_dev=keep, flat=None,
+               area_label=v[4] if nal else None, seg_off=v[5],
+               dev=dict(filtered=v[0], starts=v[1], scored_pos=v[2], gt=gt_dev, obbs=pack.obbs_dev))
+    return out
+
+
 def prepare_labels(data_dict, config, device=None):
     """Host half of get_loss: IoU labelling of every candidate box against the GT box (float64 numpy, as the reference)
     and ONE staged upload each of the integer / float label arrays. Depends only on the batch's inputs (GT labels +
@@ -162,6 +215,12 @@ def prepare_labels(data_dict, config, device=None):
     if total == 0:
         out.pop("area_label_host", None)
         return out
+    sel, pack = _selection(data_dict), data_dict.get('irx')
+    if (torch.device(device).type == "cuda" and sel is not None and 'filtered' in sel
+            and getattr(pack, 'obbs_dev', None) is not None and pack.obbs_dev.is_cuda
+            and list(sel['num_filtered_objs']) == counts):
+        return _prepare_labels_device(data_dict, out, ref_gt_obb, out.pop("area_label_host", None), sel, pack,
+                                      torch.device(device))
     obbs = np.concatenate([p.reshape(-1, 7) for p in pred_obb_batch if p.shape[0]], 0)       # (total, 7)
     scene_of = np.repeat(np.arange(batch_size), counts)
     pred_bbox = get_3d_box_batch(obbs[:, 3:6], obbs[:, 6], obbs[:, 0:3])
@@ -260,4 +319,5 @@ def get_loss(data_dict, config):
     data_dict['seg_loss'] = seg_loss
     data_dict['seg_acc'] = seg_acc
     data_dict['cluster_label'] = cluster_label
+    data_dict['_labels'] = lp                          # get_eval reuses the resident label tensors / offsets
     return data_dict

@@ -9,9 +9,12 @@ rule that a parameter without a gradient is left alone (no weight decay, no mome
 The reference is single-GPU (lib/solver.py:200-205 is a plain backward(); step()), so the multi-rank behaviour is this
 build's own: one process per GPU, scenes sharded by rank (`shard_range`), parameters and buffers broadcast from rank 0
 at construction, gradients summed over ranks (ranks whose shard produced no gradient for a parameter contribute
-zeros) and divided by the world size inside the Adam kernel. The two encoders' gradient ranges (80 % of the 32 MB) are
-reduced as soon as their backward passes are enqueued, on the encoder's own stream, while the rest of the backward still
-runs (`overlap=True`).
+zeros) and divided by the world size inside the Adam kernel. flat_g is cut into a STATIC list of segments — one per
+asynchronously issued sparse encoder of `module` (80 % of the 32 MB), plus what lies between / behind them — and every
+rank all-reduces every segment in the same order each step; an encoder segment whose gradients arrived through the sink
+is reduced as soon as its backward pass is enqueued, on the encoder's own stream, while the rest of the backward still
+runs (`overlap=True`); on a rank where that encoder did not run this step the same collective is issued after the
+gather instead, so the sequence of collectives never depends on the data.
 
 Buffer management, gather, all-reduce, broadcast and the state dict work on any device (the world-size-2 gloo test
 runs them on CPU tensors); `step()` is the HIP kernel and raises without a HIP device — there is no CPU optimizer."""
@@ -92,7 +95,6 @@ class FlatAdam:
         self._gather_cache = {}
         self._pending = []              # sink deliveries not yet waited for: (event | (lane, stream), parameter indices)
         self._todo_last = list(range(len(self.params)))
-        self._early = []                # flat ranges already all-reduced this step (encoder slots, overlap mode)
         self._works = []                # async collectives in flight
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.steps = [0] * len(self.params)           # torch.optim.Adam keeps `step` per parameter
@@ -100,6 +102,25 @@ class FlatAdam:
         self._runs_cache = {}
         self.world_size = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.overlap = bool(overlap)
+        # static segments of flat_g: [(lo, hi)] of the early groups (parameter runs of module's lane-issued encoders, in
+        # module order), then the gaps; identical on every rank because it only depends on the model structure
+        self._groups = []               # (first parameter index, lo, hi), in lane order (lane 0 = the scene encoder,
+        lanes = []                      # which runs on every rank every step and sits on the critical path: first)
+        if module is not None and self.overlap:
+            for m in module.modules():
+                if m.__dict__.get('_irx_lane') is not None:
+                    idx = sorted(self._index[id(p)] for p in m.parameters() if id(p) in self._index)
+                    if idx and idx == list(range(idx[0], idx[-1] + 1)):
+                        hi = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.offsets) else n
+                        lanes.append((m.__dict__['_irx_lane'], idx[0], self.offsets[idx[0]], hi))
+        self._groups = [g[1:] for g in sorted(lanes)]
+        self._gaps, lo = [], 0
+        for _, a, b in sorted(self._groups, key=lambda g: g[1]):
+            if a > lo:
+                self._gaps.append((lo, a))
+            lo = b
+        self._gaps.append((lo, self.n_total))            # ... and the activity flags behind the gradients
+        self._reduced = set()           # groups already all-reduced this step
         if broadcast and self.world_size > 1 and dist.is_initialized():
             dist.broadcast(self.flat_p, 0)            # replicas start from rank 0's weights whatever the local seeds
             if module is not None:
@@ -120,7 +141,7 @@ class FlatAdam:
                 p.grad = None
         self._direct.clear()
         self._direct_groups.clear()
-        self._early = []
+        self._reduced.clear()
 
     # ---- gradient-sink protocol (see __init__) ----
     def sink_slots(self, key, params):
@@ -149,14 +170,16 @@ class FlatAdam:
         ev.record()
         self._pending.append(((ev, torch.cuda.current_stream()), idx))
 
-    def _range_of(self, idx):
-        """[lo, hi) of flat elements if the parameters `idx` are one contiguous run of the flat buffer, else None."""
-        idx = sorted(idx)
-        if idx != list(range(idx[0], idx[-1] + 1)):
-            return None
-        lo = self.offsets[idx[0]]
-        hi = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.offsets) else self.n
-        return lo, hi
+    def _group_of(self, idx):
+        """Position in self._groups of the static segment whose first parameter is min(idx), or None."""
+        first = min(idx)
+        for g, (i0, _, _) in enumerate(self._groups):
+            if i0 == first:
+                return g
+        return None
+
+    def _multi_rank(self):
+        return self.world_size > 1 and dist.is_initialized()
 
     def gather_grads(self):
         """All .grad tensors -> their slots in flat_g with one multi-tensor copy (the padding between slots stays zero;
@@ -166,18 +189,23 @@ class FlatAdam:
         gradients is even enqueued."""
         if self._pending:
             cur = torch.cuda.current_stream()
+            if self._groups:             # segment order, so that a later segment can go early behind an earlier one
+                self._pending.sort(key=lambda e: (lambda g: len(self._groups) if g is None else g)(self._group_of(e[1])))
             for (ev, stream), idx in self._pending:
                 if not isinstance(ev, torch.cuda.Event):
                     from .sparse.encoder_fn import lane_wait
                     lane_wait(ev)
-                rng = self._range_of(idx) if (self.overlap and self.world_size > 1 and dist.is_initialized()) else None
-                if rng is not None:
+                g = self._group_of(idx) if self._multi_rank() else None
+                # early reduction only in segment order: an earlier segment that did not deliver on THIS rank is reduced
+                # after the gather, and the collectives of all ranks must line up
+                if g is not None and g not in self._reduced and all(h in self._reduced for h in range(g)):
+                    _, lo, hi = self._groups[g]
                     with torch.cuda.stream(stream):          # ordered behind the producer's kernels, nothing else
                         if isinstance(ev, torch.cuda.Event):
                             stream.wait_event(ev)
-                        w = dist.all_reduce(self.flat_g[rng[0]:rng[1]], op=dist.ReduceOp.SUM, async_op=True)
+                        w = dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
                     self._works.append(w)
-                    self._early.append(rng)
+                    self._reduced.add(g)
                 if isinstance(ev, torch.cuda.Event):
                     cur.wait_event(ev)
                 elif stream != cur:
@@ -210,27 +238,21 @@ class FlatAdam:
                 self.params[i].grad = None
 
     def all_reduce(self):
-        """Sum flat_g over the ranks (the division by world_size happens in the Adam kernel). Ranges reduced early
-        (overlap mode) are skipped; the activity flags travel with the gradients so that every rank skips the same
+        """Sum flat_g over the ranks (the division by world_size happens in the Adam kernel): the static segments in order,
+        skipping those reduced early; the activity flags travel with the gradients so that every rank skips the same
         parameters (a parameter is inactive only when NO rank produced a gradient for it)."""
-        if self.world_size <= 1 or not dist.is_initialized():
+        if not self._multi_rank():
             return
         self._flags.fill_(1.0)
         if self._inactive:
             self._flags[torch.as_tensor(sorted(self._inactive), device=self.device)] = 0.0
-        rest, lo = [], 0
-        for a, b in sorted(self._early):
-            if a > lo:
-                rest.append((lo, a))
-            lo = max(lo, b)
-        if lo < self.n_total:
-            rest.append((lo, self.n_total))
+        rest = [(a, b) for g, (_, a, b) in enumerate(self._groups) if g not in self._reduced] + self._gaps
         for a, b in rest:
             self._works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, async_op=True))
         for w in self._works:
             w.wait()                     # NCCL: the current stream waits for the collective; gloo: the host does
         self._works = []
-        self._early = []
+        self._reduced.update(range(len(self._groups)))
         if self._inactive:
             # A rank with gradients for everything knows every flag is > 0 and reads nothing back (the common case);
             # only a rank that skipped something has to learn whether another rank did not (one small D2H, rare)

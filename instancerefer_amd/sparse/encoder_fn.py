@@ -83,7 +83,9 @@ def _static_template(encoder, layers, params):
     """Descriptor rows with everything that does not change from batch to batch (layer shapes, residual links, parameter
     and running-stat pointers, relative stats offsets), cached per encoder; rebuilt when the parameters were re-homed
     (FlatAdam moves them into its flat buffer once)."""
-    anchor = tuple(p.data_ptr() for p in params[:3])
+    # every cached pointer is part of the anchor: parameters AND running statistics (model.to(), .float(),
+    # load_state_dict(assign=True) may move any of them on its own)
+    anchor = tuple(p.data_ptr() for p in params) + tuple(b.data_ptr() for L in layers for b in (L.bn.running_mean, L.bn.running_var))
     cached = encoder.__dict__.get("_irx_template")
     if cached is not None and cached[0] == anchor:
         return cached[1:]
@@ -98,7 +100,7 @@ def _static_template(encoder, layers, params):
         t[i, _E["GAMMA"]], t[i, _E["BETA"]] = params[3 * i + 1].data_ptr(), params[3 * i + 2].data_ptr()
         t[i, _E["RUNNING_MEAN"]], t[i, _E["RUNNING_VAR"]] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
         t[i, _E["MEAN"]], t[i, _E["INVSTD"]] = 4 * (i * 256), 4 * (i * 256 + 128)       # relative to the stats tensor
-        f[i] = (bn.eps, 0.0 if bn.momentum is None else bn.momentum)
+        f[i] = (bn.eps, bn.momentum)            # momentum None (cumulative average) is refused by can_fuse
         if bn.num_batches_tracked is not None:
             counters.append(bn.num_batches_tracked)
     cout = t[:, _E["COUT"]].copy()
@@ -301,11 +303,13 @@ def can_fuse(encoder):
     """The executor covers the training configuration of the reference (train-mode BatchNorm, fp32, no bias)."""
     if not (encoder.training and torch.is_grad_enabled()) or F_.PROFILE is not None:
         return False
+    if not all(bn.training for _, bn, _, _ in _skeleton(encoder)):
+        return False                                   # frozen BatchNorm layers: the per-layer path handles eval statistics
     ok = encoder.__dict__.get("_irx_fusable")          # structural part: decided once per encoder instance
     if ok is None:
         ok = True
         for m in encoder.modules():
-            if isinstance(m, torch.nn.BatchNorm1d) and (not m.track_running_stats or m.weight is None):
+            if isinstance(m, torch.nn.BatchNorm1d) and (not m.track_running_stats or m.weight is None or m.momentum is None):
                 ok = False
             if hasattr(m, "kernel") and getattr(m, "bias", None) is not None:
                 ok = False

@@ -18,6 +18,10 @@ _i64 = torch.int64
 _f32 = torch.float32
 
 
+RANGE_ERROR = ("voxel coordinates outside [-32768, 32768) or more than 32767 batch items: such points cannot be keyed "
+               "(irx_quantize marks them and the voxel count comes back negative); check the voxel size / units")
+
+
 def _stream():
     return _lib.stream_ptr()
 
@@ -74,6 +78,8 @@ def voxel_unique(keys):
     _lib.call("irx_voxel_select", _lib.ptr(keys), n, _lib.ptr(tk), _lib.ptr(tv), cap, _lib.ptr(winners),
               _lib.ptr(count), _stream())
     m = int(count.item())  # host sync: the voxel count sizes every later buffer
+    if m < 0:
+        raise ValueError(RANGE_ERROR)
     return winners[:m].long()
 
 
@@ -139,6 +145,8 @@ class PyramidPending:
         """-> (n0, [per-level tuples])"""
         self.event.synchronize()            # the ONE host sync of the pyramid
         m = self.counts_host.tolist()
+        if m[0] < 0:
+            raise ValueError(RANGE_ERROR)
         n0 = self.n if self.n0_known else m[0]
         m = m[1:]
         parent, koff, out_coords, out_keys, child = self.bufs

@@ -207,3 +207,44 @@ def seeded_state_dict(module, seed):
             v = rng.uniform(-0.1, 0.1, shape)
         sd[name] = torch.from_numpy(np.asarray(v)).to(t.dtype)
     return sd
+
+
+# ---- multiview frames for the projection step (lib/projection.py; scripts/project_multiview_features.py:28-29) ----
+PROJ_INTRINSICS = [[37.01983, 0, 20, 0], [0, 38.52470, 15.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]]
+PROJ_ARGS = dict(depth_min=0.1, depth_max=4.0, image_dims=[41, 32], accuracy=0.05)
+
+
+def make_frames(seed, points, num_frames=4, channels=8):
+    """Seeded camera frames looking into the cloud `points` (N, 3): camera_to_world (F, 4, 4) float32, z-buffer depth
+    maps (F, 32, 41) float32 rendered from the points themselves (+ noise, holes and out-of-range pixels, so that every
+    rejection branch of compute_projection is taken) and per-frame image features (F, channels, 32, 41) float32."""
+    rng = np.random.default_rng(seed)
+    pts = np.asarray(points, np.float64)[:, :3]
+    lo, hi = pts.min(0), pts.max(0)
+    fx, fy, cx, cy = PROJ_INTRINSICS[0][0], PROJ_INTRINSICS[1][1], PROJ_INTRINSICS[0][2], PROJ_INTRINSICS[1][2]
+    W, H = PROJ_ARGS["image_dims"]
+    poses, depths = [], []
+    for _ in range(num_frames):
+        eye = np.array([rng.uniform(lo[0], hi[0]), rng.uniform(lo[1], hi[1]), rng.uniform(1.2, 1.8)])
+        target = np.array([rng.uniform(lo[0], hi[0]), rng.uniform(lo[1], hi[1]), rng.uniform(0.0, 1.0)])
+        fwd = target - eye
+        fwd /= np.linalg.norm(fwd)
+        right = np.cross(fwd, np.array([0.0, 0.0, 1.0]))
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        c2w = np.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, eye      # camera looks along +z
+        cam = (np.linalg.inv(c2w) @ np.concatenate([pts, np.ones((len(pts), 1))], 1).T)
+        z = cam[2]
+        ok = z > 0.05
+        u = np.round(cam[0, ok] * fx / z[ok] + cx).astype(np.int64)
+        v = np.round(cam[1, ok] * fy / z[ok] + cy).astype(np.int64)
+        inside = (u >= 0) & (u < W) & (v >= 0) & (v < H)
+        depth = np.full((H, W), 10.0)
+        np.minimum.at(depth, (v[inside], u[inside]), z[ok][inside])
+        depth += rng.normal(0, 0.02, depth.shape)                # some points fail the accuracy test
+        depth[rng.uniform(size=depth.shape) < 0.05] = 0.0        # holes in the depth image
+        poses.append(c2w.astype(np.float32))
+        depths.append(depth.astype(np.float32))
+    feats = rng.standard_normal((num_frames, channels, H, W)).astype(np.float32)
+    return np.stack(poses), np.stack(depths), feats

@@ -15,6 +15,7 @@ def lib():
         l.irx_oracle_encoder_fwd_bwd.restype = ctypes.c_double
         l.irx_oracle_encoder_fwd_bwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        l.irx_oracle_set_wgrad_double.argtypes = [ctypes.c_int]
         l.irx_oracle_encoder_param_count.restype = ctypes.c_long
         l.irx_oracle_encoder_param_count.argtypes = [ctypes.c_int]
         _lib = l
@@ -35,8 +36,11 @@ def pack_encoder_params(state_dict, prefix):
     return np.ascontiguousarray(np.concatenate(parts).astype(np.float32)), order
 
 
-def encoder_fwd_bwd(coords, feats, nbatch, params, gpool, threads=0):
-    """coords (n,4) int32 (x,y,z,b), feats (n,c0) f32 -> (loss, pooled (nbatch,128), grads (like params))."""
+def encoder_fwd_bwd(coords, feats, nbatch, params, gpool, threads=0, wgrad_double=False):
+    """coords (n,4) int32 (x,y,z,b), feats (n,c0) f32 -> (loss, pooled (nbatch,128), grads (like params)).
+    wgrad_double: accumulate the weight gradients in float64 (the parity checker at full size; the timed baseline keeps
+    float, torchsparse's CPU arithmetic)."""
+    lib().irx_oracle_set_wgrad_double(int(bool(wgrad_double)))
     coords = np.ascontiguousarray(coords, dtype=np.int32)
     feats = np.ascontiguousarray(feats, dtype=np.float32)
     gpool = np.ascontiguousarray(gpool, dtype=np.float32)

@@ -86,6 +86,12 @@ static void conv_fwd(const float* x, const float* w, const kmap* m, int cin, int
     }
   }
 }
+/* Weight-gradient accumulation: float (default: what torchsparse's CPU path does, and what cpu_baseline times) or
+ * double (irx_oracle_set_wgrad_double(1): the parity checker at full size, where a sequential float sum over ~3e5 pairs
+ * per offset carries ~1e-3 of cancellation error — more than the kernels under test). */
+static int g_wgrad_double = 0;
+void irx_oracle_set_wgrad_double(int on) { g_wgrad_double = on != 0; }
+
 static void conv_bwd(const float* x, const float* w, const float* dy, const kmap* m, int cin, int cout, int nin, float* dx, float* dw) {
   if (dx) memset(dx, 0, (size_t)nin * cin * sizeof(float));
   for (int k = 0; k < m->K; ++k) {
@@ -99,7 +105,14 @@ static void conv_bwd(const float* x, const float* w, const float* dy, const kmap
     }
 #pragma omp parallel for schedule(static)
     for (int c = 0; c < cin; ++c) {                 /* each thread owns rows of dW[k]: no race */
-      float* dr = dwk + (size_t)c * cout; for (int n = 0; n < cout; ++n) dr[n] = 0.f;
+      float* dr = dwk + (size_t)c * cout;
+      if (g_wgrad_double) {
+        double acc[128]; for (int n = 0; n < cout; ++n) acc[n] = 0.0;
+        for (int p = 0; p < m->cnt[k]; ++p) { const double a = x[(size_t)m->in[k][p] * cin + c]; const float* g = dy + (size_t)m->out[k][p] * cout; for (int n = 0; n < cout; ++n) acc[n] += a * (double)g[n]; }
+        for (int n = 0; n < cout; ++n) dr[n] = (float)acc[n];
+        continue;
+      }
+      for (int n = 0; n < cout; ++n) dr[n] = 0.f;
       for (int p = 0; p < m->cnt[k]; ++p) { const float a = x[(size_t)m->in[k][p] * cin + c]; const float* g = dy + (size_t)m->out[k][p] * cout; for (int n = 0; n < cout; ++n) dr[n] += a * g[n]; }
     }
   }

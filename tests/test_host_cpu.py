@@ -74,9 +74,11 @@ def _ddp_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(100 + rank)             # replicas start DIFFERENT: the constructor must make them equal
     model = _toy()
+    model[3].__dict__['_irx_lane'] = 0        # a "lane-issued encoder": its parameters form a static all-reduce segment
     with torch.no_grad():
         model[1].running_mean.add_(rank + 1.0)
     opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, module=model)
+    out["segments_%d" % rank] = (list(opt._groups), list(opt._gaps))
     out["p0_%d" % rank] = opt.flat_p.clone()
     out["rm_%d" % rank] = model[1].running_mean.clone()
     torch.manual_seed(0)
@@ -135,6 +137,8 @@ def test_flat_adam_reducer_gloo_world2():
     assert out["inactive_local_1"] == list(range(8)) and out["inactive_local_0"] == [6, 7]
     assert out["inactive_0"] == out["inactive_1"] == [6, 7]
     assert "HIP device" in out["step_0"] and "HIP device" in out["step_1"]
+    # static segments: [Linear(16,1): parameters 4, 5] + the gaps around it (the last one carries the activity flags)
+    assert out["segments_0"] == out["segments_1"] == ([(4, 176, 208)], [(0, 176), (208, 256)])
 
 
 def test_flat_adam_state_dict_is_torch_adam_layout():

@@ -580,3 +580,24 @@ def test_pyg_surface_knn_and_message_passing(lib):
     msg = torch.tensor([[1.0, -2.0], [3.0, -5.0], [-1.0, -1.0]]).cuda()
     out = mp_.aggregate(msg, torch.tensor([2, 0, 2]).cuda(), 4).cpu()
     assert torch.equal(out, torch.tensor([[3.0, -5.0], [0.0, 0.0], [1.0, -1.0], [0.0, 0.0]]))
+
+
+def test_voxeliser_rejects_coordinates_it_cannot_key(lib):
+    """Keys hold 16 biased bits per coordinate: a point whose voxel coordinate leaves [-32768, 32768) would alias onto
+    another voxel. Both voxeliser entry points must raise instead (the count comes back negative), in-range clouds with
+    extreme but legal coordinates must not."""
+    from instancerefer_amd.sparse.utils import voxelize, voxelize_launch
+    dev = torch.device("cuda")
+    xyz = torch.rand(1000, 3, dtype=torch.float64, device=dev) * 4
+    feats = torch.rand(1000, 7, device=dev)
+    batch = torch.zeros(1000, dtype=torch.int32, device=dev)
+    ok = xyz.clone()
+    ok[0] = torch.tensor([32767 * 0.05 + 0.01, -32768 * 0.05 + 0.01, 0.0], dtype=torch.float64)
+    assert voxelize(ok, feats, batch, [0.05] * 3, 1).F.shape[0] > 0
+    for bad_value in (32768 * 0.05 + 0.01, -32768 * 0.05 - 0.01, float("nan")):
+        bad = xyz.clone()
+        bad[500, 1] = bad_value
+        with pytest.raises(ValueError, match="voxel coordinates outside"):
+            voxelize(bad, feats, batch, [0.05] * 3, 1)
+        with pytest.raises(ValueError, match="voxel coordinates outside"):
+            voxelize_launch(bad, feats, batch, [0.05] * 3, 1, 4).finish()

@@ -151,3 +151,34 @@ def test_oracle_input_pipeline_matches_reference_getitem(case):
     assert [len(t[0]) for t in d["pts_batch"]] == list(g[case + "/pts_batch_sizes"])
     c, f = _voxel_set(d["pts_batch"][0])
     assert np.array_equal(c, g[case + "/pts_batch0_C"]) and np.array_equal(f, g[case + "/pts_batch0_F"])
+
+
+def _projection_inputs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_projection", os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden_projection.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.inputs()
+
+
+def test_oracle_projection_matches_reference_fixture():
+    """oracle/projection_ref.py == the reference's ProjectionHelper.compute_projection / project (projection.npz, made by
+    tests/golden/make_golden_projection.py from lib/projection.py itself): index lists bit-exact, features exact. The
+    host algebra (frustum corners / normals, 4x4 inverse) is the product's ProjectionHelper._params (plain CPU torch)."""
+    from oracle import projection_ref as PR
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.projection import ProjectionHelper
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "projection.npz"))
+    pts, poses, depths, feats = _projection_inputs()
+    helper = ProjectionHelper(S.PROJ_INTRINSICS, cuda=False, **S.PROJ_ARGS)
+    w, h = S.PROJ_ARGS["image_dims"]
+    total = 0
+    for i in range(poses.shape[0]):
+        i3, i2 = PR.compute_projection(pts, depths[i], helper._params(torch.from_numpy(poses[i])), w, h)
+        assert len(i3) == int(g["count/%d" % i])
+        total += len(i3)
+        if len(i3):
+            assert np.array_equal(i3, g["ind3d/%d" % i]) and np.array_equal(i2, g["ind2d/%d" % i])
+            assert np.array_equal(PR.project(feats[i], i3, i2, len(pts))[:, i3], g["proj/%d" % i])
+    assert total > 1000

@@ -10,6 +10,8 @@ from instancerefer_amd.loss_helper import DatasetConfig, get_loss
 from instancerefer_amd.optim import FlatAdam
 from instancerefer_amd.sparse import SparseTensor
 _lib.load()
+import instancerefer_amd as _irx
+_irx.set_compute_dtype('bf16' if args.dtype == 'bf16' else 'fp32')
 B = args.batch or 16
 model = bench.build_model(args, "full", dev)
 cfg = DatasetConfig()
