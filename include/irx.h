@@ -341,6 +341,26 @@ int irx_gru_backward(const float* dout, const float* out, const float* gates, co
                      const float* w_hh, int B, int T, int ndir, int H, float* dgi, float* dgh,
                      void* stream);
 
+/* DynamicEdgeConv of the relation module (models/basic_blocks.py:98-133: MessagePassing(aggr='max') with
+ * message = mlp([x_i, weight([pos_j - pos_i, cls_i, cls_j]), x_j])) as one launch per direction over a fixed
+ * (n_query, k) neighbour grid (irx_knn_batched's output, -1 = no neighbour). feats [S][fin], pos [S][3]: support rows;
+ * qidx int64 [nq]: the support row of every query; cls = the last nc channels of a feature row.
+ * params[8] = weight.0.weight [hid][3+2nc], weight.0.bias, weight.2.weight [fin][hid], weight.2.bias, mlp.0.weight
+ * [fout][3 fin], mlp.0.bias, mlp.2.weight [fout][fout], mlp.2.bias (nn.Linear layouts, state-dict order).
+ * fwd: out [nq][fout] = max over the valid neighbours, arg int32 [nq][fout] = the winning neighbour slot (first maximum).
+ * bwd: grads[8] (shapes of params) from dout [nq][fout] + arg; dmin_out (optional): [nq][k][3 fin] = d(message input) per
+ * edge, thirds (d x_i, d edge weight, d x_j), followed by [nq][k][3 + 2 nc] = d(edge-weight input) per edge, for callers
+ * that need the gradient of the node features. k <= 16, hid <= 128.
+ * Deterministic (per-workgroup slabs in the workspace, summed in order). */
+size_t irx_edgeconv_workspace_bytes(int nq, int k, int fin, int nc, int hid, int fout);
+int irx_edgeconv_max_fwd(const float* feats, const float* pos, const int64_t* qidx, const int32_t* nbr, int nq, int k,
+                         int fin, int nc, int hid, int fout, const float* const* params, float* out, int32_t* arg,
+                         void* stream);
+int irx_edgeconv_max_bwd(const float* feats, const float* pos, const int64_t* qidx, const int32_t* nbr, int nq, int k,
+                         int fin, int nc, int hid, int fout, const float* const* params, const float* dout,
+                         const int32_t* arg, float* const* grads, float* dmin_out, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* ---- box labels of get_loss / get_eval --------------------------------------- */
 
 /* lib/loss_helper.py:233-258 without the per-sample host loop: IoU (float64, axis-aligned: utils/box_util.py:154-175,

@@ -76,6 +76,9 @@ _SIGNATURES = {
     "irx_project_workspace_bytes": (_Z, [_I]),
     "irx_project_points": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "irx_project_features": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
+    "irx_edgeconv_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "irx_edgeconv_max_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "irx_edgeconv_max_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "irx_iou_labels": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "irx_eval_select": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
 }

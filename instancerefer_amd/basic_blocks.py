@@ -90,9 +90,10 @@ class DynamicEdgeConv(nn.Module):
     derives from torch_geometric MessagePassing(aggr='max') and calls torch_cluster knn).
 
     message(i <- j) = mlp([x_i, weight([pos_j - pos_i, cls_i, cls_j]), x_j]); out_i = max_j message.
-    kNN runs in one HIP launch (one wave per query, batch-segmented); the edge MLPs are dense GEMMs on a
-    fixed (n_query, k) edge grid (slots beyond a scene's instance count are masked to -inf before the max),
-    so there is no data-dependent edge count and no host sync.
+    kNN runs in one HIP launch (one wave per query, batch-segmented) on a fixed (n_query, k) edge grid (slots beyond a
+    scene's instance count hold -1), so there is no data-dependent edge count and no host sync; gather, both edge MLPs
+    and the masked max are ONE launch forward and one backward (csrc/irx_edgeconv.hip, EdgeConvMaxFn below) instead of
+    ~20 + ~40 ATen ops.
     """
 
     def __init__(self, F_in, F_out, k=6, num_classes=18):
@@ -111,18 +112,65 @@ class DynamicEdgeConv(nn.Module):
             counts = torch.bincount(batch_index, minlength=nb)
             support_offsets = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
         nbr = F_.knn_batched(support_xyz, support_offsets, query_xyz, query_batch.int(), self.k)  # (nq,k)
-        valid = nbr >= 0
-        j = nbr.clamp(min=0).long()
-        nq = query_xyz.shape[0]
-        x_j = features.index_select(0, j.reshape(-1)).view(nq, self.k, -1)
-        pos_j = support_xyz.index_select(0, j.reshape(-1)).view(nq, self.k, 3)
-        x_i = query_features.unsqueeze(1).expand(-1, self.k, -1)
-        pos_i = query_xyz.unsqueeze(1)
-        nc = self.num_classes
-        edge_weights = self.weight(torch.cat([pos_j - pos_i, x_i[..., -nc:], x_j[..., -nc:]], -1))
-        msg = self.mlp(torch.cat([x_i, edge_weights, x_j], dim=-1))              # (nq, k, F_out)
-        msg = msg.masked_fill(~valid.unsqueeze(-1), float("-inf"))
-        return msg.max(dim=1)[0]
+        return EdgeConvMaxFn.apply(features, support_xyz, filtered_index, nbr, self.num_classes,
+                                   self.weight[0].weight, self.weight[0].bias, self.weight[2].weight, self.weight[2].bias,
+                                   self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias)
+
+
+class EdgeConvMaxFn(torch.autograd.Function):
+    """out_i = max_j mlp([x_i, weight([pos_j - pos_i, cls_i, cls_j]), x_j]) over the (n_query, k) neighbour grid `nbr`
+    (irx_edgeconv_max_fwd / irx_edgeconv_max_bwd, include/irx.h). Gradients: the eight MLP parameters always; the node
+    features only when they require it (the reference's features are data); positions never."""
+
+    @staticmethod
+    def forward(ctx, feats, pos, qidx, nbr, nc, *params):
+        import ctypes
+        from . import _lib
+        feats, pos = feats.contiguous().float(), pos.contiguous().float()
+        qidx, nbr = qidx.contiguous().long(), nbr.contiguous().int()
+        params = [p.contiguous().float() for p in params]
+        nq, k = nbr.shape
+        fin, hid, fout = feats.shape[1], params[0].shape[0], params[6].shape[0]
+        out = torch.empty((nq, fout), dtype=torch.float32, device=feats.device)
+        arg = torch.empty((nq, fout), dtype=torch.int32, device=feats.device)
+        pp = (ctypes.c_void_p * 8)(*[_lib.ptr(p) for p in params])
+        _lib.call("irx_edgeconv_max_fwd", _lib.ptr(feats), _lib.ptr(pos), _lib.ptr(qidx), _lib.ptr(nbr), nq, k, fin, nc, hid,
+                  fout, pp, _lib.ptr(out), _lib.ptr(arg), _lib.stream_ptr())
+        ctx.save_for_backward(feats, pos, qidx, nbr, arg, *params)
+        ctx.dims = (nq, k, fin, nc, hid, fout)
+        ctx.mark_non_differentiable(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        from . import _lib
+        feats, pos, qidx, nbr, arg, *params = ctx.saved_tensors
+        nq, k, fin, nc, hid, fout = ctx.dims
+        dev = feats.device
+        dout = dout.contiguous().float()
+        grads = [torch.empty_like(p) for p in params]
+        wsb = int(_lib.load().irx_edgeconv_workspace_bytes(nq, k, fin, nc, hid, fout))
+        ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
+        ein = 3 + 2 * nc
+        dmin = torch.empty(nq * k * (3 * fin + ein), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        pp = (ctypes.c_void_p * 8)(*[_lib.ptr(p) for p in params])
+        gp = (ctypes.c_void_p * 8)(*[_lib.ptr(g) for g in grads])
+        _lib.call("irx_edgeconv_max_bwd", _lib.ptr(feats), _lib.ptr(pos), _lib.ptr(qidx), _lib.ptr(nbr), nq, k, fin, nc, hid,
+                  fout, pp, _lib.ptr(dout), _lib.ptr(arg), gp, _lib.ptr(dmin), _lib.ptr(ws), wsb, _lib.stream_ptr())
+        dfeats = None
+        if dmin is not None:                 # rare (features are data in the reference): scatter the per-edge terms
+            dm = dmin[:nq * k * 3 * fin].view(nq, k, 3, fin)
+            de = dmin[nq * k * 3 * fin:].view(nq, k, ein)
+            j = nbr.clamp(min=0).long().view(-1)
+            dfeats = torch.zeros_like(feats)
+            dq = dm[:, :, 0].sum(1)
+            dq[:, fin - nc:] += de[:, :, 3:3 + nc].sum(1)
+            dfeats.index_add_(0, qidx, dq)
+            dj = dm[:, :, 2].reshape(-1, fin).clone()
+            dj[:, fin - nc:] += de[:, :, 3 + nc:].reshape(-1, nc)
+            dfeats.index_add_(0, j, dj)      # rows of missing neighbours carry zeros
+        return (dfeats, None, None, None, None) + tuple(grads)
 
 
 def spcrop(inputs, loc_min, loc_max):

@@ -10,6 +10,10 @@
 // One thread per scene: B <= a few hundred scenes of <= a few dozen boxes — launch latency is the whole cost.
 #include "irx_common.h"
 
+// The library is built with -ffp-contract=fast; here every product must be rounded before it is added (numpy does not
+// fuse): without this the compiler turns `v1 + v2 - inter` into fma(-a, e, v1 + v2) and the IoU loses bit-equality.
+#pragma clang fp contract(off)
+
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
 // obb = (cx, cy, cz, sx, sy, sz, heading)
