@@ -481,9 +481,13 @@ def summarise_roofline(recs, bf16=False):
         if kind in ("fwd", "dgrad"):
             if cin in (32, 64, 128) and cout in (32, 64, 128):
                 return "k_spconv2<%d,%d>" % (cin, cout)
+            if 128 < cin <= 136 and cout == 32 and kind == "fwd":
+                return "wide stem fwd (k_stem_fwd + k_spconv2<128,32>)"
             return "k_stem_fwd" if (cin <= 8 and cout == 32) else "k_spconv_fwd(generic)"
         if cin in (32, 64, 128) and cout in (32, 64, 128):
             return "k_wgrad_pairs<%d,%d>" % (cin, cout)
+        if 128 < cin <= 136 and cout == 32:
+            return "wide stem wgrad (k_spconv2_wgrad<128,32> + k_stem_wgrad)"
         return "k_stem_wgrad" if (cin <= 8 and cout == 32) else "k_spconv_wgrad(generic)"
 
     tot = dict(ms=0.0, bound_ms=0.0)

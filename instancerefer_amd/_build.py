@@ -14,6 +14,10 @@ SOURCES = ["irx_coords.hip", "irx_spconv.hip", "irx_spconv2.hip", "irx_pairs.hip
 HEADERS = ["irx_common.h", os.path.join("..", "..", "include", "irx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-pthread"]
+# Sources whose results must equal numpy / torch element-wise arithmetic bit for bit (float64 IoUs, the projection's
+# float32 plane / pixel tests): no fused multiply-adds except the explicit ones. (-ffp-contract=fast fuses in the backend,
+# so `#pragma clang fp contract(off)` inside the file does not stop it: measured, 24 v_fma_f64 vs 6.)
+EXTRA_FLAGS = {"irx_labels.hip": ["-ffp-contract=off"], "irx_project.hip": ["-ffp-contract=off"]}
 
 
 def _stale() -> bool:
@@ -51,7 +55,7 @@ def _build_locked(objdir, verbose):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -111,14 +111,15 @@ bool irx_conv_bf16();   // irx_set_compute_dtype(1): bf16 operands / fp32 accumu
 bool irx_spconv2_supported(int cin, int cout);
 bool irx_spconv2_enabled(char pass);
 int irx_spconv2_splits(int n_out, int K);
+// ldx (last argument, 0 = cin): row stride of x in floats when x is the leading `cin` columns of wider rows
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                       int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st);
+                       int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st, int ldx = 0);
 // irx_spconv_fwd with gradient accumulation (accumulate != 0: y += result; fast-path channel counts only) and an
 // optional prebuilt fragment-major weight image (wimg != NULL: the per-call permute launch is skipped)
 int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
                         int flip_k, int trans_w, float* y, int accumulate, const float* wimg, void* workspace,
                         size_t workspace_bytes, void* stream);
-int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st);
+int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st, int src_cin = 0);
 // fragment images of up to 16 layers in one launch; dims are kernel-relative (cin = reduction, cout = outputs),
 // end4[j] = running total of float4 elements (K*cin*cout/4) up to and including job j
 struct IrxPermuteJobs {
@@ -131,12 +132,14 @@ struct IrxPermuteJobs {
 int irx_permute_w_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStream_t st);
 bool irx_spconv_fast_path(const void* x, const void* w, const void* y, int cin, int cout, int trans_w);
 int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
-                             int cin, int cout, int splits, int rps, float* part, hipStream_t st);
+                             int cin, int cout, int splits, int rps, float* part, hipStream_t st, int ldx = 0);
 
 // ---- stem (small-Cin) launchers (irx_stem.hip) ------------------------------------------------------
 bool irx_stem_supported(int K, int cin, int cout);
 int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                        float* y, hipStream_t st);
+                        float* y, hipStream_t st, int ldx = 0);
 int irx_stem_wgrad_blocks(int n_out);
 int irx_stem_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int cin,
-                          int blocks, float* part, hipStream_t st);
+                          int blocks, float* part, hipStream_t st, int ldx = 0);
+// multiview stem: 3^3 conv, 129..136 input channels -> 32 (irx_spconv.hip "wide stem")
+bool irx_wide_stem(int K, int cin, int cout);

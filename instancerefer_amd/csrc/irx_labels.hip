@@ -10,9 +10,9 @@
 // One thread per scene: B <= a few hundred scenes of <= a few dozen boxes — launch latency is the whole cost.
 #include "irx_common.h"
 
-// The library is built with -ffp-contract=fast; here every product must be rounded before it is added (numpy does not
-// fuse): without this the compiler turns `v1 + v2 - inter` into fma(-a, e, v1 + v2) and the IoU loses bit-equality.
-#pragma clang fp contract(off)
+// Built with -ffp-contract=off (instancerefer_amd/_build.py EXTRA_FLAGS): every product must be rounded before it is
+// added, as numpy does — with the library-wide -ffp-contract=fast the backend turns `v1 + v2 - inter` into
+// fma(-a, e, v1 + v2) and the IoU loses bit-equality (a file-scope `#pragma clang fp contract(off)` does not prevent it).
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 

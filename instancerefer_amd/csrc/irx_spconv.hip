@@ -291,6 +291,19 @@ void irx_bracket_end(hipStream_t st) {
   if (g_br_stop) (void)hipEventRecord(g_br_stop, st);
   g_br_start = g_br_stop = nullptr;
 }
+// One bracket around a COMPOSITE operator (the wide stem = two dominant kernels): begin records the start event and
+// parks the pair so that the inner launches do not consume it; end restores it and records the stop event.
+struct IrxBracketSpan {
+  hipEvent_t stop;
+  hipStream_t st;
+  explicit IrxBracketSpan(hipStream_t s) : stop(g_br_stop), st(s) {
+    if (g_br_start) (void)hipEventRecord(g_br_start, st);
+    g_br_start = g_br_stop = nullptr;
+  }
+  ~IrxBracketSpan() {
+    if (stop) (void)hipEventRecord(stop, st);
+  }
+};
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
@@ -310,11 +323,40 @@ static void launch_fwd(int bn, dim3 grid, hipStream_t st, const float* x, const 
 
 static size_t fwd_ws_weights(int K, int cin, int cout) { return ((size_t)K * cin * cout * sizeof(float) + 255) & ~(size_t)255; }
 
+// ---- wide stem: the multiview input (reference scripts/train.py:74-75, lib/dataset.py:112-118: 128 ENet channels on
+// top of xyz / rgb / height -> C0 = 135) through the 3^3 stem conv C0 -> 32. The row is split: channels [0, 128) run on
+// the MFMA kernels of the 128-channel layers reading x with row stride C0 (rows are only 4-byte aligned: 16-byte global
+// loads at dword alignment are legal on gfx950, tools/micro/unaligned_load.hip), channels [128, C0) on the small-Cin
+// stem kernels; forward adds the two (accumulating epilogue), the weight gradient merges the two blocks.
+#define WS_MAIN 128
+bool irx_wide_stem(int K, int cin, int cout) { return K == 27 && cout == 32 && cin > WS_MAIN && cin <= WS_MAIN + 8; }
+
+// wt[k][c][n] = w[k][c0 + c][n]
+__global__ void k_slice_w(const float* __restrict__ w, int K, int cin, int c0, int ct, int cout, float* __restrict__ wt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * ct * cout) return;
+  const int n = i % cout, c = (i / cout) % ct, k = i / (cout * ct);
+  wt[i] = w[((size_t)k * cin + c0 + c) * cout + n];
+}
+// dw[k][c][n] = c < c0 ? a[k][c][n] : b[k][c - c0][n]
+__global__ void k_merge_w(const float* __restrict__ a, const float* __restrict__ b, int K, int cin, int c0, int cout,
+                          float* __restrict__ dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * cin * cout) return;
+  const int n = i % cout, c = (i / cout) % cin, k = i / (cout * cin);
+  dw[i] = (c < c0) ? a[((size_t)k * c0 + c) * cout + n] : b[((size_t)k * (cin - c0) + (c - c0)) * cout + n];
+}
+static size_t wide_tail_bytes(int K, int cin, int cout) { return ((size_t)K * (cin - WS_MAIN) * cout * sizeof(float) + 255) & ~(size_t)255; }
+
 extern "C" size_t irx_spconv_fwd_workspace_bytes(int n_out, int K, int cin, int cout, int trans_w) {
   // fast path: a fragment-major weight image (one coalesced 1 KiB load per wave fragment) + the partial-sum slabs
   // of the offset splits used for small layers
   if (n_out <= 0 || K <= 0 || cin <= 0 || cout <= 0) return 0;
-  (void)trans_w;
+  if (!trans_w && irx_wide_stem(K, cin, cout)) {
+    const int splits = irx_spconv2_splits(n_out, K);
+    return fwd_ws_weights(K, WS_MAIN, cout) + wide_tail_bytes(K, cin, cout) +
+           (splits > 1 ? (size_t)splits * n_out * cout * sizeof(float) : 0);
+  }
   if (!irx_spconv2_supported(cin, cout)) return 0;
   const int splits = irx_spconv2_splits(n_out, K);
   return fwd_ws_weights(K, cin, cout) + (splits > 1 ? (size_t)splits * n_out * cout * sizeof(float) : 0);
@@ -367,6 +409,35 @@ int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int 
     return IRX_OK;
   }
   IRX_REQUIRE(!accumulate, "irx_spconv_fwd: accumulation needs the fast path (aligned, channels in {32,64,128})");
+  if (!trans_w && !flip_k && irx_wide_stem(K, cin, cout) && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0) &&
+      irx_spconv2_enabled('f')) {
+    const size_t need = irx_spconv_fwd_workspace_bytes(n_out, K, cin, cout, 0);
+    if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+      irx_set_error("irx_spconv_fwd(wide stem): workspace %zu < %zu", workspace_bytes, need);
+      return IRX_ERR_WORKSPACE;
+    }
+    const int ct = cin - WS_MAIN;
+    IrxBracketSpan span(S(stream));
+    float* wimg_main = (float*)workspace;
+    float* wtail = (float*)((char*)workspace + fwd_ws_weights(K, WS_MAIN, cout));
+    float* slabs = (float*)((char*)wtail + wide_tail_bytes(K, cin, cout));
+    k_slice_w<<<irx_cdiv(K * ct * cout, 256), 256, 0, S(stream)>>>(w, K, cin, WS_MAIN, ct, cout, wtail);
+    IRX_CHECK_LAUNCH("irx_spconv_fwd(wide stem slice)");
+    int rc = irx_permute_w_launch(w, K, WS_MAIN, cout, 0, wimg_main, S(stream), cin);
+    if (rc) return rc;
+    rc = irx_stem_fwd_launch(x + WS_MAIN, wtail, nbr, ld, n_out, K, ct, y, S(stream), cin);    // y  = tail channels
+    if (rc) return rc;
+    const int splits = irx_spconv2_splits(n_out, K);
+    rc = irx_spconv2_launch(x, wimg_main, nbr, ld, n_out, K, WS_MAIN, cout, 0, splits > 1 ? slabs : y, splits, 1,
+                            S(stream), cin);                                                      // y += main channels
+    if (rc) return rc;
+    if (splits > 1) {
+      const size_t elems = (size_t)n_out * cout;
+      k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(slabs, splits, elems, y, 1);
+      IRX_CHECK_LAUNCH("irx_spconv_fwd(wide stem reduce)");
+    }
+    return IRX_OK;
+  }
   const int bn = cout > 64 ? 128 : (cout > 32 ? 64 : 32);
   dim3 grid(irx_cdiv(n_out, SC_TM), irx_cdiv(cout, bn));
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
@@ -395,6 +466,12 @@ static int wgrad_splits(int n_out, int K, int cin, int cout) {
 extern "C" size_t irx_spconv_wgrad_workspace_bytes(int n_out, int K, int cin, int cout) {
   if (n_out <= 0 || K <= 0 || cin <= 0 || cout <= 0) return 0;
   if (irx_stem_supported(K, cin, cout)) return (size_t)irx_stem_wgrad_blocks(n_out) * K * cin * cout * sizeof(float);
+  if (irx_wide_stem(K, cin, cout)) {
+    // [main partial slabs | main sum | tail partial slabs | tail sum]
+    const int s = wgrad_splits(n_out, K, WS_MAIN, cout);
+    return ((size_t)(s + 1) * K * WS_MAIN * cout + (size_t)(irx_stem_wgrad_blocks(n_out) + 1) * K * (cin - WS_MAIN) * cout) *
+           sizeof(float);
+  }
   const int s = wgrad_splits(n_out, K, cin, cout);
   return s <= 1 ? 0 : (size_t)s * K * cin * cout * sizeof(float);
 }
@@ -422,6 +499,30 @@ extern "C" int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* 
     if (rc) return rc;
     k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>((const float*)workspace, blocks, elems, dw);
     IRX_CHECK_LAUNCH("irx_spconv_wgrad(stem reduce)");
+    return IRX_OK;
+  }
+  if (irx_wide_stem(K, cin, cout) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0) && irx_spconv2_enabled('w')) {
+    const int ct = cin - WS_MAIN;
+    IrxBracketSpan span(S(stream));
+    const int sm = wgrad_splits(n_out, K, WS_MAIN, cout);
+    const size_t em = (size_t)K * WS_MAIN * cout, et = (size_t)K * ct * cout;
+    float* part_m = (float*)workspace;
+    float* sum_m = part_m + (size_t)sm * em;
+    const int blocks = irx_stem_wgrad_blocks(n_out);
+    float* part_t = sum_m + em;
+    float* sum_t = part_t + (size_t)blocks * et;
+    int rpm = irx_cdiv(n_out, sm);
+    rpm = irx_cdiv(rpm, WG_TQ) * WG_TQ;
+    int rc = irx_spconv2_wgrad_launch(x, dy, nbr, ld, n_out, K, WS_MAIN, cout, sm, rpm, part_m, S(stream), cin);
+    if (rc) return rc;
+    k_wgrad_reduce<<<irx_cdiv((long long)em, 256), 256, 0, S(stream)>>>(part_m, sm, em, sum_m);
+    IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem reduce)");
+    rc = irx_stem_wgrad_launch(x + WS_MAIN, dy, nbr, ld, n_out, ct, blocks, part_t, S(stream), cin);
+    if (rc) return rc;
+    k_wgrad_reduce<<<irx_cdiv((long long)et, 256), 256, 0, S(stream)>>>(part_t, blocks, et, sum_t);
+    IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem tail reduce)");
+    k_merge_w<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(sum_m, sum_t, K, cin, WS_MAIN, cout, dw);
+    IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem merge)");
     return IRX_OK;
   }
   int rps = irx_cdiv(n_out, s);

@@ -85,7 +85,7 @@ __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __
                                          const unsigned char* __restrict__ lrow, int g, int vs, int m, int g4,
                                          int n_base, const WT (&wc)[WN], WT (&wx)[WN],
                                          float4 (&sx)[NJ], const int (&nrow)[NJ], const float* __restrict__ x, int c4,
-                                         const WT* __restrict__ wnk) {
+                                         const WT* __restrict__ wnk, int ldx) {
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -108,7 +108,7 @@ __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __
 #pragma unroll
       for (int i = (BF ? (j * NT) / 2 : j * NT); i < (BF ? ((j + 1) * NT) / 2 : (j + 1) * NT); ++i)
         wx[i] = wnk[(size_t)i * 64];
-      sx[j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
+      sx[j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * ldx + c4);
     }
     if constexpr (BF) {
       // a lane's 4 consecutive floats are exactly the 4 k-slots of the 16x16x16 bf16 MFMA: one MFMA replaces four
@@ -199,7 +199,9 @@ __device__ __forceinline__ void s2_wait_vmcnt() {
 template <int CIN, int COUT, bool BF>
 __global__ __launch_bounds__(256, 2)
 void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const int32_t* __restrict__ nbr, int ld,
-               int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate) {
+               int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate, int ldx) {
+  // ldx = row stride of x in floats (CIN for a dense tensor; > CIN when x is the leading CIN columns of wider rows:
+  // the multiview stem, irx_spconv.hip "wide stem"; rows then need only 4-byte alignment)
   // accumulate != 0 (single split only): the tile is ADDED to the rows already in y (gradient accumulation).
   // blockIdx.y = offset split: this workgroup handles offsets [kb, ke) and writes its partial tile to slab
   // blockIdx.y of y (slabs are summed by k_wgrad_reduce; a single split writes the result directly).
@@ -303,7 +305,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
 #pragma unroll
     for (int i = 0; i < WN; ++i) W[T][i] = wnk[(size_t)i * 64];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
+    for (int j = 0; j < NJ; ++j) S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * ldx + c4);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -354,15 +356,15 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     int g = gp;
     if (NGP == 1 || g * 16 < vpad) {
       s2_group<CIN, COUT, NJ, NT, LDA, LDO, true, BF, WT, WN>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T], S[T],
-                                                              nrow, x, c4, wnk);
+                                                              nrow, x, c4, wnk, ldx);
       for (g += NGP; g * 16 < vpad; g += NGP)
         s2_group<CIN, COUT, NJ, NT, LDA, LDO, false, BF, WT, WN>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
-                                                                 S[T], nrow, x, c4, wnk);
+                                                                 S[T], nrow, x, c4, wnk, ldx);
     } else {                                       // a wave without a group in this item still prefetches its share
 #pragma unroll
       for (int i = 0; i < WN; ++i) W[T][i] = wnk[(size_t)i * 64];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * CIN + c4);
+      for (int j = 0; j < NJ; ++j) S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * ldx + c4);
     }
     S2_TICK(6);
   };
@@ -414,7 +416,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void k_spconv2_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const int32_t* __restrict__ nbr, int ld, int n_out,
-                                                          int K, int rows_per_split, float* __restrict__ part) {
+                                                          int K, int rows_per_split, float* __restrict__ part, int ldx) {
   constexpr int TC = CIN / 16, TN = COUT / 16;
   constexpr int CW = (TC >= 4) ? TC / 4 : 1;             // c-tiles per wave
   constexpr int NW = (TC >= 4) ? TN : TN / (4 / TC);     // n-tiles per wave
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv2_wgrad(const float* __restric
         const int p = p0 + sub;
         const int idx = __shfl(pl.in_of_pair, p & 63);
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < pl.v) val = *reinterpret_cast<const float4*>(x + (size_t)idx * CIN + c4);
+        if (p < pl.v) val = *reinterpret_cast<const float4*>(x + (size_t)idx * ldx + c4);
         if (p < vpad) *reinterpret_cast<float4*>(&sX[p * LDX + c4]) = val;
       }
     }
@@ -506,7 +508,8 @@ __device__ __forceinline__ void s2_store_frag_bf16(float* wf, size_t kcs, int nf
 }
 
 __global__ void k_permute_w(const float* __restrict__ w, int K, int cin, int cout, int trans_w, float* __restrict__ wf,
-                            int bf16) {
+                            int bf16, int src_cin) {
+  // src_cin: channel count of the SOURCE tensor per offset (forward only): the image covers its first `cin` channels
   const int NT = cout >= 128 ? 2 : 1;
   const int NCS = cout / (16 * NT);
   const int NJ = cin / 16;
@@ -525,7 +528,7 @@ __global__ void k_permute_w(const float* __restrict__ w, int K, int cin, int cou
   float* pv = reinterpret_cast<float*>(&v);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    pv[i] = trans_w ? w[((size_t)k * cout + n) * cin + c0 + i] : w[((size_t)k * cin + c0 + i) * cout + n];
+    pv[i] = trans_w ? w[((size_t)k * cout + n) * cin + c0 + i] : w[((size_t)k * src_cin + c0 + i) * cout + n];
   if (bf16)
     s2_store_frag_bf16(wf, (size_t)k * NCS + cs, NJ * NT, j * NT + t, lane, v);
   else
@@ -550,10 +553,10 @@ bool irx_spconv2_supported(int cin, int cout) {
 
 template <int CIN, bool BF>
 static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
-                        int ld, int n_out, int K, int flip_k, float* y, int kps, int acc) {
-  if (cout == 128) k_spconv2<CIN, 128, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
-  else if (cout == 64) k_spconv2<CIN, 64, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
-  else k_spconv2<CIN, 32, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+                        int ld, int n_out, int K, int flip_k, float* y, int kps, int acc, int ldx) {
+  if (cout == 128) k_spconv2<CIN, 128, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
+  else if (cout == 64) k_spconv2<CIN, 64, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
+  else k_spconv2<CIN, 32, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
 }
 
 // Output rows per workgroup: 64.  (128-row tiles stream half the weight bytes per useful FLOP but MEASURED SLOWER on
@@ -584,20 +587,21 @@ int irx_spconv2_splits(int n_out, int K) {
 
 // y: result (splits == 1; accumulate != 0 adds to it) or `splits` slabs of [n_out][cout] partial sums
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                       int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st) {
+                       int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st, int ldx) {
+  if (ldx <= 0) ldx = cin;
   const int acc = (splits == 1) ? accumulate : 0;
   IRX_REQUIRE(K <= 27, "irx_spconv_fwd: K = %d > 27 unsupported by the fast path", K);
   dim3 grid(irx_cdiv(n_out, S2_TM), splits);
   const int kps = irx_cdiv(K, splits);
   irx_bracket_begin(st);
   if (g_irx_conv_bf16) {
-    if (cin == 128) launch_fwd2<128, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
-    else if (cin == 64) launch_fwd2<64, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
-    else launch_fwd2<32, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+    if (cin == 128) launch_fwd2<128, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
+    else if (cin == 64) launch_fwd2<64, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
+    else launch_fwd2<32, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
   } else {
-    if (cin == 128) launch_fwd2<128, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
-    else if (cin == 64) launch_fwd2<64, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
-    else launch_fwd2<32, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc);
+    if (cin == 128) launch_fwd2<128, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
+    else if (cin == 64) launch_fwd2<64, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
+    else launch_fwd2<32, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
   }
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(v2)");
@@ -644,28 +648,30 @@ int irx_permute_w_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStrea
   return IRX_OK;
 }
 
-int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st) {
+int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st, int src_cin) {
   const size_t total = (size_t)K * cin * cout / 4;
-  k_permute_w<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(w, K, cin, cout, trans_w, wf, g_irx_conv_bf16);
+  k_permute_w<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(w, K, cin, cout, trans_w, wf, g_irx_conv_bf16,
+                                                              src_cin > 0 ? src_cin : cin);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(permute)");
   return IRX_OK;
 }
 
 template <int CIN>
 static void launch_wg2(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* nbr,
-                       int ld, int n_out, int K, int rps, float* part) {
-  if (cout == 128) k_spconv2_wgrad<CIN, 128><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part);
-  else if (cout == 64) k_spconv2_wgrad<CIN, 64><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part);
-  else k_spconv2_wgrad<CIN, 32><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part);
+                       int ld, int n_out, int K, int rps, float* part, int ldx) {
+  if (cout == 128) k_spconv2_wgrad<CIN, 128><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part, ldx);
+  else if (cout == 64) k_spconv2_wgrad<CIN, 64><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part, ldx);
+  else k_spconv2_wgrad<CIN, 32><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part, ldx);
 }
 
 int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
-                             int cin, int cout, int splits, int rps, float* part, hipStream_t st) {
+                             int cin, int cout, int splits, int rps, float* part, hipStream_t st, int ldx) {
+  if (ldx <= 0) ldx = cin;
   dim3 grid(splits, K);
   irx_bracket_begin(st);
-  if (cin == 128) launch_wg2<128>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part);
-  else if (cin == 64) launch_wg2<64>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part);
-  else launch_wg2<32>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part);
+  if (cin == 128) launch_wg2<128>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part, ldx);
+  else if (cin == 64) launch_wg2<64>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part, ldx);
+  else launch_wg2<32>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part, ldx);
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad(v2)");
   return IRX_OK;

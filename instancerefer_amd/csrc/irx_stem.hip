@@ -15,7 +15,7 @@
 template <int CIN>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const int32_t* __restrict__ nbr, int ld, int n_out, int K,
-                                                  float* __restrict__ y) {
+                                                  float* __restrict__ y, int ldx) {
   __shared__ __attribute__((aligned(16))) float sW[27 * CIN * ST_COUT];
   for (int i = threadIdx.x; i < K * CIN * ST_COUT; i += 256) sW[i] = w[i];
   __syncthreads();
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, c
     float xv[ST_R][CIN];
 #pragma unroll
     for (int j = 0; j < ST_R; ++j) {
-      const float* xr = x + (size_t)(idx[j] < 0 ? 0 : idx[j]) * CIN;  // missing neighbour: row 0, masked below
+      const float* xr = x + (size_t)(idx[j] < 0 ? 0 : idx[j]) * ldx;  // missing neighbour: row 0, masked below
 #pragma unroll
       for (int c = 0; c < CIN; ++c) xv[j][c] = idx[j] >= 0 ? xr[c] : 0.f;
     }
@@ -70,7 +70,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int CIN>
 __global__ __launch_bounds__(256, 2) void k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                        const int32_t* __restrict__ nbr, int ld, int n_out,
-                                                       int rows_per_block, float* __restrict__ part) {
+                                                       int rows_per_block, float* __restrict__ part, int ldx) {
   constexpr int K = 27;
   constexpr int MREAL = K * CIN;                 // 189 for CIN = 7
   constexpr int MT = (MREAL + 15) / 16;          // 12
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad(const float* __restrict__
       float v[EPT][CIN];
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        const float* xr = x + (size_t)(idx[e] < 0 ? 0 : idx[e]) * CIN;
+        const float* xr = x + (size_t)(idx[e] < 0 ? 0 : idx[e]) * ldx;
 #pragma unroll
         for (int c = 0; c < CIN; ++c) v[e][c] = idx[e] >= 0 ? xr[c] : 0.f;
       }
@@ -164,18 +164,19 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad(const float* __restrict__
 bool irx_stem_supported(int K, int cin, int cout) { return K == 27 && cout == ST_COUT && cin >= 1 && cin <= 8; }
 
 int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                        float* y, hipStream_t st) {
+                        float* y, hipStream_t st, int ldx) {
+  if (ldx <= 0) ldx = cin;
   const int grid = irx_cdiv(n_out, 32 * ST_R);
   irx_bracket_begin(st);
   switch (cin) {
-    case 1: k_stem_fwd<1><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
-    case 2: k_stem_fwd<2><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
-    case 3: k_stem_fwd<3><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
-    case 4: k_stem_fwd<4><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
-    case 5: k_stem_fwd<5><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
-    case 6: k_stem_fwd<6><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
-    case 7: k_stem_fwd<7><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
-    default: k_stem_fwd<8><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y); break;
+    case 1: k_stem_fwd<1><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
+    case 2: k_stem_fwd<2><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
+    case 3: k_stem_fwd<3><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
+    case 4: k_stem_fwd<4><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
+    case 5: k_stem_fwd<5><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
+    case 6: k_stem_fwd<6><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
+    case 7: k_stem_fwd<7><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
+    default: k_stem_fwd<8><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
   }
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(stem)");
@@ -190,19 +191,20 @@ int irx_stem_wgrad_blocks(int n_out) {
 }
 
 int irx_stem_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int cin,
-                          int blocks, float* part, hipStream_t st) {
+                          int blocks, float* part, hipStream_t st, int ldx) {
+  if (ldx <= 0) ldx = cin;
   int rpb = irx_cdiv(n_out, blocks);
   rpb = irx_cdiv(rpb, 64) * 64;
   irx_bracket_begin(st);
   switch (cin) {
-    case 1: k_stem_wgrad<1><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
-    case 2: k_stem_wgrad<2><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
-    case 3: k_stem_wgrad<3><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
-    case 4: k_stem_wgrad<4><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
-    case 5: k_stem_wgrad<5><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
-    case 6: k_stem_wgrad<6><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
-    case 7: k_stem_wgrad<7><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
-    default: k_stem_wgrad<8><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part); break;
+    case 1: k_stem_wgrad<1><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
+    case 2: k_stem_wgrad<2><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
+    case 3: k_stem_wgrad<3><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
+    case 4: k_stem_wgrad<4><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
+    case 5: k_stem_wgrad<5><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
+    case 6: k_stem_wgrad<6><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
+    case 7: k_stem_wgrad<7><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
+    default: k_stem_wgrad<8><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
   }
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad(stem)");
