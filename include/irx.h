@@ -253,6 +253,11 @@ enum {
   IRX_ENC_MEAN, IRX_ENC_INVSTD,     /* [cout] each */
   IRX_ENC_DW, IRX_ENC_DGAMMA, IRX_ENC_DBETA,     /* backward outputs */
   IRX_ENC_GY,                       /* backward: gradient w.r.t. the layer output [n_out][cout] */
+  IRX_ENC_STORE,                    /* 0: every tensor fp32. 1 (needs irx_set_compute_dtype(1 | 2)): bf16 STORAGE — C, Y, GY
+                                     * and the dc scratch are bf16 arrays (2 bytes / element) except the FIRST layer's X, the
+                                     * LAST layer's Y and GY and dx0, which stay fp32; statistics / parameter gradients fp32 */
+  IRX_ENC_PROF,                     /* 0, or a HOST pointer to 6 event handles (hipEvent_t): start / stop around this layer's
+                                     * dominant forward, data-gradient and weight-gradient kernel (measurement aid, bench.py) */
   IRX_ENC_NFIELDS
 };
 size_t irx_encoder_workspace_bytes(const int64_t* desc, const double* fdesc, int n_layers, int backward);

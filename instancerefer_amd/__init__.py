@@ -26,15 +26,25 @@ if _os.environ.get("IRX_KEEP_BLAS") != "1":
         pass
 
 
+_DTYPE_MODES = {"fp32": 0, "f32": 0, "bf16_operands": 1, "bf16op": 1, "bf16": 2}
+
+
 def set_compute_dtype(name):
-    """Compute dtype of the MFMA sparse-conv kernels (irx_set_compute_dtype, include/irx.h): "fp32" (default, exact;
-    the parity gate) or "bf16" (bf16 operands, fp32 accumulation — BASELINE configs[2]-[4]). Tensors stay fp32."""
+    """Compute dtype of the sparse encoders (irx_set_compute_dtype, include/irx.h):
+      "fp32"          (default) exact fp32 MFMA; the 1e-4 parity gate;
+      "bf16"          BASELINE configs[2]-[4]: bf16 operands with fp32 accumulation in the 32/64/128-channel convs AND bf16
+                      storage of every activation / gradient tensor inside the encoder executor (half the HBM bytes);
+                      BatchNorm statistics, accumulation, parameters and their gradients, encoder inputs / outputs fp32;
+      "bf16_operands" bf16 operands only, every tensor fp32 in HBM (round 1's mode)."""
     from . import _lib
-    if name not in ("fp32", "f32", "bf16"):
-        raise ValueError("compute dtype must be 'fp32' or 'bf16', got %r" % (name,))
-    _lib.call("irx_set_compute_dtype", 1 if name == "bf16" else 0)
+    if name not in _DTYPE_MODES:
+        raise ValueError("compute dtype must be one of %s, got %r" % (sorted(set(_DTYPE_MODES)), name))
+    from .sparse import encoder_fn
+    for lane in range(2):                     # a queued pass reads the mode when its kernels are issued: drain first
+        encoder_fn.lane_wait(lane)
+    _lib.call("irx_set_compute_dtype", _DTYPE_MODES[name])
 
 
 def get_compute_dtype():
     from . import _lib
-    return "bf16" if _lib.load().irx_get_compute_dtype() else "fp32"
+    return ("fp32", "bf16_operands", "bf16")[_lib.load().irx_get_compute_dtype()]

@@ -100,6 +100,28 @@ __device__ __forceinline__ s16x4 irx_frag_bf16(unsigned lo, unsigned hi) {
 }
 
 
+// ---- bf16 STORAGE (irx_set_compute_dtype(2)): activations / gradients inside the encoder executor are bf16 in HBM ------
+// 4 consecutive elements at ELEMENT offset `off` (a multiple of 4) of a tensor that is float32 (bf == 0) or bf16 (bf != 0;
+// the pointer is then really an unsigned short*). The flag is wave-uniform, so the branch is free in an HBM-bound kernel.
+__device__ __forceinline__ float4 irx_bf4_to_f4(uint2 u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 irx_f4_to_bf4(float4 v) { return make_uint2(irx_pk_bf16(v.x, v.y), irx_pk_bf16(v.z, v.w)); }
+__device__ __forceinline__ float4 irx_ld4(const float* p, size_t off, int bf) {
+  if (bf) return irx_bf4_to_f4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + off));
+  return *reinterpret_cast<const float4*>(p + off);
+}
+__device__ __forceinline__ void irx_st4(float* p, size_t off, int bf, float4 v) {
+  if (bf) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + off) = irx_f4_to_bf4(v);
+  else *reinterpret_cast<float4*>(p + off) = v;
+}
+static inline size_t irx_esz(int bf) { return bf ? 2 : 4; }
+// element types of one conv call inside the executor (0 = float32, 1 = bf16); the C-ABI entry points use all zeros
+struct IrxStore {
+  int x = 0, y = 0;
+};
+
 // ---- measurement aid (irx_profile_next_kernel, include/irx.h): brackets the next DOMINANT sparse-conv kernel of this
 // host thread (k_spconv2 / k_wgrad_pairs / k_spconv2_wgrad / k_stem_*) with two caller-owned events, excluding the small helper
 // launches (weight permute, split reduce) that share the C-ABI call.
@@ -107,18 +129,22 @@ void irx_bracket_begin(hipStream_t st);
 void irx_bracket_end(hipStream_t st);
 
 // ---- second-generation sparse-conv launchers (irx_spconv2.hip) ---------------------------------
-bool irx_conv_bf16();   // irx_set_compute_dtype(1): bf16 operands / fp32 accumulation in the MFMA conv kernels
+bool irx_conv_bf16();          // irx_set_compute_dtype(1 | 2): bf16 operands / fp32 accumulation in the MFMA conv kernels
+bool irx_conv_bf16_storage();  // irx_set_compute_dtype(2): ... and bf16 activations / gradients inside the encoder executor
 bool irx_spconv2_supported(int cin, int cout);
 bool irx_spconv2_enabled(char pass);
 int irx_spconv2_splits(int n_out, int K);
 // ldx (last argument, 0 = cin): row stride of x in floats when x is the leading `cin` columns of wider rows
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                       int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st, int ldx = 0);
+                       int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st, int ldx = 0,
+                       IrxStore ty = IrxStore());
 // irx_spconv_fwd with gradient accumulation (accumulate != 0: y += result; fast-path channel counts only) and an
 // optional prebuilt fragment-major weight image (wimg != NULL: the per-call permute launch is skipped)
 int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
                         int flip_k, int trans_w, float* y, int accumulate, const float* wimg, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        size_t workspace_bytes, void* stream, IrxStore ty = IrxStore());
+int irx_spconv_wgrad_impl(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
+                          float* dw, void* workspace, size_t workspace_bytes, void* stream, int dy_bf);
 int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st, int src_cin = 0);
 // fragment images of up to 16 layers in one launch; dims are kernel-relative (cin = reduction, cout = outputs),
 // end4[j] = running total of float4 elements (K*cin*cout/4) up to and including job j
@@ -132,14 +158,31 @@ struct IrxPermuteJobs {
 int irx_permute_w_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStream_t st);
 bool irx_spconv_fast_path(const void* x, const void* w, const void* y, int cin, int cout, int trans_w);
 int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
-                             int cin, int cout, int splits, int rps, float* part, hipStream_t st, int ldx = 0);
+                             int cin, int cout, int splits, int rps, float* part, hipStream_t st, int ldx = 0,
+                             int dy_bf = 0);
+
+int irx_spconv_wgrad_pairs_impl(const float* x, const float* dy, const int32_t* in_list, const int32_t* out_list, int ldp,
+                                const int32_t* counts, int n_out, int K, int cin, int cout, float* dw, void* workspace,
+                                size_t workspace_bytes, void* stream, int bf_rows);
+
+// ---- BatchNorm with per-tensor element types (irx_norm.hip; 0 = float32, 1 = bf16) — the executor's bf16 storage mode
+int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, float* mean, float* invstd,
+                   float* running_mean, float* running_var, void* workspace, size_t workspace_bytes, void* stream,
+                   int x_bf);
+int irx_bn_apply_t(const float* x, int n, int c, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, const float* residual, int relu, float* y, void* stream, int x_bf, int res_bf,
+                   int y_bf);
+int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, int c, const float* mean,
+                      const float* invstd, const float* gamma, int relu, float* dx, float* dgamma, float* dbeta,
+                      float* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int y_bf,
+                      int dy_bf, int dx_bf, int dres_bf);
 
 // ---- stem (small-Cin) launchers (irx_stem.hip) ------------------------------------------------------
 bool irx_stem_supported(int K, int cin, int cout);
 int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                        float* y, hipStream_t st, int ldx = 0);
+                        float* y, hipStream_t st, int ldx = 0, int y_bf = 0);
 int irx_stem_wgrad_blocks(int n_out);
 int irx_stem_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int cin,
-                          int blocks, float* part, hipStream_t st, int ldx = 0);
+                          int blocks, float* part, hipStream_t st, int ldx = 0, int dy_bf = 0);
 // multiview stem: 3^3 conv, 129..136 input channels -> 32 (irx_spconv.hip "wide stem")
 bool irx_wide_stem(int K, int cin, int cout);

@@ -20,6 +20,8 @@ struct Layer {
   float *x, *c, *y, *mean, *invstd;
   float *dw, *dgamma, *dbeta, *gy;
   float eps, momentum;
+  int store;   // bf16 storage of the activations / gradients in flight (IRX_ENC_STORE)
+  void** prof; // 6 event handles or NULL (IRX_ENC_PROF)
 };
 
 Layer unpack(const int64_t* d, const double* f) {
@@ -36,6 +38,8 @@ Layer unpack(const int64_t* d, const double* f) {
   L.mean = (float*)d[IRX_ENC_MEAN]; L.invstd = (float*)d[IRX_ENC_INVSTD];
   L.dw = (float*)d[IRX_ENC_DW]; L.dgamma = (float*)d[IRX_ENC_DGAMMA]; L.dbeta = (float*)d[IRX_ENC_DBETA];
   L.gy = (float*)d[IRX_ENC_GY];
+  L.store = (int)d[IRX_ENC_STORE];
+  L.prof = (void**)d[IRX_ENC_PROF];
   L.eps = (float)f[0]; L.momentum = (float)f[1];
   return L;
 }
@@ -105,18 +109,26 @@ extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int
     int rc = irx_permute_w_multi_launch(J, 0, (hipStream_t)stream);
     if (rc) return rc;
   }
+  const int st = (int)desc[IRX_ENC_STORE];
+  IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_forward: bf16 storage needs the bf16 compute mode (irx_set_compute_dtype)");
   for (int i = 0; i < n_layers; ++i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
     IRX_REQUIRE(L.res < i, "irx_encoder_forward: layer %d takes its residual from a later layer", i);
+    IRX_REQUIRE(L.store == st && (!st || L.res < n_layers - 1), "irx_encoder_forward: inconsistent storage flags");
+    IrxStore ty;
+    ty.x = (st && i > 0) ? 1 : 0;                 // the encoder's input features are fp32
+    ty.y = st;                                    // conv output c
+    const int y_bf = (st && i < n_layers - 1) ? 1 : 0;   // the encoder's output stays fp32
+    if (L.prof) irx_profile_next_kernel(L.prof[0], L.prof[1]);
     int rc = irx_spconv_fwd_impl(L.x, L.w, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, 0, 0, L.c, 0, wimg[i], ws_c, r.conv,
-                                 stream);
+                                 stream, ty);
     if (rc) return rc;
-    rc = irx_bn_stats(L.c, L.n_out, L.cout, L.eps, L.momentum, L.mean, L.invstd, L.running_mean, L.running_var, ws_b,
-                      r.bn, stream);
+    rc = irx_bn_stats_t(L.c, L.n_out, L.cout, L.eps, L.momentum, L.mean, L.invstd, L.running_mean, L.running_var, ws_b,
+                        r.bn, stream, st);
     if (rc) return rc;
     const float* res = nullptr;
     if (L.res >= 0) res = (const float*)desc[(size_t)L.res * IRX_ENC_NFIELDS + IRX_ENC_Y];
-    rc = irx_bn_apply(L.c, L.n_out, L.cout, L.mean, L.invstd, L.gamma, L.beta, res, 1, L.y, stream);
+    rc = irx_bn_apply_t(L.c, L.n_out, L.cout, L.mean, L.invstd, L.gamma, L.beta, res, 1, L.y, stream, st, st, y_bf);
     if (rc) return rc;
   }
   return IRX_OK;
@@ -164,24 +176,38 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
     const int res = (int)desc[(size_t)i * IRX_ENC_NFIELDS + IRX_ENC_RES];
     if (res >= 0) is_res_source[res] = true;
   }
+  const int st = (int)desc[IRX_ENC_STORE];
+  IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_backward: bf16 storage needs the bf16 compute mode (irx_set_compute_dtype)");
+  IRX_REQUIRE(!st || !dx0, "irx_encoder_backward: the input gradient is not available with bf16 storage");
   for (int i = n_layers - 1; i >= 0; --i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
     float* dres = nullptr;
     if (L.res >= 0) dres = (float*)desc[(size_t)L.res * IRX_ENC_NFIELDS + IRX_ENC_GY];
-    int rc = irx_bn_backward(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, dc_scratch, L.dgamma,
-                             L.dbeta, dres, ws_b, r.bn, stream);
+    const int last = (i == n_layers - 1);
+    // c: st | y, gy: fp32 for the last layer | dc scratch and the shortcut gradient (never the last layer's): st
+    int rc = irx_bn_backward_t(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, dc_scratch, L.dgamma,
+                               L.dbeta, dres, ws_b, r.bn, stream, st, (st && !last) ? 1 : 0, (st && !last) ? 1 : 0, st, st);
     if (rc) return rc;
-    if (pairs_path(L))
-      rc = irx_spconv_wgrad_pairs(L.x, dc_scratch, L.pair_in, L.pair_out, L.ld_pairs, L.pair_counts, L.n_out, L.K,
-                                  L.cin, L.cout, L.dw, ws_w, r.wgrad, stream);
-    else
-      rc = irx_spconv_wgrad(L.x, dc_scratch, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, L.dw, ws_w, r.wgrad, stream);
+    if (L.prof) irx_profile_next_kernel(L.prof[4], L.prof[5]);
+    if (pairs_path(L)) {
+      IRX_REQUIRE(!st || i > 0, "irx_encoder_backward: bf16 storage expects a stem (Cin <= 8 or 129..136) as layer 0");
+      rc = irx_spconv_wgrad_pairs_impl(L.x, dc_scratch, L.pair_in, L.pair_out, L.ld_pairs, L.pair_counts, L.n_out, L.K,
+                                       L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st);
+    } else {
+      IRX_REQUIRE(!st || i == 0, "irx_encoder_backward: layer %d (%d -> %d channels) has no bf16-storage weight-gradient path",
+                  i, L.cin, L.cout);
+      rc = irx_spconv_wgrad_impl(L.x, dc_scratch, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st);
+    }
     if (rc) return rc;
     float* dx = (i > 0) ? (float*)desc[(size_t)(i - 1) * IRX_ENC_NFIELDS + IRX_ENC_GY] : dx0;
     if (dx) {
       const int acc = (i > 0 && is_res_source[i - 1]) ? 1 : 0;
+      IrxStore ty;
+      ty.x = st;                                  // dc
+      ty.y = st;                                  // gy of layer i - 1 (never the last layer)
+      if (L.prof) irx_profile_next_kernel(L.prof[2], L.prof[3]);
       rc = irx_spconv_fwd_impl(dc_scratch, L.w, L.tbl_b, L.ld_b, L.n_in, L.K, L.cout, L.cin, L.flip_b, 1, dx, acc, wimg[i],
-                               ws_c, r.conv, stream);
+                               ws_c, r.conv, stream, ty);
       if (rc) return rc;
     }
   }

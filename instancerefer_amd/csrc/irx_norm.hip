@@ -9,6 +9,13 @@ static inline int bn_rows(int n) { return n > 262144 ? 512 : 256; }
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
+// Element types of the tensors of one BatchNorm call (0 = float32, 1 = bf16; bf16 needs the 4-wide path): the encoder
+// executor's bf16 storage mode keeps conv outputs, layer outputs and the gradients in flight as bf16 while the
+// statistics, the arithmetic and the parameter gradients stay fp32. The C-ABI entry points pass all zeros.
+struct BnTy {
+  int x, y, dy, dx, res;
+};
+
 __host__ __device__ static inline int next_pow2(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -25,7 +32,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
                                                     const float* __restrict__ dy, int n, int c,
                                                     const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, int relu,
-                                                    int qpad, int rows_per_block, float* __restrict__ part) {
+                                                    int qpad, int rows_per_block, float* __restrict__ part, BnTy ty) {
   __shared__ float s0[256 * V];
   __shared__ float s1[256 * V];
   const int cq = c / V;
@@ -53,10 +60,10 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
     auto load_row = [&](int r, float (&xv)[V], float (&yv)[V], float (&dv)[V]) __attribute__((always_inline)) {
       const size_t off = (size_t)r * c + (size_t)qd * V;
       if (V == 4) {
-        *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + off);
+        *reinterpret_cast<float4*>(xv) = irx_ld4(x, off, ty.x);
         if (MODE == 1) {
-          *reinterpret_cast<float4*>(dv) = *reinterpret_cast<const float4*>(dy + off);
-          if (relu) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + off);
+          *reinterpret_cast<float4*>(dv) = irx_ld4(dy, off, ty.dy);
+          if (relu) *reinterpret_cast<float4*>(yv) = irx_ld4(y, off, ty.y);
         }
       } else {
         xv[0] = x[off];
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, i
                                                   const float* __restrict__ gamma,
                                                   const float* __restrict__ beta,
                                                   const float* __restrict__ res, int relu,
-                                                  float* __restrict__ y) {
+                                                  float* __restrict__ y, BnTy ty) {
   const int cq = c / V;
   const int qd = threadIdx.x % qpad;
   if (qd >= cq) return;
@@ -188,8 +195,8 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, i
     const size_t off = (size_t)r * c + (size_t)qd * V;
     float xv[V], rv[V], ov[V];
     if (V == 4) {
-      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + off);
-      if (res) *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(res + off);
+      *reinterpret_cast<float4*>(xv) = irx_ld4(x, off, ty.x);
+      if (res) *reinterpret_cast<float4*>(rv) = irx_ld4(res, off, ty.res);
     } else {
       xv[0] = x[off];
       if (res) rv[0] = res[off];
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, i
       ov[j] = o;
     }
     if (V == 4)
-      *reinterpret_cast<float4*>(y + off) = *reinterpret_cast<float4*>(ov);
+      irx_st4(y, off, ty.y, *reinterpret_cast<float4*>(ov));
     else
       y[off] = ov[0];
   }
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ sum_g,
                                                       const float* __restrict__ sum_gx, int relu,
-                                                      float* __restrict__ dx, float* __restrict__ dres) {
+                                                      float* __restrict__ dx, float* __restrict__ dres, BnTy ty) {
   const int cq = c / V;
   const int qd = threadIdx.x % qpad;
   if (qd >= cq) return;
@@ -238,9 +245,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     const size_t off = (size_t)r * c + (size_t)qd * V;
     float xv[V], yv[V], dv[V], ox[V], og[V];
     if (V == 4) {
-      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + off);
-      *reinterpret_cast<float4*>(dv) = *reinterpret_cast<const float4*>(dy + off);
-      if (relu) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + off);
+      *reinterpret_cast<float4*>(xv) = irx_ld4(x, off, ty.x);
+      *reinterpret_cast<float4*>(dv) = irx_ld4(dy, off, ty.dy);
+      if (relu) *reinterpret_cast<float4*>(yv) = irx_ld4(y, off, ty.y);
     } else {
       xv[0] = x[off];
       dv[0] = dy[off];
@@ -255,8 +262,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
       og[j] = gval;
     }
     if (V == 4) {
-      *reinterpret_cast<float4*>(dx + off) = *reinterpret_cast<float4*>(ox);
-      if (dres) *reinterpret_cast<float4*>(dres + off) = *reinterpret_cast<float4*>(og);
+      irx_st4(dx, off, ty.dx, *reinterpret_cast<float4*>(ox));
+      if (dres) irx_st4(dres, off, ty.res, *reinterpret_cast<float4*>(og));
     } else {
       dx[off] = ox[0];
       if (dres) dres[off] = og[0];
@@ -292,6 +299,18 @@ static inline int row_grid(int n, int qpad) {
 extern "C" int irx_bn_stats(const float* x, int n, int c, float eps, float momentum, float* mean,
                             float* invstd, float* running_mean, float* running_var, void* workspace,
                             size_t workspace_bytes, void* stream) {
+  return irx_bn_stats_t(x, n, c, eps, momentum, mean, invstd, running_mean, running_var, workspace, workspace_bytes,
+                        stream, 0);
+}
+
+static int bn_bf_ok(const char* who, bool any_bf, bool v4) {
+  IRX_REQUIRE(!any_bf || v4, "%s: bf16 tensors need c %% 4 == 0 and 16-byte aligned pointers", who);
+  return IRX_OK;
+}
+
+int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, float* mean, float* invstd,
+                   float* running_mean, float* running_var, void* workspace, size_t workspace_bytes, void* stream,
+                   int x_bf) {
   int rc = bn_check("irx_bn_stats", n, c, workspace, workspace_bytes);
   if (rc) return rc;
   if (n == 0) return IRX_OK;
@@ -299,13 +318,16 @@ extern "C" int irx_bn_stats(const float* x, int n, int c, float eps, float momen
   const int nblk = irx_cdiv(n, bn_rows(n));
   float* part = (float*)workspace;
   const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  const BnTy ty = {x_bf, 0, 0, 0, 0};
+  rc = bn_bf_ok("irx_bn_stats", x_bf != 0, v4);
+  if (rc) return rc;
   if (v4)
     k_bn_partial<0, 4><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                   next_pow2(c / 4), bn_rows(n), part);
+                                                   next_pow2(c / 4), bn_rows(n), part, ty);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_stats: c=%d needs c %% 4 == 0 or c <= 256", c);
     k_bn_partial<0, 1><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                   next_pow2(c), bn_rows(n), part);
+                                                   next_pow2(c), bn_rows(n), part, ty);
   }
   IRX_CHECK_LAUNCH("irx_bn_stats(partial)");
   k_bn_finalize<0><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, eps, momentum, mean,
@@ -317,18 +339,27 @@ extern "C" int irx_bn_stats(const float* x, int n, int c, float eps, float momen
 extern "C" int irx_bn_apply(const float* x, int n, int c, const float* mean, const float* invstd,
                             const float* gamma, const float* beta, const float* residual, int relu,
                             float* y, void* stream) {
+  return irx_bn_apply_t(x, n, c, mean, invstd, gamma, beta, residual, relu, y, stream, 0, 0, 0);
+}
+
+int irx_bn_apply_t(const float* x, int n, int c, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, const float* residual, int relu, float* y, void* stream, int x_bf, int res_bf,
+                   int y_bf) {
   IRX_REQUIRE(n >= 0 && c >= 1, "irx_bn_apply: bad sizes");
   if (n == 0) return IRX_OK;
   IRX_REQUIRE(x && mean && invstd && gamma && beta && y, "irx_bn_apply: null pointer");
   const bool v4 = (c % 4 == 0) && (c / 4 <= 256) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
                   (residual == nullptr || ((uintptr_t)residual & 15) == 0);
+  const BnTy ty = {x_bf, y_bf, 0, 0, res_bf};
+  int rc = bn_bf_ok("irx_bn_apply", (x_bf | res_bf | y_bf) != 0, v4);
+  if (rc) return rc;
   if (v4) {
     const int qpad = next_pow2(c / 4);
-    k_bn_apply<4><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y);
+    k_bn_apply<4><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y, ty);
   } else {
     IRX_REQUIRE(c <= 256, "irx_bn_apply: c=%d needs c %% 4 == 0 or c <= 256", c);
     const int qpad = next_pow2(c);
-    k_bn_apply<1><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y);
+    k_bn_apply<1><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y, ty);
   }
   IRX_CHECK_LAUNCH("irx_bn_apply");
   return IRX_OK;
@@ -338,6 +369,16 @@ extern "C" int irx_bn_backward(const float* x, const float* y, const float* dy, 
                                const float* mean, const float* invstd, const float* gamma, int relu,
                                float* dx, float* dgamma, float* dbeta, float* dresidual,
                                void* workspace, size_t workspace_bytes, void* stream) {
+  return irx_bn_backward_t(x, y, dy, n, c, mean, invstd, gamma, relu, dx, dgamma, dbeta, dresidual, workspace,
+                           workspace_bytes, stream, 0, 0, 0, 0, 0);
+}
+
+// x_bf / y_bf / dy_bf: types of the saved conv output, the layer output and the incoming gradient; dx_bf / dres_bf:
+// types of the two gradients written
+int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, int c, const float* mean,
+                      const float* invstd, const float* gamma, int relu, float* dx, float* dgamma, float* dbeta,
+                      float* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int y_bf,
+                      int dy_bf, int dx_bf, int dres_bf) {
   int rc = bn_check("irx_bn_backward", n, c, workspace, workspace_bytes);
   if (rc) return rc;
   IRX_REQUIRE(dgamma && dbeta, "irx_bn_backward: null dgamma/dbeta");
@@ -353,13 +394,16 @@ extern "C" int irx_bn_backward(const float* x, const float* y, const float* dy, 
   const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)dy & 15) == 0) &&
                   (((uintptr_t)dx & 15) == 0) && (!relu || ((uintptr_t)y & 15) == 0) &&
                   (dresidual == nullptr || ((uintptr_t)dresidual & 15) == 0);
+  const BnTy ty = {x_bf, y_bf, dy_bf, dx_bf, dres_bf};
+  rc = bn_bf_ok("irx_bn_backward", (x_bf | y_bf | dy_bf | dx_bf | dres_bf) != 0, v4);
+  if (rc) return rc;
   if (v4)
     k_bn_partial<1, 4><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                   next_pow2(c / 4), bn_rows(n), part);
+                                                   next_pow2(c / 4), bn_rows(n), part, ty);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_backward: c=%d needs c %% 4 == 0 or c <= 256", c);
     k_bn_partial<1, 1><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, next_pow2(c),
-                                                   bn_rows(n), part);
+                                                   bn_rows(n), part, ty);
   }
   IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
   k_bn_finalize<1><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
@@ -368,11 +412,11 @@ extern "C" int irx_bn_backward(const float* x, const float* y, const float* dy, 
   if (v4) {
     const int qpad = next_pow2(c / 4);
     k_bn_bwd_apply<4><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
-                                                               dgamma, relu, dx, dresidual);
+                                                               dgamma, relu, dx, dresidual, ty);
   } else {
     const int qpad = next_pow2(c);
     k_bn_bwd_apply<1><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
-                                                               dgamma, relu, dx, dresidual);
+                                                               dgamma, relu, dx, dresidual, ty);
   }
   IRX_CHECK_LAUNCH("irx_bn_backward(apply)");
   return IRX_OK;

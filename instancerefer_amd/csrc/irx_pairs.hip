@@ -9,6 +9,7 @@
 // -> LDS -> v_mfma_f32_16x16x4_f32 with the pairs as the reduction dimension; the next stage's indices and rows are
 // prefetched into registers before the current stage's MFMAs. Per-(split, offset) partial sums, deterministic reduce.
 #include <stdlib.h>
+#include <type_traits>
 #include "irx_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -93,7 +94,17 @@ __device__ __forceinline__ int pairs_shares(const int32_t* __restrict__ counts, 
 }
 
 // part[s][k][c][n] = sum over share s of list k:  x[in][c] * dy[out][n]   (s < pairs_shares(k); grid = (smax, K))
-template <int CIN, int COUT, bool BF>
+// ST (bf16 storage, with BF only): x and dy rows are bf16 in HBM; a staging thread loads 8 bytes (its 4 channels) and
+// widens them to fp32 when it writes the LDS tiles (the fragment reads below are unchanged).
+template <bool ST>
+__device__ __forceinline__ typename std::conditional<ST, uint2, float4>::type wp_ld(const float* __restrict__ p, size_t elem) {
+  if constexpr (ST) return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + elem);
+  else return *reinterpret_cast<const float4*>(p + elem);
+}
+__device__ __forceinline__ float4 wp_f4(float4 v) { return v; }
+__device__ __forceinline__ float4 wp_f4(uint2 v) { return irx_bf4_to_f4(v); }
+
+template <int CIN, int COUT, bool BF, bool ST>
 __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const int32_t* __restrict__ in_list,
                                                         const int32_t* __restrict__ out_list, int ldp,
@@ -132,7 +143,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
 #pragma unroll
     for (int b = 0; b < NW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 rx[NX], rd[ND];
+  static_assert(BF || !ST, "bf16 storage implies bf16 operands");
+  using RT = typename std::conditional<ST, uint2, float4>::type;
+  RT rx[NX], rd[ND];
   int par = 0;
   // prologue: indices + rows of the first stage
   if (st0 < st1) {
@@ -145,21 +158,21 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int idx = sIn[0][xr + i * PX];
-      rx[i] = idx >= 0 ? *reinterpret_cast<const float4*>(x + (size_t)idx * CIN + xc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[i] = idx >= 0 ? wp_ld<ST>(x, (size_t)idx * CIN + xc) : RT{};
     }
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int idx = sOutRow[0][dr + i * PD];
-      rd[i] = idx >= 0 ? *reinterpret_cast<const float4*>(dy + (size_t)idx * COUT + dc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rd[i] = idx >= 0 ? wp_ld<ST>(dy, (size_t)idx * COUT + dc) : RT{};
     }
   }
   for (int st = st0; st < st1; ++st) {
     __syncthreads();                                     // previous stage's fragment reads are done
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the rows requested during the previous chain
 #pragma unroll
-    for (int i = 0; i < NX; ++i) *reinterpret_cast<float4*>(&sX[(xr + i * PX) * LDX + xc]) = rx[i];
+    for (int i = 0; i < NX; ++i) *reinterpret_cast<float4*>(&sX[(xr + i * PX) * LDX + xc]) = wp_f4(rx[i]);
 #pragma unroll
-    for (int i = 0; i < ND; ++i) *reinterpret_cast<float4*>(&sD[(dr + i * PD) * LDD + dc]) = rd[i];
+    for (int i = 0; i < ND; ++i) *reinterpret_cast<float4*>(&sD[(dr + i * PD) * LDD + dc]) = wp_f4(rd[i]);
     // next stage's indices (other parity buffer), visible after the barrier below
     const int parn = par ^ 1;
     if (st + 1 < st1 && tid < 64) {
@@ -199,13 +212,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
               const int ks = k16 * 4 + i4;
               if (ks < NX) {
                 const int idx = sIn[parn][xr + ks * PX];
-                const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(idx < 0 ? 0 : idx) * CIN + xc);
-                rx[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                const RT v = wp_ld<ST>(x, (size_t)(idx < 0 ? 0 : idx) * CIN + xc);
+                rx[ks] = idx >= 0 ? v : RT{};
               }
               if (ks < ND) {
                 const int idx = sOutRow[parn][dr + ks * PD];
-                const float4 v = *reinterpret_cast<const float4*>(dy + (size_t)(idx < 0 ? 0 : idx) * COUT + dc);
-                rd[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                const RT v = wp_ld<ST>(dy, (size_t)(idx < 0 ? 0 : idx) * COUT + dc);
+                rd[ks] = idx >= 0 ? v : RT{};
               }
             }
           }
@@ -499,17 +512,21 @@ extern "C" size_t irx_spconv_wgrad_pairs_workspace_bytes(int n_out, int K, int c
 
 template <int CIN>
 static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* il,
-                      const int32_t* ol, int ldp, const int32_t* counts, int K, int G, int smax, float* part) {
+                      const int32_t* ol, int ldp, const int32_t* counts, int K, int G, int smax, float* part, bool bf_rows) {
   irx_bracket_begin(st);
-  if (irx_conv_bf16()) {
-    if (cout == 128) k_wgrad_pairs<CIN, 128, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-    else if (cout == 64) k_wgrad_pairs<CIN, 64, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-    else k_wgrad_pairs<CIN, 32, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-    return;
+  if (irx_conv_bf16() && bf_rows) {
+    if (cout == 128) k_wgrad_pairs<CIN, 128, true, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    else if (cout == 64) k_wgrad_pairs<CIN, 64, true, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    else k_wgrad_pairs<CIN, 32, true, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+  } else if (irx_conv_bf16()) {
+    if (cout == 128) k_wgrad_pairs<CIN, 128, true, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    else if (cout == 64) k_wgrad_pairs<CIN, 64, true, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    else k_wgrad_pairs<CIN, 32, true, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+  } else {
+    if (cout == 128) k_wgrad_pairs<CIN, 128, false, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    else if (cout == 64) k_wgrad_pairs<CIN, 64, false, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    else k_wgrad_pairs<CIN, 32, false, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
   }
-  if (cout == 128) k_wgrad_pairs<CIN, 128, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-  else if (cout == 64) k_wgrad_pairs<CIN, 64, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-  else k_wgrad_pairs<CIN, 32, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
   irx_bracket_end(st);
 }
 
@@ -517,6 +534,15 @@ extern "C" int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int
                                       const int32_t* out_list, int ldp, const int32_t* counts, int n_out, int K,
                                       int cin, int cout, float* dw, void* workspace, size_t workspace_bytes,
                                       void* stream) {
+  return irx_spconv_wgrad_pairs_impl(x, dy, in_list, out_list, ldp, counts, n_out, K, cin, cout, dw, workspace,
+                                     workspace_bytes, stream, 0);
+}
+
+// bf_rows != 0 (executor, bf16 storage mode): x and dy are bf16 tensors
+int irx_spconv_wgrad_pairs_impl(const float* x, const float* dy, const int32_t* in_list, const int32_t* out_list, int ldp,
+                                const int32_t* counts, int n_out, int K, int cin, int cout, float* dw, void* workspace,
+                                size_t workspace_bytes, void* stream, int bf_rows) {
+  IRX_REQUIRE(!bf_rows || irx_conv_bf16(), "irx_spconv_wgrad_pairs: bf16 rows need the bf16 compute mode");
   IRX_REQUIRE(n_out >= 0 && K >= 1 && dw, "irx_spconv_wgrad_pairs: bad arguments");
   IRX_REQUIRE(irx_spconv2_supported(cin, cout), "irx_spconv_wgrad_pairs: channels (%d, %d) unsupported (32/64/128)", cin, cout);
   const size_t elems = (size_t)K * cin * cout;
@@ -534,9 +560,9 @@ extern "C" int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int
   }
   float* part = (float*)workspace;
   dim3 grid(smax, K);
-  if (cin == 128) launch_wp<128>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part);
-  else if (cin == 64) launch_wp<64>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part);
-  else launch_wp<32>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part);
+  if (cin == 128) launch_wp<128>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0);
+  else if (cin == 64) launch_wp<64>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0);
+  else launch_wp<32>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad_pairs");
   k_pairs_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(part, counts, K, G, smax, (size_t)cin * cout, elems,
                                                                        dw);

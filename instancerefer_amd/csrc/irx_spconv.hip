@@ -16,7 +16,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t elems, float* __restrict__ dw,
-                               int accumulate = 0);
+                               int accumulate = 0, int out_bf = 0);
 
 #define SC_TM 64  // output rows per workgroup (4 waves x 16 rows)
 #define SC_KC 32  // reduction (input-channel) chunk staged per barrier pair
@@ -258,8 +258,9 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float* __restrict__ 
   }
 }
 
+// out_bf: dw is a bf16 tensor (conv output of the executor's bf16 storage mode; the slabs are always fp32)
 __global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t elems,
-                               float* __restrict__ dw, int accumulate) {
+                               float* __restrict__ dw, int accumulate, int out_bf) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= elems) return;
   // loads in batches of 8 (memory-level parallelism: one load per add left the kernel latency-bound), adds in the
@@ -274,6 +275,12 @@ __global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t ele
     for (int u = 0; u < 8; ++u) s += v[u];
   }
   for (; j < S; ++j) s += part[(size_t)j * elems + i];
+  if (out_bf) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(dw) + i;
+    if (accumulate) s = __uint_as_float((unsigned)*o << 16) + s;
+    *o = (unsigned short)(irx_pk_bf16(s, 0.f) & 0xffffu);
+    return;
+  }
   dw[i] = accumulate ? dw[i] + s : s;            // (old + sum), the order of the unfused `old.add_(sum)`
 }
 
@@ -376,14 +383,14 @@ bool irx_spconv_fast_path(const void* x, const void* w, const void* y, int cin, 
 
 int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
                         int flip_k, int trans_w, float* y, int accumulate, const float* wimg, void* workspace,
-                        size_t workspace_bytes, void* stream) {
+                        size_t workspace_bytes, void* stream, IrxStore ty) {
   IRX_REQUIRE(n_out >= 0 && K >= 1 && cin >= 1 && cout >= 1, "irx_spconv_fwd: bad sizes");
   if (n_out == 0) return IRX_OK;
   IRX_REQUIRE(x && w && nbr && y, "irx_spconv_fwd: null pointer");
   IRX_REQUIRE(ld >= n_out, "irx_spconv_fwd: ld %d < n_out %d", ld, n_out);
   const bool aligned = (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0;
-  if (!accumulate && !trans_w && !flip_k && irx_stem_supported(K, cin, cout) && (((uintptr_t)y & 15) == 0))
-    return irx_stem_fwd_launch(x, w, nbr, ld, n_out, K, cin, y, S(stream));
+  if (!accumulate && !trans_w && !flip_k && !ty.x && irx_stem_supported(K, cin, cout) && (((uintptr_t)y & 15) == 0))
+    return irx_stem_fwd_launch(x, w, nbr, ld, n_out, K, cin, y, S(stream), 0, ty.y);
   if (aligned && irx_spconv2_supported(cin, cout) && irx_spconv2_enabled(trans_w ? 'd' : 'f')) {
     const size_t need = irx_spconv_fwd_workspace_bytes(n_out, K, cin, cout, trans_w);
     if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
@@ -399,16 +406,17 @@ int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int 
       wimg = (const float*)workspace;
     }
     rc = irx_spconv2_launch(x, wimg, nbr, ld, n_out, K, cin, cout, flip_k,
-                            splits > 1 ? slabs : y, splits, accumulate, S(stream));
+                            splits > 1 ? slabs : y, splits, accumulate, S(stream), 0, ty);
     if (rc) return rc;
     if (splits > 1) {
       const size_t elems = (size_t)n_out * cout;
-      k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(slabs, splits, elems, y, accumulate);
+      k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(slabs, splits, elems, y, accumulate, ty.y);
       IRX_CHECK_LAUNCH("irx_spconv_fwd(split reduce)");
     }
     return IRX_OK;
   }
   IRX_REQUIRE(!accumulate, "irx_spconv_fwd: accumulation needs the fast path (aligned, channels in {32,64,128})");
+  IRX_REQUIRE(!ty.x, "irx_spconv_fwd: a bf16 input needs the fast path (aligned, channels in {32,64,128})");
   if (!trans_w && !flip_k && irx_wide_stem(K, cin, cout) && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0) &&
       irx_spconv2_enabled('f')) {
     const size_t need = irx_spconv_fwd_workspace_bytes(n_out, K, cin, cout, 0);
@@ -425,19 +433,22 @@ int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int 
     IRX_CHECK_LAUNCH("irx_spconv_fwd(wide stem slice)");
     int rc = irx_permute_w_launch(w, K, WS_MAIN, cout, 0, wimg_main, S(stream), cin);
     if (rc) return rc;
-    rc = irx_stem_fwd_launch(x + WS_MAIN, wtail, nbr, ld, n_out, K, ct, y, S(stream), cin);    // y  = tail channels
+    rc = irx_stem_fwd_launch(x + WS_MAIN, wtail, nbr, ld, n_out, K, ct, y, S(stream), cin, ty.y);   // y  = tail channels
     if (rc) return rc;
     const int splits = irx_spconv2_splits(n_out, K);
+    IrxStore tm;
+    tm.y = ty.y;
     rc = irx_spconv2_launch(x, wimg_main, nbr, ld, n_out, K, WS_MAIN, cout, 0, splits > 1 ? slabs : y, splits, 1,
-                            S(stream), cin);                                                      // y += main channels
+                            S(stream), cin, tm);                                                  // y += main channels
     if (rc) return rc;
     if (splits > 1) {
       const size_t elems = (size_t)n_out * cout;
-      k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(slabs, splits, elems, y, 1);
+      k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(slabs, splits, elems, y, 1, ty.y);
       IRX_CHECK_LAUNCH("irx_spconv_fwd(wide stem reduce)");
     }
     return IRX_OK;
   }
+  IRX_REQUIRE(!ty.y, "irx_spconv_fwd: a bf16 output needs the fast paths (stem, wide stem, channels in {32,64,128})");
   const int bn = cout > 64 ? 128 : (cout > 32 ? 64 : 32);
   dim3 grid(irx_cdiv(n_out, SC_TM), irx_cdiv(cout, bn));
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
@@ -479,6 +490,12 @@ extern "C" size_t irx_spconv_wgrad_workspace_bytes(int n_out, int K, int cin, in
 extern "C" int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int ld,
                                 int n_out, int K, int cin, int cout, float* dw, void* workspace,
                                 size_t workspace_bytes, void* stream) {
+  return irx_spconv_wgrad_impl(x, dy, nbr, ld, n_out, K, cin, cout, dw, workspace, workspace_bytes, stream, 0);
+}
+
+// dy_bf != 0 (executor, bf16 storage mode): dy is a bf16 tensor; x stays fp32 (this entry only serves the stems there)
+int irx_spconv_wgrad_impl(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
+                          float* dw, void* workspace, size_t workspace_bytes, void* stream, int dy_bf) {
   IRX_REQUIRE(n_out >= 0 && K >= 1 && cin >= 1 && cout >= 1 && dw, "irx_spconv_wgrad: bad arguments");
   const size_t elems = (size_t)K * cin * cout;
   if (n_out == 0) {
@@ -495,7 +512,7 @@ extern "C" int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* 
   }
   if (irx_stem_supported(K, cin, cout)) {
     const int blocks = irx_stem_wgrad_blocks(n_out);
-    int rc = irx_stem_wgrad_launch(x, dy, nbr, ld, n_out, cin, blocks, (float*)workspace, S(stream));
+    int rc = irx_stem_wgrad_launch(x, dy, nbr, ld, n_out, cin, blocks, (float*)workspace, S(stream), 0, dy_bf);
     if (rc) return rc;
     k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>((const float*)workspace, blocks, elems, dw);
     IRX_CHECK_LAUNCH("irx_spconv_wgrad(stem reduce)");
@@ -513,11 +530,11 @@ extern "C" int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* 
     float* sum_t = part_t + (size_t)blocks * et;
     int rpm = irx_cdiv(n_out, sm);
     rpm = irx_cdiv(rpm, WG_TQ) * WG_TQ;
-    int rc = irx_spconv2_wgrad_launch(x, dy, nbr, ld, n_out, K, WS_MAIN, cout, sm, rpm, part_m, S(stream), cin);
+    int rc = irx_spconv2_wgrad_launch(x, dy, nbr, ld, n_out, K, WS_MAIN, cout, sm, rpm, part_m, S(stream), cin, dy_bf);
     if (rc) return rc;
     k_wgrad_reduce<<<irx_cdiv((long long)em, 256), 256, 0, S(stream)>>>(part_m, sm, em, sum_m);
     IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem reduce)");
-    rc = irx_stem_wgrad_launch(x + WS_MAIN, dy, nbr, ld, n_out, ct, blocks, part_t, S(stream), cin);
+    rc = irx_stem_wgrad_launch(x + WS_MAIN, dy, nbr, ld, n_out, ct, blocks, part_t, S(stream), cin, dy_bf);
     if (rc) return rc;
     k_wgrad_reduce<<<irx_cdiv((long long)et, 256), 256, 0, S(stream)>>>(part_t, blocks, et, sum_t);
     IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem tail reduce)");
@@ -525,6 +542,7 @@ extern "C" int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* 
     IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem merge)");
     return IRX_OK;
   }
+  IRX_REQUIRE(!dy_bf, "irx_spconv_wgrad: a bf16 gradient needs the stem / wide-stem paths");
   int rps = irx_cdiv(n_out, s);
   rps = irx_cdiv(rps, WG_TQ) * WG_TQ;
   const int nct_n = irx_cdiv(cout, 64);

@@ -24,15 +24,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Compute dtype of the fast sparse-conv kernels (irx_set_compute_dtype, include/irx.h): 0 = exact fp32 MFMA
 // (v_mfma_f32_16x16x4_f32), 1 = bf16 operands (round-to-nearest-even of x and w at use) with fp32 accumulation
-// (v_mfma_f32_16x16x16_bf16). Tensors in HBM stay fp32 in both modes.
+// (v_mfma_f32_16x16x16_bf16), tensors in HBM fp32; 2 = as 1 plus bf16 STORAGE of every activation / gradient tensor
+// inside the encoder executor (irx_encoder.hip): the conv gathers 8-byte bf16 quads straight into the LDS A tile and
+// its epilogue rounds the fp32 tile on the way out; statistics, accumulation and parameter gradients stay fp32.
 static int g_irx_conv_bf16 = 0;
-extern "C" int irx_set_compute_dtype(int bf16) {
-  IRX_REQUIRE(bf16 == 0 || bf16 == 1, "irx_set_compute_dtype: %d is not 0 (fp32) or 1 (bf16)", bf16);
-  g_irx_conv_bf16 = bf16;
+extern "C" int irx_set_compute_dtype(int mode) {
+  IRX_REQUIRE(mode >= 0 && mode <= 2, "irx_set_compute_dtype: %d is not 0 (fp32), 1 (bf16 operands) or 2 (bf16 storage)", mode);
+  g_irx_conv_bf16 = mode;
   return IRX_OK;
 }
 extern "C" int irx_get_compute_dtype(void) { return g_irx_conv_bf16; }
 bool irx_conv_bf16() { return g_irx_conv_bf16 != 0; }
+bool irx_conv_bf16_storage() { return g_irx_conv_bf16 == 2; }
 
 #define S2_TM 64
 
@@ -80,11 +83,19 @@ __device__ static inline PairList compact_pairs(int my, int lane) {
 // issues exactly NJ * (NT + 1) loads and the consumer can wait with an exact s_waitcnt vmcnt(n).
 // Weights: fp32 mode  WT = float4, one per fragment f = j * NT + t (4 consecutive reduction channels of one column);
 //          bf16 mode  WT = uint4 = fragments 2p (.xy) and 2p + 1 (.zw) as 4 bf16 each, WN = NJ * NT / 2 per item.
-template <int CIN, int COUT, int NJ, int NT, int LDA, int LDO, bool PREFETCH, bool BF, typename WT, int WN>
+// RT: one lane's share of a gathered row — float4 (fp32 storage) or uint2 = 4 bf16 (bf16 storage, ST)
+template <bool ST>
+__device__ __forceinline__ typename std::conditional<ST, uint2, float4>::type s2_ldrow(const float* __restrict__ x, size_t elem) {
+  if constexpr (ST) return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + elem);
+  else return *reinterpret_cast<const float4*>(x + elem);
+}
+
+template <int CIN, int COUT, int NJ, int NT, int LDA, int LDO, bool PREFETCH, bool BF, bool ST, typename WT, int WN,
+          typename RT>
 __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __restrict__ sOut,
                                          const unsigned char* __restrict__ lrow, int g, int vs, int m, int g4,
                                          int n_base, const WT (&wc)[WN], WT (&wx)[WN],
-                                         float4 (&sx)[NJ], const int (&nrow)[NJ], const float* __restrict__ x, int c4,
+                                         RT (&sx)[NJ], const int (&nrow)[NJ], const float* __restrict__ x, int c4,
                                          const WT* __restrict__ wnk, int ldx) {
   f32x4 acc[NT];
 #pragma unroll
@@ -108,7 +119,7 @@ __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __
 #pragma unroll
       for (int i = (BF ? (j * NT) / 2 : j * NT); i < (BF ? ((j + 1) * NT) / 2 : (j + 1) * NT); ++i)
         wx[i] = wnk[(size_t)i * 64];
-      sx[j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * ldx + c4);
+      sx[j] = s2_ldrow<ST>(x, (size_t)nrow[j] * ldx + c4);
     }
     if constexpr (BF) {
       // a lane's 4 consecutive floats are exactly the 4 k-slots of the 16x16x16 bf16 MFMA: one MFMA replaces four
@@ -196,10 +207,13 @@ __device__ __forceinline__ void s2_wait_vmcnt() {
 //           is shorter than the L2 latency (measured before: 30 % of the 64->64 wave cycles waiting in vmcnt(0)).
 // Register discipline: the item loop is unrolled DEPTH + 1 times so that every register set is a compile-time name
 // (no copies), and the explicit exact vmcnt tells the compiler's waitcnt pass that nothing consumed is pending.
-template <int CIN, int COUT, bool BF>
+// ST (with BF only): x is bf16 in HBM — a lane gathers 8 bytes (its 4 channels) and the LDS writer stores them as they
+// are; y_bf (run time): the output tile is rounded to bf16 on the way out (a single split; offset-split slabs stay fp32).
+template <int CIN, int COUT, bool BF, bool ST>
 __global__ __launch_bounds__(256, 2)
 void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const int32_t* __restrict__ nbr, int ld,
-               int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate, int ldx) {
+               int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate, int ldx, int y_bf) {
+  static_assert(BF || !ST, "bf16 storage implies bf16 operands");
   // ldx = row stride of x in floats (CIN for a dense tensor; > CIN when x is the leading CIN columns of wider rows:
   // the multiview stem, irx_spconv.hip "wide stem"; rows then need only 4-byte alignment)
   // accumulate != 0 (single split only): the tile is ADDED to the rows already in y (gradient accumulation).
@@ -208,7 +222,8 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   constexpr int TM = S2_TM;
   const int kb = blockIdx.y * k_per_split;
   const int ke = (kb + k_per_split < K) ? kb + k_per_split : K;
-  y += (size_t)blockIdx.y * n_out * COUT;
+  y += (size_t)blockIdx.y * n_out * COUT;         // (slabs of an offset split are fp32: y_bf is 0 then)
+  using RT = typename std::conditional<ST, uint2, float4>::type;
   constexpr int NT = (COUT >= 128) ? 2 : 1;       // 16-column tiles per wave
   constexpr int NCS = COUT / (16 * NT);           // channel slices (waves along N)
   constexpr int NGP = 4 / NCS;                    // waves along the pair-group dimension
@@ -290,7 +305,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   // ---- register sets and the prologue.  Sets are only ever indexed by compile-time constants (integral_constant
   // arguments of the generic lambdas below): a run-time choice of set would demote the arrays to scratch memory. ----
   WT W[3][WN];
-  float4 S[3][NJ];
+  RT S[3][NJ];
   int kk[3] = {-1, -1, -1}, vv[3] = {0, 0, 0};     // offset / pair count of the item living in each set
   // the item whose loads are issued next: offset kq, pair count vq (kq = -1: past the end -> dummy loads of offset kl)
   int kq, vq, kl = kb;
@@ -305,7 +320,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
 #pragma unroll
     for (int i = 0; i < WN; ++i) W[T][i] = wnk[(size_t)i * 64];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * ldx + c4);
+    for (int j = 0; j < NJ; ++j) S[T][j] = s2_ldrow<ST>(x, (size_t)nrow[j] * ldx + c4);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -334,7 +349,10 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
       if (it < npass)                              // (component-wise: a struct copy out of S[][] keeps the sets in scratch)
-        if constexpr (BF)
+        if constexpr (ST)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(sA) + (pbase + it * PPP) * (CIN + 8) + c4) =
+              make_uint2(S[C][it].x, S[C][it].y);
+        else if constexpr (BF)
           *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(sA) + (pbase + it * PPP) * (CIN + 8) + c4) =
               make_uint2(irx_pk_bf16(S[C][it].x, S[C][it].y), irx_pk_bf16(S[C][it].z, S[C][it].w));
         else
@@ -355,16 +373,16 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     const unsigned char* lrow = sRow + k * TM;
     int g = gp;
     if (NGP == 1 || g * 16 < vpad) {
-      s2_group<CIN, COUT, NJ, NT, LDA, LDO, true, BF, WT, WN>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T], S[T],
-                                                              nrow, x, c4, wnk, ldx);
+      s2_group<CIN, COUT, NJ, NT, LDA, LDO, true, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
+                                                                      S[T], nrow, x, c4, wnk, ldx);
       for (g += NGP; g * 16 < vpad; g += NGP)
-        s2_group<CIN, COUT, NJ, NT, LDA, LDO, false, BF, WT, WN>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
-                                                                 S[T], nrow, x, c4, wnk, ldx);
+        s2_group<CIN, COUT, NJ, NT, LDA, LDO, false, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
+                                                                         S[T], nrow, x, c4, wnk, ldx);
     } else {                                       // a wave without a group in this item still prefetches its share
 #pragma unroll
       for (int i = 0; i < WN; ++i) W[T][i] = wnk[(size_t)i * 64];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) S[T][j] = *reinterpret_cast<const float4*>(x + (size_t)nrow[j] * ldx + c4);
+      for (int j = 0; j < NJ; ++j) S[T][j] = s2_ldrow<ST>(x, (size_t)nrow[j] * ldx + c4);
     }
     S2_TICK(6);
   };
@@ -401,12 +419,12 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     const int row = f / F4, cc = (f % F4) * 4;
     if (q0 + row < n_out) {
       float4 o = *reinterpret_cast<const float4*>(&sOut[row * LDO + cc]);
-      float4* dst = reinterpret_cast<float4*>(y + (size_t)(q0 + row) * COUT + cc);
+      const size_t off = (size_t)(q0 + row) * COUT + cc;
       if (accumulate) {
-        const float4 e = *dst;
+        const float4 e = irx_ld4(y, off, y_bf);
         o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
       }
-      *dst = o;
+      irx_st4(y, off, y_bf, o);
     }
   }
 }
@@ -416,7 +434,8 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void k_spconv2_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const int32_t* __restrict__ nbr, int ld, int n_out,
-                                                          int K, int rows_per_split, float* __restrict__ part, int ldx) {
+                                                          int K, int rows_per_split, float* __restrict__ part, int ldx,
+                                                          int dy_bf) {
   constexpr int TC = CIN / 16, TN = COUT / 16;
   constexpr int CW = (TC >= 4) ? TC / 4 : 1;             // c-tiles per wave
   constexpr int NW = (TC >= 4) ? TN : TN / (4 / TC);     // n-tiles per wave
@@ -464,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv2_wgrad(const float* __restric
         const int p = p0 + sub;
         const int orow = __shfl(pl.row_of_pair, p & 63);
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < pl.v) val = *reinterpret_cast<const float4*>(dy + (size_t)(q0 + orow) * COUT + c4);
+        if (p < pl.v) val = irx_ld4(dy, (size_t)(q0 + orow) * COUT + c4, dy_bf);
         if (p < vpad) *reinterpret_cast<float4*>(&sD[p * LDD + c4]) = val;
       }
     }
@@ -551,12 +570,12 @@ bool irx_spconv2_supported(int cin, int cout) {
   return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128);
 }
 
-template <int CIN, bool BF>
+template <int CIN, bool BF, bool ST>
 static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
-                        int ld, int n_out, int K, int flip_k, float* y, int kps, int acc, int ldx) {
-  if (cout == 128) k_spconv2<CIN, 128, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
-  else if (cout == 64) k_spconv2<CIN, 64, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
-  else k_spconv2<CIN, 32, BF><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
+                        int ld, int n_out, int K, int flip_k, float* y, int kps, int acc, int ldx, int y_bf) {
+  if (cout == 128) k_spconv2<CIN, 128, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+  else if (cout == 64) k_spconv2<CIN, 64, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+  else k_spconv2<CIN, 32, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
 }
 
 // Output rows per workgroup: 64.  (128-row tiles stream half the weight bytes per useful FLOP but MEASURED SLOWER on
@@ -587,21 +606,27 @@ int irx_spconv2_splits(int n_out, int K) {
 
 // y: result (splits == 1; accumulate != 0 adds to it) or `splits` slabs of [n_out][cout] partial sums
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                       int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st, int ldx) {
+                       int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st, int ldx, IrxStore ty) {
   if (ldx <= 0) ldx = cin;
+  IRX_REQUIRE(!ty.x || g_irx_conv_bf16, "irx_spconv_fwd: a bf16 input needs the bf16 compute mode");
+  const int y_bf = (splits == 1) ? ty.y : 0;
   const int acc = (splits == 1) ? accumulate : 0;
   IRX_REQUIRE(K <= 27, "irx_spconv_fwd: K = %d > 27 unsupported by the fast path", K);
   dim3 grid(irx_cdiv(n_out, S2_TM), splits);
   const int kps = irx_cdiv(K, splits);
   irx_bracket_begin(st);
-  if (g_irx_conv_bf16) {
-    if (cin == 128) launch_fwd2<128, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
-    else if (cin == 64) launch_fwd2<64, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
-    else launch_fwd2<32, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
+  if (g_irx_conv_bf16 && ty.x) {
+    if (cin == 128) launch_fwd2<128, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    else if (cin == 64) launch_fwd2<64, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    else launch_fwd2<32, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+  } else if (g_irx_conv_bf16) {
+    if (cin == 128) launch_fwd2<128, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    else if (cin == 64) launch_fwd2<64, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    else launch_fwd2<32, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
   } else {
-    if (cin == 128) launch_fwd2<128, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
-    else if (cin == 64) launch_fwd2<64, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
-    else launch_fwd2<32, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx);
+    if (cin == 128) launch_fwd2<128, false, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    else if (cin == 64) launch_fwd2<64, false, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    else launch_fwd2<32, false, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
   }
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(v2)");
@@ -658,20 +683,20 @@ int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, 
 
 template <int CIN>
 static void launch_wg2(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* nbr,
-                       int ld, int n_out, int K, int rps, float* part, int ldx) {
-  if (cout == 128) k_spconv2_wgrad<CIN, 128><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part, ldx);
-  else if (cout == 64) k_spconv2_wgrad<CIN, 64><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part, ldx);
-  else k_spconv2_wgrad<CIN, 32><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part, ldx);
+                       int ld, int n_out, int K, int rps, float* part, int ldx, int dy_bf) {
+  if (cout == 128) k_spconv2_wgrad<CIN, 128><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part, ldx, dy_bf);
+  else if (cout == 64) k_spconv2_wgrad<CIN, 64><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part, ldx, dy_bf);
+  else k_spconv2_wgrad<CIN, 32><<<grid, 256, 0, st>>>(x, dy, nbr, ld, n_out, K, rps, part, ldx, dy_bf);
 }
 
 int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
-                             int cin, int cout, int splits, int rps, float* part, hipStream_t st, int ldx) {
+                             int cin, int cout, int splits, int rps, float* part, hipStream_t st, int ldx, int dy_bf) {
   if (ldx <= 0) ldx = cin;
   dim3 grid(splits, K);
   irx_bracket_begin(st);
-  if (cin == 128) launch_wg2<128>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part, ldx);
-  else if (cin == 64) launch_wg2<64>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part, ldx);
-  else launch_wg2<32>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part, ldx);
+  if (cin == 128) launch_wg2<128>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part, ldx, dy_bf);
+  else if (cin == 64) launch_wg2<64>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part, ldx, dy_bf);
+  else launch_wg2<32>(cout, grid, st, x, dy, nbr, ld, n_out, K, rps, part, ldx, dy_bf);
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad(v2)");
   return IRX_OK;

@@ -15,7 +15,7 @@
 template <int CIN>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const int32_t* __restrict__ nbr, int ld, int n_out, int K,
-                                                  float* __restrict__ y, int ldx) {
+                                                  float* __restrict__ y, int ldx, int y_bf) {
   __shared__ __attribute__((aligned(16))) float sW[27 * CIN * ST_COUT];
   for (int i = threadIdx.x; i < K * CIN * ST_COUT; i += 256) sW[i] = w[i];
   __syncthreads();
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, c
 #pragma unroll
   for (int j = 0; j < ST_R; ++j) {
     const int row = row0 + 32 * j;
-    if (row < n_out) *reinterpret_cast<float4*>(y + (size_t)row * ST_COUT + c4) = acc[j];
+    if (row < n_out) irx_st4(y, (size_t)row * ST_COUT + c4, y_bf, acc[j]);
   }
 }
 
@@ -70,7 +70,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int CIN>
 __global__ __launch_bounds__(256, 2) void k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                        const int32_t* __restrict__ nbr, int ld, int n_out,
-                                                       int rows_per_block, float* __restrict__ part, int ldx) {
+                                                       int rows_per_block, float* __restrict__ part, int ldx,
+                                                       int dy_bf) {
   constexpr int K = 27;
   constexpr int MREAL = K * CIN;                 // 189 for CIN = 7
   constexpr int MT = (MREAL + 15) / 16;          // 12
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad(const float* __restrict__
     for (int f = tid; f < 64 * (ST_COUT / 4); f += 256) {
       const int r = f >> 3, c4 = (f & 7) * 4;
       float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q0 + r < r1) d = *reinterpret_cast<const float4*>(dy + (size_t)(q0 + r) * ST_COUT + c4);
+      if (q0 + r < r1) d = irx_ld4(dy, (size_t)(q0 + r) * ST_COUT + c4, dy_bf);
       *reinterpret_cast<float4*>(&sD[r * LDD + c4]) = d;
     }
     __syncthreads();
@@ -164,19 +165,19 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad(const float* __restrict__
 bool irx_stem_supported(int K, int cin, int cout) { return K == 27 && cout == ST_COUT && cin >= 1 && cin <= 8; }
 
 int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin,
-                        float* y, hipStream_t st, int ldx) {
+                        float* y, hipStream_t st, int ldx, int y_bf) {
   if (ldx <= 0) ldx = cin;
   const int grid = irx_cdiv(n_out, 32 * ST_R);
   irx_bracket_begin(st);
   switch (cin) {
-    case 1: k_stem_fwd<1><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
-    case 2: k_stem_fwd<2><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
-    case 3: k_stem_fwd<3><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
-    case 4: k_stem_fwd<4><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
-    case 5: k_stem_fwd<5><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
-    case 6: k_stem_fwd<6><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
-    case 7: k_stem_fwd<7><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
-    default: k_stem_fwd<8><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx); break;
+    case 1: k_stem_fwd<1><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx, y_bf); break;
+    case 2: k_stem_fwd<2><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx, y_bf); break;
+    case 3: k_stem_fwd<3><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx, y_bf); break;
+    case 4: k_stem_fwd<4><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx, y_bf); break;
+    case 5: k_stem_fwd<5><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx, y_bf); break;
+    case 6: k_stem_fwd<6><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx, y_bf); break;
+    case 7: k_stem_fwd<7><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx, y_bf); break;
+    default: k_stem_fwd<8><<<grid, 256, 0, st>>>(x, w, nbr, ld, n_out, K, y, ldx, y_bf); break;
   }
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(stem)");
@@ -191,20 +192,20 @@ int irx_stem_wgrad_blocks(int n_out) {
 }
 
 int irx_stem_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int cin,
-                          int blocks, float* part, hipStream_t st, int ldx) {
+                          int blocks, float* part, hipStream_t st, int ldx, int dy_bf) {
   if (ldx <= 0) ldx = cin;
   int rpb = irx_cdiv(n_out, blocks);
   rpb = irx_cdiv(rpb, 64) * 64;
   irx_bracket_begin(st);
   switch (cin) {
-    case 1: k_stem_wgrad<1><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
-    case 2: k_stem_wgrad<2><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
-    case 3: k_stem_wgrad<3><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
-    case 4: k_stem_wgrad<4><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
-    case 5: k_stem_wgrad<5><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
-    case 6: k_stem_wgrad<6><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
-    case 7: k_stem_wgrad<7><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
-    default: k_stem_wgrad<8><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx); break;
+    case 1: k_stem_wgrad<1><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx, dy_bf); break;
+    case 2: k_stem_wgrad<2><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx, dy_bf); break;
+    case 3: k_stem_wgrad<3><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx, dy_bf); break;
+    case 4: k_stem_wgrad<4><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx, dy_bf); break;
+    case 5: k_stem_wgrad<5><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx, dy_bf); break;
+    case 6: k_stem_wgrad<6><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx, dy_bf); break;
+    case 7: k_stem_wgrad<7><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx, dy_bf); break;
+    default: k_stem_wgrad<8><<<blocks, 256, 0, st>>>(x, dy, nbr, ld, n_out, rpb, part, ldx, dy_bf); break;
   }
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad(stem)");

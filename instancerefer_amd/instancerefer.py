@@ -148,7 +148,7 @@ class InstanceRefer(nn.Module):
         if _ATTR_EARLY is not None:
             return _ATTR_EARLY != '0'
         from . import get_compute_dtype
-        return get_compute_dtype() == 'bf16'
+        return get_compute_dtype() != 'fp32'
 
     def _encoder_stream(self, device):
         """The scene encoder's stream. Priority follows the compute dtype (measured on MI355X, B = 16, alternating runs in
@@ -161,7 +161,7 @@ class InstanceRefer(nn.Module):
             prio = int(env)
         else:
             from . import get_compute_dtype
-            prio = -1 if get_compute_dtype() == 'bf16' else 0
+            prio = -1 if get_compute_dtype() != 'fp32' else 0
         cache = self.__dict__.setdefault('_enc_streams', {})     # not module attributes: never pickled with the state
         st = cache.get((str(device), prio))
         if st is None:

@@ -69,7 +69,7 @@ def _ws(nbytes, dev):
 # field order of the descriptor table: include/irx.h, enum IRX_ENC_* (tests/test_abi_cpu.py checks the two agree)
 ENC_FIELDS = ("K", "CIN", "COUT", "N_IN", "N_OUT", "RES", "TBL", "LD", "TBL_B", "LD_B", "FLIP_B", "PAIR_IN", "PAIR_OUT",
               "PAIR_COUNTS", "LD_PAIRS", "W", "GAMMA", "BETA", "RUNNING_MEAN", "RUNNING_VAR", "X", "C", "Y", "MEAN",
-              "INVSTD", "DW", "DGAMMA", "DBETA", "GY")
+              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "PROF")
 _E = {n: i for i, n in enumerate(ENC_FIELDS)}
 _NF = len(ENC_FIELDS)
 _ALIGN = 64                                           # float32 elements (256 B)
@@ -77,6 +77,16 @@ _ALIGN = 64                                           # float32 elements (256 B)
 
 def _up(n):
     return (n + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
+def _up256(nbytes):
+    return (nbytes + 255) // 256 * 256
+
+
+def storage_bf16(need_input_grad=False):
+    """bf16 STORAGE of the activations / gradients inside the executor (set_compute_dtype("bf16"), library mode 2)?
+    Not when the caller wants the gradient of the input features (that path is fp32 only)."""
+    return _lib.load().irx_get_compute_dtype() == 2 and not need_input_grad
 
 
 def _static_template(encoder, layers, params):
@@ -158,15 +168,24 @@ class EncoderFn(torch.autograd.Function):
         desc[:, _E["N_OUT"]] = n_out
         desc[:, _E["TBL"]] = np.fromiter((L.tbl.data_ptr() for L in layers), dtype=np.int64, count=nl)
         desc[:, _E["LD"]] = np.fromiter((L.ld for L in layers), dtype=np.int64, count=nl)
-        # activation arena: conv output c_i and layer output y_i of every layer
-        sz = _up_np(n_out * cout)
-        start = np.concatenate([[0], np.cumsum(2 * sz)[:-1]])
-        total = int(2 * sz.sum())
-        arena = torch.empty(total, dtype=_f32, device=dev)
+        # activation arena (bytes): conv output c_i and layer output y_i of every layer; with bf16 storage every tensor
+        # but the last layer's output is 2 bytes per element
+        store = storage_bf16(ctx.needs_input_grad[0])
+        esz = np.full(nl, 2 if store else 4, dtype=np.int64)
+        ysz = esz.copy()
+        ysz[-1] = 4
+        cb, yb = _up256(n_out * cout * esz), _up256(n_out * cout * ysz)
+        start = np.concatenate([[0], np.cumsum(cb + yb)[:-1]])
+        total = int((cb + yb).sum())
+        arena = torch.empty(total, dtype=torch.uint8, device=dev)
         stats = torch.empty((nl, 2, 128), dtype=_f32, device=dev)       # mean / invstd rows (cout <= 128)
         base, sbase = arena.data_ptr(), stats.data_ptr()
-        desc[:, _E["C"]] = base + 4 * start
-        desc[:, _E["Y"]] = base + 4 * (start + sz)
+        desc[:, _E["STORE"]] = int(store)
+        prof = _profile_slots(layers, store) if F_.PROFILE is not None else None
+        if prof is not None:
+            desc[:, _E["PROF"]] = prof[1]
+        desc[:, _E["C"]] = base + start
+        desc[:, _E["Y"]] = base + start + cb
         desc[0, _E["X"]] = x0.data_ptr()
         desc[1:, _E["X"]] = desc[:-1, _E["Y"]]
         desc[:, _E["MEAN"]] += sbase
@@ -177,7 +196,7 @@ class EncoderFn(torch.autograd.Function):
         if lane is not None:
             rc = lib.irx_encoder_submit(lane, 0, desc.ctypes.data, fdesc.ctypes.data, nl, None, None, ws.data_ptr(),
                                         nbytes, _lib.stream_ptr())
-            _HELD.setdefault(lane, []).append((ws, x0, arena, stats))
+            _HELD.setdefault(lane, []).append((ws, x0, arena, stats, prof))
         else:
             rc = lib.irx_encoder_forward(desc.ctypes.data, fdesc.ctypes.data, nl, ws.data_ptr(), nbytes, _lib.stream_ptr())
         if rc:
@@ -186,12 +205,13 @@ class EncoderFn(torch.autograd.Function):
         if counters:
             torch._foreach_add_(counters, 1)
         ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = layers, desc, fdesc, (n_out, cout, poffs, ptotal)
+        ctx.store, ctx.prof = store, prof
         # gradient sink (optim.FlatAdam): parameter gradients can go straight into the optimizer's flat buffer
         sink = getattr(params[0], "_irx_sink", None)
         ctx.sink = (sink[0], id(encoder), params) if sink is not None else None
         ctx.save_for_backward(x0, arena, stats, *params)
-        o0 = int(start[-1] + sz[-1])
-        return arena[o0:o0 + layers[-1].n_out * layers[-1].cout].view(layers[-1].n_out, layers[-1].cout)
+        o0 = int(start[-1] + cb[-1])
+        return arena[o0:o0 + 4 * layers[-1].n_out * layers[-1].cout].view(_f32).view(layers[-1].n_out, layers[-1].cout)
 
     @staticmethod
     def backward(ctx, dout):
@@ -200,12 +220,15 @@ class EncoderFn(torch.autograd.Function):
         n_out, cout, poffs, ptotal = ctx.extra
         dev = dout.device
         dout = dout.contiguous().float()
-        # gradients in flight: gy_i for every layer but the last (that one IS dout) + the shared dc scratch
-        gsz = _up_np(n_out * cout)
+        # gradients in flight (bytes): gy_i for every layer but the last (that one IS dout) + the shared dc scratch
+        store = ctx.store
+        if store and _lib.load().irx_get_compute_dtype() == 0:
+            raise RuntimeError("the compute dtype was switched to fp32 between this encoder's forward (bf16 storage) and its backward")
+        gsz = _up256(n_out * cout * (2 if store else 4))
         goffs = np.concatenate([[0], np.cumsum(gsz[:-1])])              # nl entries; the last one = start of dc
         dc_off = int(goffs[-1])
         total = dc_off + int(gsz.max())
-        garena = torch.empty(total, dtype=_f32, device=dev)
+        garena = torch.empty(total, dtype=torch.uint8, device=dev)
         slots = None
         if ctx.sink is not None:
             owner, key, sparams = ctx.sink
@@ -252,7 +275,7 @@ class EncoderFn(torch.autograd.Function):
         desc[:, _E["TBL_B"]:_E["FLIP_B"] + 1] = np.array(tb, dtype=np.int64)
         desc[:, _E["PAIR_IN"]:_E["LD_PAIRS"] + 1] = np.array(pr, dtype=np.int64)
         desc[:, _E["DW"]:_E["DBETA"] + 1] = pptr
-        desc[:-1, _E["GY"]] = gbase + 4 * goffs[:-1]
+        desc[:-1, _E["GY"]] = gbase + goffs[:-1]
         desc[-1, _E["GY"]] = dout.data_ptr()
         dfeats = torch.empty((layers[0].n_in, layers[0].cin), dtype=_f32, device=dev) if need_dx0 else None
         fdesc = ctx.fdesc
@@ -261,15 +284,15 @@ class EncoderFn(torch.autograd.Function):
         if ctx.lane is not None and slots is not None and not need_dx0:
             # nothing autograd will touch depends on this pass: a library thread issues it; the optimizer waits for the
             # lane before it records the delivery event (FlatAdam.gather_grads)
-            rc = lib.irx_encoder_submit(ctx.lane, 1, desc.ctypes.data, fdesc.ctypes.data, nl, gbase + 4 * dc_off, None,
+            rc = lib.irx_encoder_submit(ctx.lane, 1, desc.ctypes.data, fdesc.ctypes.data, nl, gbase + dc_off, None,
                                         ws.data_ptr(), nbytes, _lib.stream_ptr())
             if rc:
                 _lib.check(rc, "irx_encoder_submit")
-            _HELD.setdefault(ctx.lane, []).append((ws, garena, dout, slots, ctx.saved_tensors))
+            _HELD.setdefault(ctx.lane, []).append((ws, garena, dout, slots, ctx.saved_tensors, ctx.prof))
             owner.sink_delivered(key, sparams, lane=ctx.lane)
             return (None, None, None) + (None,) * (3 * nl)
         lane_wait(ctx.lane)                                  # same-stream order with the (possibly queued) forward
-        rc = lib.irx_encoder_backward(desc.ctypes.data, fdesc.ctypes.data, nl, gbase + 4 * dc_off,
+        rc = lib.irx_encoder_backward(desc.ctypes.data, fdesc.ctypes.data, nl, gbase + dc_off,
                                       dfeats.data_ptr() if need_dx0 else None, ws.data_ptr(), nbytes,
                                       _lib.stream_ptr())
         if rc:
@@ -287,6 +310,30 @@ class EncoderFn(torch.autograd.Function):
         return (dfeats, None, None) + tuple(grads)
 
 
+def _profile_slots(layers, store):
+    """bench.py's instrumented steps: six timing events per layer (start / stop around the dominant forward, data-gradient
+    and weight-gradient kernel; recorded by the library on the launch stream: IRX_ENC_PROF) and the matching PROFILE
+    records (kind, n_out, K, cin, cout, pairs, start, stop, element size of the gathered / written activations)."""
+    import ctypes
+    nl = len(layers)
+    evs, handles = [], (ctypes.c_void_p * (6 * nl))()
+    for i, L in enumerate(layers):
+        row = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        for j, e in enumerate(row):
+            e.record()                                    # instantiates the HIP event; re-recorded by the library
+            handles[6 * i + j] = e.cuda_event
+        evs.append(row)
+        m = F_._pairs(L.tbl, L.K, L.n_out)
+        esz = 2 if (store and i > 0) else 4
+        F_.PROFILE.append(("fwd", L.n_out, L.K, L.cin, L.cout, m, row[0], row[1], esz))
+        if i > 0:
+            F_.PROFILE.append(("dgrad", L.n_in, L.K, L.cout, L.cin, m, row[2], row[3], 2 if store else 4))
+        F_.PROFILE.append(("wgrad", L.n_out, L.K, L.cin, L.cout, m, row[4], row[5], 2 if store else 4))
+    base = ctypes.addressof(handles)
+    ptrs = base + 6 * ctypes.sizeof(ctypes.c_void_p) * np.arange(nl, dtype=np.int64)
+    return (evs, handles), ptrs
+
+
 def run_encoder(encoder, st):
     """Fused training forward of a SparseConvEncoder on a canonical SparseTensor -> SparseTensor at stride 16."""
     from .tensor import SparseTensor
@@ -301,7 +348,7 @@ def run_encoder(encoder, st):
 
 def can_fuse(encoder):
     """The executor covers the training configuration of the reference (train-mode BatchNorm, fp32, no bias)."""
-    if not (encoder.training and torch.is_grad_enabled()) or F_.PROFILE is not None:
+    if not (encoder.training and torch.is_grad_enabled()):
         return False
     if not all(bn.training for _, bn, _, _ in _skeleton(encoder)):
         return False                                   # frozen BatchNorm layers: the per-layer path handles eval statistics

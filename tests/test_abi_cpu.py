@@ -63,7 +63,9 @@ def test_argument_validation_and_error_string(lib):
 
 def test_mode_switch_and_lane_calls_validate_their_arguments(lib):
     assert lib.irx_get_compute_dtype() == 0                      # fp32 (exact) is the default
-    assert lib.irx_set_compute_dtype(2) == -1 and b"irx_set_compute_dtype" in lib.irx_last_error()
+    assert lib.irx_set_compute_dtype(3) == -1 and b"irx_set_compute_dtype" in lib.irx_last_error()
+    assert lib.irx_set_compute_dtype(2) == 0 and lib.irx_get_compute_dtype() == 2     # bf16 storage in the executor
+    assert lib.irx_set_compute_dtype(0) == 0
     assert lib.irx_set_compute_dtype(1) == 0 and lib.irx_get_compute_dtype() == 1
     assert lib.irx_set_compute_dtype(0) == 0 and lib.irx_get_compute_dtype() == 0
     assert lib.irx_encoder_wait(0) == 0                          # an idle lane returns at once
