@@ -118,8 +118,8 @@ __global__ void k_voxel_select(const uint64_t* __restrict__ keys, int n,
   if (ballot == 0ull) return;
   int lane = threadIdx.x & 63;
   int base = 0;
-  if (lane == (__ffsll((long long)ballot) - 1)) base = atomicAdd(count, __popcll(ballot));
-  base = __shfl(base, __ffsll((long long)ballot) - 1);
+  if (lane == (__ffsll((long long)ballot) - 1)) base = atomicAdd(count, __popcll(ballot)) & 0x7fffffff;   // (sign bit =
+  base = __shfl(base, __ffsll((long long)ballot) - 1);                                                       //  range error)
   if (win) {
     unsigned long long lower = ballot & ((1ull << lane) - 1ull);
     winners[base + __popcll(lower)] = i;
