@@ -427,19 +427,19 @@ def test_bf16_modes_track_the_fp32_reference(lib, mode):
 
 def test_bf16_storage_encoder_vs_fp32(lib):
     """The encoder executor with bf16 storage (irx_set_compute_dtype(2): conv outputs, layer outputs, gradients in flight
-    as bf16 in HBM; fp32 statistics / accumulation / parameter gradients) against the same encoder in fp32: pooled
-    features within 3e-2 of their max-norm, every parameter gradient within 6e-2 in relative L2 and cosine >= 0.998,
-    BatchNorm running statistics within 1e-2; and it really is a different arithmetic than the operand-only mode."""
+    as bf16 in HBM; fp32 statistics / accumulation / parameter gradients) against the same encoder in fp32 and with bf16
+    operands only. The loss is a dense inner product with the stride-16 feature map (a max-pool would route the whole
+    gradient through arg-max picks that bf16 noise re-draws). Output within 3e-2 of its max-norm; every parameter
+    gradient within 8e-2 in relative L2 of the fp32 one (cosine >= 0.995) and within 5e-2 of the operand-only mode's;
+    BatchNorm running statistics within 1e-2; and it is a different arithmetic than the operand-only mode."""
     import instancerefer_amd as irx
     from helpers import device_batch, surface_cloud
     from instancerefer_amd.basic_blocks import SparseConvEncoder
-    from instancerefer_amd.sparse import nn as spnn
     rng = np.random.default_rng(15)
     clouds = [surface_cloud(rng, 4000, rng.uniform(0, 3, 3), rng.uniform(0.8, 2.0, 3)) for _ in range(4)]
     torch.manual_seed(2)
     enc = SparseConvEncoder(7).cuda().train()
-    g = torch.from_numpy(rng.standard_normal((4, 128)).astype(np.float32)).cuda()
-    res = {}
+    res, g = {}, None
     try:
         for mode in ("fp32", "bf16_operands", "bf16"):
             irx.set_compute_dtype(mode)
@@ -447,25 +447,31 @@ def test_bf16_storage_encoder_vs_fp32(lib):
             for m in enc.modules():
                 if isinstance(m, torch.nn.BatchNorm1d):
                     m.reset_running_stats()
-            pooled = spnn.GlobalMaxPooling()(enc(device_batch(clouds, 0.05)))
-            (pooled * g).sum().backward()
+            out = enc(device_batch(clouds, 0.05)).F
+            if g is None:
+                g = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
+            (out * g).sum().backward()
             torch.cuda.synchronize()
-            res[mode] = (pooled.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters()},
+            res[mode] = (out.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters()},
                          {n: b.clone() for n, b in enc.named_buffers() if b.dtype.is_floating_point})
     finally:
         irx.set_compute_dtype("fp32")
-    ref, got = res["fp32"], res["bf16"]
+    ref, ops, got = res["fp32"], res["bf16_operands"], res["bf16"]
     assert bool(torch.isfinite(got[0]).all())
     assert float((got[0] - ref[0]).abs().max()) <= 3e-2 * float(ref[0].abs().max())
-    worst = {}
+
+    def rel(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return float((a - b).norm() / a.norm()), float((a @ b) / (a.norm() * b.norm()))
+    bad = {}
     for n in ref[1]:
-        a, b = ref[1][n].double().flatten(), got[1][n].double().flatten()
-        worst[n] = (float((a - b).norm() / a.norm()), float((a @ b) / (a.norm() * b.norm())))
-    bad = {n: v for n, v in worst.items() if v[0] > 6e-2 or v[1] < 0.998}
+        r32, rop = rel(ref[1][n], got[1][n]), rel(ops[1][n], got[1][n])
+        if r32[0] > 8e-2 or r32[1] < 0.995 or rop[0] > 5e-2:
+            bad[n] = (r32, rop)
     assert not bad, bad
     for n in ref[2]:
         assert float((got[2][n] - ref[2][n]).abs().max()) <= 1e-2 * max(1.0, float(ref[2][n].abs().max())), n
-    assert not torch.equal(got[0], res["bf16_operands"][0])
+    assert not torch.equal(got[0], ops[0])
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
