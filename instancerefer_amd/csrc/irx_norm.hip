@@ -16,6 +16,34 @@ struct BnTy {
   int x, y, dy, dx, res;
 };
 
+// TY == false: every tensor is fp32 and the loads are the plain float4 loads the compiler batches (a run-time type
+// flag in front of each load kept it from issuing the rows' loads together: k_bn_partial<1> 14.7 -> 27 us);
+// TY == true (V == 4 only): mixed element types, run-time flags — the executor's LAST layer in bf16 storage mode.
+template <bool TY>
+__device__ __forceinline__ float4 bn_ld4(const float* p, size_t off, int bf) {
+  if constexpr (TY) return irx_ld4(p, off, bf);
+  else return *reinterpret_cast<const float4*>(p + off);
+}
+template <bool TY>
+__device__ __forceinline__ void bn_st4(float* p, size_t off, int bf, float4 v) {
+  if constexpr (TY) irx_st4(p, off, bf, v);
+  else *reinterpret_cast<float4*>(p + off) = v;
+}
+
+// V == 8: every tensor of the call is bf16 and a thread owns 8 channels = one 16-byte load / store per tensor and row
+// (with V == 4 a bf16 row quad is only 8 bytes per lane and the streaming kernels run at half their bytes in flight)
+__device__ __forceinline__ void bn_ld8(const float* p, size_t off, float (&v)[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p) + off);
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void bn_st8(float* p, size_t off, const float (&v)[8]) {
+  *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p) + off) =
+      make_uint4(irx_pk_bf16(v[0], v[1]), irx_pk_bf16(v[2], v[3]), irx_pk_bf16(v[4], v[5]), irx_pk_bf16(v[6], v[7]));
+}
+
 __host__ __device__ static inline int next_pow2(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -26,7 +54,7 @@ __host__ __device__ static inline int next_pow2(int v) {
 //   MODE 0: (sum x, sum x^2)
 //   MODE 1: (sum g, sum g*xhat), g = dy * (RELU ? y > 0 : 1), xhat = (x - mean) * invstd
 // V = vector width (4 when c % 4 == 0 else 1). part layout [blk][2][c].
-template <int MODE, int V>
+template <int MODE, int V, bool TY>
 __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
                                                     const float* __restrict__ y,
                                                     const float* __restrict__ dy, int n, int c,
@@ -59,11 +87,17 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
     constexpr int U = 4;
     auto load_row = [&](int r, float (&xv)[V], float (&yv)[V], float (&dv)[V]) __attribute__((always_inline)) {
       const size_t off = (size_t)r * c + (size_t)qd * V;
-      if (V == 4) {
-        *reinterpret_cast<float4*>(xv) = irx_ld4(x, off, ty.x);
+      if constexpr (V == 8) {
+        bn_ld8(x, off, xv);
         if (MODE == 1) {
-          *reinterpret_cast<float4*>(dv) = irx_ld4(dy, off, ty.dy);
-          if (relu) *reinterpret_cast<float4*>(yv) = irx_ld4(y, off, ty.y);
+          bn_ld8(dy, off, dv);
+          if (relu) bn_ld8(y, off, yv);
+        }
+      } else if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(xv) = bn_ld4<TY>(x, off, ty.x);
+        if (MODE == 1) {
+          *reinterpret_cast<float4*>(dv) = bn_ld4<TY>(dy, off, ty.dy);
+          if (relu) *reinterpret_cast<float4*>(yv) = bn_ld4<TY>(y, off, ty.y);
         }
       } else {
         xv[0] = x[off];
@@ -172,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
 // Apply kernels: every thread owns ONE channel group of V channels (its scale / shift live in registers) and walks
 // rows with a fixed stride, so the inner loop is load - fma - store with no index arithmetic beyond an add.
 // qpad = power of two >= c / V threads per row; rows_per_pass = 256 / qpad per workgroup.
-template <int V>
+template <int V, bool TY>
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, int n, int c, int qpad,
                                                   const float* __restrict__ mean,
                                                   const float* __restrict__ invstd,
@@ -194,9 +228,12 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, i
   for (int r = blockIdx.x * rpp + threadIdx.x / qpad; r < n; r += row_stride) {
     const size_t off = (size_t)r * c + (size_t)qd * V;
     float xv[V], rv[V], ov[V];
-    if (V == 4) {
-      *reinterpret_cast<float4*>(xv) = irx_ld4(x, off, ty.x);
-      if (res) *reinterpret_cast<float4*>(rv) = irx_ld4(res, off, ty.res);
+    if constexpr (V == 8) {
+      bn_ld8(x, off, xv);
+      if (res) bn_ld8(res, off, rv);
+    } else if constexpr (V == 4) {
+      *reinterpret_cast<float4*>(xv) = bn_ld4<TY>(x, off, ty.x);
+      if (res) *reinterpret_cast<float4*>(rv) = bn_ld4<TY>(res, off, ty.res);
     } else {
       xv[0] = x[off];
       if (res) rv[0] = res[off];
@@ -208,15 +245,17 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, i
       if (relu) o = o > 0.f ? o : 0.f;
       ov[j] = o;
     }
-    if (V == 4)
-      irx_st4(y, off, ty.y, *reinterpret_cast<float4*>(ov));
+    if constexpr (V == 8)
+      bn_st8(y, off, ov);
+    else if constexpr (V == 4)
+      bn_st4<TY>(y, off, ty.y, *reinterpret_cast<float4*>(ov));
     else
       y[off] = ov[0];
   }
 }
 
 // dx = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n);  dres = g
-template <int V>
+template <int V, bool TY>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x,
                                                       const float* __restrict__ y,
                                                       const float* __restrict__ dy, int n, int c, int qpad,
@@ -244,10 +283,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   for (int r = blockIdx.x * rpp + threadIdx.x / qpad; r < n; r += row_stride) {
     const size_t off = (size_t)r * c + (size_t)qd * V;
     float xv[V], yv[V], dv[V], ox[V], og[V];
-    if (V == 4) {
-      *reinterpret_cast<float4*>(xv) = irx_ld4(x, off, ty.x);
-      *reinterpret_cast<float4*>(dv) = irx_ld4(dy, off, ty.dy);
-      if (relu) *reinterpret_cast<float4*>(yv) = irx_ld4(y, off, ty.y);
+    if constexpr (V == 8) {
+      bn_ld8(x, off, xv);
+      bn_ld8(dy, off, dv);
+      if (relu) bn_ld8(y, off, yv);
+    } else if constexpr (V == 4) {
+      *reinterpret_cast<float4*>(xv) = bn_ld4<TY>(x, off, ty.x);
+      *reinterpret_cast<float4*>(dv) = bn_ld4<TY>(dy, off, ty.dy);
+      if (relu) *reinterpret_cast<float4*>(yv) = bn_ld4<TY>(y, off, ty.y);
     } else {
       xv[0] = x[off];
       dv[0] = dy[off];
@@ -261,9 +304,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
       ox[j] = gi[j] * (gval - sg[j] - xh * sgx[j]);
       og[j] = gval;
     }
-    if (V == 4) {
-      irx_st4(dx, off, ty.dx, *reinterpret_cast<float4*>(ox));
-      if (dres) irx_st4(dres, off, ty.res, *reinterpret_cast<float4*>(og));
+    if constexpr (V == 8) {
+      bn_st8(dx, off, ox);
+      if (dres) bn_st8(dres, off, og);
+    } else if constexpr (V == 4) {
+      bn_st4<TY>(dx, off, ty.dx, *reinterpret_cast<float4*>(ox));
+      if (dres) bn_st4<TY>(dres, off, ty.res, *reinterpret_cast<float4*>(og));
     } else {
       dx[off] = ox[0];
       if (dres) dres[off] = og[0];
@@ -321,12 +367,18 @@ int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, floa
   const BnTy ty = {x_bf, 0, 0, 0, 0};
   rc = bn_bf_ok("irx_bn_stats", x_bf != 0, v4);
   if (rc) return rc;
-  if (v4)
-    k_bn_partial<0, 4><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                   next_pow2(c / 4), bn_rows(n), part, ty);
+  if (v4 && x_bf && c % 8 == 0)
+    k_bn_partial<0, 8, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+                                                   next_pow2(c / 8), bn_rows(n), part, ty);
+  else if (v4 && x_bf)
+    k_bn_partial<0, 4, true><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+                                                         next_pow2(c / 4), bn_rows(n), part, ty);
+  else if (v4)
+    k_bn_partial<0, 4, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+                                                          next_pow2(c / 4), bn_rows(n), part, ty);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_stats: c=%d needs c %% 4 == 0 or c <= 256", c);
-    k_bn_partial<0, 1><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+    k_bn_partial<0, 1, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
                                                    next_pow2(c), bn_rows(n), part, ty);
   }
   IRX_CHECK_LAUNCH("irx_bn_stats(partial)");
@@ -353,13 +405,19 @@ int irx_bn_apply_t(const float* x, int n, int c, const float* mean, const float*
   const BnTy ty = {x_bf, y_bf, 0, 0, res_bf};
   int rc = bn_bf_ok("irx_bn_apply", (x_bf | res_bf | y_bf) != 0, v4);
   if (rc) return rc;
-  if (v4) {
+  if (v4 && x_bf && y_bf && (!residual || res_bf) && c % 8 == 0) {
+    const int qpad = next_pow2(c / 8);
+    k_bn_apply<8, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y, ty);
+  } else if (v4 && (x_bf | res_bf | y_bf)) {
     const int qpad = next_pow2(c / 4);
-    k_bn_apply<4><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y, ty);
+    k_bn_apply<4, true><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y, ty);
+  } else if (v4) {
+    const int qpad = next_pow2(c / 4);
+    k_bn_apply<4, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y, ty);
   } else {
     IRX_REQUIRE(c <= 256, "irx_bn_apply: c=%d needs c %% 4 == 0 or c <= 256", c);
     const int qpad = next_pow2(c);
-    k_bn_apply<1><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y, ty);
+    k_bn_apply<1, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y, ty);
   }
   IRX_CHECK_LAUNCH("irx_bn_apply");
   return IRX_OK;
@@ -397,25 +455,41 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   const BnTy ty = {x_bf, y_bf, dy_bf, dx_bf, dres_bf};
   rc = bn_bf_ok("irx_bn_backward", (x_bf | y_bf | dy_bf | dx_bf | dres_bf) != 0, v4);
   if (rc) return rc;
-  if (v4)
-    k_bn_partial<1, 4><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                   next_pow2(c / 4), bn_rows(n), part, ty);
+  const bool any_bf = (x_bf | y_bf | dy_bf | dx_bf | dres_bf) != 0;
+  const bool v8 = v4 && x_bf && (y_bf || !relu) && dy_bf && dx_bf && (!dresidual || dres_bf) && c % 8 == 0;
+  if (v8)
+    k_bn_partial<1, 8, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
+                                                   next_pow2(c / 8), bn_rows(n), part, ty);
+  else if (v4 && any_bf)
+    k_bn_partial<1, 4, true><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
+                                                         next_pow2(c / 4), bn_rows(n), part, ty);
+  else if (v4)
+    k_bn_partial<1, 4, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
+                                                          next_pow2(c / 4), bn_rows(n), part, ty);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_backward: c=%d needs c %% 4 == 0 or c <= 256", c);
-    k_bn_partial<1, 1><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, next_pow2(c),
+    k_bn_partial<1, 1, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, next_pow2(c),
                                                    bn_rows(n), part, ty);
   }
   IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
   k_bn_finalize<1><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
                                                           nullptr, nullptr);
   IRX_CHECK_LAUNCH("irx_bn_backward(finalize)");
-  if (v4) {
-    const int qpad = next_pow2(c / 4);
-    k_bn_bwd_apply<4><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
+  if (v8) {
+    const int qpad = next_pow2(c / 8);
+    k_bn_bwd_apply<8, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
                                                                dgamma, relu, dx, dresidual, ty);
+  } else if (v4 && any_bf) {
+    const int qpad = next_pow2(c / 4);
+    k_bn_bwd_apply<4, true><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
+                                                                     dgamma, relu, dx, dresidual, ty);
+  } else if (v4) {
+    const int qpad = next_pow2(c / 4);
+    k_bn_bwd_apply<4, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
+                                                                      dgamma, relu, dx, dresidual, ty);
   } else {
     const int qpad = next_pow2(c);
-    k_bn_bwd_apply<1><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
+    k_bn_bwd_apply<1, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
                                                                dgamma, relu, dx, dresidual, ty);
   }
   IRX_CHECK_LAUNCH("irx_bn_backward(apply)");

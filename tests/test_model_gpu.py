@@ -429,9 +429,12 @@ def test_bf16_storage_encoder_vs_fp32(lib):
     """The encoder executor with bf16 storage (irx_set_compute_dtype(2): conv outputs, layer outputs, gradients in flight
     as bf16 in HBM; fp32 statistics / accumulation / parameter gradients) against the same encoder in fp32 and with bf16
     operands only. The loss is a dense inner product with the stride-16 feature map (a max-pool would route the whole
-    gradient through arg-max picks that bf16 noise re-draws). Output within 3e-2 of its max-norm; every parameter
-    gradient within 8e-2 in relative L2 of the fp32 one (cosine >= 0.995) and within 5e-2 of the operand-only mode's;
-    BatchNorm running statistics within 1e-2; and it is a different arithmetic than the operand-only mode."""
+    gradient through arg-max picks that bf16 noise re-draws). Output within 3e-2 of its max-norm. Gradients: with these
+    random weights bf16 OPERAND rounding alone moves the parameter gradients by 5 % (deepest stage) to 20-25 % (stem) in
+    relative L2 — 13 train-mode BatchNorms amplify a 1 % forward perturbation (measured, tools/storage_diag.py) — so the
+    bar for the storage mode is "no worse than that": relative L2 vs fp32 <= 1.6 x the operand-only mode's + 3e-2,
+    cosine vs fp32 >= 0.93; BatchNorm running statistics within 1e-2; and it is a different arithmetic than the
+    operand-only mode."""
     import instancerefer_amd as irx
     from helpers import device_batch, surface_cloud
     from instancerefer_amd.basic_blocks import SparseConvEncoder
@@ -465,9 +468,9 @@ def test_bf16_storage_encoder_vs_fp32(lib):
         return float((a - b).norm() / a.norm()), float((a @ b) / (a.norm() * b.norm()))
     bad = {}
     for n in ref[1]:
-        r32, rop = rel(ref[1][n], got[1][n]), rel(ops[1][n], got[1][n])
-        if r32[0] > 8e-2 or r32[1] < 0.995 or rop[0] > 5e-2:
-            bad[n] = (r32, rop)
+        r32, o32 = rel(ref[1][n], got[1][n]), rel(ref[1][n], ops[1][n])
+        if r32[0] > 1.6 * o32[0] + 3e-2 or r32[1] < 0.93:
+            bad[n] = (r32, o32)
     assert not bad, bad
     for n in ref[2]:
         assert float((got[2][n] - ref[2][n]).abs().max()) <= 1e-2 * max(1.0, float(ref[2][n].abs().max())), n
