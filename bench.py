@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--prep-thread", action="store_true",
                     help="run the input preparation on a helper thread instead of inline behind the step (same speed: "
                          "the loop is GIL-bound, tools/micro/ab_thread.py)")
+    ap.add_argument("--prep-at-backward", action="store_true",
+                    help="issue the launch phase of the next batch's input preparation from a helper thread WHILE the "
+                         "autograd engine runs this step's backward (the Python thread is parked in loss.backward() and the "
+                         "engine's C++ nodes do not hold the GIL)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do the input preparation of each step inline instead of on a side stream during the previous backward")
     args = ap.parse_args()
@@ -169,7 +173,8 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
     dd = take_prepared(model, state) if state is not None else None
     if dd is None:
         dd = fresh_batch(resident)
-    if state is not None and state.get("pipeline"):
+    at_bwd = state is not None and state.get("pipeline") and state.get("at_backward")
+    if state is not None and state.get("pipeline") and not at_bwd:
         # batch N+1: threaded -> the whole preparation runs beside this step; inline -> only its launch phase now
         prepare_next(model, resident, state, phase="launch")
     opt.zero_grad()
@@ -188,11 +193,48 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
             zero = torch.zeros_like(dd["attribute_scores"])
             ref = ContrastiveFn.apply(dd["attribute_scores"], zero, zero, lp["lab"], lp["seg_off"], lp["keep_dev"], 5.0, 0.2)
             loss = loss + 10.0 * ref / lp["batch_size"]
+    if at_bwd:
+        w = state.get("worker")
+        if w is None:
+            w = state["worker"] = _Worker(torch.cuda.current_device())
+        w.post(lambda: prepare_next(model, resident, state, phase="launch"))
     loss.backward()
+    if at_bwd:
+        state["worker"].wait()
     opt.backward_step()          # one cat -> one all-reduce (N > 1) -> one fused Adam launch
     if state is not None and state.get("pipeline") and not state.get("threaded", True):
         prepare_next(model, resident, state, phase="finish")   # level sizes arrived during the step: no wait
     return loss
+
+
+class _Worker:
+    """A persistent helper thread (no thread start per step): post() a callable, wait() for it (re-raises)."""
+
+    def __init__(self, device):
+        import queue
+        import threading
+        self.q, self.done, self.err = queue.Queue(), threading.Event(), None
+
+        def loop():
+            torch.cuda.set_device(device)
+            while True:
+                fn = self.q.get()
+                try:
+                    fn()
+                except BaseException as e:
+                    self.err = e
+                self.done.set()
+        threading.Thread(target=loop, name="irx-prep-worker", daemon=True).start()
+
+    def post(self, fn):
+        self.done.clear()
+        self.q.put(fn)
+
+    def wait(self):
+        self.done.wait()
+        if self.err is not None:
+            e, self.err = self.err, None
+            raise e
 
 
 def usable_cores():
@@ -367,7 +409,8 @@ def main():
     # IRX_BENCH_SHARE_GPU test rig) stalled ~250 ms per sync behind a third stream, so N > 1 used the main stream; since
     # the preparation is sync-free that rig runs the side stream faster than the main one (1054-1090 vs 1019-1038
     # scenes/s for 2 ranks on one GPU), and the main-stream variant costs 5 % on a GPU of its own.
-    state = {"pipeline": not args.no_pipeline, "threaded": bool(args.prep_thread) and world == 1}
+    state = {"pipeline": not args.no_pipeline, "threaded": bool(args.prep_thread) and world == 1,
+             "at_backward": bool(args.prep_at_backward) and not args.prep_thread}
     if os.environ.get("IRX_BENCH_PREP_MAIN") == "1":   # dev A/B: the preparation on the main stream
         state["side"] = torch.cuda.current_stream()
     from instancerefer_amd.loss_helper import prepare_labels
@@ -573,11 +616,12 @@ def summarise_roofline(recs, bf16=False):
                       "algo_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
                       "frac_of_bound": round(v["bound_ms"] / v["ms"], 4)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     traffic = None
-    try:   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json; see its _note)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+    try:   # HBM bytes per launch from the committed PMC passes (profiles/r02_pmc_traffic*.json; see their _note)
+        name = "r02_pmc_traffic_bf16.json" if bf16 else "r02_pmc_traffic.json"
+        pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
         key = dom.replace(",", ", ")
-        if key.startswith(("k_spconv2<", "k_wgrad_pairs<")):       # template flag: bf16 operand mode
-            key = key[:-1] + (", true>" if bf16 else ", false>")
+        if key.startswith(("k_spconv2<", "k_wgrad_pairs<")):       # template flags: <..., bf16 operands, bf16 storage>
+            key = key[:-1] + (", true, true>" if bf16 else ", false, false>")
         if key in pmc:
             traffic = pmc[key]["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
