@@ -166,7 +166,7 @@ __device__ static inline uint64_t parent_key(uint64_t key, int level) {
 __global__ void k_ds_count(const uint64_t* __restrict__ keys, int n, int level,
                            int32_t* __restrict__ tile_counts, const int32_t* __restrict__ n_dev) {
   __shared__ int s_wave[DS_BLOCK / 64];
-  if (n_dev) n = *n_dev;                           // row count produced on the device by the previous level
+  if (n_dev) n = *n_dev < 0 ? 0 : *n_dev;   // (negative = the voxeliser's range-error flag: an empty level)                           // row count produced on the device by the previous level
   int base = blockIdx.x * DS_TILE;
   int cnt = 0;
   for (int it = 0; it < DS_ITEMS; ++it) {
@@ -196,7 +196,7 @@ __global__ void k_ds_write(const uint64_t* __restrict__ keys, const int4* __rest
                            int32_t* __restrict__ child, int ld, int32_t* __restrict__ n_out,
                            const int32_t* __restrict__ n_dev) {
   __shared__ int s_red[DS_BLOCK / 64];
-  if (n_dev) n = *n_dev;
+  if (n_dev) n = *n_dev < 0 ? 0 : *n_dev;   // (negative = the voxeliser's range-error flag: an empty level)
   __shared__ int s_wave_base[DS_BLOCK / 64];
   __shared__ int s_tile_base;
   // exclusive prefix of tile counts for this tile
@@ -453,7 +453,7 @@ extern "C" int irx_downsample(const uint64_t* keys, const int32_t* coords, int n
 
 // child[k][p] = -1 for p < n (n on the device when n_dev != NULL): only the columns a level can use are touched
 __global__ void k_fill_child(int32_t* __restrict__ child, int ld, int n, const int32_t* __restrict__ n_dev) {
-  if (n_dev) n = *n_dev;
+  if (n_dev) n = *n_dev < 0 ? 0 : *n_dev;   // (negative = the voxeliser's range-error flag: an empty level)
   const size_t total = (size_t)8 * n;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;

@@ -334,7 +334,7 @@ def test_pipelined_training_steps_equal_inline_steps(lib):
     dev = torch.device("cuda")
     bench.step_fn.cfg = DatasetConfig()
     out = {}
-    for mode in ("inline", "pipelined", "pipelined-thread"):
+    for mode in ("inline", "pipelined", "pipelined-thread", "pipelined-at-backward"):
         torch.manual_seed(99)
         model = bench.build_model(argparse.Namespace(), "full", dev)
         resident = S.to_device(S.make_batch(4, seed=11, num_points=6000, num_instances=6, num_candidates=3,
@@ -342,7 +342,8 @@ def test_pipelined_training_steps_equal_inline_steps(lib):
         lidar = resident.pop("lidar")
         resident["lidar_F"], resident["lidar_C"], resident["B"] = lidar.F, lidar.C, 4
         opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
-        state = {"pipeline": mode != "inline", "threaded": mode == "pipelined-thread"}
+        state = {"pipeline": mode != "inline", "threaded": mode == "pipelined-thread",
+                 "at_backward": mode == "pipelined-at-backward"}
         if mode != "inline":
             state["labels"] = lambda dd: prepare_labels(dd, bench.step_fn.cfg, dev) if "_attr_prepared" in dd else None
         losses = [float(bench.step_fn(model, resident, "full", None, opt, state)) for _ in range(4)]
@@ -351,7 +352,7 @@ def test_pipelined_training_steps_equal_inline_steps(lib):
         if th is not None:
             th.join()
         out[mode] = (losses, torch.cat([p.detach().flatten() for p in model.parameters()]).clone())
-    for mode in ("pipelined", "pipelined-thread"):
+    for mode in ("pipelined", "pipelined-thread", "pipelined-at-backward"):
         assert out["inline"][0] == out[mode][0], (mode, out["inline"][0], out[mode][0])
         assert torch.equal(out["inline"][1], out[mode][1]), mode
 
