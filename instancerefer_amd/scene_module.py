@@ -5,7 +5,6 @@ kernels summed over 5 z-bins) -> BN2d/ReLU -> 2 x Conv2d 3x3 -> language-guided 
 cells -> 9-way area classifier + cosine score between the scene vector and each candidate's obj_feats.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -15,20 +14,6 @@ from .data import idx_tensor
 from .dense import cosine_rows
 from .sparse.encoder_fn import lane_of, lane_wait
 from .sparse import nn as spnn
-
-
-class _SceneHeadCore(nn.Module):
-    """The static-shape part of SceneModule.forward (everything behind the BEV rows up to the scene vector), as a
-    tensor-in / tensor-out module that a hipGraph can replay (see SceneModule._head)."""
-
-    def __init__(self, scene, batch_size):
-        super().__init__()
-        self.__dict__['scene'] = scene             # not registered: the BEVEncoder's parameters are no inputs of this graph
-        self.bn0, self.vis_emb_fc, self.lang_emb_fc, self.cls = scene.to_bev[2], scene.vis_emb_fc, scene.lang_emb_fc, scene.cls
-        self.batch_size = batch_size
-
-    def forward(self, rows, lang_feats):
-        return self.scene._head_eager(rows, lang_feats, self.batch_size)
 
 
 class SceneModule(nn.Module):
@@ -66,55 +51,6 @@ class SceneModule(nn.Module):
         data_dict['_scene_encoded'] = self.net(feats)
         return data_dict
 
-    def _head_eager(self, rows, lang_feats, batch_size):
-        """BEV rows (B*15*25, 128) + language scene vector (B, 256) -> attention (B, 11*21), scene vector, area scores."""
-        nx, ny = self.to_bev[1].bev_shape
-        rows = batchnorm_rows(self.to_bev[2], rows, relu=True)                  # BatchNorm2d + ReLU
-        rows = conv2d_rows(self.vis_emb_fc[0], rows, batch_size, nx, ny)        # Conv2d 3x3 -> (B*13*23, D)
-        rows = batchnorm_rows(self.vis_emb_fc[1], rows, relu=True)
-        rows = self.vis_emb_fc[3](rows)                                         # Dropout
-        rows = conv2d_rows(self.vis_emb_fc[4], rows, batch_size, nx - 2, ny - 2)  # -> (B*11*21, D)
-        h, w = nx - 4, ny - 4
-        feats = rows.view(batch_size, h * w, self.h_dim)                        # (B, n_vis, D)
-        lang_feats = self.lang_emb_fc(lang_feats).unsqueeze(2)
-        atten = torch.bmm(feats, lang_feats) / math.sqrt(feats.shape[2])
-        atten = torch.softmax(atten.squeeze(2), dim=1)
-        scene_feats = torch.sum(feats * atten.unsqueeze(2), dim=1)
-        return atten, scene_feats, self.cls(scene_feats)
-
-    def _head(self, rows, lang_feats, batch_size):
-        """Training on a HIP device: the head is ~45 forward + ~90 backward launches on shapes that depend on the batch
-        size only -> replayed from a hipGraph captured once per batch size (as LangModule does; IRX_HEAD_GRAPH=0 switches
-        it off). Same kernels in the same order: bit-identical to the eager head."""
-        if (rows.is_cuda and self.training and torch.is_grad_enabled() and os.environ.get("IRX_HEAD_GRAPH", "1") != "0"
-                and not torch.cuda.is_current_stream_capturing()):
-            from .sparse import functional as F_
-            cache = self.__dict__.setdefault('_graphs', {})
-            own = [p for n, p in self.named_parameters() if not n.startswith('net.')]
-            anchor = tuple(p.data_ptr() for p in own)
-            if cache.get('anchor') != anchor:
-                cache.clear()
-                cache['anchor'] = anchor
-            key = (batch_size, torch.cuda.current_device(), F_.PROFILE is not None)
-            g = cache.get(key)
-            if g is None and F_.PROFILE is None:
-                core = _SceneHeadCore(self, batch_size)
-                saved = [(b, b.clone()) for b in core.buffers()]      # the capture's warm-up passes must not count as
-                try:                                                   # training steps of the BatchNorm running statistics
-                    g = torch.cuda.make_graphed_callables(core, (rows.detach().clone().requires_grad_(True),
-                                                                 lang_feats.detach().clone().requires_grad_(True)))
-                    with torch.no_grad():
-                        for b, v in saved:
-                            b.copy_(v)
-                except Exception as e:
-                    import warnings
-                    warnings.warn("SceneModule: hipGraph capture of the head failed (%r); running eagerly" % (e,))
-                    g = False
-                cache[key] = g
-            if g:
-                return g(rows, lang_feats)
-        return self._head_eager(rows, lang_feats, batch_size)
-
     def forward(self, data_dict):
         feats = data_dict['lidar']
         batch_size = data_dict['point_min'].shape[0]
@@ -133,9 +69,20 @@ class SceneModule(nn.Module):
         # The dense head runs on channels-last cell rows (cells, C) with the irx conv / BatchNorm kernels.
         nx, ny = self.to_bev[1].bev_shape
         rows, _ = self.to_bev[1].rows(feats)                                    # (B*15*25, 128)
-        atten, scene_feats, seg_scores = self._head(rows, lang_feats, batch_size)
-        data_dict['vis_atten'] = atten.reshape(batch_size, nx - 4, ny - 4)
-        data_dict['seg_scores'] = seg_scores
+        rows = batchnorm_rows(self.to_bev[2], rows, relu=True)                  # BatchNorm2d + ReLU
+        rows = conv2d_rows(self.vis_emb_fc[0], rows, batch_size, nx, ny)        # Conv2d 3x3 -> (B*13*23, D)
+        rows = batchnorm_rows(self.vis_emb_fc[1], rows, relu=True)
+        rows = self.vis_emb_fc[3](rows)                                         # Dropout
+        rows = conv2d_rows(self.vis_emb_fc[4], rows, batch_size, nx - 2, ny - 2)  # -> (B*11*21, D)
+        h, w = nx - 4, ny - 4
+        feats = rows.view(batch_size, h * w, self.h_dim)                        # (B, n_vis, D)
+        lang_feats = self.lang_emb_fc(lang_feats).unsqueeze(2)
+        atten = torch.bmm(feats, lang_feats) / math.sqrt(feats.shape[2])
+        atten = torch.softmax(atten.squeeze(2), dim=1)
+        data_dict['vis_atten'] = atten.reshape(batch_size, h, w)
+
+        scene_feats = torch.sum(feats * atten.unsqueeze(2), dim=1)
+        data_dict['seg_scores'] = self.cls(scene_feats)
 
         cand_scene = [i for i in range(batch_size) for _ in range(len(pred_obb_batch[i]))
                       if len(pred_obb_batch[i]) >= 2]
