@@ -15,12 +15,6 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset.npz")
 
 
-@pytest.fixture(scope="module")
-def lib():
-    from instancerefer_amd import _lib
-    return _lib.load()
-
-
 def _rows_sorted(c, f):
     c = np.asarray(c)[:, :3].astype(np.int64)
     o = np.lexsort((c[:, 2], c[:, 1], c[:, 0]))
