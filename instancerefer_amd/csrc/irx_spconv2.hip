@@ -54,6 +54,13 @@ extern "C" int irx_debug_s2_prof(unsigned long long* out, int reset) {
 #define S2_TICK(i) do { } while (0)
 #endif
 
+// Dev-only ablation of k_spconv2 (tools/micro/run_abl.sh builds -DIRX_S2_ABL=<mask> variants; results are WRONG, only the
+// timing is of interest): 1 = every weight load hits the same 1 KiB (no L2->L1 weight stream), 2 = every gathered row
+// is row 0, 4 = no MFMA, 8 = no read-modify-write of the LDS output tile, 16 = every offset reads W[0] (weights certainly L2-resident).
+#ifndef IRX_S2_ABL
+#define IRX_S2_ABL 0
+#endif
+
 struct PairList {
   int in_of_pair;   // lane p holds the input row of pair p (p < v)
   int row_of_pair;  // lane p holds the tile-local output row of pair p
@@ -118,9 +125,16 @@ __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __
       // this step's share of the item's weight loads
 #pragma unroll
       for (int i = (BF ? (j * NT) / 2 : j * NT); i < (BF ? ((j + 1) * NT) / 2 : (j + 1) * NT); ++i)
-        wx[i] = wnk[(size_t)i * 64];
+        wx[i] = wnk[(IRX_S2_ABL & 1) ? 0 : (size_t)i * 64];
       sx[j] = s2_ldrow<ST>(x, (size_t)nrow[j] * ldx + c4);
     }
+    if constexpr ((IRX_S2_ABL & 4) != 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if constexpr (BF) acc[t][0] += __uint_as_float(a4.x ^ wc[(j * NT + t) >> 1].x);
+        else acc[t][0] += a4.x * wc[j * NT + t].x + a4.w * wc[j * NT + t].w;
+      }
+    } else
     if constexpr (BF) {
       // a lane's 4 consecutive floats are exactly the 4 k-slots of the 16x16x16 bf16 MFMA: one MFMA replaces four
       const s16x4 pa = irx_frag_bf16(a4.x, a4.y);
@@ -145,6 +159,11 @@ __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __
   }
   // D layout: col = lane&15, row = (lane>>4)*4 + r -> pair 16g + 4*g4 + r.  Branch-free, batched read-modify-write:
   // padded pairs go to the dump row (row 64); this wave owns its channel slice, so there is no race.
+  if constexpr ((IRX_S2_ABL & 8) != 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(acc[t]));
+    return;
+  }
   float o[4][NT];
   int oaddr[4];
 #pragma unroll
@@ -163,10 +182,13 @@ __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __
 }
 
 // Pop the lowest active offset of the mask: kq = offset (or -1 past the end), vq = its pair count, kl = last real offset.
-__device__ __forceinline__ void s2_next_offset(unsigned& act, const int* __restrict__ sCnt, int& kq, int& vq, int& kl) {
+__device__ __forceinline__ void s2_next_offset(unsigned& act, const int* __restrict__ sCnt, int& kq, int& vq, int& kl,
+                                               int rot = 0, int K = 27) {
   if (act) {
     kq = __builtin_ctz(act);
     act &= act - 1;
+    kq += rot;                                     // act is the mask rotated right by rot (mod K)
+    if (kq >= K) kq -= K;
     vq = __builtin_amdgcn_readfirstlane(sCnt[kq]);
     kl = kq;
   } else {
@@ -182,7 +204,7 @@ __device__ __forceinline__ void s2_gather_rows(const int* __restrict__ list, int
   for (int it = 0; it < NIT; ++it) {
     const int p = pbase + it * PPP;                // < 64: always inside the list (entries >= vq are stale, unused)
     const int r = list[p];
-    nrow[it] = (p < vq) ? r : 0;
+    nrow[it] = ((IRX_S2_ABL & 2) || p >= vq) ? 0 : r;
   }
 }
 
@@ -301,6 +323,13 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     const int c = (lane < 32) ? sCnt[lane] : 0;
     act = (unsigned)__ballot(c > 0);
   }
+  // every tile walks the offsets from its own starting point: the workgroups resident at one time then stream
+  // DIFFERENT weight slices instead of all asking the L2 for the same few lines at once
+  int rot = 0;
+  if ((IRX_S2_ABL & 32) && gridDim.y == 1 && K > 1) {
+    rot = (int)((blockIdx.x * 11u) % (unsigned)K);
+    act = ((act >> rot) | (act << (K - rot))) & ((1u << K) - 1u);
+  }
 
   // ---- register sets and the prologue.  Sets are only ever indexed by compile-time constants (integral_constant
   // arguments of the generic lambdas below): a run-time choice of set would demote the arrays to scratch memory. ----
@@ -311,14 +340,14 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   int kq, vq, kl = kb;
   auto issue = [&](auto T_) __attribute__((always_inline)) {   // prologue: plain back-to-back issue into set T
     constexpr int T = decltype(T_)::value;
-    s2_next_offset(act, sCnt, kq, vq, kl);
+    s2_next_offset(act, sCnt, kq, vq, kl, rot, K);
     kk[T] = kq;
     vv[T] = vq;
     int nrow[NJ];
     s2_gather_rows<NIT, PPP>(sIn + kl * TM, pbase, vq, nrow);
-    const WT* wnk = reinterpret_cast<const WT*>(wn) + (((size_t)kl * NCS + cs) * WN) * 64 + lane;
+    const WT* wnk = reinterpret_cast<const WT*>(wn) + (((size_t)((IRX_S2_ABL & 16) ? 0 : kl) * NCS + cs) * WN) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < WN; ++i) W[T][i] = wnk[(size_t)i * 64];
+    for (int i = 0; i < WN; ++i) W[T][i] = wnk[(IRX_S2_ABL & 1) ? 0 : (size_t)i * 64];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) S[T][j] = s2_ldrow<ST>(x, (size_t)nrow[j] * ldx + c4);
   };
@@ -348,7 +377,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     S2_TICK(2);
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
-      if (it < npass)                              // (component-wise: a struct copy out of S[][] keeps the sets in scratch)
+      if (it < npass) {                            // (component-wise: a struct copy out of S[][] keeps the sets in scratch)
         if constexpr (ST)
           *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(sA) + (pbase + it * PPP) * (CIN + 8) + c4) =
               make_uint2(S[C][it].x, S[C][it].y);
@@ -358,16 +387,17 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
         else
           *reinterpret_cast<float4*>(&sA[(pbase + it * PPP) * LDA + c4]) =
               make_float4(S[C][it].x, S[C][it].y, S[C][it].z, S[C][it].w);
+      }
     S2_TICK(3);
     __syncthreads();
     S2_TICK(4);
     // ---- the item to prefetch ----
-    s2_next_offset(act, sCnt, kq, vq, kl);
+    s2_next_offset(act, sCnt, kq, vq, kl, rot, K);
     kk[T] = kq;
     vv[T] = vq;
     int nrow[NJ];
     s2_gather_rows<NIT, PPP>(sIn + kl * TM, pbase, vq, nrow);
-    const WT* wnk = reinterpret_cast<const WT*>(wn) + (((size_t)kl * NCS + cs) * WN) * 64 + lane;
+    const WT* wnk = reinterpret_cast<const WT*>(wn) + (((size_t)((IRX_S2_ABL & 16) ? 0 : kl) * NCS + cs) * WN) * 64 + lane;
     S2_TICK(5);
     // ---- MFMA over dense 16-pair groups; this wave's channel slice ----
     const unsigned char* lrow = sRow + k * TM;
@@ -380,7 +410,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
                                                                          S[T], nrow, x, c4, wnk, ldx);
     } else {                                       // a wave without a group in this item still prefetches its share
 #pragma unroll
-      for (int i = 0; i < WN; ++i) W[T][i] = wnk[(size_t)i * 64];
+      for (int i = 0; i < WN; ++i) W[T][i] = wnk[(IRX_S2_ABL & 1) ? 0 : (size_t)i * 64];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) S[T][j] = s2_ldrow<ST>(x, (size_t)nrow[j] * ldx + c4);
     }
@@ -578,8 +608,11 @@ static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, con
   else k_spconv2<CIN, 32, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
 }
 
-// Output rows per workgroup: 64.  (128-row tiles stream half the weight bytes per useful FLOP but MEASURED SLOWER on
-// MI355X -- N = 81 k, 128->128: 498 vs 441 us -- one resident workgroup per CU leaves nothing to overlap with.)
+// Output rows per workgroup: 64.  128-row tiles stream half the weight bytes per useful FLOP but MEASURED SLOWER twice:
+// round 1, 4 waves (N = 81 k, 128->128: 498 vs 441 us: half the waves per CU); round 2, 8 waves x 16 columns, double-
+// buffered A tile, prefetch distance 2 (429 vs 379 us; tools/micro/k_spconv3_tall_tile.hip.txt): the 68 KB fp32 tile
+// leaves room for ONE workgroup per CU, every wave is then in the same phase of the item (one barrier domain) and the
+// MFMA pipe idles through each gather-write / barrier / look-ahead phase -- MFMA utilisation 48 % against 73 % here.
 int irx_spconv2_tile(int n_out) {
   (void)n_out;
   return S2_TM;

@@ -27,6 +27,13 @@ if os.environ.get('IRX_DTYPE'): irx.set_compute_dtype(os.environ['IRX_DTYPE'])
 print('compute dtype', irx.get_compute_dtype())
 lib.irx_debug_s2_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
 F_.spconv_gather_gemm(x, w, tbl, ld, n, 27, cin, cout, 1, 1); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): F_.spconv_gather_gemm(x, w, tbl, ld, n, 27, cin, cout, 1, 1)
+e1.record(); torch.cuda.synchronize()
+pairs = int((tbl[:27 * ld].view(27, ld)[:, :n] >= 0).sum())
+us = e0.elapsed_time(e1) * 100.0
+print('launch (incl. weight permute) %.1f us, pairs %d (%.1f per row), %.1f TFLOP/s' % (us, pairs, pairs / n, 2.0 * pairs * cin * cout / us / 1e6))
 lib.irx_debug_s2_prof(None, 1)
 F_.spconv_gather_gemm(x, w, tbl, ld, n, 27, cin, cout, 1, 1); torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 16)()
