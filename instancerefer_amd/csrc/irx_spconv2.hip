@@ -56,9 +56,13 @@ extern "C" int irx_debug_s2_prof(unsigned long long* out, int reset) {
 
 // Dev-only ablation of k_spconv2 (tools/micro/run_abl.sh builds -DIRX_S2_ABL=<mask> variants; results are WRONG, only the
 // timing is of interest): 1 = every weight load hits the same 1 KiB (no L2->L1 weight stream), 2 = every gathered row
-// is row 0, 4 = no MFMA, 8 = no read-modify-write of the LDS output tile, 16 = every offset reads W[0] (weights certainly L2-resident).
+// is row 0, 4 = no MFMA, 8 = no read-modify-write of the LDS output tile, 16 = every offset reads W[0] (weights certainly L2-resident),
+// 64 = every wave reads slice 0 of W[0] (16 KiB: distinct load instructions, L1-resident), 32 = per-tile offset rotation.
 #ifndef IRX_S2_ABL
 #define IRX_S2_ABL 0
+#endif
+#ifndef IRX_S2_SPLITPF
+#define IRX_S2_SPLITPF 1
 #endif
 
 struct PairList {
@@ -97,7 +101,7 @@ __device__ __forceinline__ typename std::conditional<ST, uint2, float4>::type s2
   else return *reinterpret_cast<const float4*>(x + elem);
 }
 
-template <int CIN, int COUT, int NJ, int NT, int LDA, int LDO, bool PREFETCH, bool BF, bool ST, typename WT, int WN,
+template <int CIN, int COUT, int NJ, int NT, int LDA, int LDO, int PREFETCH, bool BF, bool ST, typename WT, int WN,
           typename RT>
 __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __restrict__ sOut,
                                          const unsigned char* __restrict__ lrow, int g, int vs, int m, int g4,
@@ -121,7 +125,9 @@ __device__ __forceinline__ void s2_group(const float* __restrict__ sA, float* __
   for (int j = 0; j < NJ; ++j) {
     const AT a4 = a_nxt;                           // fragment j was requested one step ago
     if (j + 1 < NJ) a_nxt = pa[4 * (j + 1)];       // 16 channels further: 4 elements of either type
-    if (PREFETCH) {
+    // PREFETCH: 0 = none, 1 = the whole chain, 2 / 3 = its first / second half (an item with two or more groups spreads
+    // its requests over two MFMA chains: half the burst the L1 has to take)
+    if (PREFETCH == 1 || (PREFETCH == 2 && j < NJ / 2) || (PREFETCH == 3 && j >= NJ / 2)) {
       // this step's share of the item's weight loads
 #pragma unroll
       for (int i = (BF ? (j * NT) / 2 : j * NT); i < (BF ? ((j + 1) * NT) / 2 : (j + 1) * NT); ++i)
@@ -345,7 +351,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     vv[T] = vq;
     int nrow[NJ];
     s2_gather_rows<NIT, PPP>(sIn + kl * TM, pbase, vq, nrow);
-    const WT* wnk = reinterpret_cast<const WT*>(wn) + (((size_t)((IRX_S2_ABL & 16) ? 0 : kl) * NCS + cs) * WN) * 64 + lane;
+    const WT* wnk = reinterpret_cast<const WT*>(wn) + (((size_t)((IRX_S2_ABL & (16 | 64)) ? 0 : kl) * NCS + ((IRX_S2_ABL & 64) ? 0 : cs)) * WN) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < WN; ++i) W[T][i] = wnk[(IRX_S2_ABL & 1) ? 0 : (size_t)i * 64];
 #pragma unroll
@@ -397,17 +403,28 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     vv[T] = vq;
     int nrow[NJ];
     s2_gather_rows<NIT, PPP>(sIn + kl * TM, pbase, vq, nrow);
-    const WT* wnk = reinterpret_cast<const WT*>(wn) + (((size_t)((IRX_S2_ABL & 16) ? 0 : kl) * NCS + cs) * WN) * 64 + lane;
+    const WT* wnk = reinterpret_cast<const WT*>(wn) + (((size_t)((IRX_S2_ABL & (16 | 64)) ? 0 : kl) * NCS + ((IRX_S2_ABL & 64) ? 0 : cs)) * WN) * 64 + lane;
     S2_TICK(5);
     // ---- MFMA over dense 16-pair groups; this wave's channel slice ----
     const unsigned char* lrow = sRow + k * TM;
     int g = gp;
-    if (NGP == 1 || g * 16 < vpad) {
-      s2_group<CIN, COUT, NJ, NT, LDA, LDO, true, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
-                                                                      S[T], nrow, x, c4, wnk, ldx);
+    // bf16, Cin 128: an item with two or more groups for this wave issues half of the chain's loads in each of the first
+    // two (128->128: 131.7 -> 125.4 us; no effect in fp32, slightly worse for Cin 64)
+    if (IRX_S2_SPLITPF && BF && NJ >= 8 && (g + NGP) * 16 < vpad) {
+      s2_group<CIN, COUT, NJ, NT, LDA, LDO, 2, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
+                                                                   S[T], nrow, x, c4, wnk, ldx);
+      g += NGP;
+      s2_group<CIN, COUT, NJ, NT, LDA, LDO, 3, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
+                                                                   S[T], nrow, x, c4, wnk, ldx);
       for (g += NGP; g * 16 < vpad; g += NGP)
-        s2_group<CIN, COUT, NJ, NT, LDA, LDO, false, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
-                                                                         S[T], nrow, x, c4, wnk, ldx);
+        s2_group<CIN, COUT, NJ, NT, LDA, LDO, 0, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
+                                                                     S[T], nrow, x, c4, wnk, ldx);
+    } else if (NGP == 1 || g * 16 < vpad) {
+      s2_group<CIN, COUT, NJ, NT, LDA, LDO, 1, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
+                                                                   S[T], nrow, x, c4, wnk, ldx);
+      for (g += NGP; g * 16 < vpad; g += NGP)
+        s2_group<CIN, COUT, NJ, NT, LDA, LDO, 0, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
+                                                                     S[T], nrow, x, c4, wnk, ldx);
     } else {                                       // a wave without a group in this item still prefetches its share
 #pragma unroll
       for (int i = 0; i < WN; ++i) W[T][i] = wnk[(IRX_S2_ABL & 1) ? 0 : (size_t)i * 64];
