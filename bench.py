@@ -514,6 +514,11 @@ def main():
         }
         if alt is not None:
             out["alt_dtype"] = alt
+        if world == 1 and args.workload != "attr":
+            try:
+                out["dense_path"] = measure_dense_path(model, resident, device)
+            except Exception as e:
+                out["dense_path"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:   # contract: the CPU leg runs on rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.workload)
@@ -523,6 +528,53 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_dense_path(model, resident, device, reps=20):
+    """north_star's dense path (language encoder: word-projection GEMMs, 2-layer GRU, attention pooling, classifier),
+    forward + backward, timed alone with events on the current stream; FLOPs from the module's own dimensions
+    (backward = 2 x forward). These are (16 x 30)-row GEMMs and a 30-step serial recurrence: the figure documents how
+    little of the matrix core such shapes can use, it is not a tuning target."""
+    import torch
+    lang = getattr(model, "lang", None)
+    if lang is None:
+        return None
+    feat, length = resident["lang_feat"], resident["lang_len"]
+    Bn = int(feat.shape[0])
+    T = int(resident.get("lang_len_max", int(length.max().item())))
+    H = lang.gru.hidden_size
+    nd = 2 if lang.use_bidir else 1
+    lin = [m for m in lang.word_projection if isinstance(m, torch.nn.Linear)]
+    fwd = sum(2.0 * Bn * T * m.in_features * m.out_features for m in lin)
+    for layer in range(lang.gru.num_layers):
+        inp = lang.gru.input_size if layer == 0 else H * nd
+        fwd += nd * 2.0 * Bn * T * 3 * H * (inp + H)
+    fwd += 2.0 * Bn * T * H * nd * 4 + 2.0 * Bn * 4 * T * lin[-1].out_features
+    if lang.use_lang_classifier:
+        fwd += 2.0 * Bn * lang.lang_cls[0].in_features * lang.lang_cls[0].out_features
+    params = [q for q in lang.parameters() if q.requires_grad]
+
+    def once():
+        dd = lang({"lang_feat": feat, "lang_len": length, "lang_len_max": T})
+        loss = (dd["lang_attr_feats"].sum() + dd["lang_rel_feats"].sum() + dd["lang_scene_feats"].sum() +
+                dd["lang_scores"].sum())
+        torch.autograd.grad(loss, params, allow_unused=True)
+
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = 3.0 * fwd / (ms * 1e-3) / 1e12
+    return {"what": "LangModule forward + backward alone (word projection, %d-layer GRU(%d), attention pooling, classifier); "
+                    "host-issue time included" % (lang.gru.num_layers, H),
+            "sentences": Bn, "tokens": T, "gflop": 3.0 * fwd / 1e9, "ms": ms, "achieved": tf, "unit": "TFLOP/s",
+            "peak": 157.3, "frac": tf / 157.3}
 
 
 class serial_issue:

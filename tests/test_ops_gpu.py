@@ -601,3 +601,47 @@ def test_voxeliser_rejects_coordinates_it_cannot_key(lib):
             voxelize(bad, feats, batch, [0.05] * 3, 1)
         with pytest.raises(ValueError, match="voxel coordinates outside"):
             voxelize_launch(bad, feats, batch, [0.05] * 3, 1, 4).finish()
+
+
+@pytest.mark.parametrize("stride", [16, 4])
+def test_sparse_crop_and_dense_bev_op_level(lib, stride):
+    """SparseCrop + ToDenseBEVConvolution on their own (reference models/scene_module.py:26-32, basic_blocks.py:195-243):
+    voxels at `stride` spacing, some outside the [0,240)x[0,400)x[0,80)-style window on every side (negative, past the end,
+    z out of range), several per (x, y) cell, an empty scene in the batch -> dense (B, C, nx, ny) map and the gradients of
+    the features and of the per-z-bin kernels, against oracle/model_ref.ToDenseBEV (the crop-then-index_add
+    restatement pinned to the reference's own model fixture). fp32, 1e-5."""
+    from instancerefer_amd.basic_blocks import ToDenseBEVConvolution
+    from instancerefer_amd.sparse import SparseTensor
+    from oracle.model_ref import ToDenseBEV
+    from oracle.torchsparse import SparseTensor as OST
+    rng = np.random.default_rng(11 + stride)
+    nx, ny, nz, B, cin, cout = 15, 25, 5, 4, 32, 64
+    coords = []
+    for b in (0, 1, 3):                                  # scene 2 stays empty
+        n = 400 if b else 900
+        c = np.stack([rng.integers(-3, nx + 3, n), rng.integers(-2, ny + 4, n), rng.integers(-1, nz + 2, n)], 1) * stride
+        c = np.unique(c, axis=0)
+        coords.append(np.concatenate([c, np.full((len(c), 1), b)], 1))
+    C = np.concatenate(coords).astype(np.int32)
+    C = C[rng.permutation(len(C))]
+    F = rng.standard_normal((len(C), cin)).astype(np.float32)
+    kern = (rng.standard_normal((nz, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    g = rng.standard_normal((B, cout, nx, ny)).astype(np.float32)
+
+    ref = ToDenseBEV(cin, cout, [nx, ny, nz])
+    ref.kernel.data.copy_(torch.from_numpy(kern))
+    Fr = torch.from_numpy(F).requires_grad_(True)
+    yr = ref(OST(Fr, torch.from_numpy(C), stride), B)
+    yr.backward(torch.from_numpy(g))
+
+    dev = torch.device("cuda")
+    mod = ToDenseBEVConvolution(cin, cout, shape=[nx, ny, nz], z_dim=2, offset=[0, 0, 0]).to(dev)
+    mod.kernel.data.copy_(torch.from_numpy(kern))
+    Fd = torch.from_numpy(F).to(dev).requires_grad_(True)
+    y = mod(SparseTensor(Fd, torch.from_numpy(C).to(dev), stride, batch_size=B))
+    y.backward(torch.from_numpy(g).to(dev))
+    assert y.shape == (B, cout, nx, ny)
+    assert float(y[2].abs().max()) == 0.0                # the empty scene
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(Fd.grad.cpu().numpy(), Fr.grad.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(mod.kernel.grad.cpu().numpy(), ref.kernel.grad.numpy(), rtol=1e-4, atol=1e-4)
