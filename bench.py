@@ -360,11 +360,17 @@ def main():
     share = os.environ.get("IRX_BENCH_SHARE_GPU") == "1"
     device = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(device)
+    # IRX_BENCH_FORCE_DIST=1 (test only, N = 1): a one-rank RCCL group, every collective of the N > 1 path issued for real
+    force_dist = world == 1 and os.environ.get("IRX_BENCH_FORCE_DIST") == "1"
     if world > 1:
         if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+    elif force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
 
     from instancerefer_amd import _build, _lib
     _build.build_lib()
@@ -397,10 +403,11 @@ def main():
     from instancerefer_amd.optim import FlatAdam
     reducer = None
     opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=world, module=model)
+    opt._force_collectives = force_dist
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -428,7 +435,7 @@ def main():
         loss = step_fn(model, resident, args.workload, reducer, opt, state)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -525,7 +532,7 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

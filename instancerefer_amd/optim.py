@@ -179,7 +179,9 @@ class FlatAdam:
         return None
 
     def _multi_rank(self):
-        return self.world_size > 1 and dist.is_initialized()
+        # _force_collectives (tests): a one-rank process group still issues every collective, so that the RCCL stream
+        # ordering of the product path can be exercised on a single GPU
+        return dist.is_initialized() and (self.world_size > 1 or getattr(self, "_force_collectives", False))
 
     def gather_grads(self):
         """All .grad tensors -> their slots in flat_g with one multi-tensor copy (the padding between slots stays zero;

@@ -136,3 +136,56 @@ def test_two_ranks_share_one_gpu_product_path(lib, tmp_path):
     scale = float(g1.abs().max())
     assert scale > 0 and float((g2 - g1).abs().max()) <= 2e-4 * scale, (float((g2 - g1).abs().max()), scale)
     assert abs(float(g2.double().norm()) - float(g1.double().norm())) <= 1e-4 * float(g1.double().norm())
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """One rank, backend nccl (= RCCL): every collective of the product path is issued for real (FlatAdam._force_collectives)
+    and the result must equal the run without a process group bit for bit (a one-rank sum is the identity)."""
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from instancerefer_amd import _build, _lib, synthetic as S
+    from instancerefer_amd.optim import FlatAdam
+    _build.build_lib()
+    _lib.load()
+    res = {}
+    for mode in ("plain", "rccl"):
+        if mode == "rccl":
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(port)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        model = _model(321, dev).train()
+        opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1, module=model)
+        opt._force_collectives = mode == "rccl"
+        losses = []
+        for it in range(3):
+            batch = S.make_batch(2, seed=40 + it, num_candidates=[3, 2], **KW)
+            loss, g = _step(model, opt, batch, dev)
+            losses.append(loss)
+        torch.cuda.synchronize()
+        res[mode] = (losses, opt.flat_p.clone().cpu(), len(opt._reduced))
+    dist.barrier()
+    dist.destroy_process_group()
+    torch.save(res, os.path.join(out_dir, "rccl.pt"))
+
+
+def test_product_collectives_over_rccl_one_rank(lib, tmp_path):
+    """RCCL itself needs one device per rank, so the two-rank test above runs over gloo. This one drives the same calls —
+    early async all-reduce of the encoder ranges on the producers' streams, the remaining segments and the activity flags
+    after the gather, the waits — through backend "nccl" with a single rank on the one GPU there is."""
+    mp.set_start_method("spawn", force=True)
+    port = 31000 + (os.getpid() * 13 + int(time.time())) % 2000
+    ctx = mp.start_processes(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=False, start_method="spawn")
+    deadline = time.time() + 300
+    try:
+        while not ctx.join(timeout=5):
+            if time.time() > deadline:
+                raise TimeoutError("one-rank RCCL run exceeded 300 s")
+    finally:
+        for p in ctx.processes:
+            if p.is_alive():
+                p.kill()
+    res = torch.load(os.path.join(str(tmp_path), "rccl.pt"), weights_only=False)
+    assert res["rccl"][2] >= 2                         # both encoder ranges went through an all-reduce
+    assert res["plain"][0] == res["rccl"][0]
+    assert torch.equal(res["plain"][1], res["rccl"][1])
