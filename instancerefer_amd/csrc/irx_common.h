@@ -143,8 +143,19 @@ int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int 
 int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
                         int flip_k, int trans_w, float* y, int accumulate, const float* wimg, void* workspace,
                         size_t workspace_bytes, void* stream, IrxStore ty = IrxStore());
+// pair lists (optional; in_list != NULL): the wide stem's 128 leading channels then go through k_wgrad_pairs
+struct IrxPairLists {
+  const int32_t *in_list = nullptr, *out_list = nullptr, *counts = nullptr;
+  int ldp = 0;
+};
 int irx_spconv_wgrad_impl(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
-                          float* dw, void* workspace, size_t workspace_bytes, void* stream, int dy_bf);
+                          float* dw, void* workspace, size_t workspace_bytes, void* stream, int dy_bf,
+                          IrxPairLists pairs = IrxPairLists());
+size_t irx_wgrad_pairs_wide_workspace_bytes(int n_out, int K, int cout);
+int irx_wgrad_pairs_wide_launch(const float* x, int ldx, const float* dy, const int32_t* in_list, const int32_t* out_list,
+                                int ldp, const int32_t* counts, int n_out, int K, int cout, float* part, float* sum,
+                                hipStream_t st, int dy_bf);
+bool irx_wide_stem(int K, int cin, int cout);
 int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st, int src_cin = 0);
 // fragment images of up to 16 layers in one launch; dims are kernel-relative (cin = reduction, cout = outputs),
 // end4[j] = running total of float4 elements (K*cin*cout/4) up to and including job j

@@ -196,7 +196,11 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
     } else {
       IRX_REQUIRE(!st || i == 0, "irx_encoder_backward: layer %d (%d -> %d channels) has no bf16-storage weight-gradient path",
                   i, L.cin, L.cout);
-      rc = irx_spconv_wgrad_impl(L.x, dc_scratch, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st);
+      IrxPairLists pl;
+      if (L.pair_in && irx_wide_stem(L.K, L.cin, L.cout)) {   // the multiview stem: its 128 leading channels through the pair lists
+        pl.in_list = L.pair_in; pl.out_list = L.pair_out; pl.counts = L.pair_counts; pl.ldp = L.ld_pairs;
+      }
+      rc = irx_spconv_wgrad_impl(L.x, dc_scratch, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st, pl);
     }
     if (rc) return rc;
     float* dx = (i > 0) ? (float*)desc[(size_t)(i - 1) * IRX_ENC_NFIELDS + IRX_ENC_GY] : dx0;

@@ -104,12 +104,14 @@ __device__ __forceinline__ typename std::conditional<ST, uint2, float4>::type wp
 __device__ __forceinline__ float4 wp_f4(float4 v) { return v; }
 __device__ __forceinline__ float4 wp_f4(uint2 v) { return irx_bf4_to_f4(v); }
 
-template <int CIN, int COUT, bool BF, bool ST>
+// STD: element type of dy when it differs from x's (the wide stem in bf16 storage mode: fp32 input rows, bf16 gradient);
+// ldx: row stride of x in elements (CIN for a dense tensor; the wide stem reads the leading CIN columns of wider rows).
+template <int CIN, int COUT, bool BF, bool ST, bool STD = ST>
 __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const int32_t* __restrict__ in_list,
                                                         const int32_t* __restrict__ out_list, int ldp,
                                                         const int32_t* __restrict__ counts, int K, int G, int smax,
-                                                        float* __restrict__ part) {
+                                                        float* __restrict__ part, int ldx = CIN) {
   constexpr int TC = CIN / 16, TN = COUT / 16;
   constexpr int CW = (TC >= 4) ? TC / 4 : 1;             // c-tiles per wave
   constexpr int NW = (TC >= 4) ? TN : TN / (4 / TC);     // n-tiles per wave
@@ -143,9 +145,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
 #pragma unroll
     for (int b = 0; b < NW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  static_assert(BF || !ST, "bf16 storage implies bf16 operands");
+  static_assert(BF || !(ST || STD), "bf16 storage implies bf16 operands");
   using RT = typename std::conditional<ST, uint2, float4>::type;
-  RT rx[NX], rd[ND];
+  using RD = typename std::conditional<STD, uint2, float4>::type;
+  RT rx[NX];
+  RD rd[ND];
   int par = 0;
   // prologue: indices + rows of the first stage
   if (st0 < st1) {
@@ -158,12 +162,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int idx = sIn[0][xr + i * PX];
-      rx[i] = idx >= 0 ? wp_ld<ST>(x, (size_t)idx * CIN + xc) : RT{};
+      rx[i] = idx >= 0 ? wp_ld<ST>(x, (size_t)idx * ldx + xc) : RT{};
     }
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int idx = sOutRow[0][dr + i * PD];
-      rd[i] = idx >= 0 ? wp_ld<ST>(dy, (size_t)idx * COUT + dc) : RT{};
+      rd[i] = idx >= 0 ? wp_ld<STD>(dy, (size_t)idx * COUT + dc) : RD{};
     }
   }
   for (int st = st0; st < st1; ++st) {
@@ -212,13 +216,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
               const int ks = k16 * 4 + i4;
               if (ks < NX) {
                 const int idx = sIn[parn][xr + ks * PX];
-                const RT v = wp_ld<ST>(x, (size_t)(idx < 0 ? 0 : idx) * CIN + xc);
+                const RT v = wp_ld<ST>(x, (size_t)(idx < 0 ? 0 : idx) * ldx + xc);
                 rx[ks] = idx >= 0 ? v : RT{};
               }
               if (ks < ND) {
                 const int idx = sOutRow[parn][dr + ks * PD];
-                const RT v = wp_ld<ST>(dy, (size_t)(idx < 0 ? 0 : idx) * COUT + dc);
-                rd[ks] = idx >= 0 ? v : RT{};
+                const RD v = wp_ld<STD>(dy, (size_t)(idx < 0 ? 0 : idx) * COUT + dc);
+                rd[ks] = idx >= 0 ? v : RD{};
               }
             }
           }
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
       for (int ks = 0; ks < 16; ++ks) {
         if (ks < NX) {
           const int idx = sIn[parn][xr + ks * PX];
-          const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(idx < 0 ? 0 : idx) * CIN + xc);
+          const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(idx < 0 ? 0 : idx) * ldx + xc);
           rx[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (ks < ND) {
@@ -528,6 +532,32 @@ static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const
     else k_wgrad_pairs<CIN, 32, false, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
   }
   irx_bracket_end(st);
+}
+
+// The wide stem's leading 128 input channels through the pair lists (irx_spconv_wgrad_impl): x is fp32 with row stride
+// ldx (4-byte aligned rows), dy [n_out][cout = 32] fp32 or (dy_bf, bf16 storage mode) bf16; sum = [K][128][cout].
+size_t irx_wgrad_pairs_wide_workspace_bytes(int n_out, int K, int cout) {
+  return irx_spconv_wgrad_pairs_workspace_bytes(n_out, K, 128, cout);
+}
+int irx_wgrad_pairs_wide_launch(const float* x, int ldx, const float* dy, const int32_t* in_list, const int32_t* out_list,
+                                int ldp, const int32_t* counts, int n_out, int K, int cout, float* part, float* sum,
+                                hipStream_t st, int dy_bf) {
+  IRX_REQUIRE(cout == 32, "irx_spconv_wgrad(wide stem, pairs): cout = %d", cout);
+  const int G = pairs_budget(n_out, K), smax = pairs_smax(n_out, K);
+  dim3 grid(smax, K);
+  irx_bracket_begin(st);
+  if (irx_conv_bf16() && dy_bf)
+    k_wgrad_pairs<128, 32, true, false, true><<<grid, 256, 0, st>>>(x, dy, in_list, out_list, ldp, counts, K, G, smax, part, ldx);
+  else if (irx_conv_bf16())
+    k_wgrad_pairs<128, 32, true, false, false><<<grid, 256, 0, st>>>(x, dy, in_list, out_list, ldp, counts, K, G, smax, part, ldx);
+  else
+    k_wgrad_pairs<128, 32, false, false, false><<<grid, 256, 0, st>>>(x, dy, in_list, out_list, ldp, counts, K, G, smax, part, ldx);
+  irx_bracket_end(st);
+  IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem, pairs)");
+  const size_t elems = (size_t)K * 128 * cout;
+  k_pairs_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, st>>>(part, counts, K, G, smax, (size_t)128 * cout, elems, sum);
+  IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem, pairs reduce)");
+  return IRX_OK;
 }
 
 extern "C" int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int32_t* in_list,

@@ -478,9 +478,13 @@ extern "C" size_t irx_spconv_wgrad_workspace_bytes(int n_out, int K, int cin, in
   if (n_out <= 0 || K <= 0 || cin <= 0 || cout <= 0) return 0;
   if (irx_stem_supported(K, cin, cout)) return (size_t)irx_stem_wgrad_blocks(n_out) * K * cin * cout * sizeof(float);
   if (irx_wide_stem(K, cin, cout)) {
-    // [main partial slabs | main sum | tail partial slabs | tail sum]
+    // [main partial slabs | main sum | tail partial slabs | tail sum]; the main partials are the offset-major kernel's
+    // row-split slabs or, with pair lists, k_wgrad_pairs' share slabs — sized for the larger of the two
     const int s = wgrad_splits(n_out, K, WS_MAIN, cout);
-    return ((size_t)(s + 1) * K * WS_MAIN * cout + (size_t)(irx_stem_wgrad_blocks(n_out) + 1) * K * (cin - WS_MAIN) * cout) *
+    size_t main_part = (size_t)s * K * WS_MAIN * cout * sizeof(float);
+    const size_t pairs_part = irx_wgrad_pairs_wide_workspace_bytes(n_out, K, cout);
+    if (pairs_part > main_part) main_part = pairs_part;
+    return main_part + ((size_t)K * WS_MAIN * cout + (size_t)(irx_stem_wgrad_blocks(n_out) + 1) * K * (cin - WS_MAIN) * cout) *
            sizeof(float);
   }
   const int s = wgrad_splits(n_out, K, cin, cout);
@@ -495,7 +499,7 @@ extern "C" int irx_spconv_wgrad(const float* x, const float* dy, const int32_t* 
 
 // dy_bf != 0 (executor, bf16 storage mode): dy is a bf16 tensor; x stays fp32 (this entry only serves the stems there)
 int irx_spconv_wgrad_impl(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
-                          float* dw, void* workspace, size_t workspace_bytes, void* stream, int dy_bf) {
+                          float* dw, void* workspace, size_t workspace_bytes, void* stream, int dy_bf, IrxPairLists pairs) {
   IRX_REQUIRE(n_out >= 0 && K >= 1 && cin >= 1 && cout >= 1 && dw, "irx_spconv_wgrad: bad arguments");
   const size_t elems = (size_t)K * cin * cout;
   if (n_out == 0) {
@@ -524,16 +528,27 @@ int irx_spconv_wgrad_impl(const float* x, const float* dy, const int32_t* nbr, i
     const int sm = wgrad_splits(n_out, K, WS_MAIN, cout);
     const size_t em = (size_t)K * WS_MAIN * cout, et = (size_t)K * ct * cout;
     float* part_m = (float*)workspace;
-    float* sum_m = part_m + (size_t)sm * em;
+    size_t main_part = (size_t)sm * em * sizeof(float);
+    if (irx_wgrad_pairs_wide_workspace_bytes(n_out, K, cout) > main_part) main_part = irx_wgrad_pairs_wide_workspace_bytes(n_out, K, cout);
+    float* sum_m = (float*)((char*)workspace + main_part);
     const int blocks = irx_stem_wgrad_blocks(n_out);
     float* part_t = sum_m + em;
     float* sum_t = part_t + (size_t)blocks * et;
-    int rpm = irx_cdiv(n_out, sm);
-    rpm = irx_cdiv(rpm, WG_TQ) * WG_TQ;
-    int rc = irx_spconv2_wgrad_launch(x, dy, nbr, ld, n_out, K, WS_MAIN, cout, sm, rpm, part_m, S(stream), cin, dy_bf);
-    if (rc) return rc;
-    k_wgrad_reduce<<<irx_cdiv((long long)em, 256), 256, 0, S(stream)>>>(part_m, sm, em, sum_m);
-    IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem reduce)");
+    int rc;
+    if (pairs.in_list) {
+      // rulebook form: dense 64-pair stages, bf16 MFMA in the bf16 modes (the offset-major kernel below is fp32 MFMA only
+      // and walks the table with ~36 % of its rows valid: 1313 -> ... us per launch on the 200 k-point stress scenes)
+      rc = irx_wgrad_pairs_wide_launch(x, cin, dy, pairs.in_list, pairs.out_list, pairs.ldp, pairs.counts, n_out, K, cout,
+                                       part_m, sum_m, S(stream), dy_bf);
+      if (rc) return rc;
+    } else {
+      int rpm = irx_cdiv(n_out, sm);
+      rpm = irx_cdiv(rpm, WG_TQ) * WG_TQ;
+      rc = irx_spconv2_wgrad_launch(x, dy, nbr, ld, n_out, K, WS_MAIN, cout, sm, rpm, part_m, S(stream), cin, dy_bf);
+      if (rc) return rc;
+      k_wgrad_reduce<<<irx_cdiv((long long)em, 256), 256, 0, S(stream)>>>(part_m, sm, em, sum_m);
+      IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem reduce)");
+    }
     rc = irx_stem_wgrad_launch(x + WS_MAIN, dy, nbr, ld, n_out, ct, blocks, part_t, S(stream), cin, dy_bf);
     if (rc) return rc;
     k_wgrad_reduce<<<irx_cdiv((long long)et, 256), 256, 0, S(stream)>>>(part_t, blocks, et, sum_t);

@@ -21,6 +21,14 @@ _f32 = torch.float32
 _PAIR = (32, 64, 128)
 
 
+def _uses_pairs(L):
+    """Weight gradient through the rulebook pair lists (k_wgrad_pairs): the MFMA channel counts, and the 128 leading
+    channels of the multiview stem (C0 = 129..136 -> 32, csrc/irx_spconv.hip "wide stem")."""
+    if L.cin in _PAIR and L.cout in _PAIR:
+        return True
+    return (not L.down) and L.K == 27 and L.cout == 32 and 128 < L.cin <= 136
+
+
 class _Layer:
     __slots__ = ("conv", "bn", "lv_in", "lv_out", "K", "cin", "cout", "tbl", "ld", "n_in", "n_out", "down", "res")
 
@@ -244,7 +252,7 @@ class EncoderFn(torch.autograd.Function):
         # pair lists still missing for this pyramid: all of them in one library call
         missing, seen = [], set()
         for L in layers:
-            if L.cin in _PAIR and L.cout in _PAIR:
+            if _uses_pairs(L):
                 if L.down:
                     dm = L.lv_in.down()
                     if dm._pairs is None and id(dm) not in seen:
@@ -267,7 +275,7 @@ class EncoderFn(torch.autograd.Function):
                 tb.append((tbl_b.data_ptr(), ld_b, 0))
             else:
                 tb.append((L.tbl.data_ptr(), L.ld, 1))
-            if L.cin in _PAIR and L.cout in _PAIR:
+            if _uses_pairs(L):
                 il, ol, counts, ldp = L.lv_in.down().pairs() if L.down else L.lv_in.pairs27()
                 pr.append((il.data_ptr(), ol.data_ptr(), counts.data_ptr(), ldp))
             else:

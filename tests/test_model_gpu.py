@@ -195,6 +195,14 @@ def test_full_model_multiview_c135_vs_cpu_oracle(lib):
         exp = float(p.grad.double().norm())
         got = float(gp[n].grad.double().norm())
         assert abs(got - exp) <= 2e-3 * max(exp, 1e-3 * total), (n, got, exp)
+    # the two 135 -> 32 stems element by element (executor: 128 leading channels through the pair lists in k_wgrad_pairs,
+    # the 7-channel tail through the stem kernel, merged): a misplaced channel or offset would keep the norm
+    for n in ("scene.net.stem.0.net.0.kernel", "attribute.net.stem.0.net.0.kernel"):
+        exp, got = dict(oracle.named_parameters())[n].grad, gp[n].grad.cpu()
+        assert exp.shape == got.shape == (27, 135, 32)
+        assert float((got - exp).abs().max()) <= 1e-2 * float(exp.abs().max()), n
+        assert float((got[:, :128] - exp[:, :128]).norm()) <= 5e-3 * float(exp[:, :128].norm()), n
+        assert float((got[:, 128:] - exp[:, 128:]).norm()) <= 5e-3 * float(exp[:, 128:].norm()), n
 
 
 def test_use_gt_lang_false_takes_the_argmax_branch(lib):
