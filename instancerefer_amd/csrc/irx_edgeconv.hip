@@ -131,18 +131,22 @@ __global__ __launch_bounds__(EC_THREADS) void k_edgeconv_fwd(EcDims D, EcParams 
 }
 
 // part[w] += sum_e dy[e][o] * x[e][i] for (o, i) of a layer; this workgroup's slab, same thread every time.
+// first: this is the workgroup's first query — the slab element is written, not read (a read-modify-write of the slab in
+// global memory is a dependent L2 round trip per element: 320 of them per thread and query were most of this kernel's time;
+// with one query per workgroup, the usual case, the slab is write-only)
 __device__ __forceinline__ void ec_wgrad(float* __restrict__ part_w, float* __restrict__ part_b, int n_out, int n_in,
-                                         const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx, int k) {
+                                         const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx, int k,
+                                         bool first) {
   for (int idx = threadIdx.x; idx < n_out * n_in; idx += EC_THREADS) {
     const int o = idx / n_in, i = idx % n_in;
-    float acc = 0.f;
+    float acc = first ? 0.f : part_w[idx];
     for (int e = 0; e < k; ++e) acc = fmaf(dy[e * ldy + o], x[e * ldx + i], acc);
-    part_w[idx] += acc;
+    part_w[idx] = acc;
   }
   for (int o = threadIdx.x; o < n_out; o += EC_THREADS) {
-    float acc = 0.f;
+    float acc = first ? 0.f : part_b[o];
     for (int e = 0; e < k; ++e) acc += dy[e * ldy + o];
-    part_b[o] += acc;
+    part_b[o] = acc;
   }
 }
 
@@ -183,8 +187,9 @@ __global__ __launch_bounds__(EC_THREADS) void k_edgeconv_bwd(EcDims D, EcParams 
   float* g_b3 = g_w3 + (size_t)D.fout * D.min_;
   float* g_w4 = g_b3 + D.fout;
   float* g_b4 = g_w4 + (size_t)D.fout * D.fout;
-  for (size_t i = threadIdx.x; i < slab; i += EC_THREADS) mine[i] = 0.f;
+  (void)slab;
   for (int q = blockIdx.x; q < D.nq; q += gridDim.x) {
+    const bool first = q == (int)blockIdx.x;          // every slab element is written by the first query's ec_wgrad calls
     __syncthreads();
     if ((int)threadIdx.x < D.k) nb[threadIdx.x] = nbr[(size_t)q * D.k + threadIdx.x];
     __syncthreads();
@@ -195,19 +200,19 @@ __global__ __launch_bounds__(EC_THREADS) void k_edgeconv_bwd(EcDims D, EcParams 
       sDm[idx] = (arg[(size_t)q * D.fout + o] == e) ? dout[(size_t)q * D.fout + o] : 0.f;
     }
     __syncthreads();
-    ec_wgrad(g_w4, g_b4, D.fout, D.fout, sDm, D.fout, sH2, D.fout, D.k);
+    ec_wgrad(g_w4, g_b4, D.fout, D.fout, sDm, D.fout, sH2, D.fout, D.k, first);
     ec_dgrad(P.w4, D.fout, D.fout, sDm, D.fout, sDh2, D.fout, sH2, D.k);          // through relu(h2)
     __syncthreads();
-    ec_wgrad(g_w3, g_b3, D.fout, D.min_, sDh2, D.fout, sM, D.min_, D.k);
+    ec_wgrad(g_w3, g_b3, D.fout, D.min_, sDh2, D.fout, sM, D.min_, D.k, first);
     ec_dgrad(P.w3, D.fout, D.min_, sDh2, D.fout, sDmin, D.min_, nullptr, D.k);
     __syncthreads();
     if (dmin_out)
       for (int idx = threadIdx.x; idx < D.k * D.min_; idx += EC_THREADS)
         dmin_out[(size_t)q * D.k * D.min_ + idx] = (nb[idx / D.min_] >= 0) ? sDmin[idx] : 0.f;
-    ec_wgrad(g_w2, g_b2, D.fin, D.hid, sDmin + D.fin, D.min_, sH1, D.hid, D.k);   // d ew = middle third of d m_in
+    ec_wgrad(g_w2, g_b2, D.fin, D.hid, sDmin + D.fin, D.min_, sH1, D.hid, D.k, first);   // d ew = middle third of d m_in
     ec_dgrad(P.w2, D.fin, D.hid, sDmin + D.fin, D.min_, sDh1, D.hid, sH1, D.k);    // through relu(h1)
     __syncthreads();
-    ec_wgrad(g_w1, g_b1, D.hid, D.ein, sDh1, D.hid, sE, D.ein, D.k);
+    ec_wgrad(g_w1, g_b1, D.hid, D.ein, sDh1, D.hid, sE, D.ein, D.k, first);
     if (dmin_out) {                                      // d e_in behind the d m_in block of this query (feature gradients)
       float* sDein = sDm;                                // d m is dead since the layer-4 step
       ec_dgrad(P.w1, D.hid, D.ein, sDh1, D.hid, sDein, D.ein, nullptr, D.k);
@@ -253,7 +258,8 @@ static size_t ec_param_floats(const EcDims& D) {
          (size_t)D.fout * D.fout + D.fout;
 }
 
-static int ec_blocks(int nq) { return nq < 64 ? nq : 64; }
+// one query per workgroup up to 512 queries (two workgroups per CU): the slabs stay write-only (ec_wgrad)
+static int ec_blocks(int nq) { return nq < 512 ? nq : 512; }
 
 extern "C" size_t irx_edgeconv_workspace_bytes(int nq, int k, int fin, int nc, int hid, int fout) {
   if (nq <= 0) return 0;
