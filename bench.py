@@ -13,6 +13,10 @@ Inputs (scene voxels source points, instance points, utterances) are resident in
 region; per step everything the reference does inside forward/backward is redone from scratch: Morton
 sort + hash + kernel maps of the scene tensor, candidate voxelisation, 26 sparse convs, BN, heads, loss,
 backward, all-reduce, Adam.
+
+Also in the line (N = 1): `alt_dtype` (the same loop in BASELINE configs[2]'s bf16 with its own roofline), `dense_path`
+(language encoder alone against the MFMA peak) and `end_to_end` (tools/e2e_train_bench.py in its own process: the per-sample
+input pipeline inside the loop, nothing resident but the raw scans).
 """
 import argparse
 import json
@@ -56,6 +60,7 @@ def parse():
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (input pipeline in the loop, own process)")
     ap.add_argument("--prep-thread", action="store_true",
                     help="run the input preparation on a helper thread instead of inline behind the step (same speed: "
                          "the loop is GIL-bound, tools/micro/ab_thread.py)")
@@ -526,6 +531,8 @@ def main():
                 out["dense_path"] = measure_dense_path(model, resident, device)
             except Exception as e:
                 out["dense_path"] = {"error": repr(e)}
+        if world == 1 and args.workload == "full" and not args.no_e2e and not args.no_cpu_baseline:   # (quick runs skip both)
+            out["end_to_end"] = end_to_end(args)
         if not args.no_cpu_baseline and world == 1:   # contract: the CPU leg runs on rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.workload)
@@ -535,6 +542,24 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_to_end(args):
+    """The same training step with the per-sample input pipeline INSIDE the loop (tools/e2e_train_bench.py in a process of
+    its own, after this one's GPU work is done): reported beside `value`, which by contract times resident inputs."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "e2e_train_bench.py")
+    cmd = [sys.executable, tool, "--json", "--steps", "40", "--warmup", "8", "--scans", "16",
+           "--dtype", "bf16" if args.dtype == "bf16" else "f32", "--batch", str(args.batch or 16)]
+    try:
+        torch.cuda.synchronize()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+        return json.loads(line[-1])
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def measure_dense_path(model, resident, device, reps=20):

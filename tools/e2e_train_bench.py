@@ -21,6 +21,7 @@ ap.add_argument("--vertices", type=int, default=120000)
 ap.add_argument("--points", type=int, default=50000)
 ap.add_argument("--instances", type=int, default=8)
 ap.add_argument("--augment", action="store_true")
+ap.add_argument("--json", action="store_true", help="print one JSON object instead of the text line (bench.py reads it)")
 a = ap.parse_args()
 _lib.load()
 irx.set_compute_dtype("bf16" if a.dtype == "bf16" else "fp32")
@@ -98,5 +99,14 @@ for step in range(a.warmup + a.steps):
     cur = stage_finish(launched)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("end to end (%s, B=%d, %d pts from %d-vertex scans, input pipeline in the loop): %.1f scenes/s, %.2f ms/step, loss %.4f"
-      % (a.dtype, B, a.points, a.vertices, B * a.steps / dt, 1e3 * dt / a.steps, float(out["loss"])))
+if a.json:
+    import json
+    print(json.dumps({"value": B * a.steps / dt, "unit": "scenes/s", "ms_per_step": 1e3 * dt / a.steps, "steps": a.steps,
+                      "warmup": a.warmup, "dtype": a.dtype, "scenes_per_step": B, "points_per_scene": a.points,
+                      "resident_scans": a.scans, "vertices_per_scan": a.vertices, "augment": bool(a.augment),
+                      "what": "every step builds its batch from scans resident in HBM with the device-side input pipeline "
+                              "(sampling, instance split, boxes, both voxelisations), then forward + loss + backward + Adam; "
+                              "nothing cached between steps", "loss": float(out["loss"])}))
+else:
+    print("end to end (%s, B=%d, %d pts from %d-vertex scans, input pipeline in the loop): %.1f scenes/s, %.2f ms/step, loss %.4f"
+          % (a.dtype, B, a.points, a.vertices, B * a.steps / dt, 1e3 * dt / a.steps, float(out["loss"])))
