@@ -9,8 +9,10 @@
 //   out_i = max over the valid neighbours j of m                               aggr = 'max'
 // In PyTorch this is ~20 forward and ~40 backward ATen ops on (n_query * k, <= 459) tensors — tens of microseconds of
 // GPU work behind ~0.5 ms of host dispatch per training step. Here: one workgroup per query (k <= 16 edges), every
-// activation of its edges lives in LDS, the four tiny GEMMs are plain fp32 FMA loops (one output channel per thread,
-// all edges of the query as independent accumulators), weights stream from L2 (<= 330 KB, shared by all workgroups).
+// activation of its edges lives in LDS as a 16-row tile (rows >= k are zero padding), and the four tiny GEMMs — and their
+// data / weight gradients — are v_mfma_f32_16x16x4_f32 chains: the 16 edges are exactly one MFMA row tile, each wave owns
+// every fourth 16-column tile, weights stream from L2 (<= 330 KB, shared by all workgroups). (The first version ran them
+// as thread-per-channel FMA loops: 330 us forward / 780 us backward at 153 input features, 100 / 265 us at 25.)
 // Backward recomputes the activations (cheaper than storing them), routes d(out) to the arg-max edge of every channel
 // and accumulates the parameter gradients into one slab per workgroup (fixed query -> workgroup assignment, fixed order),
 // summed afterwards by k_ec_reduce in slab order: deterministic, no atomics.
@@ -19,7 +21,9 @@
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
 #define EC_MAXK 16
+#define EC_KP 16          // rows of every LDS activation tile (one MFMA row tile)
 #define EC_THREADS 256
+typedef float ec_f32x4 __attribute__((ext_vector_type(4)));
 
 struct EcDims {
   int nq, k, fin, nc, hid, fout;
@@ -31,27 +35,31 @@ struct EcParams {
   const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
 };
 
-// y[e][o] = act(b[o] + sum_i W[o][i] * x[e][i]) for the k edges of this query; x, y in LDS (row strides ldx / ldy).
+// y[e][o] = act(b[o] + sum_i W[o][i] * x[e][i]) for the 16 rows of the tile; x, y in LDS (row strides ldx / ldy).
+// MFMA operands: A[m = edge][kk] = x[m][4 s + kk], B[kk][n] = W[16 nt + n][4 s + kk]; D[row = 4 (lane >> 4) + r][col = lane & 15].
 template <bool RELU>
 __device__ __forceinline__ void ec_linear(const float* __restrict__ W, const float* __restrict__ b, int n_out, int n_in,
-                                          const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int k) {
-  // thread -> (output channel o, edge half): 128 channels x 2 halves of the edge list
-  const int o = threadIdx.x & 127, half = threadIdx.x >> 7;
-  const int e0 = half * ((k + 1) / 2), e1 = (half == 0) ? (k + 1) / 2 : k;
-  for (int oo = o; oo < n_out; oo += 128) {
-    float acc[EC_MAXK / 2];
-#pragma unroll
-    for (int e = 0; e < EC_MAXK / 2; ++e) acc[e] = b[oo];
-    const float* wr = W + (size_t)oo * n_in;
-    for (int i = 0; i < n_in; ++i) {
-      const float w = wr[i];
-#pragma unroll
-      for (int e = 0; e < EC_MAXK / 2; ++e)
-        if (e0 + e < e1) acc[e] = fmaf(w, x[(e0 + e) * ldx + i], acc[e]);
+                                          const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kk = lane >> 4;
+  const int nsteps = (n_in + 3) >> 2;
+  for (int nt = wave; nt * 16 < n_out; nt += EC_THREADS / 64) {
+    const int col = nt * 16 + m;
+    const bool cok = col < n_out;
+    const float bias = cok ? b[col] : 0.f;
+    ec_f32x4 acc = (ec_f32x4){bias, bias, bias, bias};
+    const float* wr = W + (size_t)(cok ? col : 0) * n_in;
+    for (int st = 0; st < nsteps; ++st) {
+      const int i = 4 * st + kk;
+      const bool iok = i < n_in;
+      const float av = iok ? x[m * ldx + i] : 0.f;
+      const float bv = (iok && cok) ? wr[i] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
+    if (cok) {
 #pragma unroll
-    for (int e = 0; e < EC_MAXK / 2; ++e)
-      if (e0 + e < e1) y[(e0 + e) * ldy + oo] = RELU ? fmaxf(acc[e], 0.f) : acc[e];
+      for (int r = 0; r < 4; ++r) y[(4 * kk + r) * ldy + col] = RELU ? fmaxf(acc[r], 0.f) : acc[r];
+    }
   }
 }
 
@@ -60,10 +68,10 @@ __device__ __forceinline__ void ec_forward_query(const EcDims& D, const EcParams
                                                  const float* __restrict__ pos, int qrow, const int32_t* __restrict__ nb,
                                                  float* sE, float* sH1, float* sM, float* sH2, float* sOutM) {
   const int k = D.k, fin = D.fin, nc = D.nc;
-  // e_in and the x_i / x_j thirds of m_in
-  for (int idx = threadIdx.x; idx < k * D.ein; idx += EC_THREADS) {
+  // e_in and the x_i / x_j thirds of m_in; rows of missing neighbours and the padding rows k .. 15 are zero
+  for (int idx = threadIdx.x; idx < EC_KP * D.ein; idx += EC_THREADS) {
     const int e = idx / D.ein, i = idx % D.ein;
-    const int j = nb[e];
+    const int j = (e < k) ? nb[e] : -1;
     float v = 0.f;
     if (j >= 0) {
       if (i < 3) v = pos[3 * (size_t)j + i] - pos[3 * (size_t)qrow + i];
@@ -72,35 +80,35 @@ __device__ __forceinline__ void ec_forward_query(const EcDims& D, const EcParams
     }
     sE[e * D.ein + i] = v;
   }
-  for (int idx = threadIdx.x; idx < k * fin; idx += EC_THREADS) {
+  for (int idx = threadIdx.x; idx < EC_KP * fin; idx += EC_THREADS) {
     const int e = idx / fin, i = idx % fin;
-    const int j = nb[e];
+    const int j = (e < k) ? nb[e] : -1;
     sM[e * D.min_ + i] = (j >= 0) ? feats[(size_t)qrow * fin + i] : 0.f;
     sM[e * D.min_ + 2 * fin + i] = (j >= 0) ? feats[(size_t)j * fin + i] : 0.f;
   }
   __syncthreads();
-  ec_linear<true>(P.w1, P.b1, D.hid, D.ein, sE, D.ein, sH1, D.hid, k);
+  ec_linear<true>(P.w1, P.b1, D.hid, D.ein, sE, D.ein, sH1, D.hid);
   __syncthreads();
-  ec_linear<false>(P.w2, P.b2, fin, D.hid, sH1, D.hid, sM + fin, D.min_, k);      // ew lands in the middle third of m_in
+  ec_linear<false>(P.w2, P.b2, fin, D.hid, sH1, D.hid, sM + fin, D.min_);          // ew lands in the middle third of m_in
   __syncthreads();
-  ec_linear<true>(P.w3, P.b3, D.fout, D.min_, sM, D.min_, sH2, D.fout, k);
+  ec_linear<true>(P.w3, P.b3, D.fout, D.min_, sM, D.min_, sH2, D.fout);
   __syncthreads();
-  ec_linear<false>(P.w4, P.b4, D.fout, D.fout, sH2, D.fout, sOutM, D.fout, k);
+  ec_linear<false>(P.w4, P.b4, D.fout, D.fout, sH2, D.fout, sOutM, D.fout);
   __syncthreads();
 }
 
 __device__ __forceinline__ void ec_carve(const EcDims& D, float* base, float*& sE, float*& sH1, float*& sM, float*& sH2,
                                          float*& sOutM) {
   sE = base;
-  sH1 = sE + D.k * D.ein;
-  sM = sH1 + D.k * D.hid;
-  sH2 = sM + D.k * D.min_;
-  sOutM = sH2 + D.k * D.fout;
+  sH1 = sE + EC_KP * D.ein;
+  sM = sH1 + EC_KP * D.hid;
+  sH2 = sM + EC_KP * D.min_;
+  sOutM = sH2 + EC_KP * D.fout;
 }
 
 static size_t ec_lds_floats(const EcDims& D, bool backward) {
-  size_t f = (size_t)D.k * (D.ein + D.hid + D.min_ + 2 * D.fout);
-  if (backward) f += (size_t)D.k * (D.fout + D.min_ + D.hid) + D.k;   // dh2, dm_in, dh1 (+ padding)
+  size_t f = (size_t)EC_KP * (D.ein + D.hid + D.min_ + 2 * D.fout);
+  if (backward) f += (size_t)EC_KP * (D.fout + D.min_ + D.hid) + EC_KP;   // dh2, dm_in, dh1 (+ padding)
   return f;
 }
 
@@ -131,34 +139,74 @@ __global__ __launch_bounds__(EC_THREADS) void k_edgeconv_fwd(EcDims D, EcParams 
 }
 
 // part[w] += sum_e dy[e][o] * x[e][i] for (o, i) of a layer; this workgroup's slab, same thread every time.
+// part_w[o][i] (+)= sum_e dy[e][o] * x[e][i] for (o, i) of a layer: 16 x 16 tiles, the 16 edge rows are the MFMA reduction
+// (A[m = o][kk = e] = dy[e][16 mt + m], B[kk = e][n = i] = x[e][16 nt + n]; 4 steps).
 // first: this is the workgroup's first query — the slab element is written, not read (a read-modify-write of the slab in
-// global memory is a dependent L2 round trip per element: 320 of them per thread and query were most of this kernel's time;
-// with one query per workgroup, the usual case, the slab is write-only)
+// global memory is a dependent L2 round trip per element; with one query per workgroup, the usual case, the slab is
+// write-only). Same thread for the same element every time: deterministic.
 __device__ __forceinline__ void ec_wgrad(float* __restrict__ part_w, float* __restrict__ part_b, int n_out, int n_in,
-                                         const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx, int k,
+                                         const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
                                          bool first) {
-  for (int idx = threadIdx.x; idx < n_out * n_in; idx += EC_THREADS) {
-    const int o = idx / n_in, i = idx % n_in;
-    float acc = first ? 0.f : part_w[idx];
-    for (int e = 0; e < k; ++e) acc = fmaf(dy[e * ldy + o], x[e * ldx + i], acc);
-    part_w[idx] = acc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kk = lane >> 4;
+  const int mtn = (n_out + 15) >> 4, ntn = (n_in + 15) >> 4;
+  for (int t = wave; t < mtn * ntn; t += EC_THREADS / 64) {
+    const int mt = t / ntn, nt = t % ntn;
+    const int o = mt * 16 + m, i = nt * 16 + m;
+    const bool ook = o < n_out, iok = i < n_in;
+    ec_f32x4 acc = (ec_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < EC_KP / 4; ++st) {
+      const int e = 4 * st + kk;
+      const float av = ook ? dy[e * ldy + o] : 0.f;
+      const float bv = iok ? x[e * ldx + i] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    if (iok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = mt * 16 + 4 * kk + r;
+        if (orow < n_out) {
+          float* dst = part_w + (size_t)orow * n_in + i;
+          *dst = first ? acc[r] : *dst + acc[r];
+        }
+      }
+    }
   }
   for (int o = threadIdx.x; o < n_out; o += EC_THREADS) {
     float acc = first ? 0.f : part_b[o];
-    for (int e = 0; e < k; ++e) acc += dy[e * ldy + o];
+    for (int e = 0; e < EC_KP; ++e) acc += dy[e * ldy + o];
     part_b[o] = acc;
   }
 }
 
-// dx[e][i] = sum_o dy[e][o] * W[o][i]   (optionally masked by act[e][i] > 0)
+// dx[e][i] = sum_o dy[e][o] * W[o][i]   (optionally masked by act[e][i] > 0):
+// A[m = e][kk] = dy[m][4 s + kk], B[kk][n = i] = W[4 s + kk][16 nt + n].
 __device__ __forceinline__ void ec_dgrad(const float* __restrict__ W, int n_out, int n_in, const float* __restrict__ dy,
-                                         int ldy, float* __restrict__ dx, int ldx, const float* __restrict__ act, int k) {
-  for (int idx = threadIdx.x; idx < k * n_in; idx += EC_THREADS) {
-    const int e = idx / n_in, i = idx % n_in;
-    float acc = 0.f;
-    for (int o = 0; o < n_out; ++o) acc = fmaf(dy[e * ldy + o], W[(size_t)o * n_in + i], acc);
-    if (act && !(act[e * ldx + i] > 0.f)) acc = 0.f;
-    dx[e * ldx + i] = acc;
+                                         int ldy, float* __restrict__ dx, int ldx, const float* __restrict__ act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kk = lane >> 4;
+  const int nsteps = (n_out + 3) >> 2;
+  for (int nt = wave; nt * 16 < n_in; nt += EC_THREADS / 64) {
+    const int i = nt * 16 + m;
+    const bool iok = i < n_in;
+    ec_f32x4 acc = (ec_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st < nsteps; ++st) {
+      const int o = 4 * st + kk;
+      const bool ook = o < n_out;
+      const float av = ook ? dy[m * ldy + o] : 0.f;
+      const float bv = (ook && iok) ? W[(size_t)o * n_in + i] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    if (iok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = 4 * kk + r;
+        float v = acc[r];
+        if (act && !(act[e * ldx + i] > 0.f)) v = 0.f;
+        dx[e * ldx + i] = v;
+      }
+    }
   }
 }
 
@@ -174,9 +222,9 @@ __global__ __launch_bounds__(EC_THREADS) void k_edgeconv_bwd(EcDims D, EcParams 
   float *sE, *sH1, *sM, *sH2, *sOutM;
   ec_carve(D, lds, sE, sH1, sM, sH2, sOutM);
   float* sDm = sOutM;                                   // dm overwrites m
-  float* sDh2 = sOutM + D.k * D.fout;
-  float* sDmin = sDh2 + D.k * D.fout;
-  float* sDh1 = sDmin + D.k * D.min_;
+  float* sDh2 = sOutM + EC_KP * D.fout;
+  float* sDmin = sDh2 + EC_KP * D.fout;
+  float* sDh1 = sDmin + EC_KP * D.min_;
   float* mine = part + (size_t)blockIdx.x * slab;
   // slab layout = parameter order: w1 b1 w2 b2 w3 b3 w4 b4
   float* g_w1 = mine;
@@ -195,27 +243,27 @@ __global__ __launch_bounds__(EC_THREADS) void k_edgeconv_bwd(EcDims D, EcParams 
     __syncthreads();
     ec_forward_query(D, P, feats, pos, (int)qidx[q], nb, sE, sH1, sM, sH2, sOutM);
     // d m: the arg-max edge of every channel receives d out
-    for (int idx = threadIdx.x; idx < D.k * D.fout; idx += EC_THREADS) {
+    for (int idx = threadIdx.x; idx < EC_KP * D.fout; idx += EC_THREADS) {
       const int e = idx / D.fout, o = idx % D.fout;
-      sDm[idx] = (arg[(size_t)q * D.fout + o] == e) ? dout[(size_t)q * D.fout + o] : 0.f;
+      sDm[idx] = (arg[(size_t)q * D.fout + o] == e) ? dout[(size_t)q * D.fout + o] : 0.f;   // padding rows: never the arg-max
     }
     __syncthreads();
-    ec_wgrad(g_w4, g_b4, D.fout, D.fout, sDm, D.fout, sH2, D.fout, D.k, first);
-    ec_dgrad(P.w4, D.fout, D.fout, sDm, D.fout, sDh2, D.fout, sH2, D.k);          // through relu(h2)
+    ec_wgrad(g_w4, g_b4, D.fout, D.fout, sDm, D.fout, sH2, D.fout, first);
+    ec_dgrad(P.w4, D.fout, D.fout, sDm, D.fout, sDh2, D.fout, sH2);          // through relu(h2)
     __syncthreads();
-    ec_wgrad(g_w3, g_b3, D.fout, D.min_, sDh2, D.fout, sM, D.min_, D.k, first);
-    ec_dgrad(P.w3, D.fout, D.min_, sDh2, D.fout, sDmin, D.min_, nullptr, D.k);
+    ec_wgrad(g_w3, g_b3, D.fout, D.min_, sDh2, D.fout, sM, D.min_, first);
+    ec_dgrad(P.w3, D.fout, D.min_, sDh2, D.fout, sDmin, D.min_, nullptr);
     __syncthreads();
     if (dmin_out)
       for (int idx = threadIdx.x; idx < D.k * D.min_; idx += EC_THREADS)
         dmin_out[(size_t)q * D.k * D.min_ + idx] = (nb[idx / D.min_] >= 0) ? sDmin[idx] : 0.f;
-    ec_wgrad(g_w2, g_b2, D.fin, D.hid, sDmin + D.fin, D.min_, sH1, D.hid, D.k, first);   // d ew = middle third of d m_in
-    ec_dgrad(P.w2, D.fin, D.hid, sDmin + D.fin, D.min_, sDh1, D.hid, sH1, D.k);    // through relu(h1)
+    ec_wgrad(g_w2, g_b2, D.fin, D.hid, sDmin + D.fin, D.min_, sH1, D.hid, first);   // d ew = middle third of d m_in
+    ec_dgrad(P.w2, D.fin, D.hid, sDmin + D.fin, D.min_, sDh1, D.hid, sH1);    // through relu(h1)
     __syncthreads();
-    ec_wgrad(g_w1, g_b1, D.hid, D.ein, sDh1, D.hid, sE, D.ein, D.k, first);
+    ec_wgrad(g_w1, g_b1, D.hid, D.ein, sDh1, D.hid, sE, D.ein, first);
     if (dmin_out) {                                      // d e_in behind the d m_in block of this query (feature gradients)
       float* sDein = sDm;                                // d m is dead since the layer-4 step
-      ec_dgrad(P.w1, D.hid, D.ein, sDh1, D.hid, sDein, D.ein, nullptr, D.k);
+      ec_dgrad(P.w1, D.hid, D.ein, sDh1, D.hid, sDein, D.ein, nullptr);
       __syncthreads();
       float* dst = dmin_out + (size_t)D.nq * D.k * D.min_ + (size_t)q * D.k * D.ein;
       for (int idx = threadIdx.x; idx < D.k * D.ein; idx += EC_THREADS) dst[idx] = (nb[idx / D.ein] >= 0) ? sDein[idx] : 0.f;
