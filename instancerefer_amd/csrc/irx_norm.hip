@@ -2,10 +2,22 @@
 // HBM-bound streaming kernels: 16-byte loads, one pass for statistics, one pass for apply.
 // Replaces spnn.BatchNorm + spnn.ReLU + the SparseTensor `+` of ResidualBlock
 // (reference models/basic_blocks.py:20-21,37-38,44,52,55).
+#include <stdlib.h>
 #include "irx_common.h"
 
-// voxel rows per statistics workgroup: 256, or 512 for the largest levels (keeps ~1000 partial blocks)
-static inline int bn_rows(int n) { return n > 262144 ? 512 : 256; }
+// voxel rows per statistics workgroup: ~256 KB of one fp32 tensor per workgroup (2048 rows at 32 channels, 512 at 128),
+// halved while that leaves fewer than 128 workgroups, never below 256 rows. Measured (tools/bn_microbench.py, stats /
+// backward): 489 k x 32: 24.6 / 76.8 us with 512 rows -> 16.6 / 70.6 with 2048; 259 k x 64: 24.0 / 80.7 (256) -> 16.7 / 73.5
+// (1024); smaller blocks are slower at every size (64 rows: 91 us at 489 k x 32 — the float64 fold over the partials grows).
+static inline int bn_rows(int n, int c) {
+  static const int forced = getenv("IRX_BN_ROWS") ? atoi(getenv("IRX_BN_ROWS")) : 0;   // dev A/B knob
+  if (forced > 0) return forced;
+  int rows = 65536 / (c < 32 ? 32 : c);
+  if (rows > 2048) rows = 2048;
+  while (rows > 256 && n / rows < 128) rows >>= 1;
+  if (rows < 256) rows = 256;
+  return rows;
+}
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 // ------------------------------------------------------------------------------ C entry ------
 extern "C" size_t irx_bn_workspace_bytes(int n, int c) {
   if (n <= 0 || c <= 0) return 0;
-  return (size_t)irx_cdiv(n, bn_rows(n)) * 2 * (size_t)c * sizeof(float);
+  return (size_t)irx_cdiv(n, bn_rows(n, c)) * 2 * (size_t)c * sizeof(float);
 }
 
 static int bn_check(const char* who, int n, int c, const void* ws, size_t ws_bytes) {
@@ -361,7 +373,7 @@ int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, floa
   if (rc) return rc;
   if (n == 0) return IRX_OK;
   IRX_REQUIRE(x && mean && invstd, "irx_bn_stats: null pointer");
-  const int nblk = irx_cdiv(n, bn_rows(n));
+  const int nblk = irx_cdiv(n, bn_rows(n, c));
   float* part = (float*)workspace;
   const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0);
   const BnTy ty = {x_bf, 0, 0, 0, 0};
@@ -369,17 +381,17 @@ int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, floa
   if (rc) return rc;
   if (v4 && x_bf && c % 8 == 0)
     k_bn_partial<0, 8, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                   next_pow2(c / 8), bn_rows(n), part, ty);
+                                                   next_pow2(c / 8), bn_rows(n, c), part, ty);
   else if (v4 && x_bf)
     k_bn_partial<0, 4, true><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                         next_pow2(c / 4), bn_rows(n), part, ty);
+                                                         next_pow2(c / 4), bn_rows(n, c), part, ty);
   else if (v4)
     k_bn_partial<0, 4, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                          next_pow2(c / 4), bn_rows(n), part, ty);
+                                                          next_pow2(c / 4), bn_rows(n, c), part, ty);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_stats: c=%d needs c %% 4 == 0 or c <= 256", c);
     k_bn_partial<0, 1, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                   next_pow2(c), bn_rows(n), part, ty);
+                                                   next_pow2(c), bn_rows(n, c), part, ty);
   }
   IRX_CHECK_LAUNCH("irx_bn_stats(partial)");
   k_bn_finalize<0><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, eps, momentum, mean,
@@ -447,7 +459,7 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   }
   IRX_REQUIRE(x && dy && mean && invstd && gamma && dx, "irx_bn_backward: null pointer");
   IRX_REQUIRE(!relu || y, "irx_bn_backward: relu needs y");
-  const int nblk = irx_cdiv(n, bn_rows(n));
+  const int nblk = irx_cdiv(n, bn_rows(n, c));
   float* part = (float*)workspace;
   const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)dy & 15) == 0) &&
                   (((uintptr_t)dx & 15) == 0) && (!relu || ((uintptr_t)y & 15) == 0) &&
@@ -459,17 +471,17 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   const bool v8 = v4 && x_bf && (y_bf || !relu) && dy_bf && dx_bf && (!dresidual || dres_bf) && c % 8 == 0;
   if (v8)
     k_bn_partial<1, 8, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                   next_pow2(c / 8), bn_rows(n), part, ty);
+                                                   next_pow2(c / 8), bn_rows(n, c), part, ty);
   else if (v4 && any_bf)
     k_bn_partial<1, 4, true><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                         next_pow2(c / 4), bn_rows(n), part, ty);
+                                                         next_pow2(c / 4), bn_rows(n, c), part, ty);
   else if (v4)
     k_bn_partial<1, 4, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                          next_pow2(c / 4), bn_rows(n), part, ty);
+                                                          next_pow2(c / 4), bn_rows(n, c), part, ty);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_backward: c=%d needs c %% 4 == 0 or c <= 256", c);
     k_bn_partial<1, 1, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, next_pow2(c),
-                                                   bn_rows(n), part, ty);
+                                                   bn_rows(n, c), part, ty);
   }
   IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
   k_bn_finalize<1><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
