@@ -526,7 +526,7 @@ def main():
         }
         if alt is not None:
             out["alt_dtype"] = alt
-        if world == 1 and args.workload != "attr":
+        if world == 1 and args.workload != "attr" and not args.no_cpu_baseline:   # (quick runs skip the auxiliary legs)
             try:
                 out["dense_path"] = measure_dense_path(model, resident, device)
             except Exception as e:
