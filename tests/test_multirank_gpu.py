@@ -153,7 +153,7 @@ def _rccl_worker(rank, world, port, out_dir):
         if mode == "rccl":
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ["MASTER_PORT"] = str(port)
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            dist.init_process_group("nccl", rank=0, world_size=1)   # (lazy communicator: see bench.py on device_id)
         model = _model(321, dev).train()
         opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1, module=model)
         opt._force_collectives = mode == "rccl"
@@ -164,7 +164,7 @@ def _rccl_worker(rank, world, port, out_dir):
             losses.append(loss)
         torch.cuda.synchronize()
         res[mode] = (losses, opt.flat_p.clone().cpu(), len(opt._reduced))
-    dist.barrier()
+    dist.barrier(device_ids=[0])
     dist.destroy_process_group()
     torch.save(res, os.path.join(out_dir, "rccl.pt"))
 
