@@ -441,6 +441,8 @@ def main():
     # gc.freeze(): the model, the plans and the resident tensors created so far move to the permanent generation, so the
     # cyclic collector (still enabled) stops re-scanning them on every collection — host-bound bf16: 2187 -> 2319 scenes/s
     # averaged over three 150-step runs each (IRX_BENCH_GC=none / off for the A/B); no effect on the GPU-bound fp32 line
+    if os.environ.get("IRX_BENCH_SWITCH_US"):          # dev A/B: GIL hand-over interval (default 5000 us)
+        sys.setswitchinterval(float(os.environ["IRX_BENCH_SWITCH_US"]) * 1e-6)
     import gc
     if os.environ.get("IRX_BENCH_GC", "freeze") == "freeze":
         gc.collect()

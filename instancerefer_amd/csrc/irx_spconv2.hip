@@ -57,7 +57,8 @@ extern "C" int irx_debug_s2_prof(unsigned long long* out, int reset) {
 // Dev-only ablation of k_spconv2 (tools/micro/run_abl.sh builds -DIRX_S2_ABL=<mask> variants; results are WRONG, only the
 // timing is of interest): 1 = every weight load hits the same 1 KiB (no L2->L1 weight stream), 2 = every gathered row
 // is row 0, 4 = no MFMA, 8 = no read-modify-write of the LDS output tile, 16 = every offset reads W[0] (weights certainly L2-resident),
-// 64 = every wave reads slice 0 of W[0] (16 KiB: distinct load instructions, L1-resident), 32 = per-tile offset rotation.
+// 64 = every wave reads slice 0 of W[0] (16 KiB: distinct load instructions, L1-resident), 32 = per-tile offset rotation,
+// 128 = no per-item barriers, 256 = no A-tile writes, 512 = no group work at all, 2048 = no tile store.
 #ifndef IRX_S2_ABL
 #define IRX_S2_ABL 0
 #endif
@@ -377,13 +378,13 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     const int npass = (vpad + PPP - 1) / PPP;      // block-uniform
     float* sA = sA_all + (DB ? abuf * ABUF : 0);
     if (DB) abuf ^= 1;
-    else __syncthreads();                          // previous item's fragment reads are done
+    else if (!(IRX_S2_ABL & 128)) __syncthreads(); // previous item's fragment reads are done
     S2_TICK(1);
     s2_wait_vmcnt<(DEPTH - 1) * LPC>();            // this item's rows + weights have landed (later items may be in flight)
     S2_TICK(2);
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
-      if (it < npass) {                            // (component-wise: a struct copy out of S[][] keeps the sets in scratch)
+      if (it < npass && !(IRX_S2_ABL & 256)) {     // (component-wise: a struct copy out of S[][] keeps the sets in scratch)
         if constexpr (ST)
           *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(sA) + (pbase + it * PPP) * (CIN + 8) + c4) =
               make_uint2(S[C][it].x, S[C][it].y);
@@ -395,7 +396,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
               make_float4(S[C][it].x, S[C][it].y, S[C][it].z, S[C][it].w);
       }
     S2_TICK(3);
-    __syncthreads();
+    if (!(IRX_S2_ABL & 128)) __syncthreads();
     S2_TICK(4);
     // ---- the item to prefetch ----
     s2_next_offset(act, sCnt, kq, vq, kl, rot, K);
@@ -407,7 +408,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     S2_TICK(5);
     // ---- MFMA over dense 16-pair groups; this wave's channel slice ----
     const unsigned char* lrow = sRow + k * TM;
-    int g = gp;
+    int g = (IRX_S2_ABL & 512) ? 1000 : gp;      // (ablation 512: no group work at all, the prefetch branch below runs)
     // bf16, Cin 128: an item with two or more groups for this wave issues half of the chain's loads in each of the first
     // two (128->128: 131.7 -> 125.4 us; no effect in fp32, slightly worse for Cin 64)
     if (IRX_S2_SPLITPF && BF && NJ >= 8 && (g + NGP) * 16 < vpad) {
@@ -419,7 +420,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
       for (g += NGP; g * 16 < vpad; g += NGP)
         s2_group<CIN, COUT, NJ, NT, LDA, LDO, 0, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
                                                                      S[T], nrow, x, c4, wnk, ldx);
-    } else if (NGP == 1 || g * 16 < vpad) {
+    } else if (!(IRX_S2_ABL & 512) && (NGP == 1 || g * 16 < vpad)) {
       s2_group<CIN, COUT, NJ, NT, LDA, LDO, 1, BF, ST, WT, WN, RT>(sA, sOut, lrow, g, vs, m, g4, n_base, W[C], W[T],
                                                                    S[T], nrow, x, c4, wnk, ldx);
       for (g += NGP; g * 16 < vpad; g += NGP)
@@ -464,7 +465,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   constexpr int F4 = COUT / 4;
   for (int f = tid; f < TM * F4; f += 256) {
     const int row = f / F4, cc = (f % F4) * 4;
-    if (q0 + row < n_out) {
+    if (q0 + row < n_out && !(IRX_S2_ABL & 2048)) {
       float4 o = *reinterpret_cast<const float4*>(&sOut[row * LDO + cc]);
       const size_t off = (size_t)(q0 + row) * COUT + cc;
       if (accumulate) {
