@@ -415,6 +415,14 @@ def main():
                    overlap=os.environ.get("IRX_OPT_OVERLAP", "1") != "0")   # dev A/B: early all-reduce of the encoder ranges
     opt._force_collectives = force_dist
 
+    if world > 1 or force_dist:
+        # the RCCL communicator exists now (FlatAdam broadcast / first barrier): push whatever the library printed while it
+        # was created (NCCL_DEBUG=VERSION banner, C stdio buffer) out NOW, so that rank 0's JSON line is the last line
+        dist.barrier(device_ids=None if share else [device.index])
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1 or force_dist:
