@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--sync-bn", action="store_true", help="N > 1: BatchNorm statistics over all ranks (instancerefer_amd.syncbn; "
+                    "the encoders then run layer by layer, one small all-reduce per BatchNorm layer and direction)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (input pipeline in the loop, own process)")
     ap.add_argument("--prep-thread", action="store_true",
                     help="run the input preparation on a helper thread instead of inline behind the step (same speed: "
@@ -394,6 +396,9 @@ def main():
     model_workload = "attr" if args.workload == "attr" else "full"     # stress = the full model on bigger inputs
     torch.manual_seed(1234)                              # identical replicas: the same initial weights on every rank
     model = build_model(args, model_workload, device)    # (FlatAdam broadcasts rank 0's parameters / buffers anyway)
+    if args.sync_bn:
+        from instancerefer_amd.syncbn import convert_sync_batchnorm
+        convert_sync_batchnorm(model)
     torch.manual_seed(1234 + rank)                       # dropout masks: per rank, reproducible run to run
     step_fn.cfg = DatasetConfig()
     # weak scaling: every rank owns B distinct scenes (seeds offset by rank)
@@ -517,16 +522,19 @@ def main():
         try:
             F_.PROFILE = []
             saved_world, opt.world_size = opt.world_size, 1     # rank-0-only steps: no collective (others are not in it)
+            F_.SYNC_OFF = True                                   # ... nor a sync-BatchNorm fold (--sync-bn)
             with serial_issue(model):
                 for _ in range(max(1, args.profile_steps)):
                     step_fn(model, resident, args.workload, reducer, opt)
                 torch.cuda.synchronize()
             opt.world_size = saved_world
+            F_.SYNC_OFF = False
             recs = F_.PROFILE
             F_.PROFILE = None
             roof = summarise_roofline(recs, args.dtype != "f32")
         except Exception as e:                           # never lose the throughput line to the instrumented steps
             F_.PROFILE = None
+            F_.SYNC_OFF = False
             roof_error = repr(e)
 
     if rank == 0:
@@ -545,7 +553,7 @@ def main():
                        "scenes_per_gpu": B, "global_batch": world * B, "points_per_scene": args.points,
                        "instances": args.instances, "candidates": args.candidates, "tokens": args.tokens,
                        "input_channels": 7 + args.multiview,
-                       "scene_voxels_per_gpu": n_scene_vox, "parallelism": "dp%d" % world, "loss": final_loss,
+                       "scene_voxels_per_gpu": n_scene_vox, "parallelism": "dp%d" % world, "sync_bn": bool(args.sync_bn and world > 1), "loss": final_loss,
                        "input_prep": "inline" if args.no_pipeline else "side-stream prefetch of step N+1 during step N"},
             "roofline": roof if roof_error is None else {"error": roof_error},
         }

@@ -228,6 +228,27 @@ int irx_bn_backward(const float* x, const float* y, const float* dy, int n, int 
                     float* dx, float* dgamma, float* dbeta, float* dresidual, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* Sync BatchNorm (optional; the reference has no multi-GPU path — torch.nn.SyncBatchNorm is the contract):
+ * statistics over the rows of ALL ranks. The library computes this rank's sums, the caller folds them over the ranks
+ * (torch.distributed.all_reduce) and hands the folded sums back:
+ *   forward : irx_bn_sums (sums[0..c) = sum x, sums[c..2c) = sum x^2, float64) -> all_reduce(sums, count) ->
+ *             irx_bn_stats_from_sums (mean, invstd, running statistics with the GLOBAL count) -> irx_bn_apply;
+ *   backward: irx_bn_backward_sums (dbeta = sum g, dgamma = sum g*xhat over THIS rank's rows: the parameter gradients, which
+ *             the gradient all-reduce sums like any other) -> all_reduce(copies of both) -> irx_bn_backward_apply with the
+ *             folded sums and the global row count.
+ * The folded row count can stay on the device: count < 1 means "read it from sums[2 c]" (irx_bn_stats_from_sums: the caller
+ * appends its row count to the sums before the fold) / from *count_dev (irx_bn_backward_apply) — no host round trip per layer.
+ * workspace: irx_bn_workspace_bytes(n, c). n == 0 is legal everywhere (a rank without rows still joins the collectives). */
+int irx_bn_sums(const float* x, int n, int c, double* sums, void* workspace, size_t workspace_bytes, void* stream);
+int irx_bn_stats_from_sums(const double* sums, double count, int c, float eps, float momentum, float* mean,
+                           float* invstd, float* running_mean, float* running_var, void* stream);
+int irx_bn_backward_sums(const float* x, const float* y, const float* dy, int n, int c, const float* mean,
+                         const float* invstd, int relu, float* dgamma, float* dbeta, void* workspace,
+                         size_t workspace_bytes, void* stream);
+int irx_bn_backward_apply(const float* x, const float* y, const float* dy, int n, int c, const float* mean,
+                          const float* invstd, const float* gamma, int relu, const float* sum_g, const float* sum_gx,
+                          double count, const double* count_dev, float* dx, float* dresidual, void* stream);
+
 /* Measurement aid for bench.py's `roofline` object: the next dominant sparse-conv kernel launched by THIS host thread
  * (the MFMA kernel of irx_spconv_fwd / irx_spconv_wgrad / irx_spconv_wgrad_pairs, not the weight-permute or
  * split-reduce helpers that share the call) is bracketed with the two caller-owned HIP events on its launch stream.

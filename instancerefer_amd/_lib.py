@@ -50,6 +50,10 @@ _SIGNATURES = {
     "irx_bn_stats": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "irx_bn_apply": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "irx_bn_backward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "irx_bn_sums": (_I, [_P, _I, _I, _P, _P, _Z, _P]),
+    "irx_bn_stats_from_sums": (_I, [_P, _D, _I, _F, _F, _P, _P, _P, _P, _P]),
+    "irx_bn_backward_sums": (_I, [_P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _Z, _P]),
+    "irx_bn_backward_apply": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _D, _P, _P, _P, _P]),
     "irx_profile_next_kernel": (_I, [_P, _P]),
     "irx_encoder_workspace_bytes": (_Z, [_P, _P, _I, _I]),
     "irx_encoder_forward": (_I, [_P, _P, _I, _P, _Z, _P]),

@@ -300,5 +300,6 @@ def batchnorm_rows(bn, x, relu=False):
         mom = 0.0 if bn.momentum is None else bn.momentum
         return F_.BatchNormActFn.apply(x, bn.weight, bn.bias, None,
                                        bn.running_mean if bn.track_running_stats else None,
-                                       bn.running_var if bn.track_running_stats else None, bn.eps, mom, relu)
+                                       bn.running_var if bn.track_running_stats else None, bn.eps, mom, relu,
+                                       F_.sync_group() if getattr(bn, "_irx_sync", False) else None)
     return F_.bn_eval(x, bn.weight, bn.bias, None, bn.running_mean, bn.running_var, bn.eps, relu)

@@ -208,10 +208,33 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
         running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mu);
         running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
       }
+    } else if (MODE == 2) {                       // raw float64 sums (sync BatchNorm: summed over the ranks before use)
+      reinterpret_cast<double*>(out0)[ch] = t0;
+      reinterpret_cast<double*>(out1)[ch] = t1;
     } else {
       out0[ch] = (float)t0;
       out1[ch] = (float)t1;
     }
+  }
+}
+
+// mean / invstd (+ running statistics) from (sum x, sum x^2, count) — the tail of k_bn_finalize<0> for sums that were
+// folded over the ranks first
+__global__ void k_bn_from_sums(const double* __restrict__ sums, double count, int c, float eps, float momentum,
+                               float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
+                               float* __restrict__ running_var) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  if (count < 1.0) count = sums[2 * c];          // the folded row count travels behind the sums (no host round trip)
+  const double mu = sums[ch] / count;
+  double var = sums[c + ch] / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[ch] = (float)mu;
+  invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = (count > 1.0) ? var * count / (count - 1.0) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mu);
+    running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
   }
 }
 
@@ -276,12 +299,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ sum_g,
                                                       const float* __restrict__ sum_gx, int relu,
-                                                      float* __restrict__ dx, float* __restrict__ dres, BnTy ty) {
+                                                      float* __restrict__ dx, float* __restrict__ dres, BnTy ty,
+                                                      float inv_count, const double* __restrict__ count_dev) {
+  // inv_count: 1 / (rows the sums were taken over) — 1 / n, or 1 / (rows of ALL ranks) for sync BatchNorm
   const int cq = c / V;
   const int qd = threadIdx.x % qpad;
   if (qd >= cq) return;
   const int rpp = 256 / qpad;
-  const float inv_n = 1.f / (float)n;
+  const float inv_n = count_dev ? (float)(1.0 / *count_dev) : inv_count;
   float mu[V], is[V], gi[V], sg[V], sgx[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
@@ -400,6 +425,60 @@ int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, floa
   return IRX_OK;
 }
 
+// ---- sync BatchNorm (statistics over the rows of ALL ranks): the same kernels, with the cross-rank fold of the sums left
+// to the caller (torch.distributed in instancerefer_amd/sparse/functional.py) between the two halves ----
+extern "C" int irx_bn_sums(const float* x, int n, int c, double* sums, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  int rc = bn_check("irx_bn_sums", n, c, workspace, workspace_bytes);
+  if (rc) return rc;
+  IRX_REQUIRE(sums, "irx_bn_sums: null pointer");
+  if (n == 0) {
+    IRX_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), S(stream)), "irx_bn_sums(memset)");
+    return IRX_OK;
+  }
+  IRX_REQUIRE(x, "irx_bn_sums: null pointer");
+  const int nblk = irx_cdiv(n, bn_rows(n, c));
+  float* part = (float*)workspace;
+  const BnTy ty = {0, 0, 0, 0, 0};
+  if ((c % 4 == 0) && (((uintptr_t)x & 15) == 0))
+    k_bn_partial<0, 4, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+                                                          next_pow2(c / 4), bn_rows(n, c), part, ty);
+  else {
+    IRX_REQUIRE(c <= 256, "irx_bn_sums: c=%d needs c %% 4 == 0 or c <= 256", c);
+    k_bn_partial<0, 1, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+                                                          next_pow2(c), bn_rows(n, c), part, ty);
+  }
+  IRX_CHECK_LAUNCH("irx_bn_sums(partial)");
+  k_bn_finalize<2><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(
+      part, nblk, n, c, 0.f, 0.f, reinterpret_cast<float*>(sums), reinterpret_cast<float*>(sums + c), nullptr, nullptr);
+  IRX_CHECK_LAUNCH("irx_bn_sums(finalize)");
+  return IRX_OK;
+}
+
+extern "C" int irx_bn_stats_from_sums(const double* sums, double count, int c, float eps, float momentum, float* mean,
+                                      float* invstd, float* running_mean, float* running_var, void* stream) {
+  IRX_REQUIRE(sums && mean && invstd && c >= 1, "irx_bn_stats_from_sums: bad arguments");
+  k_bn_from_sums<<<irx_cdiv(c, 128), 128, 0, S(stream)>>>(sums, count, c, eps, momentum, mean, invstd, running_mean,
+                                                         running_var);
+  IRX_CHECK_LAUNCH("irx_bn_stats_from_sums");
+  return IRX_OK;
+}
+
+extern "C" int irx_bn_backward_sums(const float* x, const float* y, const float* dy, int n, int c, const float* mean,
+                                    const float* invstd, int relu, float* dgamma, float* dbeta, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  return irx_bn_backward_t(x, y, dy, n, c, mean, invstd, nullptr, relu, nullptr, dgamma, dbeta, nullptr, workspace,
+                           workspace_bytes, stream, 0, 0, 0, 0, 0, 1);
+}
+
+extern "C" int irx_bn_backward_apply(const float* x, const float* y, const float* dy, int n, int c, const float* mean,
+                                     const float* invstd, const float* gamma, int relu, const float* sum_g,
+                                     const float* sum_gx, double count, const double* count_dev, float* dx,
+                                     float* dresidual, void* stream) {
+  return irx_bn_backward_t(x, y, dy, n, c, mean, invstd, gamma, relu, dx, nullptr, nullptr, dresidual, nullptr, 0, stream,
+                           0, 0, 0, 0, 0, 2, sum_g, sum_gx, count, count >= 1.0 ? nullptr : count_dev);
+}
+
 extern "C" int irx_bn_apply(const float* x, int n, int c, const float* mean, const float* invstd,
                             const float* gamma, const float* beta, const float* residual, int relu,
                             float* y, void* stream) {
@@ -448,28 +527,37 @@ extern "C" int irx_bn_backward(const float* x, const float* y, const float* dy, 
 int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, int c, const float* mean,
                       const float* invstd, const float* gamma, int relu, float* dx, float* dgamma, float* dbeta,
                       float* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int y_bf,
-                      int dy_bf, int dx_bf, int dres_bf) {
-  int rc = bn_check("irx_bn_backward", n, c, workspace, workspace_bytes);
+                      int dy_bf, int dx_bf, int dres_bf, int phases, const float* all_sum_g, const float* all_sum_gx,
+                      double all_count, const double* count_dev) {
+  // phases: 1 = the reduction only (dbeta = sum g, dgamma = sum g xhat over THESE rows), 2 = the apply pass only, with the
+  // sums (all_sum_g, all_sum_gx) and row count (all_count) it is given — sync BatchNorm folds the ranks' sums in between;
+  // 3 = both, on the local sums (everything else)
+  int rc = (phases & 1) ? bn_check("irx_bn_backward", n, c, workspace, workspace_bytes) : bn_check("irx_bn_backward", 0, c, nullptr, 0);
   if (rc) return rc;
-  IRX_REQUIRE(dgamma && dbeta, "irx_bn_backward: null dgamma/dbeta");
+  IRX_REQUIRE(phases >= 1 && phases <= 3, "irx_bn_backward: phases = %d", phases);
+  IRX_REQUIRE(!(phases & 1) || (dgamma && dbeta), "irx_bn_backward: null dgamma/dbeta");
+  IRX_REQUIRE(phases != 2 || (all_sum_g && all_sum_gx && (all_count >= 1.0 || count_dev)), "irx_bn_backward(apply): sums / count missing");
+  if (phases != 2) count_dev = nullptr;
   if (n == 0) {
+    if (!(phases & 1)) return IRX_OK;
     IRX_CHECK_HIP(hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream)), "irx_bn_backward(memset)");
     IRX_CHECK_HIP(hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream)), "irx_bn_backward(memset)");
     return IRX_OK;
   }
-  IRX_REQUIRE(x && dy && mean && invstd && gamma && dx, "irx_bn_backward: null pointer");
+  IRX_REQUIRE(x && dy && mean && invstd && (gamma || phases == 1) && (dx || phases == 1), "irx_bn_backward: null pointer");
   IRX_REQUIRE(!relu || y, "irx_bn_backward: relu needs y");
   const int nblk = irx_cdiv(n, bn_rows(n, c));
   float* part = (float*)workspace;
   const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)dy & 15) == 0) &&
-                  (((uintptr_t)dx & 15) == 0) && (!relu || ((uintptr_t)y & 15) == 0) &&
+                  (dx == nullptr || ((uintptr_t)dx & 15) == 0) && (!relu || ((uintptr_t)y & 15) == 0) &&
                   (dresidual == nullptr || ((uintptr_t)dresidual & 15) == 0);
   const BnTy ty = {x_bf, y_bf, dy_bf, dx_bf, dres_bf};
   rc = bn_bf_ok("irx_bn_backward", (x_bf | y_bf | dy_bf | dx_bf | dres_bf) != 0, v4);
   if (rc) return rc;
   const bool any_bf = (x_bf | y_bf | dy_bf | dx_bf | dres_bf) != 0;
   const bool v8 = v4 && x_bf && (y_bf || !relu) && dy_bf && dx_bf && (!dresidual || dres_bf) && c % 8 == 0;
-  if (v8)
+  if (!(phases & 1)) {
+  } else if (v8)
     k_bn_partial<1, 8, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
                                                    next_pow2(c / 8), bn_rows(n, c), part, ty);
   else if (v4 && any_bf)
@@ -483,26 +571,32 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
     k_bn_partial<1, 1, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, next_pow2(c),
                                                    bn_rows(n, c), part, ty);
   }
-  IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
-  k_bn_finalize<1><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
-                                                          nullptr, nullptr);
-  IRX_CHECK_LAUNCH("irx_bn_backward(finalize)");
+  if (phases & 1) {
+    IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
+    k_bn_finalize<1><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
+                                                            nullptr, nullptr);
+    IRX_CHECK_LAUNCH("irx_bn_backward(finalize)");
+  }
+  if (!(phases & 2)) return IRX_OK;
+  const float* sg = (phases == 2) ? all_sum_g : dbeta;
+  const float* sgx = (phases == 2) ? all_sum_gx : dgamma;
+  const float inv_count = (phases == 2) ? (all_count >= 1.0 ? (float)(1.0 / all_count) : 0.f) : 1.f / (float)n;
   if (v8) {
     const int qpad = next_pow2(c / 8);
-    k_bn_bwd_apply<8, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
-                                                               dgamma, relu, dx, dresidual, ty);
+    k_bn_bwd_apply<8, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
+                                                               sgx, relu, dx, dresidual, ty, inv_count, count_dev);
   } else if (v4 && any_bf) {
     const int qpad = next_pow2(c / 4);
-    k_bn_bwd_apply<4, true><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
-                                                                     dgamma, relu, dx, dresidual, ty);
+    k_bn_bwd_apply<4, true><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
+                                                                     sgx, relu, dx, dresidual, ty, inv_count, count_dev);
   } else if (v4) {
     const int qpad = next_pow2(c / 4);
-    k_bn_bwd_apply<4, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
-                                                                      dgamma, relu, dx, dresidual, ty);
+    k_bn_bwd_apply<4, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
+                                                                      sgx, relu, dx, dresidual, ty, inv_count, count_dev);
   } else {
     const int qpad = next_pow2(c);
-    k_bn_bwd_apply<1, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, dbeta,
-                                                               dgamma, relu, dx, dresidual, ty);
+    k_bn_bwd_apply<1, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
+                                                               sgx, relu, dx, dresidual, ty, inv_count, count_dev);
   }
   IRX_CHECK_LAUNCH("irx_bn_backward(apply)");
   return IRX_OK;

@@ -52,9 +52,12 @@ def to_device(data_dict, device):
 
 class Solver:
     def __init__(self, model, config, dataloader, lr=1e-3, weight_decay=1e-5, lr_decay_step=(15, 20), lr_decay_rate=0.1,
-                 out_dir=None, verbose=20, device=None, use_checkpoint=None):
+                 out_dir=None, verbose=20, device=None, use_checkpoint=None, sync_bn=False):
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.model = model.to(self.device)
+        if sync_bn:                                # world > 1: BatchNorm statistics over all ranks (syncbn.py)
+            from .syncbn import convert_sync_batchnorm
+            convert_sync_batchnorm(self.model)
         self.config = config
         self.dataloader = dataloader               # {"train": iterable, "val": iterable (optional)}
         self.world = dist.get_world_size() if dist.is_initialized() else 1

@@ -360,6 +360,8 @@ def can_fuse(encoder):
         return False
     if not all(bn.training for _, bn, _, _ in _skeleton(encoder)):
         return False                                   # frozen BatchNorm layers: the per-layer path handles eval statistics
+    if any(getattr(bn, "_irx_sync", False) for _, bn, _, _ in _skeleton(encoder)) and F_.sync_group() is not None:
+        return False                                   # sync BatchNorm: a collective between statistics and apply (syncbn.py)
     ok = encoder.__dict__.get("_irx_fusable")          # structural part: decided once per encoder instance
     if ok is None:
         ok = True

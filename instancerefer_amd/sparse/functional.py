@@ -369,11 +369,26 @@ def _bn_ws(n, c, device):
     return torch.empty(max(wsb, 4), dtype=torch.uint8, device=device), wsb
 
 
+SYNC_OFF = False   # set by a caller that runs steps on ONE rank of a live group (bench.py's instrumented steps)
+
+
+def sync_group():
+    """The process group sync BatchNorm folds its statistics over: the default group when it has more than one rank."""
+    import torch.distributed as dist
+    if SYNC_OFF:
+        return None
+    return dist.group.WORLD if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
 class BatchNormActFn(torch.autograd.Function):
-    """Train-mode BatchNorm over rows (+ residual) (+ ReLU), one statistics pass + one apply pass."""
+    """Train-mode BatchNorm over rows (+ residual) (+ ReLU), one statistics pass + one apply pass.
+    sync (a process group): the statistics are taken over the rows of all its ranks (torch.nn.SyncBatchNorm semantics;
+    include/irx.h "Sync BatchNorm"): this rank's float64 sums and row count -> all_reduce -> mean / invstd; in the backward
+    pass the two gradient sums are folded the same way before the apply pass, and the parameter gradients stay this rank's
+    own sums (the gradient all-reduce folds those like every other parameter gradient). Every rank must run the layer."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, sync=None):
         x = _f32c(x)
         n, c = x.shape
         dev = x.device
@@ -381,9 +396,20 @@ class BatchNormActFn(torch.autograd.Function):
         invstd = torch.empty(c, dtype=_f32, device=dev)
         ws, wsb = _bn_ws(n, c, dev)
         res = _f32c(residual) if residual is not None else None
-        _lib.call("irx_bn_stats", _lib.ptr(x), n, c, float(eps), float(momentum), _lib.ptr(mean),
-                  _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ws), wsb,
-                  _stream())
+        ctx.sync, ctx.count = sync, None
+        if sync is not None:
+            import torch.distributed as dist
+            sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+            _lib.call("irx_bn_sums", _lib.ptr(x), n, c, _lib.ptr(sums), _lib.ptr(ws), wsb, _stream())
+            sums[2 * c:].fill_(float(n))
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=sync)
+            _lib.call("irx_bn_stats_from_sums", _lib.ptr(sums), 0.0, c, float(eps), float(momentum), _lib.ptr(mean),
+                      _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), _stream())
+            ctx.count = sums[2 * c:]                     # folded row count, on the device
+        else:
+            _lib.call("irx_bn_stats", _lib.ptr(x), n, c, float(eps), float(momentum), _lib.ptr(mean),
+                      _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ws), wsb,
+                      _stream())
         y = torch.empty_like(x)
         g = _f32c(gamma)
         b = _f32c(beta)
@@ -405,10 +431,20 @@ class BatchNormActFn(torch.autograd.Function):
         dbeta = torch.empty(c, dtype=_f32, device=dev)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
         ws, wsb = _bn_ws(n, c, dev)
+        if ctx.sync is not None:
+            import torch.distributed as dist
+            _lib.call("irx_bn_backward_sums", _lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), n, c, _lib.ptr(mean),
+                      _lib.ptr(invstd), int(ctx.relu), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), wsb, _stream())
+            both = torch.cat([dbeta, dgamma])            # (sum g | sum g xhat) of this rank; folded copies below
+            dist.all_reduce(both, op=dist.ReduceOp.SUM, group=ctx.sync)
+            _lib.call("irx_bn_backward_apply", _lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), n, c, _lib.ptr(mean),
+                      _lib.ptr(invstd), _lib.ptr(g), int(ctx.relu), _lib.ptr(both), _lib.ptr(both[c:]), 0.0,
+                      _lib.ptr(ctx.count), _lib.ptr(dx), _lib.ptr(dres), _stream())
+            return dx, dgamma, dbeta, dres, None, None, None, None, None, None
         _lib.call("irx_bn_backward", _lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), n, c, _lib.ptr(mean),
                   _lib.ptr(invstd), _lib.ptr(g), int(ctx.relu), _lib.ptr(dx), _lib.ptr(dgamma),
                   _lib.ptr(dbeta), _lib.ptr(dres), _lib.ptr(ws), wsb, _stream())
-        return dx, dgamma, dbeta, dres, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 
 def bn_eval(x, gamma, beta, residual, running_mean, running_var, eps, relu):

@@ -83,7 +83,8 @@ class BatchNorm(nn.BatchNorm1d):
             return F_.BatchNormActFn.apply(f, self.weight, self.bias, residual,
                                            self.running_mean if self.track_running_stats else None,
                                            self.running_var if self.track_running_stats else None,
-                                           self.eps, mom, relu)
+                                           self.eps, mom, relu,
+                                           F_.sync_group() if getattr(self, "_irx_sync", False) else None)
         return F_.bn_eval(f, self.weight, self.bias, residual, self.running_mean, self.running_var,
                           self.eps, relu)
 

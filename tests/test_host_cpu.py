@@ -250,3 +250,23 @@ def test_batched_box_labels_equal_the_per_sample_reference_order_code(augment):
                 assert np.allclose(d.shift, batch[i].shift)
     finally:
         torch.rand = orig
+
+
+def test_convert_sync_batchnorm_keeps_keys_and_single_process_behaviour():
+    """syncbn.convert_sync_batchnorm: same state-dict keys / values, every BatchNorm layer marked, and without a process
+    group a converted nn.BatchNorm1d computes what it computed before (host tensors fall back to nn.BatchNorm1d)."""
+    import torch
+    import torch.nn as nn
+    from instancerefer_amd.syncbn import SyncRowsBatchNorm1d, convert_sync_batchnorm
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(6, 8), nn.BatchNorm1d(8), nn.ReLU(), nn.Conv2d(1, 1, 1), nn.BatchNorm2d(1))
+    ref = nn.Sequential(nn.Linear(6, 8), nn.BatchNorm1d(8), nn.ReLU())
+    ref.load_state_dict({k: v for k, v in net.state_dict().items() if k[0] in "01"})
+    keys = list(net.state_dict().keys())
+    out = convert_sync_batchnorm(net)
+    assert out is net and list(net.state_dict().keys()) == keys
+    assert isinstance(net[1], SyncRowsBatchNorm1d) and type(net[4]) is nn.BatchNorm2d
+    assert all(getattr(m, "_irx_sync", False) for m in net.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+    x = torch.randn(5, 6)
+    assert torch.equal(net[2](net[1](net[0](x))), ref(x))
+    assert torch.equal(net[1].running_mean, ref[1].running_mean)

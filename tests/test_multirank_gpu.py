@@ -189,3 +189,76 @@ def test_product_collectives_over_rccl_one_rank(lib, tmp_path):
     assert res["rccl"][2] >= 2                         # both encoder ranges went through an all-reduce
     assert res["plain"][0] == res["rccl"][0]
     assert torch.equal(res["plain"][1], res["rccl"][1])
+
+
+def _syncbn_worker(rank, world, port, out_dir):
+    """Sync BatchNorm: 2 ranks x 2 scenes in TRAIN mode == 1 rank x 4 scenes (BatchNorm couples the scenes of a batch, so
+    without the cross-rank statistics this does not hold)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from instancerefer_amd import _build, _lib, synthetic as S
+    from instancerefer_amd.optim import FlatAdam
+    from instancerefer_amd.syncbn import convert_sync_batchnorm
+    _build.build_lib()
+    _lib.load()
+    res = {}
+    model = convert_sync_batchnorm(_model(1200, dev)).train()
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, module=model)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = S.make_batch(2, seed=810 + 2 * rank, num_candidates=[[3, 2], [2, 4]][rank], **KW)
+    loss, g2 = _step(model, opt, batch, dev)
+    res["loss"] = loss
+    res["g_2rank"] = (g2 / world).cpu()
+    res["running_mean"] = model.scene.net.stem[0].net[1].running_mean.clone().cpu()
+    res["sync_layers"] = sum(1 for m in model.modules() if getattr(m, "_irx_sync", False))
+    dist.barrier()
+    if rank == 0:
+        model1 = _model(1201, dev).train()
+        model1.load_state_dict(sd0)
+        opt1 = FlatAdam(model1.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1, broadcast=False)
+        batch = S.make_batch(4, seed=810, num_candidates=[3, 2, 2, 4], **KW)
+        loss1, g1 = _step(model1, opt1, batch, dev)
+        res["loss_1rank"] = loss1
+        res["g_1rank"] = g1.cpu()
+        res["running_mean_1rank"] = model1.scene.net.stem[0].net[1].running_mean.clone().cpu()
+        # and WITHOUT sync the two-rank gradient is a different one: the test has teeth
+        model2 = _model(1202, dev).train()
+        model2.load_state_dict(sd0)
+        opt2 = FlatAdam(model2.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1, broadcast=False)
+        _, gl = _step(model2, opt2, S.make_batch(2, seed=810, num_candidates=[3, 2], **KW), dev)
+        res["g_local_only"] = gl.cpu()
+    torch.cuda.synchronize()
+    torch.save(res, os.path.join(out_dir, "sync%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equal_one_rank_on_the_whole_batch(lib, tmp_path):
+    mp.set_start_method("spawn", force=True)
+    port = 33000 + (os.getpid() * 11 + int(time.time())) % 2000
+    ctx = mp.start_processes(_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=False, start_method="spawn")
+    deadline = time.time() + 420
+    try:
+        while not ctx.join(timeout=5):
+            if time.time() > deadline:
+                raise TimeoutError("sync BatchNorm run exceeded 420 s")
+    finally:
+        for p in ctx.processes:
+            if p.is_alive():
+                p.kill()
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "sync%d.pt" % r), weights_only=False) for r in range(2))
+    assert r0["sync_layers"] >= 30                       # both encoders (13 + 13), the scene head, the heads' BatchNorm1d
+    assert torch.equal(r0["g_2rank"], r1["g_2rank"])
+    assert torch.equal(r0["running_mean"], r1["running_mean"])           # one set of statistics for both ranks
+    g2, g1 = r0["g_2rank"], r0["g_1rank"]
+    scale = float(g1.abs().max())
+    assert scale > 0 and float((g2 - g1).abs().max()) <= 5e-4 * scale, (float((g2 - g1).abs().max()), scale)
+    assert abs(float(g2.double().norm()) - float(g1.double().norm())) <= 2e-4 * float(g1.double().norm())
+    assert float((r0["running_mean"] - r0["running_mean_1rank"]).abs().max()) <= 1e-6
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - r0["loss_1rank"]) <= 1e-4 * abs(r0["loss_1rank"])
+    # rank 0's own half batch without the cross-rank statistics gives another gradient altogether
+    assert float((r0["g_local_only"] - g1).abs().max()) > 50 * float((g2 - g1).abs().max())
