@@ -434,7 +434,7 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
     }
     S2_TICK(6);
   };
-  if (kk[0] >= 0) {
+  if (kk[0] >= 0 && !(IRX_S2_ABL & 4096)) {   // (ablation 4096: no item loop at all)
     if (DEPTH == 1) {
       while (true) {
         item(I0{}, I1{});
