@@ -689,3 +689,82 @@ def test_dynamic_edge_conv_op_level(lib, fin_base, k):
     for (nm, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
         close(p.grad, q.grad, nm)
     close(fd.grad, fr.grad, "features")
+
+
+@pytest.mark.parametrize("n,c,relu,res,split", [(5000, 32, True, False, 1800), (777, 64, True, True, 0), (3001, 128, False, True, 3000),
+                                                 (4097, 7, True, False, 2048)])
+def test_sync_batchnorm_entries_fold_like_one_batch(lib, n, c, relu, res, split):
+    """The sync-BatchNorm halves of include/irx.h on ONE device: the rows are cut in two "ranks" (one of them may be empty),
+    each side's float64 sums are added by hand — the fold torch.distributed does in the product — and
+    irx_bn_stats_from_sums / irx_bn_apply / irx_bn_backward_sums / irx_bn_backward_apply must reproduce train-mode
+    torch.nn.BatchNorm1d on the WHOLE batch: output 1e-5, input gradient 2e-5, parameter gradients (sum of the two sides'
+    own sums) 1e-4 relative, running statistics 1e-6 / 1e-5, dresidual exact."""
+    from instancerefer_amd import _lib
+    torch.manual_seed(n + c + split)
+    x = torch.randn(n, c) * 2 + 0.5
+    r = torch.randn(n, c) if res else None
+    g = torch.randn(n, c)
+    ref = torch.nn.BatchNorm1d(c)
+    ref.weight.data.uniform_(0.5, 1.5); ref.bias.data.uniform_(-0.5, 0.5)
+    xo = x.clone().requires_grad_(True)
+    ro = r.clone().requires_grad_(True) if res else None
+    yo = ref(xo)
+    if res: yo = yo + ro
+    if relu: yo = torch.relu(yo)
+    yo.backward(g)
+
+    dev = torch.device("cuda")
+    L = _lib.load()
+    s = lambda: torch.cuda.current_stream().cuda_stream
+    gamma, beta = ref.weight.detach().to(dev), ref.bias.detach().to(dev)
+    rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    parts = [(0, split), (split, n)]
+    xs = [x[a:b].contiguous().to(dev) for a, b in parts]
+    rs = [r[a:b].contiguous().to(dev) if res else None for a, b in parts]
+    gs = [g[a:b].contiguous().to(dev) for a, b in parts]
+    sums = torch.zeros(2 * c + 1, dtype=torch.float64, device=dev)
+    for xi in xs:
+        ni = xi.shape[0]
+        wsb = int(L.irx_bn_workspace_bytes(ni, c))
+        ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
+        mine = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+        _lib.call("irx_bn_sums", _lib.ptr(xi), ni, c, _lib.ptr(mine), _lib.ptr(ws), wsb, s())
+        mine[2 * c:] = float(ni)
+        sums += mine
+    mean, invstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    _lib.call("irx_bn_stats_from_sums", _lib.ptr(sums), 0.0, c, float(ref.eps), float(ref.momentum), _lib.ptr(mean),
+              _lib.ptr(invstd), _lib.ptr(rm), _lib.ptr(rv), s())
+    assert (rm.cpu() - ref.running_mean).abs().max().item() <= 1e-6
+    assert (rv.cpu() - ref.running_var).abs().max().item() <= 1e-5
+    ys, dgs, dbs = [], [], []
+    for xi, ri, gi in zip(xs, rs, gs):
+        ni = xi.shape[0]
+        y = torch.empty_like(xi)
+        _lib.call("irx_bn_apply", _lib.ptr(xi), ni, c, _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(gamma), _lib.ptr(beta),
+                  _lib.ptr(ri), int(relu), _lib.ptr(y), s())
+        ys.append(y)
+        wsb = int(L.irx_bn_workspace_bytes(ni, c))
+        ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
+        dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        _lib.call("irx_bn_backward_sums", _lib.ptr(xi), _lib.ptr(y), _lib.ptr(gi), ni, c, _lib.ptr(mean), _lib.ptr(invstd),
+                  int(relu), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws), wsb, s())
+        dgs.append(dg); dbs.append(db)
+    y_all = torch.cat(ys).cpu()
+    assert (y_all - yo.detach()).abs().max().item() <= 1e-5
+    both = torch.cat([dbs[0] + dbs[1], dgs[0] + dgs[1]])                 # the folded (sum g | sum g xhat)
+    dxs, drs = [], []
+    for k, (xi, yi, gi) in enumerate(zip(xs, ys, gs)):
+        ni = xi.shape[0]
+        dx = torch.empty_like(xi)
+        dr = torch.empty_like(xi) if res else None
+        # one side passes the count on the host, the other reads it from the device
+        _lib.call("irx_bn_backward_apply", _lib.ptr(xi), _lib.ptr(yi), _lib.ptr(gi), ni, c, _lib.ptr(mean), _lib.ptr(invstd),
+                  _lib.ptr(gamma), int(relu), _lib.ptr(both), _lib.ptr(both[c:]), float(n) if k == 0 else 0.0,
+                  _lib.ptr(sums[2 * c:]), _lib.ptr(dx), _lib.ptr(dr), s())
+        dxs.append(dx); drs.append(dr)
+    assert (torch.cat(dxs).cpu() - xo.grad).abs().max().item() <= 2e-5
+    wg, bg = (dgs[0] + dgs[1]).cpu(), (dbs[0] + dbs[1]).cpu()
+    assert (wg - ref.weight.grad).abs().max().item() <= 1e-4 * max(1.0, ref.weight.grad.abs().max().item())
+    assert (bg - ref.bias.grad).abs().max().item() <= 1e-4 * max(1.0, ref.bias.grad.abs().max().item())
+    if res:
+        assert (torch.cat(drs).cpu() - ro.grad).abs().max().item() <= 1e-6
