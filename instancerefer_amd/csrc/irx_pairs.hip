@@ -96,6 +96,11 @@ __device__ __forceinline__ int pairs_shares(const int32_t* __restrict__ counts, 
 // part[s][k][c][n] = sum over share s of list k:  x[in][c] * dy[out][n]   (s < pairs_shares(k); grid = (smax, K))
 // ST (bf16 storage, with BF only): x and dy rows are bf16 in HBM; a staging thread loads 8 bytes (its 4 channels) and
 // widens them to fp32 when it writes the LDS tiles (the fragment reads below are unchanged).
+// Dev-only ablation of k_wgrad_pairs' fp32 full-stage chain (results WRONG, timing only): 1 = no next-stage row loads,
+// 2 = no LDS fragment reads, 4 = no MFMA.
+#ifndef IRX_WP_ABL
+#define IRX_WP_ABL 0
+#endif
 template <bool ST>
 __device__ __forceinline__ typename std::conditional<ST, uint2, float4>::type wp_ld(const float* __restrict__ p, size_t elem) {
   if constexpr (ST) return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + elem);
@@ -151,12 +156,18 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
   RT rx[NX];
   RD rd[ND];
   int par = 0;
-  // prologue: indices + rows of the first stage
+  // prologue: indices + rows of the first stage, indices of the second
+  int nin = -1, nout = -1;
   if (st0 < st1) {
     if (tid < 64) {
       const int p = st0 * 64 + tid;
       sIn[0][tid] = p < cnt ? il[p] : -1;
       sOutRow[0][tid] = p < cnt ? ol[p] : -1;
+      const int p1 = p + 64;
+      if (st0 + 1 < st1) {
+        nin = p1 < cnt ? il[p1] : -1;
+        nout = p1 < cnt ? ol[p1] : -1;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -177,12 +188,18 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
     for (int i = 0; i < NX; ++i) *reinterpret_cast<float4*>(&sX[(xr + i * PX) * LDX + xc]) = wp_f4(rx[i]);
 #pragma unroll
     for (int i = 0; i < ND; ++i) *reinterpret_cast<float4*>(&sD[(dr + i * PD) * LDD + dc]) = wp_f4(rd[i]);
-    // next stage's indices (other parity buffer), visible after the barrier below
+    // next stage's indices (other parity buffer), visible after the barrier below. They were requested ONE STAGE AGO
+    // (nin / nout, landed under the vmcnt(0) above): loading them here put a global round trip of the index lists —
+    // streamed once, so from HBM — in front of every stage's barrier
     const int parn = par ^ 1;
     if (st + 1 < st1 && tid < 64) {
-      const int p = (st + 1) * 64 + tid;
-      sIn[parn][tid] = p < cnt ? il[p] : -1;
-      sOutRow[parn][tid] = p < cnt ? ol[p] : -1;
+      sIn[parn][tid] = nin;
+      sOutRow[parn][tid] = nout;
+    }
+    if (st + 2 < st1 && tid < 64) {
+      const int p = (st + 2) * 64 + tid;
+      nin = p < cnt ? il[p] : -1;
+      nout = p < cnt ? ol[p] : -1;
     }
     __syncthreads();
     const bool has_next = st + 1 < st1;
@@ -254,18 +271,18 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
       for (int i = 0; i < NW; ++i) b[i] = sD[g4 * LDD + (nt0 + i) * 16 + m];     // B[kk = pair][n]
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        if (ks < NX) {
+        if (ks < NX && !(IRX_WP_ABL & 1)) {
           const int idx = sIn[parn][xr + ks * PX];
           const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(idx < 0 ? 0 : idx) * ldx + xc);
           rx[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (ks < ND) {
+        if (ks < ND && !(IRX_WP_ABL & 1)) {
           const int idx = sOutRow[parn][dr + ks * PD];
           const float4 v = *reinterpret_cast<const float4*>(dy + (size_t)(idx < 0 ? 0 : idx) * COUT + dc);
           rd[ks] = idx >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float an[CW], bn[NW];
-        if (ks + 1 < 16) {
+        if (ks + 1 < 16 && !(IRX_WP_ABL & 2)) {
           const int pp = (ks + 1) * 4 + g4;
 #pragma unroll
           for (int i = 0; i < CW; ++i) an[i] = sX[pp * LDX + (ct0 + i) * 16 + m];
@@ -275,10 +292,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < CW; ++i)
 #pragma unroll
-          for (int jn = 0; jn < NW; ++jn)
-            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+          for (int jn = 0; jn < NW; ++jn) {
+            if constexpr ((IRX_WP_ABL & 4) != 0) acc[i][jn][0] += a[i] * b[jn];
+            else acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+          }
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 1 < 16) {
+        if (ks + 1 < 16 && !(IRX_WP_ABL & 2)) {
 #pragma unroll
           for (int i = 0; i < CW; ++i) a[i] = an[i];
 #pragma unroll
