@@ -579,6 +579,18 @@ int irx_wgrad_pairs_wide_launch(const float* x, int ldx, const float* dy, const 
   return IRX_OK;
 }
 
+extern "C" int irx_debug_occupancy_wp(int which) {
+  int n = -1;
+  hipError_t e = hipSuccess;
+  switch (which) {
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wgrad_pairs<128, 128, false, false, false>, 256, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wgrad_pairs<64, 64, false, false, false>, 256, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wgrad_pairs<128, 128, true, true, true>, 256, 0); break;
+    default: return -2;
+  }
+  return e == hipSuccess ? n : -1;
+}
+
 extern "C" int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int32_t* in_list,
                                       const int32_t* out_list, int ldp, const int32_t* counts, int n_out, int K,
                                       int cin, int cout, float* dw, void* workspace, size_t workspace_bytes,

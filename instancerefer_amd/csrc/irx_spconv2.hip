@@ -602,6 +602,20 @@ __global__ void k_permute_w(const float* __restrict__ w, int K, int cin, int cou
     reinterpret_cast<float4*>(wf)[f] = v;
 }
 
+// Dev: resident workgroups per CU the runtime reports for the main kernels (tools/micro/occupancy.py)
+extern "C" int irx_debug_occupancy(int which) {
+  int n = -1;
+  hipError_t e = hipSuccess;
+  switch (which) {
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv2<128, 128, false, false>, 256, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv2<64, 64, false, false>, 256, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv2<128, 128, true, true>, 256, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv2<64, 64, true, true>, 256, 0); break;
+    default: return -2;
+  }
+  return e == hipSuccess ? n : -1;
+}
+
 // ---------------------------------------------------------------------------- host dispatch ---
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
