@@ -290,6 +290,9 @@ __global__ void k_ec_reduce(const float* __restrict__ part, int nslabs, size_t s
 static int ec_check(const char* who, int nq, int k, int fin, int nc, int hid, int fout) {
   IRX_REQUIRE(nq >= 0 && k >= 1 && k <= EC_MAXK && fin >= nc && nc >= 0 && hid >= 1 && hid <= 128 && fout >= 1,
               "%s: bad sizes (k <= %d, hid <= 128)", who, EC_MAXK);
+  // the backward reuses the dead d_m tile (16 x fout) as the d_e_in tile (16 x (3 + 2 nc)): reference shapes have
+  // 3 + 2*18 = 39 <= 128 (models/relation_module.py:27-29)
+  IRX_REQUIRE(3 + 2 * nc <= fout, "%s: 3 + 2*nc = %d exceeds fout = %d (edge-input gradient tile)", who, 3 + 2 * nc, fout);
   return IRX_OK;
 }
 

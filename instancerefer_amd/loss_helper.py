@@ -218,7 +218,10 @@ def prepare_labels(data_dict, config, device=None):
     sel, pack = _selection(data_dict), data_dict.get('irx')
     if (torch.device(device).type == "cuda" and sel is not None and 'filtered' in sel
             and getattr(pack, 'obbs_dev', None) is not None and pack.obbs_dev.is_cuda
-            and list(sel['num_filtered_objs']) == counts):
+            and list(sel['num_filtered_objs']) == counts
+            # k_iou_labels / k_eval_select work on axis-aligned boxes (ScanRefer: every heading is 0, lib/dataset.py:216);
+            # a rotated GT or candidate box takes the host path, which rotates the corners like get_3d_box_batch
+            and not np.any(ref_gt_obb[:, 6]) and not any(np.any(p.reshape(-1, 7)[:, 6]) for p in pred_obb_batch if p.shape[0])):
         return _prepare_labels_device(data_dict, out, ref_gt_obb, out.pop("area_label_host", None), sel, pack,
                                       torch.device(device))
     obbs = np.concatenate([p.reshape(-1, 7) for p in pred_obb_batch if p.shape[0]], 0)       # (total, 7)

@@ -97,6 +97,7 @@ class FlatAdam:
         self._todo_last = list(range(len(self.params)))
         self._works = []                # async collectives in flight
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.initial_lr = lr                          # undecayed rate (lr schedules change self.lr only; state_dict keeps both)
         self.steps = [0] * len(self.params)           # torch.optim.Adam keeps `step` per parameter
         self._inactive = frozenset()                  # parameters without a gradient this step
         self._runs_cache = {}
@@ -200,7 +201,10 @@ class FlatAdam:
                 g = self._group_of(idx) if self._multi_rank() else None
                 # early reduction only in segment order: an earlier segment that did not deliver on THIS rank is reduced
                 # after the gather, and the collectives of all ranks must line up
-                if g is not None and g not in self._reduced and all(h in self._reduced for h in range(g)):
+                # (and never for a group that autograd ALSO accumulated into — a second backward before the step,
+                # gradient accumulation: its .grad is added to the slots below, which must happen before the collective)
+                if g is not None and g not in self._reduced and all(h in self._reduced for h in range(g)) \
+                        and not any(self.params[i].grad is not None for i in idx):
                     _, lo, hi = self._groups[g]
                     with torch.cuda.stream(stream):          # ordered behind the producer's kernels, nothing else
                         if isinstance(ev, torch.cuda.Event):
@@ -310,7 +314,9 @@ class FlatAdam:
             state[i] = {"step": torch.tensor(float(self.steps[i])),
                         "exp_avg": self.exp_avg[off:off + p.numel()].view_as(p).clone(),
                         "exp_avg_sq": self.exp_avg_sq[off:off + p.numel()].view_as(p).clone()}
-        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+        # `initial_lr` is what torch's lr schedulers add to a param group (the reference's MultiStepLR does,
+        # lib/solver.py:119-124): the undecayed rate, so a resume can continue the schedule instead of decaying twice
+        group = {"lr": self.lr, "initial_lr": float(self.initial_lr if self.initial_lr is not None else self.lr), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
                  "fused": None, "decoupled_weight_decay": False, "params": list(range(len(self.params)))}
         return {"state": state, "param_groups": [group]}
@@ -324,6 +330,7 @@ class FlatAdam:
             raise ValueError("optimizer state has %d parameters, this model %d" % (len(ids), len(self.params)))
         g0 = groups[0]
         self.lr, self.betas = float(g0["lr"]), tuple(float(b) for b in g0["betas"])
+        self.initial_lr = float(g0["initial_lr"]) if "initial_lr" in g0 else None
         self.eps, self.weight_decay = float(g0["eps"]), float(g0["weight_decay"])
         if g0.get("amsgrad"):
             raise ValueError("amsgrad state is not supported")

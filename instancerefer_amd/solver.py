@@ -50,6 +50,22 @@ def to_device(data_dict, device):
     return data_dict
 
 
+def scheduled_lr(base_lr, epoch, lr_decay_step, lr_decay_rate):
+    """MultiStepLR (reference lib/solver.py:119-124): base_lr * rate ** (number of milestones <= epoch)."""
+    return base_lr * (lr_decay_rate ** sum(epoch >= s for s in lr_decay_step))
+
+
+def resume_base_lr(saved_lr, initial_lr, start_epoch, lr_decay_step, lr_decay_rate):
+    """The UNDECAYED rate of a resumed run. `saved_lr` is the group's lr in the checkpoint — already decayed by the
+    milestones the interrupted run had passed — so using it as the base would decay it a second time. `initial_lr` (what
+    torch's schedulers and this Solver record in the param group) wins; without it the decay of the last epoch trained
+    (start_epoch - 1) is divided out."""
+    if initial_lr is not None:
+        return float(initial_lr)
+    last = max(int(start_epoch) - 1, 0)
+    return float(saved_lr) / (lr_decay_rate ** sum(last >= s for s in lr_decay_step))
+
+
 class Solver:
     def __init__(self, model, config, dataloader, lr=1e-3, weight_decay=1e-5, lr_decay_step=(15, 20), lr_decay_rate=0.1,
                  out_dir=None, verbose=20, device=None, use_checkpoint=None, sync_bn=False):
@@ -67,6 +83,7 @@ class Solver:
                                   module=self.model)
         self.start_epoch = 0
         self.base_lr, self.lr_decay_step, self.lr_decay_rate = lr, tuple(lr_decay_step or ()), lr_decay_rate
+        self.optimizer.initial_lr = lr
         self.out_dir = out_dir
         self.verbose = verbose
         self.best = {"epoch": 0, "iou_rate_0.25": -float("inf"), "iou_rate_0.5": -float("inf"), "ref_acc": -float("inf")}
@@ -117,8 +134,10 @@ class Solver:
         ck = torch.load(path, map_location="cpu", weights_only=False)
         self.model.load_state_dict(ck["model_state_dict"])      # in place: parameters stay views of the flat buffer
         self.optimizer.load_state_dict(ck["optimizer_state_dict"])
-        self.base_lr = self.optimizer.lr
         self.start_epoch = int(ck.get("epoch", 0))
+        self.base_lr = resume_base_lr(self.optimizer.lr, self.optimizer.initial_lr, self.start_epoch, self.lr_decay_step,
+                                      self.lr_decay_rate)
+        self.optimizer.initial_lr = self.base_lr
         return ck
 
     def _forward(self, data_dict):
@@ -126,7 +145,7 @@ class Solver:
 
     def train_epoch(self, epoch):
         self.model.train()
-        self.optimizer.lr = self.base_lr * (self.lr_decay_rate ** sum(epoch >= s for s in self.lr_decay_step))
+        self.optimizer.lr = scheduled_lr(self.base_lr, epoch, self.lr_decay_step, self.lr_decay_rate)
         t0, seen = time.perf_counter(), 0
         for data_dict in self.dataloader["train"]:
             self.optimizer.zero_grad()

@@ -179,6 +179,38 @@ def test_flat_adam_state_dict_is_torch_adam_layout():
             assert torch.equal(fresh.exp_avg[off:off + p.numel()].view_as(p), ta.state[tp[i]]["exp_avg"])
 
 
+def test_resume_continues_the_lr_schedule_instead_of_decaying_twice():
+    """A 30-epoch run with milestones (15, 20) ends at lr * 1e-2; resumed to 40 epochs it must go on at lr * 1e-2, not
+    lr * 1e-4 (the saved rate is already decayed). Covers both checkpoint flavours: with the group's `initial_lr` (this
+    Solver's, or a reference checkpoint whose MultiStepLR recorded it) and without."""
+    from instancerefer_amd.optim import FlatAdam
+    from instancerefer_amd.solver import resume_base_lr, scheduled_lr
+    steps, rate = (15, 20), 0.1
+    for e, want in ((0, 1e-3), (14, 1e-3), (15, 1e-4), (19, 1e-4), (20, 1e-5), (39, 1e-5)):
+        assert abs(scheduled_lr(1e-3, e, steps, rate) - want) <= 1e-12 * want
+    saved = scheduled_lr(1e-3, 29, steps, rate)                      # the rate of the last epoch trained
+    for initial in (1e-3, None):
+        base = resume_base_lr(saved, initial, 30, steps, rate)
+        assert abs(base - 1e-3) <= 1e-15
+        for e in range(30, 40):
+            assert abs(scheduled_lr(base, e, steps, rate) - 1e-5) <= 1e-17
+    assert abs(resume_base_lr(scheduled_lr(1e-3, 16, steps, rate), None, 17, steps, rate) - 1e-3) <= 1e-15
+    # the optimizer state carries both rates, in a layout torch.optim.Adam accepts
+    opt = FlatAdam(_toy().parameters(), lr=1e-3)
+    opt.lr = saved
+    g = opt.state_dict()["param_groups"][0]
+    assert g["lr"] == saved and g["initial_lr"] == 1e-3
+    ta = torch.optim.Adam(_toy().parameters(), lr=1.0)
+    ta.load_state_dict(opt.state_dict())
+    assert ta.param_groups[0]["lr"] == saved and ta.param_groups[0]["initial_lr"] == 1e-3
+    back = FlatAdam(_toy().parameters(), lr=5.0)
+    back.load_state_dict(ta.state_dict())
+    assert back.lr == saved and back.initial_lr == 1e-3
+    plain = torch.optim.Adam(_toy().parameters(), lr=2e-4).state_dict()   # no scheduler ever attached
+    back.load_state_dict(plain)
+    assert back.lr == 2e-4 and back.initial_lr is None
+
+
 @pytest.mark.parametrize("case", ["plain", "augmented"])
 def test_input_pipeline_host_half_matches_reference_getitem(case):
     """scene_input.draw_sample (labels, classes, RNG consumption) against the fixture made by the reference's own

@@ -108,3 +108,22 @@ def test_device_iou_labels_bit_exact_on_random_boxes(lib):
               _lib.ptr(labels), None, None, _lib.ptr(best), _lib.stream_ptr())
     assert np.array_equal(labels.cpu().numpy(), exp_lab)
     assert np.array_equal(best.cpu().numpy(), exp_best)
+
+
+def test_rotated_boxes_take_the_host_path(lib):
+    """the device kernels assume heading 0 (true for every ScanRefer box, lib/dataset.py:216). A batch with a
+    rotated candidate box must fall back to the numpy path (which rotates the corners, utils/box_util.py:154-175) and give
+    what that path gives without a resident pack."""
+    from instancerefer_amd.loss_helper import DatasetConfig, get_loss
+    gold = dict(np.load(os.path.join(G, "loss.npz")))
+    gold["pred_obbs"] = gold["pred_obbs"].copy()
+    gold["pred_obbs"][1, 6] = 0.7
+    dev = torch.device("cuda")
+    res = {}
+    for mode in ("pack", "host"):
+        dd, _ = _batch(gold, dev, with_pack=(mode == "pack"))
+        dd = get_loss(dd, DatasetConfig())
+        assert dd["_labels"].get("dev") is None, mode
+        res[mode] = (np.concatenate([c.cpu().numpy() if len(c) else np.zeros(0) for c in dd["cluster_label"]]),
+                     float(dd["ref_loss"].detach()))
+    assert np.array_equal(res["pack"][0], res["host"][0]) and res["pack"][1] == res["host"][1]

@@ -325,6 +325,19 @@ def test_solver_trains_and_writes_reference_style_checkpoints(lib, tmp_path):
             m.p = 0.0
     s2(2)
     assert len(s2.log["train"]) == 2 and s2.log["train"][0]["loss"] < losses[0]
+    # resuming past a decay milestone continues the schedule (the saved rate is already decayed)
+    s3 = Solver(InstanceRefer(7, S.default_args()), DatasetConfig(), {"train": Repeat(1, 3, seed=40, **kw)}, lr=1e-3,
+                lr_decay_step=(1, 3), out_dir=str(tmp_path / "r3"), verbose=1,
+                use_checkpoint=os.path.join(str(tmp_path / "resumed"), "checkpoint.tar"))
+    assert s3.start_epoch == 2 and s3.base_lr == 1e-3
+    s3.train_epoch(2)
+    assert abs(s3.optimizer.lr - 1e-4) <= 1e-12
+    s3.finish(3)
+    s4 = Solver(InstanceRefer(7, S.default_args()), DatasetConfig(), {"train": Repeat(1, 3, seed=40, **kw)}, lr=1e-3,
+                lr_decay_step=(1, 3), out_dir=str(tmp_path / "r4"), verbose=1,
+                use_checkpoint=os.path.join(str(tmp_path / "r3"), "checkpoint.tar"))
+    s4.train_epoch(3)
+    assert s4.base_lr == 1e-3 and abs(s4.optimizer.lr - 1e-5) <= 1e-13
 
 
 def test_pipelined_training_steps_equal_inline_steps(lib):

@@ -86,6 +86,21 @@ def _worker(rank, world, port, out_dir):
     _, g2 = _step(model2, opt2, batch, dev)
     res["g_eval_2rank"] = (g2 / world).cpu()
     res["p_eval_2rank"] = opt2.flat_p.clone().cpu()
+    # ---- C: gradient accumulation — two backward passes before one step (the second pass arrives through
+    # autograd .grad and is added to the slots, which has to happen BEFORE the segment's collective) ----
+    from instancerefer_amd.loss_helper import DatasetConfig, get_loss
+    ba = S.make_batch(2, seed=860 + 2 * rank, num_candidates=[[3, 2], [2, 3]][rank], **KW)
+    bb = S.make_batch(2, seed=880 + 2 * rank, num_candidates=[[2, 2], [4, 2]][rank], **KW)
+
+    def reduced_grad(batches):
+        opt2.zero_grad()
+        for b in batches:
+            get_loss(model2(S.to_device(b, dev)), DatasetConfig())["loss"].backward()
+        opt2.gather_grads()
+        opt2.all_reduce()
+        torch.cuda.synchronize()
+        return opt2.flat_g[:opt2.n].clone().cpu()
+    res["g_a"], res["g_b"], res["g_ab"] = reduced_grad([ba]), reduced_grad([bb]), reduced_grad([ba, bb])
     dist.barrier()
     if rank == 0:
         model1 = _model(901, dev).eval()
@@ -136,6 +151,11 @@ def test_two_ranks_share_one_gpu_product_path(lib, tmp_path):
     scale = float(g1.abs().max())
     assert scale > 0 and float((g2 - g1).abs().max()) <= 2e-4 * scale, (float((g2 - g1).abs().max()), scale)
     assert abs(float(g2.double().norm()) - float(g1.double().norm())) <= 1e-4 * float(g1.double().norm())
+    # two backward passes before the step: same reduced buffer on both ranks, equal to the sum of the two single passes
+    assert torch.equal(r0["g_ab"], r1["g_ab"])
+    want = r0["g_a"] + r0["g_b"]
+    assert float(want.abs().max()) > 0
+    assert float((r0["g_ab"] - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
 def _rccl_worker(rank, world, port, out_dir):
