@@ -3,6 +3,7 @@
 path on synthetic ScanRefer-shaped scenes, N GPUs of one node, one process per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5        (no torchrun: starts the 8 ranks itself, self_launch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -344,6 +345,98 @@ def cpu_baseline(args, workload):
     return {"error": (r.stderr or r.stdout)[-400:], "cores": threads}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun (WORLD_SIZE unset): start the N ranks ourselves — the reference is a
+    single process (scripts/train.py:216-223), so this launcher is the build's own entry to the N-GPU path. The ranks run
+    under torch.distributed.run (standalone rendezvous on 127.0.0.1, a free port); their output is relayed, and rank 0's
+    JSON line is re-printed LAST on stdout. Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, IRX_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", "4")              # torchrun would set 1 and warn; main() caps per rank anyway
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes needs it on this driver)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_json = None
+    for line in proc.stdout:
+        t = line.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line_json = t                                # held back: printed last
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if line_json is None:
+        print("bench.py --gpus %d: the %d-rank launch produced no result line (exit %d)" % (args.gpus, args.gpus, rc),
+              file=sys.stderr)
+        return rc or 1
+    n = json.loads(line_json).get("n_gpus")
+    if n != args.gpus:
+        print("bench.py --gpus %d: result line reports n_gpus = %r" % (args.gpus, n), file=sys.stderr)
+        return 1
+    print(line_json, flush=True)
+    return rc
+
+
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out += list(range(int(a), int(b) + 1))
+        elif part:
+            out.append(int(part))
+    return out
+
+
+def bind_rank_to_cores(local_rank, world, device_index, share=False):
+    """One process per GPU: give each rank its own slice of host cores — the cores of its GPU's NUMA node (PCI bus id ->
+    /sys/bus/pci/devices/<bdf>/numa_node -> node cpulist) divided among the ranks whose GPUs sit on that node, or an even
+    slice of the allowed cores when the topology is not readable — and cap the intra-op thread pools. 8 ranks x (Python
+    + 2 library lanes + a preparation worker) otherwise wander over all cores and across sockets. Returns a description."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return {"cores": None}
+    if world <= 1 or len(allowed) < 2 * world:
+        torch.set_num_threads(max(1, min(4, len(allowed))))
+        return {"cores": len(allowed), "numa": None}
+    node_of = {}
+    if not share:
+        for r in range(world):
+            try:
+                pr = torch.cuda.get_device_properties(r)
+                bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+                with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+                    node_of[r] = int(f.read())
+            except (OSError, AttributeError, ValueError, RuntimeError):
+                node_of = {}
+                break
+    mine, numa = None, None
+    if node_of and node_of.get(local_rank, -1) >= 0:
+        numa = node_of[local_rank]
+        try:
+            with open("/sys/devices/system/node/node%d/cpulist" % numa) as f:
+                cpus = [c for c in _cpulist(f.read()) if c in set(allowed)]
+            peers = sorted(r for r, n in node_of.items() if n == numa)
+            per = len(cpus) // len(peers)
+            if per >= 2:
+                i = peers.index(local_rank)
+                mine = cpus[i * per:(i + 1) * per]
+        except (OSError, ValueError):
+            mine = None
+    if mine is None:
+        per = len(allowed) // world
+        mine = allowed[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(4, len(mine))))
+    return {"cores": len(mine), "numa": numa, "first_core": mine[0]}
+
+
 def log(msg):
     if os.environ.get("IRX_BENCH_VERBOSE"):
         print("[bench %.1fs] %s" % (time.perf_counter() - log.t0, msg), file=sys.stderr, flush=True)
@@ -360,13 +453,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                      # no torchrun around us: start the N ranks ourselves
+    if args.gpus != world:                               # never report n_gpus: 1 for --gpus 8 (or the reverse)
         raise SystemExit("--gpus %d != WORLD_SIZE %d" % (args.gpus, world))
     import torch.distributed as dist
     # IRX_BENCH_SHARE_GPU=1 (test only): all ranks use cuda:0 and gloo, to exercise the multi-rank logic on a 1-GPU box
     share = os.environ.get("IRX_BENCH_SHARE_GPU") == "1"
     device = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(device)
+    binding = bind_rank_to_cores(local_rank, world, device.index, share) if os.environ.get("IRX_BENCH_NO_BIND") != "1" else None
     # IRX_BENCH_FORCE_DIST=1 (test only, N = 1): a one-rank RCCL group, every collective of the N > 1 path issued for real
     force_dist = world == 1 and os.environ.get("IRX_BENCH_FORCE_DIST") == "1"
     if world > 1:
@@ -554,7 +650,8 @@ def main():
                        "instances": args.instances, "candidates": args.candidates, "tokens": args.tokens,
                        "input_channels": 7 + args.multiview,
                        "scene_voxels_per_gpu": n_scene_vox, "parallelism": "dp%d" % world, "sync_bn": bool(args.sync_bn and world > 1), "loss": final_loss,
-                       "input_prep": "inline" if args.no_pipeline else "side-stream prefetch of step N+1 during step N"},
+                       "input_prep": "inline" if args.no_pipeline else "side-stream prefetch of step N+1 during step N",
+                       "host_binding_rank0": binding},
             "roofline": roof if roof_error is None else {"error": roof_error},
         }
         if alt is not None:

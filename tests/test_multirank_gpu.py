@@ -282,3 +282,28 @@ def test_sync_batchnorm_two_ranks_equal_one_rank_on_the_whole_batch(lib, tmp_pat
     assert abs(0.5 * (r0["loss"] + r1["loss"]) - r0["loss_1rank"]) <= 1e-4 * abs(r0["loss_1rank"])
     # rank 0's own half batch without the cross-rank statistics gives another gradient altogether
     assert float((r0["g_local_only"] - g1).abs().max()) > 50 * float((g2 - g1).abs().max())
+
+
+def test_bench_gpus_n_launches_n_ranks_itself(lib):
+    """`python bench.py --gpus 2` WITHOUT torchrun must run two ranks (self_launch) and report n_gpus = 2 in
+    the last stdout line; here both ranks share cuda:0 over gloo (IRX_BENCH_SHARE_GPU), the only multi-rank rig one GPU
+    allows. A --gpus / WORLD_SIZE mismatch is refused instead of mislabelled."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IRX_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--points", "6000", "--no-cpu-baseline", "--no-alt-dtype", "--profile-steps", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    last = r.stdout.strip().splitlines()[-1]
+    out = json.loads(last)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["scaling"] == "weak"
+    # one rank asked to call itself eight: refused
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=env1)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
