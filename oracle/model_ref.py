@@ -18,6 +18,7 @@ from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 from .torchsparse import SparseTensor
 from .torchsparse import nn as spnn
+from .torchsparse.nn import emulate
 from .torchsparse.utils import sparse_quantize, sparse_collate_tensors
 from .torch_geometric.nn import MessagePassing, knn
 
@@ -54,7 +55,11 @@ class SparseConvEncoder(nn.Module):
         self.stage4 = nn.Sequential(BasicConvolutionBlock(128, 128, 2, 2), ResidualBlock(128, 128))
 
     def forward(self, x):
-        return self.stage4(self.stage3(self.stage2(self.stage1(self.stem(x)))))
+        # (emulate.encoder_scope: no-op unless the build's bf16 storage mode is being emulated; the build's one-call
+        # executor, where that storage lives, covers training mode only)
+        n_relu = sum(isinstance(m, spnn.ReLU) for m in self.modules())
+        with emulate.encoder_scope(n_relu, self.training and torch.is_grad_enabled()):
+            return self.stage4(self.stage3(self.stage2(self.stage1(self.stem(x)))))
 
 
 class DynamicEdgeConv(MessagePassing):
@@ -92,8 +97,13 @@ class ToDenseBEV(nn.Module):
         hi = torch.tensor([nx * s, ny * s, nz * s])
         valid = ((C[:, :3] >= 0) & (C[:, :3] < hi)).all(-1)
         F, C = F[valid], C[valid]
-        rows = torch.bmm(F.unsqueeze(1), self.kernel.index_select(0, C[:, 2] // s)).squeeze(1)
         cell = C[:, 3] * (nx * ny) + (C[:, 0] // s) * ny + (C[:, 1] // s)
+        if emulate.MODE is not None:     # the build's bf16 modes: this is a k_spconv2 launch with the z-bins as offsets
+            zb = C[:, 2] // s
+            maps = [(torch.nonzero(zb == k).flatten(), cell[zb == k]) for k in range(nz)]
+            bev = emulate.conv(F, self.kernel, maps, batch_size * nx * ny, pair_lists=False)
+            return bev.view(batch_size, nx, ny, -1).permute(0, 3, 1, 2).contiguous()
+        rows = torch.bmm(F.unsqueeze(1), self.kernel.index_select(0, C[:, 2] // s)).squeeze(1)
         bev = torch.zeros(batch_size * nx * ny, rows.shape[1]).index_add(0, cell, rows)
         return bev.view(batch_size, nx, ny, -1).permute(0, 3, 1, 2).contiguous()
 
@@ -207,7 +217,8 @@ class SceneModule(nn.Module):
         B = dd['point_min'].shape[0]
         pob = dd['pred_obb_batch']
         f = self.to_bev[3](self.to_bev[2](self.to_bev[1](self.net(dd['lidar']), B)))
-        f = self.vis_emb_fc(f)
+        for m in self.vis_emb_fc:        # (emulate.conv2d == m(f) unless a bf16 mode of the build is being emulated)
+            f = emulate.conv2d(m, f) if isinstance(m, nn.Conv2d) else m(f)
         h, w = f.shape[-2:]
         f = f.reshape(B, 128, -1).permute(0, 2, 1)
         lang = self.lang_emb_fc(dd['lang_scene_feats']).unsqueeze(2)
@@ -225,12 +236,20 @@ class InstanceRefer(nn.Module):
         super().__init__()
         self.args = args
         self.lang = LangModule(args.num_classes, True, args.use_bidir, 300, 128)
-        self.attribute = AttributeModule(input_feature_dim, args)
-        self.relation = RelationModule(input_feature_dim, args)
-        self.scene = SceneModule(input_feature_dim, args)
+        # modules named None / "" in the config are absent (models/instancerefer.py:24-34,56-68)
+        if getattr(args, "attribute_module", True):
+            self.attribute = AttributeModule(input_feature_dim, args)
+        if getattr(args, "relation_module", True):
+            self.relation = RelationModule(input_feature_dim, args)
+        if getattr(args, "scene_module", True):
+            self.scene = SceneModule(input_feature_dim, args)
 
     def forward(self, dd):
-        return self.scene(self.relation(self.attribute(self.lang(dd))))
+        dd = self.lang(dd)
+        for name in ("attribute", "relation", "scene"):
+            if getattr(self.args, name + "_module", True):
+                dd = getattr(self, name)(dd)
+        return dd
 
 
 def oracle_data_dict(dd_host, voxel_size_glp=0.05):

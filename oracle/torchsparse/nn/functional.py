@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from ..tensor import SparseTensor
+from . import emulate
 
 _R = 1 << 17  # coordinate range for packing (x,y,z,b) into one int64 key
 _OFF = 1 << 16
@@ -61,7 +62,10 @@ def build_kernel_map(in_coords, out_coords, offsets):
 
 
 def sparseconv_op(features, kernel, maps, n_out):
-    """out[o] += features[i] @ kernel[k] for every pair (i, o) of offset k — gather, GEMM, scatter-add."""
+    """out[o] += features[i] @ kernel[k] for every pair (i, o) of offset k — gather, GEMM, scatter-add.
+    (emulate.MODE set: the same sum with the build's bf16 rounding points, oracle/torchsparse/nn/emulate.py.)"""
+    if emulate.MODE is not None:
+        return emulate.conv(features, kernel, maps, n_out)
     out = torch.zeros(n_out, kernel.shape[-1], dtype=features.dtype)
     for k, (i_idx, o_idx) in enumerate(maps):
         if i_idx.numel() == 0:

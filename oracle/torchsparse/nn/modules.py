@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from ..tensor import SparseTensor
+from . import emulate
 from . import functional as spf
 
 
@@ -45,7 +46,7 @@ class BatchNorm(nn.BatchNorm1d):
 
 class ReLU(nn.ReLU):
     def forward(self, inputs):
-        out = super().forward(inputs.F)
+        out = emulate.on_relu(super().forward(inputs.F))
         t = SparseTensor(out, inputs.C, inputs.s)
         t.coord_maps = inputs.coord_maps
         t.kernel_maps = inputs.kernel_maps

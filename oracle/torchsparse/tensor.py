@@ -28,7 +28,8 @@ class SparseTensor:
         return self
 
     def __add__(self, other):
-        t = SparseTensor(self.F + other.F, self.C, self.s)
+        from .nn import emulate          # (`net(x) + shortcut`: other is the shortcut, models/basic_blocks.py:55)
+        t = SparseTensor(self.F + emulate.on_shortcut(other.F), self.C, self.s)
         t.coord_maps = self.coord_maps
         t.kernel_maps = self.kernel_maps
         return t

@@ -183,3 +183,196 @@ def test_encoder_fwd_bwd_equals_c_port_at_full_size(lib, which, weights):
         if e > tol_max * max(float(np.abs(ref).max()), 1e-3 * top) or l2 > tol_l2:
             bad[name] = (e, float(np.abs(ref).max()), l2)
     assert not bad, bad
+
+
+# ---- BASELINE configs[4]: dense-scene stress — 200 k points, 64 instances, 16 candidates, multiview C0 = 135, bf16 ----------
+STRESS = dict(batch_size=2, seed=4321, num_points=200000, num_instances=64, num_candidates=16, multiview=128)
+
+
+@pytest.fixture(scope="module")
+def stress_batch():
+    from instancerefer_amd import synthetic as S
+    return S.make_batch(**dict(STRESS))
+
+
+def test_stress_scene_pyramid_tables_and_encoder_vs_c_port(lib, stress_batch):
+    """configs[4]'s scene tensor (2 x 200 k points -> > 150 k voxels, 135 channels; reference scripts/train.py:74-75,
+    lib/dataset.py:112-118): pyramid sortedness / parent consistency, neighbour-table symmetry, pair-list counts (exact),
+    then the C0 = 135 scene encoder forward + backward in fp32 against the C/OpenMP port (pooled features <= 1e-4; with
+    kink-free BatchNorm shifts every parameter gradient <= 1e-3 of its max-norm, incl. the 27 x 135 x 32 stem kernel)."""
+    from oracle import cpu_port
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.basic_blocks import SparseConvEncoder
+    from instancerefer_amd.sparse import nn as spnn
+    from instancerefer_amd.sparse.utils import voxelize
+    dev = torch.device("cuda")
+    pts = [torch.from_numpy(p) for p in stress_batch["scene_points"]]
+    assert pts[0].shape == (200000, 135)
+    allp = torch.cat(pts).to(dev)
+    batch = torch.cat([torch.full((p.shape[0],), i, dtype=torch.int32) for i, p in enumerate(pts)]).to(dev)
+    st = voxelize(allp[:, :3].contiguous(), allp.float(), batch, [0.05] * 3, 2)
+    lv = st.level()
+    lv.build_pyramid(4)
+    assert lv.n > 150_000 and st.F.shape[1] == 135
+    stride, l = 1, lv
+    for _ in range(5):
+        assert bool((l.keys[1:] > l.keys[:-1]).all())
+        assert bool((l.coords[:, :3] % stride == 0).all())
+        tbl, _ = l.nbr27()
+        t = tbl[:, :l.n]
+        ar = torch.arange(l.n, device=dev, dtype=torch.int32)
+        assert torch.equal(t[13], ar)
+        for k in (1, 9):
+            v = t[k] >= 0
+            assert torch.equal(t[26 - k].index_select(0, t[k][v].long()), ar[v])
+        _, _, counts, _ = l.pairs27()
+        assert torch.equal(counts.long(), (t >= 0).sum(1))
+        if stride < 16:
+            dm = l.down()
+            exp = torch.div(l.coords[:, :3], 2 * stride, rounding_mode="floor") * (2 * stride)
+            got = dm.out_level.coords.index_select(0, dm.parent.long())
+            assert torch.equal(got[:, :3], exp) and torch.equal(got[:, 3], l.coords[:, 3])
+            l = dm.out_level
+        stride *= 2
+    enc = SparseConvEncoder(135)
+    sd = S.seeded_state_dict(enc, 4242)
+    for k in sd:
+        if k.endswith("net.1.bias") or k.endswith("net.4.bias"):
+            sd[k] = sd[k] + 6.0
+    enc.load_state_dict(sd)
+    enc = enc.to(dev).train()
+    g = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 128)).astype(np.float32))
+    pooled = spnn.GlobalMaxPooling()(enc(st))
+    (pooled * g.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    params, order = cpu_port.pack_encoder_params({k: v.detach().cpu() for k, v in enc.state_dict().items()}, "")
+    _, cpooled, cgrads = cpu_port.encoder_fwd_bwd(st.C.cpu().numpy(), st.F.detach().cpu().numpy(), 2, params, g.numpy(),
+                                                  wgrad_double=True)
+    assert float(np.abs(pooled.detach().cpu().numpy() - cpooled).max()) <= 1e-4
+    named = dict(enc.named_parameters())
+    refs, off = {}, 0
+    for conv, bn in order:
+        for name in (conv + ".kernel", bn + ".weight", bn + ".bias"):
+            n = named[name].numel()
+            refs[name] = cgrads[off:off + n]
+            off += n
+    assert off == cgrads.size and refs["stem.0.net.0.kernel"].size == 27 * 135 * 32
+    top = max(float(np.abs(r).max()) for r in refs.values())
+    bad = {}
+    for name, ref in refs.items():
+        got = named[name].grad.detach().cpu().numpy().reshape(-1)
+        e = float(np.abs(got - ref).max())
+        if e > 1e-3 * max(float(np.abs(ref).max()), 1e-3 * top):
+            bad[name] = (e, float(np.abs(ref).max()))
+    assert not bad, bad
+
+
+def test_stress_full_model_bf16_equals_the_emulating_oracle(lib, stress_batch):
+    """configs[4] at its own dtype and size (B = 2): the FULL model in the bf16 mode BASELINE names (bf16 operands + bf16
+    storage in both encoders: wide stem with bf16 output, pair-list weight-gradient reading x with a row stride and a
+    separately typed dy, 2 x 16 candidates of 64 instances, relation graph on 153-feature nodes) against
+    oracle/model_ref.py with the same rounding points (oracle/torchsparse/nn/emulate.py). Discrete decisions identical;
+    scores, pooled features, loss <= 1e-3 of max(1, |expected|max); total gradient norm within 1e-2."""
+    import instancerefer_amd as irx
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.instancerefer import InstanceRefer
+    from instancerefer_amd.loss_helper import DatasetConfig, get_loss
+    from oracle.model_ref import InstanceRefer as OracleModel, oracle_data_dict
+    from oracle.torchsparse.nn import emulate
+    dev = torch.device("cuda")
+    model = InstanceRefer(135, S.default_args())
+    sd = S.seeded_state_dict(model, 99)
+    model.load_state_dict(sd)
+    oracle = OracleModel(135, S.default_args())
+    oracle.load_state_dict(sd)
+    for m in list(model.modules()) + list(oracle.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.to(dev).train()
+    oracle.train()
+    host = dict(stress_batch)
+    irx.set_compute_dtype("bf16")
+    try:
+        dd = get_loss(model(S.to_device(dict(host), dev)), DatasetConfig())
+        dd["loss"].backward()
+        torch.cuda.synchronize()
+    finally:
+        irx.set_compute_dtype("fp32")
+    with emulate.mode("bf16"):
+        od = get_loss(oracle(oracle_data_dict(dict(host))), DatasetConfig())
+        od["loss"].backward()
+    assert list(dd["num_filtered_objs"]) == list(od["num_filtered_objs"]) == [16, 16]
+    lab = np.concatenate([c.cpu().numpy() for c in dd["cluster_label"]])
+    assert np.array_equal(lab, np.concatenate([c.cpu().numpy() for c in od["cluster_label"]]))
+    worst = {}
+    for k in ("lang_scores", "obj_feats", "attribute_scores", "relation_scores", "scene_scores", "seg_scores", "vis_atten",
+              "loss", "ref_loss", "lang_loss", "seg_loss"):
+        exp = od[k].detach()
+        worst[k] = float((dd[k].detach().cpu() - exp).abs().max()) / max(1.0, float(exp.abs().max()))
+    print("stress bf16 vs emulation:", {k: "%.1e" % v for k, v in worst.items()})
+    assert all(v <= 1e-3 for v in worst.values()), worst
+    tot_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in oracle.parameters() if p.grad is not None)))
+    tot_d = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    assert abs(tot_d - tot_o) <= 1e-2 * tot_o, (tot_d, tot_o)
+
+
+@pytest.mark.parametrize("which", ["full", "attr_only"])
+def test_whole_model_at_baseline_size_vs_oracle(lib, which):
+    """BASELINE configs[2] / configs[1] shapes through the WHOLE model, not only the encoders: 16 scenes x 50 k points, 8
+    instances, 4 candidates each (64 candidates), 30-token utterances, fp32, training mode — language module, candidate
+    encoder + max-pool, relation graph, BEV + scene head, the three matching heads, get_loss — vs oracle/model_ref.py
+    (pinned to the reference's own models/instancerefer.py:37-70 output by tests/test_oracle_cpu.py). "attr_only" is
+    configs[1]'s model: relation_module = scene_module = None (reference models/instancerefer.py:24-34,56-68).
+    Forward tensors <= 1e-4 absolute (the north star's bar); loss terms <= 1e-4; gradient norms 2e-3 per parameter
+    (floor: 1e-3 of the total), total 1e-3."""
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.instancerefer import InstanceRefer
+    from instancerefer_amd.loss_helper import DatasetConfig, compute_lang_classification_loss, get_loss
+    from oracle.model_ref import InstanceRefer as OracleModel, oracle_data_dict
+    dev = torch.device("cuda")
+    args = S.default_args()
+    if which == "attr_only":
+        args.relation_module = None
+        args.scene_module = None
+    model = InstanceRefer(7, args)
+    sd = S.seeded_state_dict(model, 2024)
+    model.load_state_dict(sd)
+    oracle = OracleModel(7, args)
+    oracle.load_state_dict(sd)
+    assert hasattr(oracle, "relation") == (which == "full") and hasattr(model, "relation") == (which == "full")
+    for m in list(model.modules()) + list(oracle.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.to(dev).train()
+    oracle.train()
+    host = S.make_batch(16, seed=123)                    # bench.py's batch: 50 k points, 8 instances, 4 candidates
+    dd = model(S.to_device(dict(host), dev))
+    od = oracle(oracle_data_dict(dict(host)))
+    keys = ["lang_scores", "obj_feats", "attribute_scores"]
+    if which == "full":
+        dd, od = get_loss(dd, DatasetConfig()), get_loss(od, DatasetConfig())
+        keys += ["relation_scores", "scene_scores", "seg_scores", "vis_atten", "loss", "ref_loss", "lang_loss", "seg_loss"]
+        ld, lo = dd["loss"], od["loss"]
+    else:
+        # configs[1] has no relation / scene scores for get_loss's sum: language CE + a dense functional of the scores
+        ld = compute_lang_classification_loss(dd) + (dd["attribute_scores"] * dd["attribute_scores"]).sum()
+        lo = compute_lang_classification_loss(od) + (od["attribute_scores"] * od["attribute_scores"]).sum()
+    assert list(dd["num_filtered_objs"]) == list(od["num_filtered_objs"]) == [4] * 16
+    assert dd["attribute_scores"].shape == (64,)
+    worst = {k: float((dd[k].detach().cpu() - od[k].detach()).abs().max()) for k in keys}
+    assert all(v <= 1e-4 for v in worst.values()), worst
+    ld.backward()
+    lo.backward()
+    gp = dict(model.named_parameters())
+    tot_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in oracle.parameters() if p.grad is not None)))
+    tot_d = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    assert abs(tot_d - tot_o) <= 1e-3 * tot_o, (tot_d, tot_o)
+    bad = {}
+    for n, p in oracle.named_parameters():
+        if p.grad is None:
+            assert gp[n].grad is None or float(gp[n].grad.abs().max()) == 0.0, n
+            continue
+        exp, got = float(p.grad.double().norm()), float(gp[n].grad.double().norm())
+        if abs(got - exp) > 2e-3 * max(exp, 1e-3 * tot_o):
+            bad[n] = (got, exp)
+    assert not bad, bad

@@ -182,3 +182,70 @@ def test_oracle_projection_matches_reference_fixture():
             assert np.array_equal(i3, g["ind3d/%d" % i]) and np.array_equal(i2, g["ind2d/%d" % i])
             assert np.array_equal(PR.project(feats[i], i3, i2, len(pts))[:, i3], g["proj/%d" % i])
     assert total > 1000
+
+
+def test_bf16_emulation_rounding_points():
+    """oracle/torchsparse/nn/emulate.py (the CPU bar for the build's bf16 modes, tests/test_bf16_gpu.py): with mode None the
+    oracle is untouched; its hand-written conv backward equals autograd's; "bf16_operands" = the plain conv on operands
+    rounded to bf16; "bf16" stores every layer output of an encoder pass except the last as bf16 and rounds the gradients in
+    flight, while parameters / parameter gradients / the final output stay fp32."""
+    from helpers import oracle_batch, surface_cloud
+    from oracle.model_ref import SparseConvEncoder
+    from oracle.torchsparse import nn as ospnn
+    from oracle.torchsparse.nn import emulate, functional as spf
+    rng = np.random.default_rng(2)
+    clouds = [surface_cloud(rng, 1500, rng.uniform(0, 2, 3), rng.uniform(0.8, 1.6, 3)) for _ in range(2)]
+    st = oracle_batch(clouds, 0.05)
+    n = st.C.shape[0]
+    maps = spf.build_kernel_map(st.C, st.C, spf.kernel_offsets(3, 1, 1))
+    torch.manual_seed(0)
+    x = torch.randn(n, 64, requires_grad=True)
+    w = (torch.randn(27, 64, 32) * 0.1).requires_grad_(True)
+    g = torch.randn(n, 32)
+    plain = spf.sparseconv_op(x, w, maps, n)
+    dx0, dw0 = torch.autograd.grad(plain, (x, w), g)
+    y = emulate._Conv.apply(x, w, maps, n, (False, False, False))
+    dx1, dw1 = torch.autograd.grad(y, (x, w), g)
+    assert torch.allclose(y, plain, atol=1e-6) and torch.allclose(dx1, dx0, atol=1e-5) and torch.allclose(dw1, dw0, atol=1e-4)
+    with emulate.mode("bf16_operands"):
+        yq = spf.sparseconv_op(x, w, maps, n)
+        dxq, dwq = torch.autograd.grad(yq, (x, w), g)
+    r = emulate.rb
+    xr, wr = r(x.detach()).requires_grad_(True), r(w.detach()).requires_grad_(True)
+    yr = spf.sparseconv_op(xr, wr, maps, n)
+    dxr, dwr = torch.autograd.grad(yr, (xr, wr), r(g))
+    assert torch.allclose(yq, yr, atol=1e-6) and torch.allclose(dxq, dxr, atol=1e-5) and torch.allclose(dwq, dwr, atol=1e-4)
+    assert float((yq - plain).abs().max()) > 1e-4
+    # whole encoder, storage mode
+    enc = SparseConvEncoder(7).train()
+    enc.load_state_dict(S.seeded_state_dict(enc, 5))
+    seen = []
+    hooks = [m.register_forward_hook(lambda m_, i_, o_: seen.append(o_.F.detach().clone()))
+             for m in enc.modules() if isinstance(m, ospnn.ReLU)]
+    out32 = enc(st).F.detach().clone()
+    assert len(seen) == 13 and any(not torch.equal(r(t), t) for t in seen[:12])
+    seen.clear()
+    for b in enc.modules():
+        if isinstance(b, torch.nn.BatchNorm1d):
+            b.reset_running_stats()
+    with emulate.mode("bf16"):
+        y = enc(st)
+        assert all(torch.equal(r(t), t) for t in seen[:12]), "layer outputs inside the executor are bf16 values"
+        assert not torch.equal(r(seen[12]), seen[12]), "the encoder's output stays fp32"
+        y.F.square().sum().backward()
+    for h in hooks:
+        h.remove()
+    rel = float((y.F.detach() - out32).norm() / out32.norm())
+    assert 1e-4 < rel < 1e-1, rel
+    grads = [p.grad for p in enc.parameters()]
+    assert all(gr is not None and bool(torch.isfinite(gr).all()) for gr in grads)
+    assert any(not torch.equal(r(gr), gr) for gr in grads), "parameter gradients are fp32"
+    with emulate.mode("bf16"):
+        enc.eval()                       # the executor (and with it the storage rounding) is a training-mode path
+        with torch.no_grad():
+            seen2 = []
+            h = [m.register_forward_hook(lambda m_, i_, o_: seen2.append(o_.F.clone())) for m in enc.modules() if isinstance(m, ospnn.ReLU)]
+            enc(st)
+            for hh in h:
+                hh.remove()
+        assert any(not torch.equal(r(t), t) for t in seen2[:12])
