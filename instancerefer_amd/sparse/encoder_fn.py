@@ -158,6 +158,37 @@ def lane_wait(lane):
         _lib.check(rc, "irx_encoder (asynchronous pass)")
 
 
+# Tests only (tests/test_bf16_gpu.py): a dict that receives the executor's arenas, so that every layer's stored tensors
+# (conv output c_i, layer output y_i, gradient in flight gy_i) can be compared one layer at a time; None = no tracing.
+TRACE = None
+
+
+def trace_tensors(tr):
+    """TRACE dict -> {"x": [...], "c": [...], "y": [...], "mean", "invstd", "gy": [...]} as float32 tensors on the device
+    (bf16-stored tensors widened exactly), one entry per layer; call after a device sync."""
+    f = tr["fwd"]
+    nl, n_out, cout = len(f["layers"]), f["n_out"], f["cout"]
+
+    def view(buf, off, n, c, bf):
+        if bf:
+            return buf[off:off + 2 * n * c].view(torch.bfloat16).view(n, c).float()
+        return buf[off:off + 4 * n * c].view(_f32).view(n, c).clone()
+    out = {"c": [], "y": [], "x": [f["x0"]], "mean": [], "invstd": [], "gy": []}
+    for i in range(nl):
+        n, c = int(n_out[i]), int(cout[i])
+        out["c"].append(view(f["arena"], int(f["start"][i]), n, c, f["store"]))
+        out["y"].append(view(f["arena"], int(f["start"][i] + f["cb"][i]), n, c, f["store"] and i < nl - 1))
+        out["mean"].append(f["stats"][i, 0, :c].clone())
+        out["invstd"].append(f["stats"][i, 1, :c].clone())
+    out["x"] += out["y"][:-1]
+    b = tr.get("bwd")
+    if b is not None:
+        for i in range(nl - 1):
+            out["gy"].append(view(b["garena"], int(b["goffs"][i]), int(n_out[i]), int(cout[i]), b["store"]))
+        out["gy"].append(b["dout"])
+    return out
+
+
 class EncoderFn(torch.autograd.Function):
     """forward / backward = one irx_encoder_forward / irx_encoder_backward call over a descriptor table; activations,
     gradients-in-flight and parameter gradients live in three arenas allocated once per call. The table is a cached
@@ -214,6 +245,9 @@ class EncoderFn(torch.autograd.Function):
             torch._foreach_add_(counters, 1)
         ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = layers, desc, fdesc, (n_out, cout, poffs, ptotal)
         ctx.store, ctx.prof = store, prof
+        if TRACE is not None:
+            TRACE["fwd"] = dict(layers=layers, arena=arena, stats=stats, x0=x0, start=start, cb=cb, n_out=n_out, cout=cout,
+                                store=store)
         # gradient sink (optim.FlatAdam): parameter gradients can go straight into the optimizer's flat buffer
         sink = getattr(params[0], "_irx_sink", None)
         ctx.sink = (sink[0], id(encoder), params) if sink is not None else None
@@ -247,6 +281,8 @@ class EncoderFn(torch.autograd.Function):
         else:
             pptr = np.fromiter((t.data_ptr() for t in slots), dtype=np.int64, count=3 * nl).reshape(nl, 3)
         gbase = garena.data_ptr()
+        if TRACE is not None:
+            TRACE["bwd"] = dict(garena=garena, goffs=goffs, dout=dout, store=store)
         desc = ctx.desc.copy()
         need_dx0 = ctx.needs_input_grad[0]
         # pair lists still missing for this pyramid: all of them in one library call

@@ -2,9 +2,18 @@
 bf16 modes of libirx.so (include/irx.h irx_set_compute_dtype: 1 = bf16 operands, 2 = + bf16 storage inside the encoder
 executor) is built here: the CPU oracle with the SAME rounding points (oracle/torchsparse/nn/emulate.py — operands rounded
 to bf16 where the matrix core consumes them, every conv output / layer output / gradient in flight rounded where the
-executor stores it) and fp32 everywhere else. HIP vs that emulation differs only by fp32 summation order, plus the rare
-value that sits within that round-off of a bf16 tie and is rounded the other way: relative L2 <= 1e-3 per tensor
-(measured: 1e-5 .. 3e-4), against 1e-2 .. 2e-1 for HIP-bf16 vs the fp32 oracle — the emulation explains the whole gap."""
+executor stores it) and fp32 everywhere else.
+
+Rounding is discontinuous, so two correct implementations that sum in a different order drift apart through a chain of
+rounded layers (1e-7 -> 3e-5 -> 4e-4 -> ... -> the bf16 noise floor; emulate.py's header, tools/bf16_emul_diag.py). The
+arithmetic is therefore pinned in two ways:
+  (a) LAYER BY LAYER ("teacher forced"): every layer of the executor, forward and backward, recomputed by the emulation
+      from the executor's OWN stored inputs (bit-identical) — conv output, BatchNorm statistics, layer output, data-,
+      weight-, scale- and shift-gradients, shortcut gradient: <= 2e-4 relative L2 each (measured ~3e-5: only values within
+      fp32 round-off of a bf16 tie differ, by one bf16 ulp);
+  (b) END TO END: HIP vs the emulation no further apart than the emulation is from ITSELF with another summation order
+      (float64 accumulation) — median ratio <= 1.5 over all tensors, every tensor <= 4x — and closer to the emulation than
+      to the fp32 oracle (measured on the encoder output: 6e-3 vs 1e-2)."""
 import os
 
 import numpy as np
@@ -34,80 +43,167 @@ def _encoder_pair(c0, seed):
     return enc.cuda().train(), ora.train()
 
 
-def _run_encoder_both(enc, ora, clouds, voxel, mode, rng):
-    """-> dict of (got, exp) pairs: output rows (aligned), parameter gradients, BatchNorm running statistics."""
-    import instancerefer_amd as irx
-    from oracle.torchsparse.nn import emulate
-    d = device_batch(clouds, voxel)
-    o = oracle_batch(clouds, voxel)
-    irx.set_compute_dtype(mode)
-    try:
-        yd = enc(d)
-        with emulate.mode(mode):
-            yo = ora(o)
-        ja, jb = align(yd.C.cpu().numpy(), yo.C.numpy())
-        g = torch.from_numpy(rng.standard_normal((len(ja), yd.F.shape[1])).astype(np.float32))
-        gd = torch.empty_like(g); gd[ja] = g
-        go = torch.empty_like(g); go[jb] = g
-        # dense loss on the stride-16 map: every row carries gradient (a max-pool would route all of it through arg-max
-        # picks that a single re-drawn bf16 rounding can move)
-        (yd.F * gd.cuda()).sum().backward()
-        with emulate.mode(mode):
-            (yo.F * go).sum().backward()
-        torch.cuda.synchronize()
-    finally:
-        irx.set_compute_dtype("fp32")
-    out = {"out": (yd.F.detach().cpu()[ja], yo.F.detach()[jb])}
-    op = dict(ora.named_parameters())
-    for n, p in enc.named_parameters():
-        out["grad/" + n] = (p.grad.detach().cpu(), op[n].grad)
-    ob = dict(ora.named_buffers())
-    for n, b in enc.named_buffers():
-        if b.dtype.is_floating_point:
-            out["buf/" + n] = (b.detach().cpu(), ob[n])
-    return out
+def _maps_from_table(tbl, K, n_out):
+    t = tbl[:K, :n_out].cpu().long()
+    maps = []
+    for k in range(K):
+        v = torch.nonzero(t[k] >= 0).flatten()
+        maps.append((t[k][v], v))
+    return maps
 
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("c0", [7, 135])
-def test_encoder_bf16_modes_equal_the_emulating_oracle(lib, c0, mode):
-    """The 13-conv encoder through the one-call executor, training mode, C0 = 7 and the multiview C0 = 135 (reference
-    scripts/train.py:74-75: wide stem with bf16 output, k_wgrad_pairs reading x with a row stride and a separately typed
-    dy) in both bf16 modes, against the oracle with the same rounding points: output, all 39 parameter gradients and
-    the BatchNorm running statistics <= 1e-3 relative L2 each; and the emulation is not vacuous — the same HIP results are
-    >= 10x further from the fp32 oracle."""
+def test_executor_bf16_layer_by_layer(lib, c0, mode):
+    """(a) of the module docstring, for C0 = 7 and the multiview C0 = 135 (reference scripts/train.py:74-75: wide stem with
+    bf16 output and double rounding, k_wgrad_pairs reading x with a row stride and a separately typed dy), in both modes:
+    the one-call executor runs forward + backward with its arenas traced (sparse/encoder_fn.TRACE); then each of the 13
+    layers is recomputed on the CPU by the emulation from the executor's stored x_i / c_i / y_i / gy_i. Bars: bf16 storage
+    3e-4 relative L2 (measured <= 1.6e-4: one-ulp re-roundings of values within fp32 round-off of a tie); bf16 operands
+    2e-5 (the stored tensors are fp32 and rounding the SAME fp32 input is deterministic: summation order only)."""
+    import torch.nn.functional as TF
+    import instancerefer_amd as irx
+    from instancerefer_amd.sparse import encoder_fn
+    from oracle.torchsparse.nn import emulate
     rng = np.random.default_rng(15 + c0)
     clouds = [surface_cloud(rng, 4000, rng.uniform(0, 3, 3), rng.uniform(0.8, 2.0, 3), c_extra=c0 - 3) for _ in range(4)]
-    enc, ora = _encoder_pair(c0, 31 + c0)
-    res = _run_encoder_both(enc, ora, clouds, 0.05, mode, np.random.default_rng(3))
-    rel = {k: _rel(*v) for k, v in res.items()}
-    bad = {k: v for k, v in rel.items() if not v <= 1e-3}
-    print("bf16 emulation parity c0=%d %s: out %.2e, worst grad %.2e (%s), worst buf %.2e" % (
-        c0, mode, rel["out"], max(v for k, v in rel.items() if k.startswith("grad/")),
-        max((k for k in rel if k.startswith("grad/")), key=rel.get),
-        max(v for k, v in rel.items() if k.startswith("buf/"))))
+    enc, _ = _encoder_pair(c0, 31 + c0)
+    st = mode == "bf16"
+    irx.set_compute_dtype(mode)
+    encoder_fn.TRACE = tr = {}
+    try:
+        out = enc(device_batch(clouds, 0.05)).F
+        g = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
+        (out * g).sum().backward()
+        torch.cuda.synchronize()
+        T = {k: [t.cpu() for t in v] for k, v in encoder_fn.trace_tensors(tr).items()}
+    finally:
+        encoder_fn.TRACE = None
+        irx.set_compute_dtype("fp32")
+    layers = tr["fwd"]["layers"]
+    nl = len(layers)
+    assert nl == 13 and tr["fwd"]["store"] == tr["bwd"]["store"] == st
+    # what the executor stores IS bf16 in mode 2 (every stored value survives a bf16 round trip; the last layer's output
+    # does not) and fp32 in mode 1
+    r = emulate.rb if st else (lambda t: t)
+    assert all(torch.equal(emulate.rb(T["c"][i]), T["c"][i]) == st for i in range(nl))
+    assert all(torch.equal(emulate.rb(T["y"][i]), T["y"][i]) == st for i in range(nl - 1))
+    assert not torch.equal(emulate.rb(T["y"][-1]), T["y"][-1])
+    assert all(torch.equal(emulate.rb(T["gy"][i]), T["gy"][i]) == st for i in range(nl - 1))
+    worst, dres_pending = {}, {}
+
+    def note(key, got, exp):
+        worst[key] = max(worst.get(key, 0.0), _rel(got, exp))
+    with emulate.mode(mode), emulate.encoder_scope(10 ** 9):
+        for i in range(nl - 1, -1, -1):
+            L = layers[i]
+            maps = _maps_from_table(L.tbl, L.K, L.n_out)
+            x = T["x"][i].clone().requires_grad_(i > 0)
+            w = L.conv.kernel.detach().cpu().clone().requires_grad_(True)
+            c_em = emulate.conv(x, w, maps, L.n_out)
+            note("conv output c", c_em.detach(), T["c"][i])
+            c = T["c"][i].clone().requires_grad_(True)
+            gamma = L.bn.weight.detach().cpu().clone().requires_grad_(True)
+            beta = L.bn.bias.detach().cpu().clone().requires_grad_(True)
+            note("mean", c.detach().mean(0), T["mean"][i])
+            note("invstd", torch.rsqrt(c.detach().double().var(0, unbiased=False) + L.bn.eps).float(), T["invstd"][i])
+            pre = TF.batch_norm(c, None, None, gamma, beta, True, 0.0, L.bn.eps)
+            res = None
+            if L.res >= 0:
+                res = T["y"][L.res].clone().requires_grad_(True)
+                pre = pre + emulate.on_shortcut(res)
+            y_em = torch.relu(pre)
+            if i < nl - 1 and st:
+                y_em = emulate.q(y_em, True, True)
+            note("layer output y", y_em.detach(), T["y"][i])
+            y_em.backward(T["gy"][i])
+            note("d gamma", gamma.grad, L.bn.weight.grad.cpu())
+            note("d beta", beta.grad, L.bn.bias.grad.cpu())
+            if res is not None:
+                dres_pending[L.res] = res.grad
+            c_em.backward(r(c.grad))                       # d c_i as the executor stores it
+            note("d kernel", w.grad, L.conv.kernel.grad.cpu())
+            if i > 0:
+                gy_prev = r(x.grad + dres_pending.pop(i - 1)) if (i - 1) in dres_pending else r(x.grad)
+                note("gradient in flight gy", gy_prev, T["gy"][i - 1])
+    print("teacher-forced parity, c0 = %d, %s:" % (c0, mode), {k: "%.1e" % v for k, v in worst.items()})
+    assert not dres_pending
+    bad = {k: v for k, v in worst.items() if not v <= (3e-4 if st else 2e-5)}
     assert not bad, bad
-    # the fp32 oracle on the same inputs is far away: the rounding points are what makes the difference
-    enc2, ora2 = _encoder_pair(c0, 31 + c0)
+
+
+def _emulated_encoder(c0, seed, clouds, voxel, mode, g_aligned_fn, acc64):
+    from oracle.torchsparse.nn import emulate
+    _, ora = _encoder_pair(c0, seed)
+    with emulate.mode(mode), emulate.acc64(acc64):
+        yo = ora(oracle_batch(clouds, voxel))
+        (yo.F * g_aligned_fn(yo)).sum().backward()
+    return yo, ora
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("c0", [7, 135])
+def test_encoder_bf16_end_to_end_within_the_reordering_distance(lib, c0, mode):
+    """(b) of the module docstring: the 13-conv encoder through the one-call executor, training mode, dense loss on the
+    stride-16 map. For the output, each of the 39 parameter gradients and the running statistics, with
+    d_pe = dist(HIP, emulation), d_ee = dist(emulation, emulation with float64 sums), d_p32 = dist(HIP, fp32 oracle):
+    every tensor d_pe <= 4 d_ee + 1e-5, the median of d_pe / d_ee over the tensors <= 1.5 (HIP is as close to the emulation
+    as the emulation is to itself), and for the output d_pe <= 0.85 d_p32 (measured 0.6-0.7: the rounding points explain
+    what is explainable before the drift decorrelates the remainder)."""
     import instancerefer_amd as irx
     from oracle.torchsparse.nn import emulate
+    rng = np.random.default_rng(15 + c0)
+    clouds = [surface_cloud(rng, 4000, rng.uniform(0, 3, 3), rng.uniform(0.8, 2.0, 3), c_extra=c0 - 3) for _ in range(4)]
+    enc, _ = _encoder_pair(c0, 31 + c0)
     irx.set_compute_dtype(mode)
     try:
-        yd = enc2(device_batch(clouds, 0.05))
+        yd = enc(device_batch(clouds, 0.05))
+        gdev = torch.from_numpy(np.random.default_rng(3).standard_normal(tuple(yd.F.shape)).astype(np.float32))
+        (yd.F * gdev.cuda()).sum().backward()
+        torch.cuda.synchronize()
     finally:
         irx.set_compute_dtype("fp32")
-    with emulate.mode(None):
-        yo = ora2(oracle_batch(clouds, 0.05))
-    ja, jb = align(yd.C.cpu().numpy(), yo.C.numpy())
-    far = _rel(yd.F.detach().cpu()[ja], yo.F.detach()[jb])
-    assert far >= 10 * max(rel["out"], 1e-5), (far, rel["out"])
+    cd = yd.C.cpu().numpy()
+
+    def g_for(yo):                                  # the same upstream gradient, row-aligned to the oracle's order
+        ja, jb = align(cd, yo.C.numpy())
+        go = torch.empty_like(gdev); go[jb] = gdev[ja]
+        return go
+    runs = {}
+    for name, m, a64 in (("emu", mode, False), ("emu64", mode, True), ("fp32", None, False)):
+        yo, ora = _emulated_encoder(c0, 31 + c0, clouds, 0.05, m, g_for, a64)
+        ja, jb = align(cd, yo.C.numpy())
+        t = {"out": (yo.F.detach()[jb], ja)}
+        t.update({"grad/" + n: (p.grad, None) for n, p in ora.named_parameters()})
+        t.update({"buf/" + n: (b, None) for n, b in ora.named_buffers() if b.dtype.is_floating_point})
+        runs[name] = t
+    got = {"out": yd.F.detach().cpu()}
+    got.update({"grad/" + n: p.grad.detach().cpu() for n, p in enc.named_parameters()})
+    got.update({"buf/" + n: b.detach().cpu() for n, b in enc.named_buffers() if b.dtype.is_floating_point})
+    bad, rows = {}, []
+    for k, v in got.items():
+        ja = runs["emu"][k][1]
+        v = v[ja] if ja is not None else v
+        d_pe, d_ee = _rel(v, runs["emu"][k][0]), _rel(runs["emu64"][k][0], runs["emu"][k][0])
+        d_p32 = _rel(v, runs["fp32"][k][0])
+        rows.append((k, d_pe, d_ee, d_p32))
+        if d_pe > 4.0 * d_ee + 1e-5:
+            bad[k] = (d_pe, d_ee)
+    top = sorted(rows, key=lambda r_: -r_[1])[:3]
+    print("end to end c0=%d %s: out HIP-emu %.1e, emu-emu64 %.1e, HIP-fp32 %.1e; worst grads %s" % (
+        c0, mode, rows[0][1], rows[0][2], rows[0][3], [(k, "%.1e" % a, "%.1e" % b) for k, a, b, _ in top]))
+    assert not bad, bad
+    ratios = sorted(a / max(b, 1e-12) for _, a, b, _ in rows)
+    assert ratios[len(ratios) // 2] <= 1.5, ratios[len(ratios) // 2]
+    assert rows[0][0] == "out" and rows[0][1] <= 0.85 * rows[0][3], rows[0]
 
 
 @pytest.mark.parametrize("mode", MODES)
 def test_wide_stem_conv_bf16_op_level(lib, mode):
     """The multiview stem 135 -> 32 as a single per-layer op (no executor, so no storage rounding in either mode): 128 leading
-    channels with bf16 operands on k_spconv2<128,32> / the pair-list weight-gradient, the 7-channel tail in fp32 on the stem
-    kernels — forward and weight-gradient vs the emulation, 2e-5 of the max-norm (summation order only)."""
+    channels with bf16 operands on k_spconv2<128,32>, the 7-channel tail in fp32 on the stem kernels; the weight-gradient of
+    this per-layer op has no pair lists and stays fp32 (the executor's goes through k_wgrad_pairs with bf16 operands: covered
+    by test_executor_bf16_layer_by_layer) — forward and weight-gradient vs the emulation, 2e-5 of the max-norm."""
     import instancerefer_amd as irx
     import oracle.torchsparse.nn as ospnn
     from oracle.torchsparse import SparseTensor as OT
@@ -136,7 +232,7 @@ def test_wide_stem_conv_bf16_op_level(lib, mode):
         torch.cuda.synchronize()
     finally:
         irx.set_compute_dtype("fp32")
-    with emulate.mode(mode):
+    with emulate.mode(mode), emulate.per_layer_ops():
         yo = oconv(OT(fo, o.C, 1))
         yo.F.backward(go)
     got, exp = yd.F.detach().cpu()[ia], yo.F.detach()[ib]
@@ -148,7 +244,8 @@ def test_wide_stem_conv_bf16_op_level(lib, mode):
     assert float((got - y32).abs().max()) > 1e-4 * float(y32.abs().max()), "the mode did not change the arithmetic"
 
 
-def _model_pair(cfg, seed, c0, mode):
+def _model_runs(cfg, seed, c0, mode):
+    """-> (product model, product dict), {"emu" | "emu64" | "fp32": (oracle model, oracle dict)}; backward done everywhere."""
     import instancerefer_amd as irx
     from instancerefer_amd import synthetic as S
     from instancerefer_amd.instancerefer import InstanceRefer
@@ -156,16 +253,15 @@ def _model_pair(cfg, seed, c0, mode):
     from oracle.model_ref import InstanceRefer as OracleModel, oracle_data_dict
     from oracle.torchsparse.nn import emulate
     dev = torch.device("cuda")
-    model = InstanceRefer(c0, S.default_args())
-    sd = S.seeded_state_dict(model, seed)
-    model.load_state_dict(sd)
-    oracle = OracleModel(c0, S.default_args())
-    oracle.load_state_dict(sd)
-    for m in list(model.modules()) + list(oracle.modules()):
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
-    model.to(dev).train()
-    oracle.train()
+
+    def fresh(cls):
+        m = cls(c0, S.default_args())
+        m.load_state_dict(S.seeded_state_dict(m, seed))
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m.train()
+    model = fresh(InstanceRefer).to(dev)
     irx.set_compute_dtype(mode)
     try:
         dd = get_loss(model(S.to_device(S.make_batch(**dict(cfg)), dev)), DatasetConfig())
@@ -173,47 +269,60 @@ def _model_pair(cfg, seed, c0, mode):
         torch.cuda.synchronize()
     finally:
         irx.set_compute_dtype("fp32")
-    with emulate.mode(mode):
-        od = get_loss(oracle(oracle_data_dict(S.make_batch(**dict(cfg)))), DatasetConfig())
-        od["loss"].backward()
-    return model, oracle, dd, od
+    runs = {}
+    for name, m, a64 in (("emu", mode, False), ("emu64", mode, True)):
+        oracle = fresh(OracleModel)
+        with emulate.mode(m), emulate.acc64(a64):
+            od = get_loss(oracle(oracle_data_dict(S.make_batch(**dict(cfg)))), DatasetConfig())
+            od["loss"].backward()
+        runs[name] = (oracle, od)
+    return (model, dd), runs
+
+
+SCORE_KEYS = ("lang_scores", "obj_feats", "attribute_scores", "relation_scores", "scene_scores", "seg_scores", "vis_atten",
+              "loss", "ref_loss", "lang_loss", "seg_loss")
+
+
+def check_model_against_emulation(model, dd, runs, tag):
+    """Shared by the golden / multiview / stress-size tests: same discrete decisions as the emulation; every score tensor
+    no further from the emulation than 5x the emulation's own reordering distance for that tensor + 2e-4, and than 2x the
+    largest reordering distance of any tensor, in units of max(1, |expected|max); total gradient norm within 2 %
+    (individual gradients sit at the bf16 noise floor, tests above)."""
+    oracle, od = runs["emu"]
+    assert list(dd["num_filtered_objs"]) == list(od["num_filtered_objs"])
+    lab = np.concatenate([c.cpu().numpy() if len(c) else np.zeros(0) for c in dd["cluster_label"]])
+    olab = np.concatenate([c.cpu().numpy() if len(c) else np.zeros(0) for c in od["cluster_label"]])
+    assert np.array_equal(lab, olab)
+    pe, ee = {}, {}
+    for k in SCORE_KEYS:
+        exp = od[k].detach()
+        scale = max(1.0, float(exp.abs().max()))
+        pe[k] = float((dd[k].detach().cpu() - exp).abs().max()) / scale
+        ee[k] = float((runs["emu64"][1][k].detach() - exp).abs().max()) / scale
+    bar = 2.0 * max(ee.values()) + 2e-5
+    print("%s: HIP-emu %s | emu-emu64 %s | pooled bar %.1e" % (tag, {k: "%.0e" % v for k, v in pe.items()},
+          {k: "%.0e" % v for k, v in ee.items()}, bar))
+    assert all(v <= bar for v in pe.values()), (pe, bar)
+    assert all(pe[k] <= 5.0 * ee[k] + 2e-4 for k in SCORE_KEYS), (pe, ee)
+
+    def gnorm(m):
+        return float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+    n_p, n_e = gnorm(model), gnorm(oracle)
+    assert abs(n_p - n_e) <= 2e-2 * n_e, (n_p, n_e)
+    return pe, ee
 
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", ["golden", "multiview"])
-def test_full_model_bf16_modes_equal_the_emulating_oracle(lib, case, mode):
+def test_full_model_bf16_modes_within_the_reordering_distance(lib, case, mode):
     """The whole model (language, attribute, relation, scene heads + get_loss), training mode, in both bf16 modes: the golden
     batch (C0 = 7) and the multiview batch (C0 = 135, configs[4]'s input width) vs oracle/model_ref.py with the build's
-    rounding points (both encoders, the BEV conv and the two 3x3 head convs with bf16 operands; heads fp32). Same discrete
-    decisions; scores / features / loss <= 1e-3 of max(1, |expected|max) (measured 1e-5 .. 2e-4; vs the fp32 fixture the
-    same outputs are 2e-4 .. 4e-3 off); every parameter gradient's norm within 2e-2 and the total within 5e-3 (the
-    backward enters the encoders through max-pool arg-max picks and ReLU kinks: tests/test_fullsize_gpu.py)."""
+    rounding points (both encoders; the BEV conv and the two 3x3 head convs with bf16 operands in forward and data-gradient;
+    heads fp32) — see check_model_against_emulation."""
     if case == "golden":
         cfg, c0, seed = dict(GOLDEN_CFG), 7, WEIGHT_SEED
     else:
         cfg, c0, seed = dict(batch_size=2, seed=950, num_points=4000, num_instances=5, num_candidates=[3, 2], tokens=[20, 11],
                              points_per_instance=200, multiview=128), 135, 78
-    model, oracle, dd, od = _model_pair(cfg, seed, c0, mode)
-    assert list(dd["num_filtered_objs"]) == list(od["num_filtered_objs"])
-    lab = np.concatenate([c.cpu().numpy() if len(c) else np.zeros(0) for c in dd["cluster_label"]])
-    olab = np.concatenate([c.cpu().numpy() if len(c) else np.zeros(0) for c in od["cluster_label"]])
-    assert np.array_equal(lab, olab)
-    worst = {}
-    for k in ("lang_scores", "obj_feats", "attribute_scores", "relation_scores", "scene_scores", "seg_scores", "vis_atten",
-              "loss", "ref_loss", "lang_loss", "seg_loss"):
-        exp = od[k].detach()
-        worst[k] = float((dd[k].detach().cpu() - exp).abs().max()) / max(1.0, float(exp.abs().max()))
-    print("full model %s %s:" % (case, mode), {k: "%.1e" % v for k, v in worst.items()})
-    assert all(v <= 1e-3 for v in worst.values()), worst
-    gp = dict(model.named_parameters())
-    tot_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in oracle.parameters() if p.grad is not None)))
-    tot_d = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
-    assert abs(tot_d - tot_o) <= 5e-3 * tot_o, (tot_d, tot_o)
-    bad = {}
-    for n, p in oracle.named_parameters():
-        if p.grad is None:
-            continue
-        exp, got = float(p.grad.double().norm()), float(gp[n].grad.double().norm())
-        if abs(got - exp) > 2e-2 * max(exp, 1e-3 * tot_o):
-            bad[n] = (got, exp)
-    assert not bad, bad
+    (model, dd), runs = _model_runs(cfg, seed, c0, mode)
+    check_model_against_emulation(model, dd, runs, "full model %s %s" % (case, mode))

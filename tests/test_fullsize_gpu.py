@@ -267,53 +267,18 @@ def test_stress_scene_pyramid_tables_and_encoder_vs_c_port(lib, stress_batch):
     assert not bad, bad
 
 
-def test_stress_full_model_bf16_equals_the_emulating_oracle(lib, stress_batch):
+def test_stress_full_model_bf16_within_the_reordering_distance(lib, stress_batch):
     """configs[4] at its own dtype and size (B = 2): the FULL model in the bf16 mode BASELINE names (bf16 operands + bf16
     storage in both encoders: wide stem with bf16 output, pair-list weight-gradient reading x with a row stride and a
     separately typed dy, 2 x 16 candidates of 64 instances, relation graph on 153-feature nodes) against
-    oracle/model_ref.py with the same rounding points (oracle/torchsparse/nn/emulate.py). Discrete decisions identical;
-    scores, pooled features, loss <= 1e-3 of max(1, |expected|max); total gradient norm within 1e-2."""
-    import instancerefer_amd as irx
-    from instancerefer_amd import synthetic as S
-    from instancerefer_amd.instancerefer import InstanceRefer
-    from instancerefer_amd.loss_helper import DatasetConfig, get_loss
-    from oracle.model_ref import InstanceRefer as OracleModel, oracle_data_dict
-    from oracle.torchsparse.nn import emulate
-    dev = torch.device("cuda")
-    model = InstanceRefer(135, S.default_args())
-    sd = S.seeded_state_dict(model, 99)
-    model.load_state_dict(sd)
-    oracle = OracleModel(135, S.default_args())
-    oracle.load_state_dict(sd)
-    for m in list(model.modules()) + list(oracle.modules()):
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
-    model.to(dev).train()
-    oracle.train()
-    host = dict(stress_batch)
-    irx.set_compute_dtype("bf16")
-    try:
-        dd = get_loss(model(S.to_device(dict(host), dev)), DatasetConfig())
-        dd["loss"].backward()
-        torch.cuda.synchronize()
-    finally:
-        irx.set_compute_dtype("fp32")
-    with emulate.mode("bf16"):
-        od = get_loss(oracle(oracle_data_dict(dict(host))), DatasetConfig())
-        od["loss"].backward()
-    assert list(dd["num_filtered_objs"]) == list(od["num_filtered_objs"]) == [16, 16]
-    lab = np.concatenate([c.cpu().numpy() for c in dd["cluster_label"]])
-    assert np.array_equal(lab, np.concatenate([c.cpu().numpy() for c in od["cluster_label"]]))
-    worst = {}
-    for k in ("lang_scores", "obj_feats", "attribute_scores", "relation_scores", "scene_scores", "seg_scores", "vis_atten",
-              "loss", "ref_loss", "lang_loss", "seg_loss"):
-        exp = od[k].detach()
-        worst[k] = float((dd[k].detach().cpu() - exp).abs().max()) / max(1.0, float(exp.abs().max()))
-    print("stress bf16 vs emulation:", {k: "%.1e" % v for k, v in worst.items()})
-    assert all(v <= 1e-3 for v in worst.values()), worst
-    tot_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in oracle.parameters() if p.grad is not None)))
-    tot_d = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
-    assert abs(tot_d - tot_o) <= 1e-2 * tot_o, (tot_d, tot_o)
+    oracle/model_ref.py with the same rounding points (oracle/torchsparse/nn/emulate.py): identical discrete decisions,
+    every score tensor within 2x the emulation's own reordering distance (tests/test_bf16_gpu.py explains the bar)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_bf16_gpu as TB
+    (model, dd), runs = TB._model_runs(dict(STRESS), 99, 135, "bf16")
+    assert list(dd["num_filtered_objs"]) == [16, 16]
+    TB.check_model_against_emulation(model, dd, runs, "stress 200k x 64, C0 = 135, bf16")
 
 
 @pytest.mark.parametrize("which", ["full", "attr_only"])

@@ -419,7 +419,8 @@ def test_bf16_modes_track_the_fp32_reference(lib, mode):
     encoders (statistics, parameters, heads fp32): same discrete decisions (candidates, labels), matching
     scores and features within bf16 round-off (2e-2 of max(1, |reference|max); measured: scores 2-4e-4, pooled
     features 4e-3), loss within 2 %, finite
-    gradients whose norm is within 5 % of the fp32 reference's. The fp32 mode stays the 1e-4 parity gate."""
+    gradients whose norm is within 5 % of the fp32 reference's. The fp32 mode stays the 1e-4 parity gate; the bf16 arithmetic
+    itself is pinned against the emulating oracle in tests/test_bf16_gpu.py (layer by layer <= 3e-4)."""
     import instancerefer_amd as irx
     from instancerefer_amd.loss_helper import DatasetConfig, get_loss
     gold = np.load(os.path.join(G, "model.npz"))
@@ -445,58 +446,6 @@ def test_bf16_modes_track_the_fp32_reference(lib, mode):
     total = float(np.sqrt(sum(float(gold[k]) ** 2 for k in gold.files if k.startswith("grad_norm/"))))
     got = float(np.sqrt(sum(float(p.grad.double().norm()) ** 2 for p in model.parameters() if p.grad is not None)))
     assert np.isfinite(got) and abs(got - total) <= 5e-2 * total, (got, total)
-
-
-def test_bf16_storage_encoder_vs_fp32(lib):
-    """The encoder executor with bf16 storage (irx_set_compute_dtype(2): conv outputs, layer outputs, gradients in flight
-    as bf16 in HBM; fp32 statistics / accumulation / parameter gradients) against the same encoder in fp32 and with bf16
-    operands only. The loss is a dense inner product with the stride-16 feature map (a max-pool would route the whole
-    gradient through arg-max picks that bf16 noise re-draws). Output within 3e-2 of its max-norm. Gradients: with these
-    random weights bf16 OPERAND rounding alone moves the parameter gradients by 5 % (deepest stage) to 20-25 % (stem) in
-    relative L2 — 13 train-mode BatchNorms amplify a 1 % forward perturbation (measured, tools/storage_diag.py) — so the
-    bar for the storage mode is "no worse than that": relative L2 vs fp32 <= 1.6 x the operand-only mode's + 3e-2,
-    cosine vs fp32 >= 0.93; BatchNorm running statistics within 1e-2; and it is a different arithmetic than the
-    operand-only mode."""
-    import instancerefer_amd as irx
-    from helpers import device_batch, surface_cloud
-    from instancerefer_amd.basic_blocks import SparseConvEncoder
-    rng = np.random.default_rng(15)
-    clouds = [surface_cloud(rng, 4000, rng.uniform(0, 3, 3), rng.uniform(0.8, 2.0, 3)) for _ in range(4)]
-    torch.manual_seed(2)
-    enc = SparseConvEncoder(7).cuda().train()
-    res, g = {}, None
-    try:
-        for mode in ("fp32", "bf16_operands", "bf16"):
-            irx.set_compute_dtype(mode)
-            enc.zero_grad()
-            for m in enc.modules():
-                if isinstance(m, torch.nn.BatchNorm1d):
-                    m.reset_running_stats()
-            out = enc(device_batch(clouds, 0.05)).F
-            if g is None:
-                g = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
-            (out * g).sum().backward()
-            torch.cuda.synchronize()
-            res[mode] = (out.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters()},
-                         {n: b.clone() for n, b in enc.named_buffers() if b.dtype.is_floating_point})
-    finally:
-        irx.set_compute_dtype("fp32")
-    ref, ops, got = res["fp32"], res["bf16_operands"], res["bf16"]
-    assert bool(torch.isfinite(got[0]).all())
-    assert float((got[0] - ref[0]).abs().max()) <= 3e-2 * float(ref[0].abs().max())
-
-    def rel(a, b):
-        a, b = a.double().flatten(), b.double().flatten()
-        return float((a - b).norm() / a.norm()), float((a @ b) / (a.norm() * b.norm()))
-    bad = {}
-    for n in ref[1]:
-        r32, o32 = rel(ref[1][n], got[1][n]), rel(ref[1][n], ops[1][n])
-        if r32[0] > 1.6 * o32[0] + 3e-2 or r32[1] < 0.93:
-            bad[n] = (r32, o32)
-    assert not bad, bad
-    for n in ref[2]:
-        assert float((got[2][n] - ref[2][n]).abs().max()) <= 1e-2 * max(1.0, float(ref[2][n].abs().max())), n
-    assert not torch.equal(got[0], ops[0])
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
