@@ -59,8 +59,9 @@ def test_executor_bf16_layer_by_layer(lib, c0, mode):
     bf16 output and double rounding, k_wgrad_pairs reading x with a row stride and a separately typed dy), in both modes:
     the one-call executor runs forward + backward with its arenas traced (sparse/encoder_fn.TRACE); then each of the 13
     layers is recomputed on the CPU by the emulation from the executor's stored x_i / c_i / y_i / gy_i. Bars: bf16 storage
-    3e-4 relative L2 (measured <= 1.6e-4: one-ulp re-roundings of values within fp32 round-off of a tie); bf16 operands
-    2e-5 (the stored tensors are fp32 and rounding the SAME fp32 input is deterministic: summation order only)."""
+    3e-4 relative L2 (measured <= 1.6e-4: one-ulp re-roundings of values within fp32 round-off of a tie); bf16 operands:
+    forward quantities 2e-5 (the stored tensors are fp32 and rounding the SAME fp32 input is deterministic: measured 1e-7),
+    data- / weight-gradients 3e-4 (measured 4e-5)."""
     import torch.nn.functional as TF
     import instancerefer_amd as irx
     from instancerefer_amd.sparse import encoder_fn
@@ -128,7 +129,10 @@ def test_executor_bf16_layer_by_layer(lib, c0, mode):
                 note("gradient in flight gy", gy_prev, T["gy"][i - 1])
     print("teacher-forced parity, c0 = %d, %s:" % (c0, mode), {k: "%.1e" % v for k, v in worst.items()})
     assert not dres_pending
-    bad = {k: v for k, v in worst.items() if not v <= (3e-4 if st else 2e-5)}
+    # (operand mode: the forward quantities see bit-identical fp32 inputs; d c_i is not a stored tensor there, it is
+    # recomputed from gy_i by both sides and THEN rounded at use, so the backward quantities carry one-ulp re-roundings too)
+    fwd_keys = ("conv output c", "mean", "invstd", "layer output y", "d gamma", "d beta")
+    bad = {k: v for k, v in worst.items() if not v <= (2e-5 if (not st and k in fwd_keys) else 3e-4)}
     assert not bad, bad
 
 

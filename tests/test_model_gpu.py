@@ -490,45 +490,95 @@ def test_asynchronous_encoder_issue_changes_nothing(lib, dtype):
 
 def test_training_trajectory_tracks_the_oracle(lib, tmp_path):
     """The only accuracy proxy available without ScanRefer (north star: Acc@0.25/0.5 within +-0.2 of the reference): 50
-    fp32 optimisation steps of the product's Solver (FlatAdam, one fused launch; reference lib/solver.py:200-205 is
-    backward(); step() with torch.optim.Adam(lr=1e-3, weight_decay=1e-5), scripts/train.py:121) on 50 different synthetic
-    batches, against oracle/model_ref.py stepped by a real torch.optim.Adam on the same batches from the same weights:
-    the loss SEQUENCE agrees within 1e-3 relative at every step (so forward, backward, BatchNorm running statistics and the
-    optimizer all track), and after 50 steps the parameters agree within 1e-3 of their norm."""
+    fp32 optimisation steps (reference lib/solver.py:200-205: backward(); step() with torch.optim.Adam(lr=1e-3,
+    weight_decay=1e-5), scripts/train.py:121) on 50 different synthetic batches, product (FlatAdam: one fused launch over
+    the flat buffer) vs oracle/model_ref.py + a real torch.optim.Adam.
+
+    Free-running trajectories cannot be compared beyond a few steps: Adam's update lr * m / (sqrt(v) + 1e-8) is sign-like,
+    so a parameter whose true gradient is a near-cancellation (|g| ~ fp32 noise of its terms) moves by +-lr in a direction
+    the noise decides — measured here: loss deviation 1e-7, 5e-5, 8e-4, 2e-2 at steps 0..3, with ANY second fp32
+    implementation. So the trajectory is checked state by state ("teacher forced"): at each of the 50 steps the oracle is
+    given the product's current parameters, buffers and Adam moments, both run forward / backward / step on the same batch:
+      * loss, every step: <= 1e-4 relative;  gradient (all parameters, flat): cosine >= 1 - 1e-6, norm within 1e-4;
+      * parameters after the step: || p_product - p_oracle || <= 2e-2 || update || (the noise-decided elements are few);
+      * BatchNorm running statistics after the step: <= 1e-5;
+    and the free-running first three steps agree within 1e-3; the model is learning (mean loss of the last 10 steps below
+    the first 10)."""
     from instancerefer_amd import synthetic as S
     from instancerefer_amd.instancerefer import InstanceRefer
     from instancerefer_amd.loss_helper import DatasetConfig, get_loss
-    from instancerefer_amd.solver import Solver, SyntheticLoader
+    from instancerefer_amd.optim import FlatAdam
     from oracle.model_ref import InstanceRefer as OracleModel, oracle_data_dict
     steps, bs = 50, 3
     kw = dict(num_points=4000, num_instances=5, num_candidates=3, points_per_instance=128)
-    model = InstanceRefer(7, S.default_args())
-    sd = S.seeded_state_dict(model, 61)
-    model.load_state_dict(sd)
-    oracle = OracleModel(7, S.default_args())
-    oracle.load_state_dict(sd)
-    for m in list(model.modules()) + list(oracle.modules()):
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
-    solver = Solver(model, DatasetConfig(), {"train": SyntheticLoader(steps, bs, seed=500, **kw)}, lr=1e-3, weight_decay=1e-5,
-                    out_dir=None, verbose=1)
-    solver.train_epoch(0)
-    got = [r["loss"] for r in solver.log["train"]]
-    oracle.train()
-    opt = torch.optim.Adam(oracle.parameters(), lr=1e-3, weight_decay=1e-5)
-    exp = []
-    for b in range(steps):
-        opt.zero_grad()
-        od = get_loss(oracle(oracle_data_dict(S.make_batch(bs, seed=500 + b * bs, **dict(kw)))), DatasetConfig())
-        od["loss"].backward()
-        opt.step()
-        exp.append(float(od["loss"].detach()))
-    got, exp = np.asarray(got), np.asarray(exp)
-    dev = np.abs(got - exp) / np.maximum(np.abs(exp), 1e-6)
-    print("trajectory: max rel dev %.2e at step %d; first/last loss %.4f / %.4f" % (dev.max(), int(dev.argmax()), exp[0], exp[-1]))
-    assert len(got) == steps and float(dev.max()) <= 1e-3, (dev.max(), int(dev.argmax()))
-    assert exp[-5:].mean() < exp[:5].mean(), "the oracle itself must be learning on this data"
-    op = dict(oracle.named_parameters())
-    num = sum(float(((p.detach().cpu() - op[n].detach()).double() ** 2).sum()) for n, p in model.named_parameters())
-    den = sum(float((q.detach().double() ** 2).sum()) for q in op.values())
-    assert (num / den) ** 0.5 <= 1e-3, (num / den) ** 0.5
+    dev = torch.device("cuda")
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(8, nthreads))          # the CPU oracle's small ops crawl with one thread per core of a big host
+
+    def fresh(cls):
+        m = cls(7, S.default_args())
+        m.load_state_dict(S.seeded_state_dict(m, 61))
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m.train()
+    try:
+        model, oracle, free = fresh(InstanceRefer).to(dev), fresh(OracleModel), fresh(OracleModel)
+        opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
+        o_opt = torch.optim.Adam(oracle.parameters(), lr=1e-3, weight_decay=1e-5)
+        f_opt = torch.optim.Adam(free.parameters(), lr=1e-3, weight_decay=1e-5)
+        names = [n for n, _ in model.named_parameters()]
+        worst = dict(loss=0.0, cos=0.0, gnorm=0.0, step=0.0, buf=0.0)
+        losses, free_dev = [], []
+        for b in range(steps):
+            host = lambda: S.make_batch(bs, seed=500 + b * bs, **dict(kw))
+            # teacher forcing: the oracle starts this step from the product's state (parameters, buffers, Adam moments)
+            oracle.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+            if b > 0:
+                o_opt.load_state_dict(opt.state_dict())
+            before = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+            opt.zero_grad()
+            dd = get_loss(model(S.to_device(host(), dev)), DatasetConfig())
+            dd["loss"].backward()
+            opt.gather_grads()
+            flat_g = opt.flat_g[:opt.n].clone()
+            opt.all_reduce()
+            opt.step()
+            o_opt.zero_grad()
+            od = get_loss(oracle(oracle_data_dict(host())), DatasetConfig())
+            od["loss"].backward()
+            lp, lo = float(dd["loss"].detach()), float(od["loss"].detach())
+            losses.append(lp)
+            worst["loss"] = max(worst["loss"], abs(lp - lo) / abs(lo))
+            gp = torch.cat([flat_g[off:off + p.numel()].cpu().double() for p, off in zip(opt.params, opt.offsets)])
+            go = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1).double()
+                            for q in (dict(oracle.named_parameters())[n] for n in names)])
+            worst["cos"] = max(worst["cos"], 1.0 - float(gp @ go / (gp.norm() * go.norm())))
+            worst["gnorm"] = max(worst["gnorm"], abs(float(gp.norm() / go.norm()) - 1.0))
+            o_opt.step()
+            torch.cuda.synchronize()
+            num = den = 0.0
+            op = dict(oracle.named_parameters())
+            for n, p in model.named_parameters():
+                pc = p.detach().cpu().double()
+                num += float(((pc - op[n].detach().double()) ** 2).sum())
+                den += float(((pc - before[n].double()) ** 2).sum())
+            worst["step"] = max(worst["step"], (num / den) ** 0.5)
+            ob = dict(oracle.named_buffers())
+            for n, buf in model.named_buffers():
+                if buf.dtype.is_floating_point:
+                    worst["buf"] = max(worst["buf"], float((buf.detach().cpu() - ob[n]).abs().max()) / max(1.0, float(ob[n].abs().max())))
+            if b < 3:                                   # free-running oracle: never re-synchronised
+                f_opt.zero_grad()
+                fd = get_loss(free(oracle_data_dict(host())), DatasetConfig())
+                fd["loss"].backward()
+                f_opt.step()
+                free_dev.append(abs(lp - float(fd["loss"].detach())) / abs(lp))
+    finally:
+        torch.set_num_threads(nthreads)
+    print("trajectory (teacher forced, %d steps):" % steps, {k: "%.1e" % v for k, v in worst.items()},
+          "free-running first steps:", ["%.1e" % v for v in free_dev], "loss %.3f -> %.3f" % (np.mean(losses[:10]), np.mean(losses[-10:])))
+    assert worst["loss"] <= 1e-4 and worst["cos"] <= 1e-6 and worst["gnorm"] <= 1e-4, worst
+    assert worst["step"] <= 2e-2 and worst["buf"] <= 1e-5, worst
+    assert max(free_dev) <= 1e-3, free_dev
+    assert np.mean(losses[-10:]) < np.mean(losses[:10]), losses

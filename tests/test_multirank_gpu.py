@@ -95,7 +95,7 @@ def _worker(rank, world, port, out_dir):
     def reduced_grad(batches):
         opt2.zero_grad()
         for b in batches:
-            get_loss(model2(S.to_device(b, dev)), DatasetConfig())["loss"].backward()
+            get_loss(model2(S.to_device(dict(b), dev)), DatasetConfig())["loss"].backward()
         opt2.gather_grads()
         opt2.all_reduce()
         torch.cuda.synchronize()
