@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--cpu-timeout", type=int, default=150)
-    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--profile-steps", type=int, default=2, help="instrumented (serially issued) steps behind the timed region; 0 = none")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1: BatchNorm statistics over all ranks (instancerefer_amd.syncbn; "
                     "the encoders then run layer by layer, one small all-reduce per BatchNorm layer and direction)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (input pipeline in the loop, own process)")
@@ -597,7 +597,7 @@ def main():
             try:                                       # its own roofline (HBM-bound: algorithmic bytes at 2 B / element)
                 F_.PROFILE = []
                 with serial_issue(model):
-                    for _ in range(max(1, args.profile_steps)):
+                    for _ in range(args.profile_steps):
                         step_fn(model, resident, args.workload, reducer, opt)
                     torch.cuda.synchronize()
                 recs, F_.PROFILE = F_.PROFILE, None
@@ -614,13 +614,13 @@ def main():
     # ---- instrumented steps: per-launch events on the launch stream for the sparse-conv kernels ----
     roof = None
     roof_error = None
-    if rank == 0:
+    if rank == 0 and args.profile_steps > 0:
         try:
             F_.PROFILE = []
             saved_world, opt.world_size = opt.world_size, 1     # rank-0-only steps: no collective (others are not in it)
             F_.SYNC_OFF = True                                   # ... nor a sync-BatchNorm fold (--sync-bn)
             with serial_issue(model):
-                for _ in range(max(1, args.profile_steps)):
+                for _ in range(args.profile_steps):
                     step_fn(model, resident, args.workload, reducer, opt)
                 torch.cuda.synchronize()
             opt.world_size = saved_world
@@ -656,6 +656,14 @@ def main():
         }
         if alt is not None:
             out["alt_dtype"] = alt
+        if world == 1 and not args.no_cpu_baseline and roof_error is None and roof:   # (quick runs keep the committed figure)
+            torch.cuda.synchronize()
+            pmc = measure_pmc_traffic(args, args.dtype != "f32")
+            traffic_for(out["roofline"], pmc, args.dtype != "f32")
+            if isinstance(pmc, dict) and "error" in pmc:
+                out["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic*.json (live PMC pass failed: %s)" % pmc["error"]
+            if alt is not None and isinstance(alt.get("roofline"), dict) and "kernel" in alt["roofline"]:
+                traffic_for(alt["roofline"], measure_pmc_traffic(args, True), True)
         if world == 1 and args.workload != "attr" and not args.no_cpu_baseline:   # (quick runs skip the auxiliary legs)
             try:
                 out["dense_path"] = measure_dense_path(model, resident, device)
@@ -672,6 +680,69 @@ def main():
     if world > 1 or force_dist:
         dist.barrier(device_ids=None if share else [device.index])
         dist.destroy_process_group()
+
+
+def measure_pmc_traffic(args, bf16=False):
+    """HBM bytes per launch of every k_* kernel, measured NOW on this box: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE —
+    separate runs, with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes) over a short child run of this
+    same script (2 steps, serial issue so that dispatches are attributed cleanly), folded per kernel:
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 — both counters are in KB, and on gfx950 FETCH_SIZE reports half of a wide
+    (16 B/lane) coalesced read stream (same section). -> {kernel name: bytes per launch} or {"error": ...}."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return {"error": "rocprofv3 not found"}
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-pipeline", "--no-cpu-baseline",
+             "--no-alt-dtype", "--profile-steps", "0", "--workload", args.workload, "--dtype", "bf16" if bf16 else args.dtype]
+    if args.batch:
+        child += ["--batch", str(args.batch)]
+    sums = {}
+    tmp = tempfile.mkdtemp(prefix="irx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", IRX_BENCH_NO_BIND="1")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--"] + child
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=env)
+            files = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if not files:
+                return {"error": "%s pass wrote no counter_collection.csv (exit %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-200:])}
+            acc = {}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = re.sub(r"^void ", "", row["Kernel_Name"])
+                if not name.startswith("k_"):
+                    continue
+                m = re.match(r"([A-Za-z0-9_]+)(<[^>]*>)?", name)
+                key = (m.group(1) + (m.group(2) or "")) if m else name
+                a = acc.setdefault(key, [0.0, 0])
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+            for k, (tot, n) in acc.items():
+                sums.setdefault(k, {})[counter] = tot / max(n, 1)
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {k: int((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024) for k, v in sums.items()}
+
+
+def traffic_for(roof, pmc, bf16):
+    """Fill roof['traffic'] (HBM bytes per launch of the dominant kernel) from a live PMC measurement."""
+    if not roof or not isinstance(pmc, dict) or "error" in pmc:
+        return
+    key = roof["kernel"].replace(",", ", ")
+    if key.startswith(("k_spconv2<", "k_wgrad_pairs<")):           # template flags: <..., bf16 operands, bf16 storage>
+        key = key[:-1] + (", true, true>" if bf16 else ", false, false>")
+    hit = [k for k in pmc if k == key or k.startswith(key[:-1] + ",")]
+    if hit:
+        roof["traffic"] = pmc[hit[0]]
+        roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py on this box (2 steps, serial issue)"
 
 
 def end_to_end(args):
@@ -841,7 +912,7 @@ def summarise_roofline(recs, bf16=False):
             traffic = pmc[key]["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
-    return {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm",
+    return {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm", "traffic_source": "profiles/%s (committed PMC passes)" % name if traffic is not None else None,
             "achieved": tf if mfma_bound else gbs, "peak": peak_tf if mfma_bound else PEAK_HBM_GBS,
             "unit": "TFLOP/s" if mfma_bound else "GB/s",
             "frac": (tf / peak_tf) if mfma_bound else (gbs / PEAK_HBM_GBS),
