@@ -71,6 +71,19 @@ int irx_device_props(int device, int* out8_host);
 /* keys[i] = (b<<48)|morton(x,y,z) for coords[i]. */
 int irx_coords_to_keys(const int32_t* coords, int n, uint64_t* keys, void* stream);
 
+/* Stable ascending radix sort (8-bit digits, LSD) of 64-bit keys by their bits [begin_bit, end_bit), with the permutation
+ * it applies: keys_out[i] = keys[order_out[i]]. The ordering step of the voxeliser: rows of every SparseTensor are kept
+ * in ascending Morton-key order — what torchsparse obtains from `np.unique(hash, return_index=True)` inside
+ * sparse_quantize (reference call sites models/attribute_module.py:65-69, lib/dataset.py:229-233,256-260), and the grouping
+ * of sampled points by instance slot in the device-side input pipeline (lib/dataset.py:207-213: np.nonzero per instance id).
+ * n_dev != NULL: only the first *n_dev elements are real (the count lives on the device: no host sync); the remaining
+ * n - *n_dev elements are treated as the key `pad` (must compare above every real key within the sorted bits) and come out
+ * behind the real ones. Deterministic (no global atomics). workspace: irx_sort_workspace_bytes(n). */
+size_t irx_sort_workspace_bytes(int n);
+int irx_sort_pairs_u64(const uint64_t* keys, int n, const int32_t* n_dev, uint64_t pad, int begin_bit, int end_bit,
+                       uint64_t* keys_out, int32_t* order_out, void* workspace, size_t workspace_bytes, void* stream);
+
+
 /* Quantise points to voxel coordinates exactly as torchsparse.utils.sparse_quantize does
  * before hashing: coord = floor(xyz / voxel) evaluated in float64 (no min-shift; negatives
  * kept) — replaces the `np.floor(coords / quantization_size)` step reached from

@@ -457,10 +457,10 @@ def build_batch_device(scans, object_ids, tables, device, num_points=40000, augm
     # points grouped by slot: a stable sort on 16-bit keys (ascending point index inside a slot, like np.nonzero); the
     # segment bounds come from a binary search in the sorted keys and the first point of a slot is the segment's head
     # (bincount / scatter-amin would be 800 k atomics on ~150 addresses: measured 1.7 ms)
-    kdt = torch.int16 if S < 32768 else torch.int32
-    skeys, order = torch.sort(gs.to(kdt), stable=True)
-    order32 = order.to(torch.int32)
-    seg = torch.searchsorted(skeys, torch.arange(S + 1, device=device, dtype=kdt))
+    from .sparse import functional as F_
+    skeys, order32 = F_.sort_keys(gs.to(torch.int64), max(int(S).bit_length(), 1))   # the build's stable radix sort
+    order = order32.long()
+    seg = torch.searchsorted(skeys, torch.arange(S + 1, device=device, dtype=torch.int64))
     seg32 = seg.to(torch.int32)
     counts = seg[1:] - seg[:-1]
     # semantic id of each instance's FIRST sampled point (lib/dataset.py:213: semantic_labels[ind[0]])

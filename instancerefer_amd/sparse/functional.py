@@ -51,6 +51,33 @@ def coords_to_keys(coords):
     return keys
 
 
+def sort_keys(keys, end_bit=63, n_dev=None, pad=None, begin_bit=0):
+    """Stable ascending sort of int64 `keys` (non-negative) by bits [begin_bit, end_bit) -> (sorted keys, order int32) with
+    sorted[i] = keys[order[i]]: irx_sort_pairs_u64 (csrc/irx_sort.hip), the build's own radix sort. n_dev (int32 device
+    tensor, 1 element) + pad: only the first n_dev keys are real, the rest sorts behind them as `pad` (no host sync)."""
+    n = keys.shape[0]
+    dev = keys.device
+    out = torch.empty(n, dtype=_i64, device=dev)
+    order = torch.empty(n, dtype=_i32, device=dev)
+    if n == 0:
+        return out, order
+    keys = keys.contiguous()
+    wsb = int(_lib.load().irx_sort_workspace_bytes(n))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.call("irx_sort_pairs_u64", _lib.ptr(keys), n, _lib.ptr(n_dev), int(pad or 0), int(begin_bit), int(end_bit), _lib.ptr(out),
+              _lib.ptr(order), _lib.ptr(ws), wsb, _stream())
+    return out, order
+
+
+def morton_bits(batch_size, with_pad=False):
+    """Bits of a Morton key (batch << 48 | 48-bit interleave) that can differ for batch indices < batch_size (<= batch_size
+    when a padding key `batch_size << 48` is in play); None = unknown batch size -> all 63."""
+    if batch_size is None:
+        return 63
+    top = int(batch_size) if with_pad else max(int(batch_size) - 1, 0)
+    return 48 + max(top.bit_length(), 1)
+
+
 def quantize(xyz, batch, voxel):
     """xyz (N,3) f32/f64 cuda, batch (N,) int32 or None, voxel: 3 floats -> coords (N,4) i32, keys (N,) i64."""
     n = xyz.shape[0]

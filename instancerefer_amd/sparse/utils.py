@@ -28,7 +28,7 @@ def voxelize(xyz, feats, batch, voxel_size, batch_size):
     coords, keys = F_.quantize(xyz, batch, _voxel3(voxel_size))
     win = F_.voxel_unique(keys)
     wkeys = keys.index_select(0, win)
-    skeys, order = torch.sort(wkeys)
+    skeys, order = F_.sort_keys(wkeys, F_.morton_bits(batch_size))
     idx = win.index_select(0, order)
     C = coords.index_select(0, idx).contiguous()
     Fv = feats.index_select(0, idx).float().contiguous()
@@ -56,7 +56,6 @@ class VoxelizePending:
         return SparseTensor(Fv, C, 1, self.batch_size, lv0)
 
 
-_KEY_PAD = (1 << 63) - 1        # sorts behind every real Morton key (batch index < 2^15)
 
 
 def voxelize_launch(xyz, feats, batch, voxel_size, batch_size, levels):
@@ -64,9 +63,10 @@ def voxelize_launch(xyz, feats, batch, voxel_size, batch_size, levels):
     coords, keys = F_.quantize(xyz, batch, _voxel3(voxel_size))
     n = keys.shape[0]
     win, count = F_.voxel_unique_launch(keys)                    # winners first, zeros behind; count on the device
-    valid = torch.arange(n, device=keys.device, dtype=torch.int32) < count
-    wkeys = torch.where(valid, keys.index_select(0, win), torch.full((), _KEY_PAD, dtype=keys.dtype, device=keys.device))
-    skeys, order = torch.sort(wkeys)                             # padding rows sort to the end
+    # rows behind the device-side count are padding: the sort reads the count itself and gives them the key
+    # `batch_size << 48`, which sorts behind every real Morton key (batch index < batch_size)
+    skeys, order = F_.sort_keys(keys.index_select(0, win), F_.morton_bits(batch_size, True), n_dev=count,
+                                pad=int(batch_size) << 48)
     idx = win.index_select(0, order)
     C = coords.index_select(0, idx).contiguous()
     Fv = feats.index_select(0, idx).float().contiguous()
@@ -89,7 +89,7 @@ def sparse_quantize(coords, feats=None, labels=None, ignore_label=255, return_in
     c4, keys = F_.quantize(xyz, None, _voxel3(quantization_size))
     win = F_.voxel_unique(keys)
     wkeys = keys.index_select(0, win)
-    _, order = torch.sort(wkeys)
+    _, order = F_.sort_keys(wkeys, F_.morton_bits(1))
     idx = win.index_select(0, order)
     if return_index or feats is None:
         return idx

@@ -768,3 +768,39 @@ def test_sync_batchnorm_entries_fold_like_one_batch(lib, n, c, relu, res, split)
     assert (bg - ref.bias.grad).abs().max().item() <= 1e-4 * max(1.0, ref.bias.grad.abs().max().item())
     if res:
         assert (torch.cat(drs).cpu() - ro.grad).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4095, 4097, 20000, 700001])
+def test_radix_sort_is_a_stable_sort(lib, n):
+    """csrc/irx_sort.hip (the ordering step of the voxeliser; torchsparse gets it from np.unique(hash, return_index=True),
+    reference models/attribute_module.py:65-69) against torch.sort(stable=True): Morton-shaped 53-bit keys with many
+    duplicates, a 16-bit key range (the input pipeline's slot sort: ties must keep their input order), a bit window, and
+    the device-side count with a padding key. Bit-exact."""
+    from instancerefer_amd.sparse import functional as F_
+    g = torch.Generator(device="cuda").manual_seed(n)
+    dev = torch.device("cuda")
+    # (a) 53-bit keys, heavy duplication
+    keys = (torch.randint(0, 1 << 20, (n,), generator=g, device=dev) * 0x1F3D5B79) % (1 << 48)
+    keys = keys | (torch.randint(0, 17, (n,), generator=g, device=dev) << 48)
+    keys[::3] = keys[0]
+    exp, eo = torch.sort(keys, stable=True)
+    got, order = F_.sort_keys(keys, F_.morton_bits(17))
+    assert torch.equal(got, exp) and torch.equal(order.long(), eo)
+    # (b) 16-bit slot ids: stability is what groups the points of a slot in ascending point index
+    slots = torch.randint(0, 150, (n,), generator=g, device=dev)
+    exp, eo = torch.sort(slots, stable=True)
+    got, order = F_.sort_keys(slots, 8)
+    assert torch.equal(got, exp) and torch.equal(order.long(), eo)
+    # (c) a bit window: sort by bits [8, 24) only, ties (equal window) in input order
+    exp_o = torch.sort((keys >> 8) & 0xFFFF, stable=True)[1]
+    got, order = F_.sort_keys(keys, 24, begin_bit=8)
+    assert torch.equal(order.long(), exp_o) and torch.equal(got, keys[exp_o])
+    # (d) device-side count: only the first m keys are real, the tail is padding that sorts behind them
+    m = max(n * 2 // 3, 0)
+    count = torch.tensor([m], dtype=torch.int32, device=dev)
+    junk = keys.clone()
+    junk[m:] = 5                                   # whatever sits behind the count must not matter
+    got, order = F_.sort_keys(junk, F_.morton_bits(17, True), n_dev=count, pad=17 << 48)
+    exp, eo = torch.sort(keys[:m], stable=True)
+    assert torch.equal(got[:m], exp) and torch.equal(order[:m].long(), eo)
+    assert bool((got[m:] == (17 << 48)).all()) and torch.equal(order[m:].long(), torch.arange(m, n, device=dev))
