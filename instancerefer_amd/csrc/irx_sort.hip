@@ -8,7 +8,8 @@
 //   k_rs_count   : workgroup = RS_TILE consecutive elements, wave w owns the w-th quarter of them; per 64-element chunk the
 //                  lanes holding the same digit find each other with 8 ballots (one per digit bit) and the lowest lane of
 //                  each peer group adds the group size to the wave's LDS counter -> counts[bin][4 * block + wave]
-//   k_rs_scan    : exclusive prefix sum over that bin-major table (one workgroup; <= 256 x a few hundred entries)
+//   k_rs_rowscan : one workgroup per digit value: exclusive scan of its row of the table + the bin total (the scatter
+//                  kernel scans the 256 totals itself) — a single-workgroup scan of the whole table was 200 us per pass
 //   k_rs_scatter : same walk; position = base[digit] + (peers below me); stable because waves, chunks and lanes are
 //                  visited in element order and the table is scanned bin-major, (block, wave)-minor
 // No atomics on global memory, no float: the result is deterministic and bit-exact by construction.
@@ -61,40 +62,62 @@ __global__ __launch_bounds__(256) void k_rs_count(const uint64_t* __restrict__ k
   }
 }
 
-// exclusive scan of `total` ints in place, one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_rs_scan(int32_t* __restrict__ v, int total) {
-  __shared__ int part[1024];
+// One workgroup per digit value: exclusive scan of that bin's row counts[bin][0 .. nslots) in place (coalesced loads, LDS
+// scan in chunks of 1024) and the bin's total -> totals[bin]. The scatter kernel adds the exclusive scan over the 256 totals.
+__global__ __launch_bounds__(1024) void k_rs_rowscan(int32_t* __restrict__ counts, int nslots, int32_t* __restrict__ totals) {
+  __shared__ int buf[1024];
+  __shared__ int carry_s;
+  int32_t* row = counts + (size_t)blockIdx.x * nslots;
   const int tid = threadIdx.x;
-  const int per = (total + 1023) / 1024;
-  const int lo = tid * per, hi = (lo + per < total) ? lo + per : total;
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += v[i];
-  part[tid] = s;
+  if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {           // Hillis-Steele inclusive scan of the 1024 partial sums
-    const int t = (tid >= off) ? part[tid - off] : 0;
+  for (int base = 0; base < nslots; base += 1024) {
+    const int i = base + tid;
+    const int v = (i < nslots) ? row[i] : 0;
+    buf[tid] = v;
     __syncthreads();
-    part[tid] += t;
+    for (int off = 1; off < 1024; off <<= 1) {         // Hillis-Steele inclusive scan
+      const int t = (tid >= off) ? buf[tid - off] : 0;
+      __syncthreads();
+      buf[tid] += t;
+      __syncthreads();
+    }
+    const int carry = carry_s;
+    if (i < nslots) row[i] = carry + buf[tid] - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + buf[1023];
     __syncthreads();
   }
-  int run = part[tid] - s;                             // exclusive offset of this thread's chunk
-  for (int i = lo; i < hi; ++i) {
-    const int c = v[i];
-    v[i] = run;
-    run += c;
-  }
+  if (tid == 0) totals[blockIdx.x] = carry_s;
 }
 
 // idx_in == NULL: the incoming order is the identity (first pass)
 __global__ __launch_bounds__(256) void k_rs_scatter(const uint64_t* __restrict__ keys, const int32_t* __restrict__ idx_in,
                                                     int n, const int32_t* __restrict__ n_dev, uint64_t pad, int shift,
                                                     int nslots, const int32_t* __restrict__ offsets,
+                                                    const int32_t* __restrict__ totals,
                                                     uint64_t* __restrict__ keys_out, int32_t* __restrict__ idx_out) {
   __shared__ int base_s[4][RS_BINS];
+  __shared__ int bin_base[RS_BINS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {  // exclusive scan over the 256 bin totals (thread == bin)
+    const int v = totals[tid];
+    bin_base[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < RS_BINS; off <<= 1) {
+      const int t = (tid >= off) ? bin_base[tid - off] : 0;
+      __syncthreads();
+      bin_base[tid] += t;
+      __syncthreads();
+    }
+    const int ex = bin_base[tid] - v;
+    __syncthreads();
+    bin_base[tid] = ex;
+    __syncthreads();
+  }
   for (int i = tid; i < 4 * RS_BINS; i += 256) {
     const int w = i / RS_BINS, bin = i % RS_BINS;
-    base_s[w][bin] = offsets[(size_t)bin * nslots + 4 * blockIdx.x + w];
+    base_s[w][bin] = bin_base[bin] + offsets[(size_t)bin * nslots + 4 * blockIdx.x + w];
   }
   __syncthreads();
   const int n_real = n_dev ? (*n_dev < n ? (*n_dev < 0 ? 0 : *n_dev) : n) : n;
@@ -126,6 +149,7 @@ extern "C" size_t irx_sort_workspace_bytes(int n) {
   const size_t nslots = 4 * (size_t)irx_cdiv(n, RS_TILE);
   size_t b = RS_BINS * nslots * sizeof(int32_t);       // digit counts / offsets
   b = (b + 255) & ~(size_t)255;
+  b += 1024;                                           // bin totals
   b += (((size_t)n * sizeof(uint64_t) + 255) & ~(size_t)255) + (((size_t)n * sizeof(int32_t) + 255) & ~(size_t)255);   // ping-pong
   return b + 256;
 }
@@ -145,6 +169,8 @@ extern "C" int irx_sort_pairs_u64(const uint64_t* keys, int n, const int32_t* n_
   char* p = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   int32_t* counts = (int32_t*)p;
   p += ((size_t)RS_BINS * nslots * sizeof(int32_t) + 255) & ~(size_t)255;
+  int32_t* totals = (int32_t*)p;
+  p += 1024;
   uint64_t* kb = (uint64_t*)p;
   p += ((size_t)n * sizeof(uint64_t) + 255) & ~(size_t)255;
   int32_t* ib = (int32_t*)p;
@@ -160,8 +186,8 @@ extern "C" int irx_sort_pairs_u64(const uint64_t* keys, int n, const int32_t* n_
     // after the first pass the padding has been materialised into the key buffer: no device count needed any more
     const int32_t* nd = (ps == 0) ? n_dev : nullptr;
     k_rs_count<<<nblk, 256, 0, S(stream)>>>(kin, n, nd, pad, shift, nslots, counts);
-    k_rs_scan<<<1, 1024, 0, S(stream)>>>(counts, RS_BINS * nslots);
-    k_rs_scatter<<<nblk, 256, 0, S(stream)>>>(kin, iin, n, nd, pad, shift, nslots, counts, ko, io);
+    k_rs_rowscan<<<RS_BINS, 1024, 0, S(stream)>>>(counts, nslots, totals);
+    k_rs_scatter<<<nblk, 256, 0, S(stream)>>>(kin, iin, n, nd, pad, shift, nslots, counts, totals, ko, io);
     kin = ko;
     iin = io;
   }

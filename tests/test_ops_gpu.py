@@ -782,7 +782,7 @@ def test_radix_sort_is_a_stable_sort(lib, n):
     # (a) 53-bit keys, heavy duplication
     keys = (torch.randint(0, 1 << 20, (n,), generator=g, device=dev) * 0x1F3D5B79) % (1 << 48)
     keys = keys | (torch.randint(0, 17, (n,), generator=g, device=dev) << 48)
-    keys[::3] = keys[0]
+    keys[::3] = keys[0].clone()
     exp, eo = torch.sort(keys, stable=True)
     got, order = F_.sort_keys(keys, F_.morton_bits(17))
     assert torch.equal(got, exp) and torch.equal(order.long(), eo)
