@@ -5,7 +5,12 @@
 // ~12 ms of host launch time). The recurrence is inherently sequential but tiny (H = 128), so it is run by ONE
 // workgroup per (sequence, direction) that keeps W_hh in VGPRs (one gate row per thread, 128 floats), h in LDS
 // (broadcast reads) and walks the T steps with two barriers per step; the time-parallel parts (input
-// projections X*W_ih^T, dW_ih, dW_hh, dX) stay dense GEMMs (hipBLASLt on MFMA) in the host layer.
+// projections X*W_ih^T, dW_ih, dW_hh, dX) stay dense GEMMs (rocBLAS on MFMA) in the host layer.
+// Why the recurrence itself is NOT on the matrix core (round 3, costed): h(t) W_hh^T for all 16 sequences of a direction
+// is a 16 x 128 x 384 product = 24 column tiles x 32 v_mfma_f32_16x16x4_f32 per step; one workgroup (it cannot be split
+// over CUs without a cross-CU hand-off of h every step) has 4 SIMDs, i.e. 24 * 32 * 32 / 4 = 6144 cycles = 2.6 us per step
+// on 2 CUs, against ~0.3 us of FMA work per step per workgroup here, spread over 32 CUs. The steps are latency chains, not
+// throughput: what cost 135 us per launch was a global load at the top of every step (now prefetched one step ahead).
 // Packed-sequence semantics: forward direction runs t = 0..len-1, reverse runs t = len-1..0; outputs (and
 // gradients) at t >= len are zero, exactly what pack_padded_sequence / pad_packed_sequence produce.
 #include "irx_common.h"
@@ -38,10 +43,18 @@ __global__ __launch_bounds__(3 * H) void k_gru_fwd(const float* __restrict__ gi,
   const float bh = b_hh[dir * 3 * H + g];
   if (g < H) sH[g] = 0.f;
   __syncthreads();
+  // the input projection of step s + 1 is requested before the arithmetic of step s: a load at the top of every step put a
+  // full L2 / HBM round trip on the serial chain (135 us per launch for 30 steps of ~0.3 us of arithmetic each)
+  auto gi_at = [&](int step) {
+    const int t = dir == 0 ? step : len - 1 - step;
+    return gi[(((size_t)b * T + t) * ndir + dir) * 3 * H + g];
+  };
+  float gi_next = (len > 0) ? gi_at(0) : 0.f;
   for (int step = 0; step < len; ++step) {
     const int t = dir == 0 ? step : len - 1 - step;
     const size_t row = ((size_t)b * T + t) * ndir + dir;
-    const float gi_val = gi[row * 3 * H + g];
+    const float gi_val = gi_next;
+    if (step + 1 < len) gi_next = gi_at(step + 1);
     float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int c = 0; c < H; c += 4) {
@@ -90,18 +103,32 @@ __global__ __launch_bounds__(3 * H) void k_gru_bwd(const float* __restrict__ dou
 #pragma unroll
   for (int i = 0; i < H; ++i) wt[i] = wbase[(size_t)i * H];
   float dh_carry = 0.f;
+  // the six per-step inputs of step s - 1 are requested before the arithmetic of step s (see k_gru_fwd)
+  struct In { float r, z, n, hn, hprev, dout; };
+  auto load_in = [&](int step) {
+    const int t = dir == 0 ? step : len - 1 - step;
+    const size_t bt = (size_t)b * T + t;
+    const float* gp = gates + (bt * ndir + dir) * 4 * H;
+    In v;
+    v.r = gp[j]; v.z = gp[H + j]; v.n = gp[2 * H + j]; v.hn = gp[3 * H + j];
+    v.hprev = 0.f;
+    if (step > 0) {
+      const int tp = dir == 0 ? t - 1 : t + 1;
+      v.hprev = out[((size_t)b * T + tp) * ndir * H + dir * H + j];
+    }
+    v.dout = dout[bt * ndir * H + dir * H + j];
+    return v;
+  };
+  In nxt = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (len > 0) nxt = load_in(len - 1);
   for (int step = len - 1; step >= 0; --step) {
     const int t = dir == 0 ? step : len - 1 - step;
     const size_t bt = (size_t)b * T + t;
     const size_t row = bt * ndir + dir;
-    const float* gp = gates + row * 4 * H;
-    const float r = gp[j], z = gp[H + j], n = gp[2 * H + j], hn = gp[3 * H + j];
-    float hprev = 0.f;
-    if (step > 0) {
-      const int tp = dir == 0 ? t - 1 : t + 1;
-      hprev = out[((size_t)b * T + tp) * ndir * H + dir * H + j];
-    }
-    const float dh = dout[bt * ndir * H + dir * H + j] + dh_carry;
+    const In cur = nxt;
+    if (step > 0) nxt = load_in(step - 1);
+    const float r = cur.r, z = cur.z, n = cur.n, hn = cur.hn, hprev = cur.hprev;
+    const float dh = cur.dout + dh_carry;
     const float dn_pre = dh * (1.f - z) * (1.f - n * n);
     const float dz_pre = dh * (hprev - n) * z * (1.f - z);
     const float dr_pre = dn_pre * hn * r * (1.f - r);
