@@ -290,6 +290,9 @@ enum {
   IRX_ENC_STORE,                    /* 0: every tensor fp32. 1 (needs irx_set_compute_dtype(1 | 2)): bf16 STORAGE — C, Y, GY
                                      * and the dc scratch are bf16 arrays (2 bytes / element) except the FIRST layer's X, the
                                      * LAST layer's Y and GY and dx0, which stay fp32; statistics / parameter gradients fp32 */
+  IRX_ENC_MODE,                     /* compute mode of this pass (the values of irx_set_compute_dtype: 0 fp32, 1 bf16 operands, 2 +
+                                     * bf16 storage), recorded by the caller when it builds the table for the forward pass and
+                                     * carried into the backward pass: the executor uses THIS, not the process-wide setting */
   IRX_ENC_PROF,                     /* 0, or a HOST pointer to 6 event handles (hipEvent_t): start / stop around this layer's
                                      * dominant forward, data-gradient and weight-gradient kernel (measurement aid, bench.py) */
   IRX_ENC_NFIELDS

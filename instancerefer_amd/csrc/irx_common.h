@@ -129,6 +129,12 @@ void irx_bracket_begin(hipStream_t st);
 void irx_bracket_end(hipStream_t st);
 
 // ---- second-generation sparse-conv launchers (irx_spconv2.hip) ---------------------------------
+// pins the compute mode of the calling thread's launches for its lifetime (irx_spconv2.hip); mode < 0 = no override
+struct IrxModeScope {
+  int prev;
+  explicit IrxModeScope(int mode);
+  ~IrxModeScope();
+};
 bool irx_conv_bf16();          // irx_set_compute_dtype(1 | 2): bf16 operands / fp32 accumulation in the MFMA conv kernels
 bool irx_conv_bf16_storage();  // irx_set_compute_dtype(2): ... and bf16 activations / gradients inside the encoder executor
 bool irx_spconv2_supported(int cin, int cout);

@@ -75,6 +75,7 @@ Regions regions(const int64_t* desc, const double* fdesc, int n, bool backward) 
 
 extern "C" size_t irx_encoder_workspace_bytes(const int64_t* desc, const double* fdesc, int n_layers, int backward) {
   if (!desc || !fdesc || n_layers <= 0) return 0;
+  const IrxModeScope pin((int)desc[IRX_ENC_MODE]);
   const Regions r = regions(desc, fdesc, n_layers, backward != 0);
   return r.conv + r.wgrad + r.bn + r.wimg + 256;
 }
@@ -82,6 +83,9 @@ extern "C" size_t irx_encoder_workspace_bytes(const int64_t* desc, const double*
 extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int n_layers, void* workspace,
                                    size_t workspace_bytes, void* stream) {
   IRX_REQUIRE(desc && fdesc && n_layers > 0, "irx_encoder_forward: empty descriptor table");
+  const int mode = (int)desc[IRX_ENC_MODE];
+  IRX_REQUIRE(mode >= 0 && mode <= 2, "irx_encoder_forward: IRX_ENC_MODE = %d", mode);
+  const IrxModeScope pin(mode);                      // every launch of this call uses the table's mode
   const Regions r = regions(desc, fdesc, n_layers, false);
   IRX_REQUIRE(workspace && workspace_bytes >= r.conv + r.bn + r.wimg + 255, "irx_encoder_forward: workspace %zu < %zu",
               workspace_bytes, r.conv + r.bn + r.wimg + 255);
@@ -110,7 +114,7 @@ extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int
     if (rc) return rc;
   }
   const int st = (int)desc[IRX_ENC_STORE];
-  IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_forward: bf16 storage needs the bf16 compute mode (irx_set_compute_dtype)");
+  IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_forward: bf16 storage needs a bf16 compute mode in IRX_ENC_MODE");
   for (int i = 0; i < n_layers; ++i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
     IRX_REQUIRE(L.res < i, "irx_encoder_forward: layer %d takes its residual from a later layer", i);
@@ -139,6 +143,9 @@ extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int
 extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch,
                                     float* dx0, void* workspace, size_t workspace_bytes, void* stream) {
   IRX_REQUIRE(desc && fdesc && n_layers > 0 && dc_scratch, "irx_encoder_backward: bad arguments");
+  const int mode = (int)desc[IRX_ENC_MODE];
+  IRX_REQUIRE(mode >= 0 && mode <= 2, "irx_encoder_backward: IRX_ENC_MODE = %d", mode);
+  const IrxModeScope pin(mode);                      // the mode the forward pass ran under, whatever the setting is now
   const Regions r = regions(desc, fdesc, n_layers, true);
   IRX_REQUIRE(workspace && workspace_bytes >= r.conv + r.wgrad + r.bn + r.wimg + 255,
               "irx_encoder_backward: workspace %zu < %zu", workspace_bytes, r.conv + r.wgrad + r.bn + r.wimg + 255);
@@ -177,7 +184,7 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
     if (res >= 0) is_res_source[res] = true;
   }
   const int st = (int)desc[IRX_ENC_STORE];
-  IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_backward: bf16 storage needs the bf16 compute mode (irx_set_compute_dtype)");
+  IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_backward: bf16 storage needs a bf16 compute mode in IRX_ENC_MODE");
   IRX_REQUIRE(!st || !dx0, "irx_encoder_backward: the input gradient is not available with bf16 storage");
   for (int i = n_layers - 1; i >= 0; --i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);

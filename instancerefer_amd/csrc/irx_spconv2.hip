@@ -28,14 +28,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // inside the encoder executor (irx_encoder.hip): the conv gathers 8-byte bf16 quads straight into the LDS A tile and
 // its epilogue rounds the fp32 tile on the way out; statistics, accumulation and parameter gradients stay fp32.
 static int g_irx_conv_bf16 = 0;
+// The mode a launch uses: the calling thread's override when one is in force (IrxModeScope: the encoder executor pins the
+// mode recorded in its descriptor table, so a pass issued by a library thread — or a backward whose forward ran under another
+// setting — never reads a process-wide variable that the application may be changing), else the process-wide setting.
+static thread_local int t_irx_mode = -1;
+static inline int irx_mode_now() { return t_irx_mode >= 0 ? t_irx_mode : g_irx_conv_bf16; }
+IrxModeScope::IrxModeScope(int mode) : prev(t_irx_mode) { t_irx_mode = mode; }
+IrxModeScope::~IrxModeScope() { t_irx_mode = prev; }
 extern "C" int irx_set_compute_dtype(int mode) {
   IRX_REQUIRE(mode >= 0 && mode <= 2, "irx_set_compute_dtype: %d is not 0 (fp32), 1 (bf16 operands) or 2 (bf16 storage)", mode);
   g_irx_conv_bf16 = mode;
   return IRX_OK;
 }
 extern "C" int irx_get_compute_dtype(void) { return g_irx_conv_bf16; }
-bool irx_conv_bf16() { return g_irx_conv_bf16 != 0; }
-bool irx_conv_bf16_storage() { return g_irx_conv_bf16 == 2; }
+bool irx_conv_bf16() { return irx_mode_now() != 0; }
+bool irx_conv_bf16_storage() { return irx_mode_now() == 2; }
 
 #define S2_TM 64
 
@@ -673,18 +680,18 @@ int irx_spconv2_splits(int n_out, int K) {
 int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int ld, int n_out, int K, int cin,
                        int cout, int flip_k, float* y, int splits, int accumulate, hipStream_t st, int ldx, IrxStore ty) {
   if (ldx <= 0) ldx = cin;
-  IRX_REQUIRE(!ty.x || g_irx_conv_bf16, "irx_spconv_fwd: a bf16 input needs the bf16 compute mode");
+  IRX_REQUIRE(!ty.x || irx_mode_now(), "irx_spconv_fwd: a bf16 input needs the bf16 compute mode");
   const int y_bf = (splits == 1) ? ty.y : 0;
   const int acc = (splits == 1) ? accumulate : 0;
   IRX_REQUIRE(K <= 27, "irx_spconv_fwd: K = %d > 27 unsupported by the fast path", K);
   dim3 grid(irx_cdiv(n_out, S2_TM), splits);
   const int kps = irx_cdiv(K, splits);
   irx_bracket_begin(st);
-  if (g_irx_conv_bf16 && ty.x) {
+  if (irx_mode_now() && ty.x) {
     if (cin == 128) launch_fwd2<128, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
     else if (cin == 64) launch_fwd2<64, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
     else launch_fwd2<32, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-  } else if (g_irx_conv_bf16) {
+  } else if (irx_mode_now()) {
     if (cin == 128) launch_fwd2<128, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
     else if (cin == 64) launch_fwd2<64, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
     else launch_fwd2<32, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
@@ -733,14 +740,14 @@ __global__ void k_permute_w_multi(IrxPermuteJobs J, int trans_w, int bf16) {
 int irx_permute_w_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStream_t st) {
   if (jobs.n == 0) return IRX_OK;
   const size_t total = jobs.end4[jobs.n - 1];
-  k_permute_w_multi<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(jobs, trans_w, g_irx_conv_bf16);
+  k_permute_w_multi<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(jobs, trans_w, irx_mode_now());
   IRX_CHECK_LAUNCH("irx_encoder(permute)");
   return IRX_OK;
 }
 
 int irx_permute_w_launch(const float* w, int K, int cin, int cout, int trans_w, float* wf, hipStream_t st, int src_cin) {
   const size_t total = (size_t)K * cin * cout / 4;
-  k_permute_w<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(w, K, cin, cout, trans_w, wf, g_irx_conv_bf16,
+  k_permute_w<<<irx_cdiv((long long)total, 256), 256, 0, st>>>(w, K, cin, cout, trans_w, wf, irx_mode_now(),
                                                               src_cin > 0 ? src_cin : cin);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(permute)");
   return IRX_OK;

@@ -77,7 +77,7 @@ def _ws(nbytes, dev):
 # field order of the descriptor table: include/irx.h, enum IRX_ENC_* (tests/test_abi_cpu.py checks the two agree)
 ENC_FIELDS = ("K", "CIN", "COUT", "N_IN", "N_OUT", "RES", "TBL", "LD", "TBL_B", "LD_B", "FLIP_B", "PAIR_IN", "PAIR_OUT",
               "PAIR_COUNTS", "LD_PAIRS", "W", "GAMMA", "BETA", "RUNNING_MEAN", "RUNNING_VAR", "X", "C", "Y", "MEAN",
-              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "PROF")
+              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "MODE", "PROF")
 _E = {n: i for i, n in enumerate(ENC_FIELDS)}
 _NF = len(ENC_FIELDS)
 _ALIGN = 64                                           # float32 elements (256 B)
@@ -220,6 +220,7 @@ class EncoderFn(torch.autograd.Function):
         stats = torch.empty((nl, 2, 128), dtype=_f32, device=dev)       # mean / invstd rows (cout <= 128)
         base, sbase = arena.data_ptr(), stats.data_ptr()
         desc[:, _E["STORE"]] = int(store)
+        desc[:, _E["MODE"]] = int(lib.irx_get_compute_dtype())      # pinned for this pass and its backward (include/irx.h)
         prof = _profile_slots(layers, store) if F_.PROFILE is not None else None
         if prof is not None:
             desc[:, _E["PROF"]] = prof[1]
@@ -263,9 +264,7 @@ class EncoderFn(torch.autograd.Function):
         dev = dout.device
         dout = dout.contiguous().float()
         # gradients in flight (bytes): gy_i for every layer but the last (that one IS dout) + the shared dc scratch
-        store = ctx.store
-        if store and _lib.load().irx_get_compute_dtype() == 0:
-            raise RuntimeError("the compute dtype was switched to fp32 between this encoder's forward (bf16 storage) and its backward")
+        store = ctx.store                # (the table carries the forward pass's compute mode: IRX_ENC_MODE)
         gsz = _up256(n_out * cout * (2 if store else 4))
         goffs = np.concatenate([[0], np.cumsum(gsz[:-1])])              # nl entries; the last one = start of dc
         dc_off = int(goffs[-1])

@@ -330,3 +330,30 @@ def test_full_model_bf16_modes_within_the_reordering_distance(lib, case, mode):
                              points_per_instance=200, multiview=128), 135, 78
     (model, dd), runs = _model_runs(cfg, seed, c0, mode)
     check_model_against_emulation(model, dd, runs, "full model %s %s" % (case, mode))
+
+
+def test_compute_mode_is_pinned_per_encoder_pass(lib):
+    """VERDICT r2 hygiene: the executor's descriptor table carries the compute mode (IRX_ENC_MODE), so a pass — and its backward
+    — uses the mode it was BUILT under even when the process-wide setting changes in between (library threads issue these
+    passes asynchronously; the application may flip the setting for the next pass meanwhile). Forward under "bf16", switch to
+    "fp32", backward: bit-identical to the run that never switched."""
+    import instancerefer_amd as irx
+    rng = np.random.default_rng(77)
+    clouds = [surface_cloud(rng, 3000, rng.uniform(0, 3, 3), rng.uniform(0.8, 2.0, 3)) for _ in range(3)]
+    res = {}
+    for switch in (False, True):
+        enc, _ = _encoder_pair(7, 5)
+        irx.set_compute_dtype("bf16")
+        try:
+            out = enc(device_batch(clouds, 0.05)).F
+            if switch:
+                irx.set_compute_dtype("fp32")
+            g = torch.linspace(-1, 1, out.numel(), device="cuda").view_as(out)
+            out.backward(g)
+            torch.cuda.synchronize()
+        finally:
+            irx.set_compute_dtype("fp32")
+        res[switch] = (out.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters()})
+    assert torch.equal(res[False][0], res[True][0])
+    for n in res[False][1]:
+        assert torch.equal(res[False][1][n], res[True][1][n]), n
