@@ -20,7 +20,7 @@ def _offsets(batch, nb):
     return torch.searchsorted(batch.contiguous(), edges).to(torch.int32)
 
 
-def knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1):
+def knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1, batch_size=None):
     """torch_cluster.knn: for every row of `y` (queries) its k nearest rows of `x` (support) among the rows with the
     same batch index, Euclidean. -> LongTensor [2, E]: row 0 = query index, row 1 = support index, queries in order,
     neighbours by ascending distance; a batch item with fewer than k support rows yields fewer edges.
@@ -36,7 +36,10 @@ def knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1):
         batch_x = torch.zeros(x.shape[0], dtype=torch.long, device=x.device)
     if batch_y is None:
         batch_y = torch.zeros(nq, dtype=torch.long, device=x.device)
-    nb = int(torch.maximum(batch_x.max(), batch_y.max())) + 1         # host sync, as upstream's batch_size deduction
+    # batch_size (torch_cluster >= 1.6.1 has the same keyword) saves the host round trip of deducing it; the [2, E] result has
+    # a data-dependent length either way (fewer than k neighbours in small scenes), which is one sync this compat surface
+    # cannot avoid — the drop-in RelationModule does not go through here (fused k_edgeconv_* on the (nq, k) table)
+    nb = int(batch_size) if batch_size is not None else int(torch.maximum(batch_x.max(), batch_y.max())) + 1
     nbr = F_.knn_batched(x, _offsets(batch_x, nb), y, batch_y.to(torch.int32).contiguous(), int(k))      # (nq, k), -1 = none
     valid = nbr >= 0
     row = torch.arange(nq, device=x.device).unsqueeze(1).expand_as(nbr)[valid]
