@@ -193,7 +193,8 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
                       const float* invstd, const float* gamma, int relu, float* dx, float* dgamma, float* dbeta,
                       float* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int y_bf,
                       int dy_bf, int dx_bf, int dres_bf, int phases = 3, const float* all_sum_g = nullptr,
-                      const float* all_sum_gx = nullptr, double all_count = 0.0, const double* count_dev = nullptr);
+                      const float* all_sum_gx = nullptr, double all_count = 0.0, const double* count_dev = nullptr,
+                      const float* beta = nullptr);
 
 // ---- stem (small-Cin) launchers (irx_stem.hip) ------------------------------------------------------
 bool irx_stem_supported(int K, int cin, int cout);

@@ -192,8 +192,11 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
     if (L.res >= 0) dres = (float*)desc[(size_t)L.res * IRX_ENC_NFIELDS + IRX_ENC_GY];
     const int last = (i == n_layers - 1);
     // c: st | y, gy: fp32 for the last layer | dc scratch and the shortcut gradient (never the last layer's): st
+    // a layer without a shortcut hands over beta: its ReLU mask is recomputed from c and y is not read (irx_norm.hip)
+    static const bool remask = !(getenv("IRX_BN_REMASK") && atoi(getenv("IRX_BN_REMASK")) == 0);   // dev A/B knob
     int rc = irx_bn_backward_t(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, dc_scratch, L.dgamma,
-                               L.dbeta, dres, ws_b, r.bn, stream, st, (st && !last) ? 1 : 0, (st && !last) ? 1 : 0, st, st);
+                               L.dbeta, dres, ws_b, r.bn, stream, st, (st && !last) ? 1 : 0, (st && !last) ? 1 : 0, st, st,
+                               3, nullptr, nullptr, 0.0, nullptr, (L.res < 0 && remask) ? L.beta : nullptr);
     if (rc) return rc;
     if (L.prof) irx_profile_next_kernel(L.prof[4], L.prof[5]);
     if (pairs_path(L)) {

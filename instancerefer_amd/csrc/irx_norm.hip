@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
                                                     const float* __restrict__ dy, int n, int c,
                                                     const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, int relu,
-                                                    int qpad, int rows_per_block, float* __restrict__ part, BnTy ty) {
+                                                    int qpad, int rows_per_block, float* __restrict__ part, BnTy ty,
+                                                    const float* __restrict__ mk_gamma, const float* __restrict__ mk_beta) {
+  // mk_gamma / mk_beta != NULL (MODE 1, relu, a layer WITHOUT a shortcut): the ReLU mask is recomputed from x —
+  // y > 0  <=>  fma(x, invstd * gamma, fma(-mean, invstd * gamma, beta)) > 0, the very expression k_bn_apply evaluated — so y
+  // is never read (a third of this pass's bytes)
   __shared__ float s0[256 * V];
   __shared__ float s1[256 * V];
   const int cq = c / V;
@@ -86,12 +90,18 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
 #pragma unroll
   for (int j = 0; j < V; ++j) a0[j] = a1[j] = 0.f;
   if (qd < cq) {
-    float mu[V], is[V];
+    float mu[V], is[V], msc[V], msh[V];
+    const bool remask = MODE == 1 && relu && mk_beta != nullptr;
     if (MODE == 1) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         mu[j] = mean[qd * V + j];
         is[j] = invstd[qd * V + j];
+        msc[j] = msh[j] = 0.f;
+        if (remask) {
+          msc[j] = is[j] * mk_gamma[qd * V + j];
+          msh[j] = fmaf(-mu[j], msc[j], mk_beta[qd * V + j]);
+        }
       }
     }
     // U rows per trip: all their loads are issued before the first add (memory-level parallelism; a load per add left
@@ -103,20 +113,24 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
         bn_ld8(x, off, xv);
         if (MODE == 1) {
           bn_ld8(dy, off, dv);
-          if (relu) bn_ld8(y, off, yv);
+          if (relu && !remask) bn_ld8(y, off, yv);
         }
       } else if constexpr (V == 4) {
         *reinterpret_cast<float4*>(xv) = bn_ld4<TY>(x, off, ty.x);
         if (MODE == 1) {
           *reinterpret_cast<float4*>(dv) = bn_ld4<TY>(dy, off, ty.dy);
-          if (relu) *reinterpret_cast<float4*>(yv) = bn_ld4<TY>(y, off, ty.y);
+          if (relu && !remask) *reinterpret_cast<float4*>(yv) = bn_ld4<TY>(y, off, ty.y);
         }
       } else {
         xv[0] = x[off];
         if (MODE == 1) {
           dv[0] = dy[off];
-          if (relu) yv[0] = y[off];
+          if (relu && !remask) yv[0] = y[off];
         }
+      }
+      if (MODE == 1 && remask) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) yv[j] = fmaf(xv[j], msc[j], msh[j]);
       }
     };
     auto add_row = [&](const float (&xv)[V], const float (&yv)[V], const float (&dv)[V]) __attribute__((always_inline)) {
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, i
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     sc[j] = invstd[qd * V + j] * gamma[qd * V + j];
-    sh[j] = beta[qd * V + j] - mean[qd * V + j] * sc[j];
+    sh[j] = fmaf(-mean[qd * V + j], sc[j], beta[qd * V + j]);    // (k_bn_partial<1> / k_bn_bwd_apply re-evaluate exactly this)
   }
   const int row_stride = gridDim.x * rpp;
   for (int r = blockIdx.x * rpp + threadIdx.x / qpad; r < n; r += row_stride) {
@@ -300,14 +314,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ sum_g,
                                                       const float* __restrict__ sum_gx, int relu,
                                                       float* __restrict__ dx, float* __restrict__ dres, BnTy ty,
-                                                      float inv_count, const double* __restrict__ count_dev) {
+                                                      float inv_count, const double* __restrict__ count_dev,
+                                                      const float* __restrict__ mk_beta) {
   // inv_count: 1 / (rows the sums were taken over) — 1 / n, or 1 / (rows of ALL ranks) for sync BatchNorm
   const int cq = c / V;
   const int qd = threadIdx.x % qpad;
   if (qd >= cq) return;
   const int rpp = 256 / qpad;
   const float inv_n = count_dev ? (float)(1.0 / *count_dev) : inv_count;
-  float mu[V], is[V], gi[V], sg[V], sgx[V];
+  float mu[V], is[V], gi[V], sg[V], sgx[V], msc[V], msh[V];
+  const bool remask = relu && mk_beta != nullptr;          // see k_bn_partial
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     mu[j] = mean[qd * V + j];
@@ -315,6 +331,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     gi[j] = gamma[qd * V + j] * is[j];
     sg[j] = sum_g[qd * V + j] * inv_n;
     sgx[j] = sum_gx[qd * V + j] * inv_n;
+    msc[j] = is[j] * gamma[qd * V + j];
+    msh[j] = remask ? fmaf(-mu[j], msc[j], mk_beta[qd * V + j]) : 0.f;
   }
   const int row_stride = gridDim.x * rpp;
   for (int r = blockIdx.x * rpp + threadIdx.x / qpad; r < n; r += row_stride) {
@@ -323,15 +341,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     if constexpr (V == 8) {
       bn_ld8(x, off, xv);
       bn_ld8(dy, off, dv);
-      if (relu) bn_ld8(y, off, yv);
+      if (relu && !remask) bn_ld8(y, off, yv);
     } else if constexpr (V == 4) {
       *reinterpret_cast<float4*>(xv) = bn_ld4<TY>(x, off, ty.x);
       *reinterpret_cast<float4*>(dv) = bn_ld4<TY>(dy, off, ty.dy);
-      if (relu) *reinterpret_cast<float4*>(yv) = bn_ld4<TY>(y, off, ty.y);
+      if (relu && !remask) *reinterpret_cast<float4*>(yv) = bn_ld4<TY>(y, off, ty.y);
     } else {
       xv[0] = x[off];
       dv[0] = dy[off];
-      if (relu) yv[0] = y[off];
+      if (relu && !remask) yv[0] = y[off];
+    }
+    if (remask) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) yv[j] = fmaf(xv[j], msc[j], msh[j]);
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -406,17 +428,17 @@ int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, floa
   if (rc) return rc;
   if (v4 && x_bf && c % 8 == 0)
     k_bn_partial<0, 8, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                   next_pow2(c / 8), bn_rows(n, c), part, ty);
+                                                   next_pow2(c / 8), bn_rows(n, c), part, ty, nullptr, nullptr);
   else if (v4 && x_bf)
     k_bn_partial<0, 4, true><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                         next_pow2(c / 4), bn_rows(n, c), part, ty);
+                                                         next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr);
   else if (v4)
     k_bn_partial<0, 4, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                          next_pow2(c / 4), bn_rows(n, c), part, ty);
+                                                          next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_stats: c=%d needs c %% 4 == 0 or c <= 256", c);
     k_bn_partial<0, 1, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                   next_pow2(c), bn_rows(n, c), part, ty);
+                                                   next_pow2(c), bn_rows(n, c), part, ty, nullptr, nullptr);
   }
   IRX_CHECK_LAUNCH("irx_bn_stats(partial)");
   k_bn_finalize<0><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, eps, momentum, mean,
@@ -442,11 +464,11 @@ extern "C" int irx_bn_sums(const float* x, int n, int c, double* sums, void* wor
   const BnTy ty = {0, 0, 0, 0, 0};
   if ((c % 4 == 0) && (((uintptr_t)x & 15) == 0))
     k_bn_partial<0, 4, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                          next_pow2(c / 4), bn_rows(n, c), part, ty);
+                                                          next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_sums: c=%d needs c %% 4 == 0 or c <= 256", c);
     k_bn_partial<0, 1, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                          next_pow2(c), bn_rows(n, c), part, ty);
+                                                          next_pow2(c), bn_rows(n, c), part, ty, nullptr, nullptr);
   }
   IRX_CHECK_LAUNCH("irx_bn_sums(partial)");
   k_bn_finalize<2><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(
@@ -528,7 +550,10 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
                       const float* invstd, const float* gamma, int relu, float* dx, float* dgamma, float* dbeta,
                       float* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int y_bf,
                       int dy_bf, int dx_bf, int dres_bf, int phases, const float* all_sum_g, const float* all_sum_gx,
-                      double all_count, const double* count_dev) {
+                      double all_count, const double* count_dev, const float* beta) {
+  // beta != NULL (with relu): the forward pass had NO shortcut, i.e. y = relu(fma(x, invstd * gamma, fma(-mean, invstd * gamma,
+  // beta))): the ReLU mask is recomputed from x in both passes and y is not read (the encoder executor passes it for the 9
+  // of 13 layers without a shortcut; the C-ABI entry points below keep reading y)
   // phases: 1 = the reduction only (dbeta = sum g, dgamma = sum g xhat over THESE rows), 2 = the apply pass only, with the
   // sums (all_sum_g, all_sum_gx) and row count (all_count) it is given — sync BatchNorm folds the ranks' sums in between;
   // 3 = both, on the local sums (everything else)
@@ -552,6 +577,8 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
                   (dx == nullptr || ((uintptr_t)dx & 15) == 0) && (!relu || ((uintptr_t)y & 15) == 0) &&
                   (dresidual == nullptr || ((uintptr_t)dresidual & 15) == 0);
   const BnTy ty = {x_bf, y_bf, dy_bf, dx_bf, dres_bf};
+  const float* mk_beta = (relu && beta && gamma) ? beta : nullptr;
+  const float* mk_gamma = mk_beta ? gamma : nullptr;
   rc = bn_bf_ok("irx_bn_backward", (x_bf | y_bf | dy_bf | dx_bf | dres_bf) != 0, v4);
   if (rc) return rc;
   const bool any_bf = (x_bf | y_bf | dy_bf | dx_bf | dres_bf) != 0;
@@ -559,17 +586,17 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   if (!(phases & 1)) {
   } else if (v8)
     k_bn_partial<1, 8, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                   next_pow2(c / 8), bn_rows(n, c), part, ty);
+                                                   next_pow2(c / 8), bn_rows(n, c), part, ty, mk_gamma, mk_beta);
   else if (v4 && any_bf)
     k_bn_partial<1, 4, true><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                         next_pow2(c / 4), bn_rows(n, c), part, ty);
+                                                         next_pow2(c / 4), bn_rows(n, c), part, ty, mk_gamma, mk_beta);
   else if (v4)
     k_bn_partial<1, 4, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                          next_pow2(c / 4), bn_rows(n, c), part, ty);
+                                                          next_pow2(c / 4), bn_rows(n, c), part, ty, mk_gamma, mk_beta);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_backward: c=%d needs c %% 4 == 0 or c <= 256", c);
     k_bn_partial<1, 1, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, next_pow2(c),
-                                                   bn_rows(n, c), part, ty);
+                                                   bn_rows(n, c), part, ty, mk_gamma, mk_beta);
   }
   if (phases & 1) {
     IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
@@ -584,19 +611,19 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   if (v8) {
     const int qpad = next_pow2(c / 8);
     k_bn_bwd_apply<8, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
-                                                               sgx, relu, dx, dresidual, ty, inv_count, count_dev);
+                                                               sgx, relu, dx, dresidual, ty, inv_count, count_dev, mk_beta);
   } else if (v4 && any_bf) {
     const int qpad = next_pow2(c / 4);
     k_bn_bwd_apply<4, true><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
-                                                                     sgx, relu, dx, dresidual, ty, inv_count, count_dev);
+                                                                     sgx, relu, dx, dresidual, ty, inv_count, count_dev, mk_beta);
   } else if (v4) {
     const int qpad = next_pow2(c / 4);
     k_bn_bwd_apply<4, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
-                                                                      sgx, relu, dx, dresidual, ty, inv_count, count_dev);
+                                                                      sgx, relu, dx, dresidual, ty, inv_count, count_dev, mk_beta);
   } else {
     const int qpad = next_pow2(c);
     k_bn_bwd_apply<1, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
-                                                               sgx, relu, dx, dresidual, ty, inv_count, count_dev);
+                                                               sgx, relu, dx, dresidual, ty, inv_count, count_dev, mk_beta);
   }
   IRX_CHECK_LAUNCH("irx_bn_backward(apply)");
   return IRX_OK;
