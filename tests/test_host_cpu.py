@@ -302,3 +302,25 @@ def test_convert_sync_batchnorm_keeps_keys_and_single_process_behaviour():
     x = torch.randn(5, 6)
     assert torch.equal(net[2](net[1](net[0](x))), ref(x))
     assert torch.equal(net[1].running_mean, ref[1].running_mean)
+
+
+def test_bench_launcher_helpers_and_sort_key_widths():
+    """Host logic added in round 3 that needs no GPU: the cpulist parser behind the per-rank core binding, the refusal of a
+    --gpus / WORLD_SIZE mismatch, and the number of key bits the radix sort has to look at."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and bench._cpulist("") == []
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "--gpus 8 != WORLD_SIZE 1" in (r.stderr + r.stdout)
+    from instancerefer_amd.sparse.functional import morton_bits
+    assert morton_bits(None) == 63
+    assert morton_bits(1) == 49 and morton_bits(16) == 52 and morton_bits(17) == 53      # batch indices < batch_size
+    assert morton_bits(16, True) == 53 and morton_bits(64, True) == 55                   # + the padding key batch_size << 48
+    for bs in (1, 2, 16, 17, 64, 1000):
+        assert ((bs - 1) << 48 | ((1 << 48) - 1)) < (1 << morton_bits(bs))
+        assert (bs << 48) < (1 << morton_bits(bs, True))
