@@ -293,10 +293,21 @@ enum {
   IRX_ENC_MODE,                     /* compute mode of this pass (the values of irx_set_compute_dtype: 0 fp32, 1 bf16 operands, 2 +
                                      * bf16 storage), recorded by the caller when it builds the table for the forward pass and
                                      * carried into the backward pass: the executor uses THIS, not the process-wide setting */
+  IRX_ENC_ORDER,                    /* 0, or a device pointer to the launch order of this layer's 64-row output tiles
+                                     * (irx_tile_order over TBL; stride-1 layers only: the same order serves the data-gradient,
+                                     * whose table is TBL with flipped offsets) */
   IRX_ENC_PROF,                     /* 0, or a HOST pointer to 6 event handles (hipEvent_t): start / stop around this layer's
                                      * dominant forward, data-gradient and weight-gradient kernel (measurement aid, bench.py) */
   IRX_ENC_NFIELDS
 };
+/* Launch order of the 64-row output tiles of a stride-1 convolution over table `nbr` (int32 [K][ld], the irx_kmap_build_s1
+ * table): order[i] = i-th tile to start, heaviest cost class first (cost = per active offset a fixed part + one part per
+ * 16-pair group), ties in tile order; deterministic. Pure scheduling aid for irx_encoder_forward / _backward (IRX_ENC_ORDER):
+ * torchsparse has no counterpart (its gather-GEMM-scatter launches are per offset, reference models/basic_blocks.py:32-44 reach
+ * them through spnn.Conv3d); the convolution's results do not depend on it. workspace: irx_tile_order_workspace_bytes(n_out). */
+size_t irx_tile_order_workspace_bytes(int n_out);
+int irx_tile_order(const int32_t* nbr, int ld, int n_out, int K, int32_t* order, void* workspace, size_t workspace_bytes,
+                   void* stream);
 size_t irx_encoder_workspace_bytes(const int64_t* desc, const double* fdesc, int n_layers, int backward);
 int irx_encoder_forward(const int64_t* desc, const double* fdesc, int n_layers, void* workspace,
                         size_t workspace_bytes, void* stream);

@@ -120,6 +120,7 @@ static inline size_t irx_esz(int bf) { return bf ? 2 : 4; }
 // element types of one conv call inside the executor (0 = float32, 1 = bf16); the C-ABI entry points use all zeros
 struct IrxStore {
   int x = 0, y = 0;
+  const int32_t* order = nullptr;   // launch order of the 64-row output tiles (irx_tile_order) or NULL = blockIdx order
 };
 
 // ---- measurement aid (irx_profile_next_kernel, include/irx.h): brackets the next DOMINANT sparse-conv kernel of this

@@ -21,6 +21,7 @@ struct Layer {
   float *dw, *dgamma, *dbeta, *gy;
   float eps, momentum;
   int store;   // bf16 storage of the activations / gradients in flight (IRX_ENC_STORE)
+  const int32_t* order;   // launch order of the output tiles or NULL (IRX_ENC_ORDER)
   void** prof; // 6 event handles or NULL (IRX_ENC_PROF)
 };
 
@@ -39,6 +40,7 @@ Layer unpack(const int64_t* d, const double* f) {
   L.dw = (float*)d[IRX_ENC_DW]; L.dgamma = (float*)d[IRX_ENC_DGAMMA]; L.dbeta = (float*)d[IRX_ENC_DBETA];
   L.gy = (float*)d[IRX_ENC_GY];
   L.store = (int)d[IRX_ENC_STORE];
+  L.order = (const int32_t*)d[IRX_ENC_ORDER];
   L.prof = (void**)d[IRX_ENC_PROF];
   L.eps = (float)f[0]; L.momentum = (float)f[1];
   return L;
@@ -122,6 +124,7 @@ extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int
     IrxStore ty;
     ty.x = (st && i > 0) ? 1 : 0;                 // the encoder's input features are fp32
     ty.y = st;                                    // conv output c
+    ty.order = L.order;
     const int y_bf = (st && i < n_layers - 1) ? 1 : 0;   // the encoder's output stays fp32
     if (L.prof) irx_profile_next_kernel(L.prof[0], L.prof[1]);
     int rc = irx_spconv_fwd_impl(L.x, L.w, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, 0, 0, L.c, 0, wimg[i], ws_c, r.conv,
@@ -219,6 +222,7 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
       IrxStore ty;
       ty.x = st;                                  // dc
       ty.y = st;                                  // gy of layer i - 1 (never the last layer)
+      ty.order = (L.tbl_b == L.tbl) ? L.order : nullptr;   // stride-1: the forward table with flipped offsets, same tile costs
       if (L.prof) irx_profile_next_kernel(L.prof[2], L.prof[3]);
       rc = irx_spconv_fwd_impl(dc_scratch, L.w, L.tbl_b, L.ld_b, L.n_in, L.K, L.cout, L.cin, L.flip_b, 1, dx, acc, wimg[i],
                                ws_c, r.conv, stream, ty);

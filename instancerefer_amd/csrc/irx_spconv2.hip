@@ -248,7 +248,8 @@ __device__ __forceinline__ void s2_wait_vmcnt() {
 template <int CIN, int COUT, bool BF, bool ST>
 __global__ __launch_bounds__(256, 2)
 void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const int32_t* __restrict__ nbr, int ld,
-               int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate, int ldx, int y_bf) {
+               int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate, int ldx, int y_bf,
+               const int32_t* __restrict__ tile_order) {
   static_assert(BF || !ST, "bf16 storage implies bf16 operands");
   // ldx = row stride of x in floats (CIN for a dense tensor; > CIN when x is the leading CIN columns of wider rows:
   // the multiview stem, irx_spconv.hip "wide stem"; rows then need only 4-byte alignment)
@@ -297,7 +298,8 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   const int m = lane & 15, g4 = lane >> 4;
   const int cs = wave % NCS, gp = wave / NCS;
   const int n_base = cs * 16 * NT;
-  const int q0 = blockIdx.x * TM;
+  // tile_order (irx_sched.hip): the heaviest tiles start first, so that the last round of workgroups is short
+  const int q0 = (tile_order ? __builtin_amdgcn_readfirstlane(tile_order[blockIdx.x]) : (int)blockIdx.x) * TM;
   const int sub = lane / LPR;                     // which of the PPI pairs of a pass this lane serves
   const int c4 = (lane % LPR) * 4;
   const int pbase = wave * PPI + sub;             // this lane's item-local pair in pass 0
@@ -641,10 +643,11 @@ bool irx_spconv2_supported(int cin, int cout) {
 
 template <int CIN, bool BF, bool ST>
 static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
-                        int ld, int n_out, int K, int flip_k, float* y, int kps, int acc, int ldx, int y_bf) {
-  if (cout == 128) k_spconv2<CIN, 128, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-  else if (cout == 64) k_spconv2<CIN, 64, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-  else k_spconv2<CIN, 32, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+                        int ld, int n_out, int K, int flip_k, float* y, int kps, int acc, int ldx, int y_bf,
+                        const int32_t* ord) {
+  if (cout == 128) k_spconv2<CIN, 128, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ord);
+  else if (cout == 64) k_spconv2<CIN, 64, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ord);
+  else k_spconv2<CIN, 32, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ord);
 }
 
 // Output rows per workgroup: 64.  128-row tiles stream half the weight bytes per useful FLOP but MEASURED SLOWER twice:
@@ -688,17 +691,17 @@ int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int 
   const int kps = irx_cdiv(K, splits);
   irx_bracket_begin(st);
   if (irx_mode_now() && ty.x) {
-    if (cin == 128) launch_fwd2<128, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-    else if (cin == 64) launch_fwd2<64, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-    else launch_fwd2<32, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    if (cin == 128) launch_fwd2<128, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ty.order);
+    else if (cin == 64) launch_fwd2<64, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ty.order);
+    else launch_fwd2<32, true, true>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ty.order);
   } else if (irx_mode_now()) {
-    if (cin == 128) launch_fwd2<128, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-    else if (cin == 64) launch_fwd2<64, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-    else launch_fwd2<32, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    if (cin == 128) launch_fwd2<128, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ty.order);
+    else if (cin == 64) launch_fwd2<64, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ty.order);
+    else launch_fwd2<32, true, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ty.order);
   } else {
-    if (cin == 128) launch_fwd2<128, false, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-    else if (cin == 64) launch_fwd2<64, false, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-    else launch_fwd2<32, false, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    if (cin == 128) launch_fwd2<128, false, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ty.order);
+    else if (cin == 64) launch_fwd2<64, false, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ty.order);
+    else launch_fwd2<32, false, false>(cout, grid, st, x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ty.order);
   }
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_fwd(v2)");

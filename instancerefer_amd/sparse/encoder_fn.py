@@ -77,7 +77,7 @@ def _ws(nbytes, dev):
 # field order of the descriptor table: include/irx.h, enum IRX_ENC_* (tests/test_abi_cpu.py checks the two agree)
 ENC_FIELDS = ("K", "CIN", "COUT", "N_IN", "N_OUT", "RES", "TBL", "LD", "TBL_B", "LD_B", "FLIP_B", "PAIR_IN", "PAIR_OUT",
               "PAIR_COUNTS", "LD_PAIRS", "W", "GAMMA", "BETA", "RUNNING_MEAN", "RUNNING_VAR", "X", "C", "Y", "MEAN",
-              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "MODE", "PROF")
+              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "MODE", "ORDER", "PROF")
 _E = {n: i for i, n in enumerate(ENC_FIELDS)}
 _NF = len(ENC_FIELDS)
 _ALIGN = 64                                           # float32 elements (256 B)
@@ -158,6 +158,11 @@ def lane_wait(lane):
         _lib.check(rc, "irx_encoder (asynchronous pass)")
 
 
+# Launch order of k_spconv2's output tiles (csrc/irx_sched.hip): on for the stride-1 layers of levels with >= 512 tiles (more
+# than one round of workgroups on 256 CUs x 2); IRX_TILE_ORDER=0 switches it off (dev A/B; results are bit-identical).
+TILE_ORDER = os.environ.get("IRX_TILE_ORDER", "1") != "0"
+TILE_ORDER_MIN_ROWS = int(os.environ.get("IRX_TILE_ORDER_MIN_ROWS", str(512 * 64)))
+
 # Tests only (tests/test_bf16_gpu.py): a dict that receives the executor's arenas, so that every layer's stored tensors
 # (conv output c_i, layer output y_i, gradient in flight gy_i) can be compared one layer at a time; None = no tracing.
 TRACE = None
@@ -221,6 +226,9 @@ class EncoderFn(torch.autograd.Function):
         base, sbase = arena.data_ptr(), stats.data_ptr()
         desc[:, _E["STORE"]] = int(store)
         desc[:, _E["MODE"]] = int(lib.irx_get_compute_dtype())      # pinned for this pass and its backward (include/irx.h)
+        if TILE_ORDER:                           # heaviest output tiles first on the levels with more than one round of tiles
+            desc[:, _E["ORDER"]] = np.fromiter((0 if (L.down or L.n_out < TILE_ORDER_MIN_ROWS) else L.lv_in.order27().data_ptr()
+                                                for L in layers), dtype=np.int64, count=nl)
         prof = _profile_slots(layers, store) if F_.PROFILE is not None else None
         if prof is not None:
             desc[:, _E["PROF"]] = prof[1]

@@ -139,6 +139,17 @@ def kmap_build_s1(coords, stride, table):
     return nbr
 
 
+def tile_order(tbl, ld, n_out, K):
+    """Launch order of the 64-row output tiles of a stride-1 conv over `tbl` (irx_tile_order): int32 [ceil(n_out / 64)]."""
+    dev = tbl.device
+    nt = (n_out + 63) // 64
+    order = torch.empty(max(nt, 1), dtype=_i32, device=dev)
+    wsb = int(_lib.load().irx_tile_order_workspace_bytes(n_out))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.call("irx_tile_order", _lib.ptr(tbl), ld, n_out, K, _lib.ptr(order), _lib.ptr(ws), wsb, _stream())
+    return order[:nt]
+
+
 def downsample(keys, coords, stride):
     """-> parent (n,) i32, koff (n,) u8, out_coords (n_out,4), out_keys (n_out,), child (8, ld) i32, ld, n_out."""
     n = coords.shape[0]

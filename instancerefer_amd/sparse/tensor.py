@@ -52,6 +52,7 @@ class Level:
         self._table = None
         self._nbr27 = None
         self._pairs27 = None
+        self._order27 = None
         self._down = None
         self._offsets = None
         self._bev = {}
@@ -69,6 +70,13 @@ class Level:
         if self._nbr27 is None:
             self._nbr27 = F_.kmap_build_s1(self.coords, self.stride, self.table())
         return self._nbr27, max(self.n, 1)
+
+    def order27(self):
+        """Launch order of the 64-row output tiles of this level's 3^3 convolutions (heaviest first; csrc/irx_sched.hip)."""
+        if self._order27 is None:
+            tbl, ld = self.nbr27()
+            self._order27 = F_.tile_order(tbl, ld, self.n, 27)
+        return self._order27
 
     def pairs27(self):
         """Compacted pair lists of the 27-neighbour table (weight-gradients of both convs of a ResidualBlock)."""
@@ -93,6 +101,8 @@ class Level:
             out.append(self._nbr27)
         if self._pairs27 is not None:
             out += list(self._pairs27[:3])
+        if self._order27 is not None:
+            out.append(self._order27)
         if self._offsets is not None:
             out.append(self._offsets)
         for v in self._bev.values():

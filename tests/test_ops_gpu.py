@@ -804,3 +804,29 @@ def test_radix_sort_is_a_stable_sort(lib, n):
     exp, eo = torch.sort(keys[:m], stable=True)
     assert torch.equal(got[:m], exp) and torch.equal(order[:m].long(), eo)
     assert bool((got[m:] == (17 << 48)).all()) and torch.equal(order[m:].long(), torch.arange(m, n, device=dev))
+
+
+def test_tile_launch_order_is_a_cost_sorted_permutation(lib, clouds):
+    """csrc/irx_sched.hip: order[i] = i-th 64-row output tile k_spconv2 starts. It must be a permutation of the tiles, sorted by
+    the cost class of the tile (per active offset a fixed part + one part per 16-pair group; heaviest first, ties in tile
+    order) — recomputed here from the neighbour table with torch. It only changes when a tile is computed: the encoder's
+    results with and without it are bit-identical (tests/test_model_gpu.py::test_encoder_executor_equals_per_layer_path runs
+    the executor, which uses it, against the per-layer path, which does not)."""
+    from instancerefer_amd.sparse import functional as F_
+    st = device_batch(clouds * 6, 0.02)                      # a few thousand voxels -> a few dozen tiles
+    lv = st.level()
+    tbl, ld = lv.nbr27()
+    n = lv.n
+    order = F_.tile_order(tbl, ld, n, 27).cpu().numpy()
+    nt = (n + 63) // 64
+    assert sorted(order.tolist()) == list(range(nt))
+    valid = (tbl[:, :n] >= 0).cpu().numpy()
+    pad = nt * 64 - n
+    v = np.pad(valid, ((0, 0), (0, pad))).reshape(27, nt, 64).sum(2)             # pairs per (offset, tile)
+    cost = (3 * (v > 0) + 5 * ((v + 15) // 16)).sum(0)
+    shift = 0
+    while ((27 * 23) >> shift) >= 64:
+        shift += 1
+    cls = np.minimum(cost >> shift, 63)
+    exp = np.argsort(-cls, kind="stable")
+    assert np.array_equal(order, exp)
