@@ -227,8 +227,9 @@ class EncoderFn(torch.autograd.Function):
         desc[:, _E["STORE"]] = int(store)
         desc[:, _E["MODE"]] = int(lib.irx_get_compute_dtype())      # pinned for this pass and its backward (include/irx.h)
         if TILE_ORDER:                           # heaviest output tiles first on the levels with more than one round of tiles
-            desc[:, _E["ORDER"]] = np.fromiter((0 if (L.down or L.n_out < TILE_ORDER_MIN_ROWS) else L.lv_in.order27().data_ptr()
-                                                for L in layers), dtype=np.int64, count=nl)
+            desc[:, _E["ORDER"]] = np.fromiter((L.lv_in.order27().data_ptr() if (not L.down and L.n_out >= TILE_ORDER_MIN_ROWS and
+                                                                                 L.cin in _PAIR and L.cout in _PAIR) else 0
+                                                for L in layers), dtype=np.int64, count=nl)      # (k_spconv2 layers only)
         prof = _profile_slots(layers, store) if F_.PROFILE is not None else None
         if prof is not None:
             desc[:, _E["PROF"]] = prof[1]
