@@ -820,16 +820,12 @@ class serial_issue:
 
     def __enter__(self):
         from instancerefer_amd.sparse import encoder_fn
-        from instancerefer_amd import _lib
         self.saved = (getattr(self.model.args, "overlap_streams", True), encoder_fn.ASYNC)
         self.model.args.overlap_streams, encoder_fn.ASYNC = False, False
-        self.wgrad = _lib.load().irx_encoder_set_wgrad_overlap(0)     # weight-gradients on the caller's stream too
 
     def __exit__(self, *exc):
         from instancerefer_amd.sparse import encoder_fn
-        from instancerefer_amd import _lib
         self.model.args.overlap_streams, encoder_fn.ASYNC = self.saved
-        _lib.load().irx_encoder_set_wgrad_overlap(self.wgrad)
         return False
 
 

@@ -293,12 +293,6 @@ enum {
   IRX_ENC_MODE,                     /* compute mode of this pass (the values of irx_set_compute_dtype: 0 fp32, 1 bf16 operands, 2 +
                                      * bf16 storage), recorded by the caller when it builds the table for the forward pass and
                                      * carried into the backward pass: the executor uses THIS, not the process-wide setting */
-  IRX_ENC_DC,                       /* backward: 0, or this layer's OWN buffer for d(loss)/d(conv output) [n_out][cout] (element
-                                     * type as C). With a buffer per layer the weight-gradients are issued on an auxiliary HIP
-                                     * stream of the library behind the event of their layer's BatchNorm backward and run beside
-                                     * the BatchNorm / data-gradient chain of the shallower layers (joined before the call's last
-                                     * launch returns the stream to the caller); 0 = the shared dc_scratch argument, everything on
-                                     * the caller's stream */
   IRX_ENC_ORDER,                    /* 0, or a device pointer to the launch order of this layer's 64-row output tiles
                                      * (irx_tile_order over TBL; stride-1 layers only: the same order serves the data-gradient,
                                      * whose table is TBL with flipped offsets) */
@@ -311,9 +305,6 @@ enum {
  * 16-pair group), ties in tile order; deterministic. Pure scheduling aid for irx_encoder_forward / _backward (IRX_ENC_ORDER):
  * torchsparse has no counterpart (its gather-GEMM-scatter launches are per offset, reference models/basic_blocks.py:32-44 reach
  * them through spnn.Conv3d); the convolution's results do not depend on it. workspace: irx_tile_order_workspace_bytes(n_out). */
-/* 1 (default; env IRX_WGRAD_OVERLAP=0 at load time): irx_encoder_backward may use its auxiliary stream when the table carries
- * IRX_ENC_DC buffers; 0: never (measurement: kernels timed alone on the caller's stream). Returns the previous setting. */
-int irx_encoder_set_wgrad_overlap(int on);
 size_t irx_tile_order_workspace_bytes(int n_out);
 int irx_tile_order(const int32_t* nbr, int ld, int n_out, int K, int32_t* order, void* workspace, size_t workspace_bytes,
                    void* stream);

@@ -26,7 +26,6 @@ _SIGNATURES = {
     "irx_coords_to_keys": (_I, [_P, _I, _P, _P]),
     "irx_sort_workspace_bytes": (_Z, [_I]),
     "irx_sort_pairs_u64": (_I, [_P, _I, _P, _c.c_uint64, _I, _I, _P, _P, _P, _Z, _P]),
-    "irx_encoder_set_wgrad_overlap": (_I, [_I]),
     "irx_tile_order_workspace_bytes": (_Z, [_I]),
     "irx_tile_order": (_I, [_P, _I, _I, _I, _P, _P, _Z, _P]),
     "irx_quantize": (_I, [_P, _I, _P, _I, _D, _D, _D, _P, _P, _P]),

@@ -22,7 +22,6 @@ struct Layer {
   float eps, momentum;
   int store;   // bf16 storage of the activations / gradients in flight (IRX_ENC_STORE)
   const int32_t* order;   // launch order of the output tiles or NULL (IRX_ENC_ORDER)
-  float* dc;              // own d(conv output) buffer or NULL (IRX_ENC_DC)
   void** prof; // 6 event handles or NULL (IRX_ENC_PROF)
 };
 
@@ -42,7 +41,6 @@ Layer unpack(const int64_t* d, const double* f) {
   L.gy = (float*)d[IRX_ENC_GY];
   L.store = (int)d[IRX_ENC_STORE];
   L.order = (const int32_t*)d[IRX_ENC_ORDER];
-  L.dc = (float*)d[IRX_ENC_DC];
   L.prof = (void**)d[IRX_ENC_PROF];
   L.eps = (float)f[0]; L.momentum = (float)f[1];
   return L;
@@ -143,53 +141,6 @@ extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int
   return IRX_OK;
 }
 
-// ---- auxiliary stream for the weight-gradients (IRX_ENC_DC) ----------------------------------------------------------
-// The backward chain of an encoder is BatchNorm-backward(i) -> data-gradient(i) -> BatchNorm-backward(i - 1) ...; the
-// weight-gradient of layer i only needs d c_i and feeds nothing but the optimizer, yet issued in between it sat on that chain
-// (1.7 of the scene encoder's ~4.5 ms). With a d c buffer per layer it is issued on a second stream behind an event and
-// overlaps the small, latency-bound kernels of the chain; the call joins the two streams before it returns.
-#include <map>
-#include <mutex>
-#include <vector>
-#include <stdlib.h>
-namespace {
-struct AuxStream {
-  hipStream_t stream = nullptr;
-  std::vector<hipEvent_t> ev;     // one per layer + the join event
-};
-std::mutex g_aux_mu;
-std::map<std::pair<int, void*>, AuxStream> g_aux;       // (device, caller's stream) -> auxiliary stream + events
-int g_wgrad_overlap = (getenv("IRX_WGRAD_OVERLAP") && atoi(getenv("IRX_WGRAD_OVERLAP")) == 0) ? 0 : 1;
-
-AuxStream* aux_for(void* main_stream, int n_events) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lk(g_aux_mu);
-  AuxStream& a = g_aux[std::make_pair(dev, main_stream)];
-  if (!a.stream) {
-    int lo = 0, hi = 0;                                  // numerically lowest value = highest priority
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // off the critical chain: the lowest priority, so that the chain's kernels get their CUs first
-    if (hipStreamCreateWithPriority(&a.stream, hipStreamNonBlocking, lo) != hipSuccess) {
-      a.stream = nullptr;
-      return nullptr;
-    }
-  }
-  while ((int)a.ev.size() < n_events) {
-    hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    a.ev.push_back(e);
-  }
-  return &a;
-}
-}  // namespace
-
-extern "C" int irx_encoder_set_wgrad_overlap(int on) {
-  const int prev = g_wgrad_overlap;
-  g_wgrad_overlap = on ? 1 : 0;
-  return prev;
-}
-
 // gy of the last layer holds d(loss)/d(output) on entry.  On return dw / dgamma / dbeta of every layer are written and,
 // when dx0 != NULL, dx0 [n_in0][cin0] = d(loss)/d(input features).  gy of the other layers is scratch.
 extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch,
@@ -238,37 +189,23 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
   const int st = (int)desc[IRX_ENC_STORE];
   IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_backward: bf16 storage needs a bf16 compute mode in IRX_ENC_MODE");
   IRX_REQUIRE(!st || !dx0, "irx_encoder_backward: the input gradient is not available with bf16 storage");
-  // weight-gradients on the auxiliary stream: only when EVERY layer brought its own d c buffer
-  AuxStream* aux = nullptr;
-  if (g_wgrad_overlap && n_layers > 1) {
-    bool all = true;
-    for (int i = 0; i < n_layers; ++i) all = all && desc[(size_t)i * IRX_ENC_NFIELDS + IRX_ENC_DC] != 0;
-    if (all) aux = aux_for(stream, n_layers + 1);
-  }
   for (int i = n_layers - 1; i >= 0; --i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
-    float* dc_i = (aux && L.dc) ? L.dc : dc_scratch;
-    void* wstream = stream;
     float* dres = nullptr;
     if (L.res >= 0) dres = (float*)desc[(size_t)L.res * IRX_ENC_NFIELDS + IRX_ENC_GY];
     const int last = (i == n_layers - 1);
     // c: st | y, gy: fp32 for the last layer | dc scratch and the shortcut gradient (never the last layer's): st
     // a layer without a shortcut hands over beta: its ReLU mask is recomputed from c and y is not read (irx_norm.hip)
     static const bool remask = !(getenv("IRX_BN_REMASK") && atoi(getenv("IRX_BN_REMASK")) == 0);   // dev A/B knob
-    int rc = irx_bn_backward_t(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, dc_i, L.dgamma,
+    int rc = irx_bn_backward_t(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, dc_scratch, L.dgamma,
                                L.dbeta, dres, ws_b, r.bn, stream, st, (st && !last) ? 1 : 0, (st && !last) ? 1 : 0, st, st,
                                3, nullptr, nullptr, 0.0, nullptr, (L.res < 0 && remask) ? L.beta : nullptr);
     if (rc) return rc;
-    if (aux) {                                           // d c_i is complete on the caller's stream: the auxiliary one may read it
-      IRX_CHECK_HIP(hipEventRecord(aux->ev[i], (hipStream_t)stream), "irx_encoder_backward(event)");
-      IRX_CHECK_HIP(hipStreamWaitEvent(aux->stream, aux->ev[i], 0), "irx_encoder_backward(wait)");
-      wstream = (void*)aux->stream;
-    }
     if (L.prof) irx_profile_next_kernel(L.prof[4], L.prof[5]);
     if (pairs_path(L)) {
       IRX_REQUIRE(!st || i > 0, "irx_encoder_backward: bf16 storage expects a stem (Cin <= 8 or 129..136) as layer 0");
-      rc = irx_spconv_wgrad_pairs_impl(L.x, dc_i, L.pair_in, L.pair_out, L.ld_pairs, L.pair_counts, L.n_out, L.K,
-                                       L.cin, L.cout, L.dw, ws_w, r.wgrad, wstream, st);
+      rc = irx_spconv_wgrad_pairs_impl(L.x, dc_scratch, L.pair_in, L.pair_out, L.ld_pairs, L.pair_counts, L.n_out, L.K,
+                                       L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st);
     } else {
       IRX_REQUIRE(!st || i == 0, "irx_encoder_backward: layer %d (%d -> %d channels) has no bf16-storage weight-gradient path",
                   i, L.cin, L.cout);
@@ -276,7 +213,7 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
       if (L.pair_in && irx_wide_stem(L.K, L.cin, L.cout)) {   // the multiview stem: its 128 leading channels through the pair lists
         pl.in_list = L.pair_in; pl.out_list = L.pair_out; pl.counts = L.pair_counts; pl.ldp = L.ld_pairs;
       }
-      rc = irx_spconv_wgrad_impl(L.x, dc_i, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, L.dw, ws_w, r.wgrad, wstream, st, pl);
+      rc = irx_spconv_wgrad_impl(L.x, dc_scratch, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st, pl);
     }
     if (rc) return rc;
     float* dx = (i > 0) ? (float*)desc[(size_t)(i - 1) * IRX_ENC_NFIELDS + IRX_ENC_GY] : dx0;
@@ -287,14 +224,10 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
       ty.y = st;                                  // gy of layer i - 1 (never the last layer)
       ty.order = (L.tbl_b == L.tbl) ? L.order : nullptr;   // stride-1: the forward table with flipped offsets, same tile costs
       if (L.prof) irx_profile_next_kernel(L.prof[2], L.prof[3]);
-      rc = irx_spconv_fwd_impl(dc_i, L.w, L.tbl_b, L.ld_b, L.n_in, L.K, L.cout, L.cin, L.flip_b, 1, dx, acc, wimg[i],
+      rc = irx_spconv_fwd_impl(dc_scratch, L.w, L.tbl_b, L.ld_b, L.n_in, L.K, L.cout, L.cin, L.flip_b, 1, dx, acc, wimg[i],
                                ws_c, r.conv, stream, ty);
       if (rc) return rc;
     }
-  }
-  if (aux) {                                             // join: the caller's stream owns every result again
-    IRX_CHECK_HIP(hipEventRecord(aux->ev[n_layers], aux->stream), "irx_encoder_backward(join event)");
-    IRX_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, aux->ev[n_layers], 0), "irx_encoder_backward(join)");
   }
   return IRX_OK;
 }

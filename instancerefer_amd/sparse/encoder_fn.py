@@ -77,7 +77,7 @@ def _ws(nbytes, dev):
 # field order of the descriptor table: include/irx.h, enum IRX_ENC_* (tests/test_abi_cpu.py checks the two agree)
 ENC_FIELDS = ("K", "CIN", "COUT", "N_IN", "N_OUT", "RES", "TBL", "LD", "TBL_B", "LD_B", "FLIP_B", "PAIR_IN", "PAIR_OUT",
               "PAIR_COUNTS", "LD_PAIRS", "W", "GAMMA", "BETA", "RUNNING_MEAN", "RUNNING_VAR", "X", "C", "Y", "MEAN",
-              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "MODE", "DC", "ORDER", "PROF")
+              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "MODE", "ORDER", "PROF")
 _E = {n: i for i, n in enumerate(ENC_FIELDS)}
 _NF = len(ENC_FIELDS)
 _ALIGN = 64                                           # float32 elements (256 B)
@@ -157,9 +157,6 @@ def lane_wait(lane):
     if rc:
         _lib.check(rc, "irx_encoder (asynchronous pass)")
 
-
-# Weight-gradients of an encoder pass on the library's auxiliary stream (IRX_ENC_DC); IRX_WGRAD_OVERLAP=0 switches it off.
-WGRAD_OVERLAP = os.environ.get("IRX_WGRAD_OVERLAP", "1") != "0"
 
 # Launch order of k_spconv2's output tiles (csrc/irx_sched.hip): on for the stride-1 layers of levels with >= 512 tiles (more
 # than one round of workgroups on 256 CUs x 2); IRX_TILE_ORDER=0 switches it off (dev A/B; results are bit-identical).
@@ -280,10 +277,7 @@ class EncoderFn(torch.autograd.Function):
         gsz = _up256(n_out * cout * (2 if store else 4))
         goffs = np.concatenate([[0], np.cumsum(gsz[:-1])])              # nl entries; the last one = start of dc
         dc_off = int(goffs[-1])
-        # WGRAD_OVERLAP: a d c buffer per layer instead of one shared scratch, so that the library can run the weight-
-        # gradients on its auxiliary stream beside the BatchNorm / data-gradient chain (IRX_ENC_DC, csrc/irx_encoder.hip)
-        own_dc = WGRAD_OVERLAP and nl > 1
-        total = dc_off + (int(gsz.sum()) if own_dc else int(gsz.max()))
+        total = dc_off + int(gsz.max())
         garena = torch.empty(total, dtype=torch.uint8, device=dev)
         slots = None
         if ctx.sink is not None:
@@ -333,8 +327,6 @@ class EncoderFn(torch.autograd.Function):
         desc[:, _E["TBL_B"]:_E["FLIP_B"] + 1] = np.array(tb, dtype=np.int64)
         desc[:, _E["PAIR_IN"]:_E["LD_PAIRS"] + 1] = np.array(pr, dtype=np.int64)
         desc[:, _E["DW"]:_E["DBETA"] + 1] = pptr
-        if own_dc:
-            desc[:, _E["DC"]] = gbase + dc_off + np.concatenate([[0], np.cumsum(gsz[:-1])])
         desc[:-1, _E["GY"]] = gbase + goffs[:-1]
         desc[-1, _E["GY"]] = dout.data_ptr()
         dfeats = torch.empty((layers[0].n_in, layers[0].cin), dtype=_f32, device=dev) if need_dx0 else None
