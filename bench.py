@@ -656,14 +656,6 @@ def main():
         }
         if alt is not None:
             out["alt_dtype"] = alt
-        if world == 1 and not args.no_cpu_baseline and roof_error is None and roof:   # (quick runs keep the committed figure)
-            torch.cuda.synchronize()
-            pmc = measure_pmc_traffic(args, args.dtype != "f32")
-            traffic_for(out["roofline"], pmc, args.dtype != "f32")
-            if isinstance(pmc, dict) and "error" in pmc:
-                out["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic*.json (live PMC pass failed: %s)" % pmc["error"]
-            if alt is not None and isinstance(alt.get("roofline"), dict) and "kernel" in alt["roofline"]:
-                traffic_for(alt["roofline"], measure_pmc_traffic(args, True), True)
         if world == 1 and args.workload != "attr" and not args.no_cpu_baseline:   # (quick runs skip the auxiliary legs)
             try:
                 out["dense_path"] = measure_dense_path(model, resident, device)
@@ -676,6 +668,16 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, args.workload)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline and roof_error is None and roof:   # (quick runs keep the committed figure)
+            # LAST of the auxiliary legs: counter collection changes the GPU's clock management, and the end-to-end leg run right
+            # behind it measured 17-22 % below the resident-input step instead of 1-2 %
+            torch.cuda.synchronize()
+            pmc = measure_pmc_traffic(args, args.dtype != "f32")
+            traffic_for(out["roofline"], pmc, args.dtype != "f32")
+            if isinstance(pmc, dict) and "error" in pmc:
+                out["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic*.json (live PMC pass failed: %s)" % pmc["error"]
+            if alt is not None and isinstance(alt.get("roofline"), dict) and "kernel" in alt["roofline"]:
+                traffic_for(alt["roofline"], measure_pmc_traffic(args, True), True)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.barrier(device_ids=None if share else [device.index])
