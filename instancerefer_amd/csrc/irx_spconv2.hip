@@ -660,16 +660,17 @@ int irx_spconv2_tile(int n_out) {
   return S2_TM;
 }
 
-// (Threshold: a layer with >= 256 tiles is left whole. In the training step the other encoder's stream fills the CUs
-// a 256..768-tile launch leaves idle, so splitting those only added slab traffic and a reduce launch: 768 -> 256
-// measured +1 % end to end, 128 equal, 64 worse.)
+// (Threshold: a layer with >= 400 tiles is left whole. In the training step the other encoder's stream fills the CUs
+// a 400..768-tile launch leaves idle, so splitting those only added slab traffic and a reduce launch: 768 -> 256
+// measured +1 % end to end, 128 equal, 64 worse (round 2). Round 3, four alternating 80-step runs on one box: 256 -> 400,
+// which splits the 317-tile stride-8 level of the scene encoder four ways (150 -> ~60 us alone): 9.537 -> 9.505 ms/step.)
 // Offset splits for latency-bound (small) layers: a tile's 27 offsets form a serial chain of ~4 us each, so
 // when there are too few tiles to fill the chip the offsets are spread over `splits` workgroups per tile.
 int irx_spconv2_splits(int n_out, int K) {
   static const char* e = getenv("IRX_SPCONV_KSPLIT");
   if (e) { int s = atoi(e); return s < 1 ? 1 : (s > K ? K : s); }
   const int tiles = irx_cdiv(n_out, irx_spconv2_tile(n_out));
-  static const int full = getenv("IRX_SPCONV_SPLIT_BELOW") ? atoi(getenv("IRX_SPCONV_SPLIT_BELOW")) : 256;
+  static const int full = getenv("IRX_SPCONV_SPLIT_BELOW") ? atoi(getenv("IRX_SPCONV_SPLIT_BELOW")) : 400;
   if (tiles >= full || K < 4) return 1;
   static const int target = getenv("IRX_SPCONV_SPLIT_TARGET") ? atoi(getenv("IRX_SPCONV_SPLIT_TARGET")) : 1024;   // dev A/B knob
   int s = irx_cdiv(target, tiles);
