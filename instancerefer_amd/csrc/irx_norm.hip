@@ -66,7 +66,7 @@ __host__ __device__ static inline int next_pow2(int v) {
 //   MODE 0: (sum x, sum x^2)
 //   MODE 1: (sum g, sum g*xhat), g = dy * (RELU ? y > 0 : 1), xhat = (x - mean) * invstd
 // V = vector width (4 when c % 4 == 0 else 1). part layout [blk][2][c].
-template <int MODE, int V, bool TY>
+template <int MODE, int V, bool TY, bool RM = false>
 __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
                                                     const float* __restrict__ y,
                                                     const float* __restrict__ dy, int n, int c,
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
                                                     const float* __restrict__ invstd, int relu,
                                                     int qpad, int rows_per_block, float* __restrict__ part, BnTy ty,
                                                     const float* __restrict__ mk_gamma, const float* __restrict__ mk_beta) {
-  // mk_gamma / mk_beta != NULL (MODE 1, relu, a layer WITHOUT a shortcut): the ReLU mask is recomputed from x —
+  // RM (compile time: a run-time flag in front of the loads keeps the compiler from batching a row group's loads, measured
+  // again in round 3: 15.8 -> 21.8 us) with mk_gamma / mk_beta (MODE 1, relu, a layer WITHOUT a shortcut): the ReLU mask is recomputed from x —
   // y > 0  <=>  fma(x, invstd * gamma, fma(-mean, invstd * gamma, beta)) > 0, the very expression k_bn_apply evaluated — so y
   // is never read (a third of this pass's bytes)
   __shared__ float s0[256 * V];
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
   for (int j = 0; j < V; ++j) a0[j] = a1[j] = 0.f;
   if (qd < cq) {
     float mu[V], is[V], msc[V], msh[V];
-    const bool remask = MODE == 1 && relu && mk_beta != nullptr;
+    constexpr bool remask = RM;
     if (MODE == 1) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
@@ -128,10 +129,6 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
           if (relu && !remask) yv[0] = y[off];
         }
       }
-      if (MODE == 1 && remask) {
-#pragma unroll
-        for (int j = 0; j < V; ++j) yv[j] = fmaf(xv[j], msc[j], msh[j]);
-      }
     };
     auto add_row = [&](const float (&xv)[V], const float (&yv)[V], const float (&dv)[V]) __attribute__((always_inline)) {
 #pragma unroll
@@ -141,7 +138,10 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
           a1[j] += xv[j] * xv[j];
         } else {
           float gval = dv[j];
-          if (relu && !(yv[j] > 0.f)) gval = 0.f;
+          // (the recomputed mask belongs HERE, behind all the loads of the row group: inside load_row it put a wait for x
+          // between the rows' loads — 15.7 -> 18.3 us)
+          const float yy = remask ? fmaf(xv[j], msc[j], msh[j]) : yv[j];
+          if (relu && !(yy > 0.f)) gval = 0.f;
           a0[j] += gval;
           a1[j] += gval * ((xv[j] - mu[j]) * is[j]);
         }
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, i
 }
 
 // dx = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n);  dres = g
-template <int V, bool TY>
+template <int V, bool TY, bool RM = false>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x,
                                                       const float* __restrict__ y,
                                                       const float* __restrict__ dy, int n, int c, int qpad,
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   const int rpp = 256 / qpad;
   const float inv_n = count_dev ? (float)(1.0 / *count_dev) : inv_count;
   float mu[V], is[V], gi[V], sg[V], sgx[V], msc[V], msh[V];
-  const bool remask = relu && mk_beta != nullptr;          // see k_bn_partial
+  constexpr bool remask = RM;                              // see k_bn_partial
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     mu[j] = mean[qd * V + j];
@@ -331,8 +331,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     gi[j] = gamma[qd * V + j] * is[j];
     sg[j] = sum_g[qd * V + j] * inv_n;
     sgx[j] = sum_gx[qd * V + j] * inv_n;
-    msc[j] = is[j] * gamma[qd * V + j];
-    msh[j] = remask ? fmaf(-mu[j], msc[j], mk_beta[qd * V + j]) : 0.f;
+    msc[j] = msh[j] = 0.f;
+    if constexpr (RM) {
+      msc[j] = is[j] * gamma[qd * V + j];
+      msh[j] = fmaf(-mu[j], msc[j], mk_beta[qd * V + j]);
+    }
   }
   const int row_stride = gridDim.x * rpp;
   for (int r = blockIdx.x * rpp + threadIdx.x / qpad; r < n; r += row_stride) {
@@ -583,21 +586,31 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   if (rc) return rc;
   const bool any_bf = (x_bf | y_bf | dy_bf | dx_bf | dres_bf) != 0;
   const bool v8 = v4 && x_bf && (y_bf || !relu) && dy_bf && dx_bf && (!dresidual || dres_bf) && c % 8 == 0;
+  const bool rm = mk_beta != nullptr;            // mask recomputed from x: separate instantiations (see k_bn_partial)
+  // Measured per kernel (rocprofv3, same box, the 9 shortcut-free layers of both encoders): the apply pass gains from not
+  // reading y (14.4 -> 11.7 us average), the statistics pass LOSES (15.7 -> 18.3 us: it is bound by the latency of a row
+  // group's loads, not by their bytes, and the recomputation lengthens the dependent chain behind them) — so only the apply
+  // pass recomputes the mask; the statistics pass keeps reading y.
+  static const bool rm_stats = getenv("IRX_BN_REMASK_STATS") && atoi(getenv("IRX_BN_REMASK_STATS")) != 0;   // dev A/B knob
+#define BN_PARTIAL1(V_, TY_, QP_)                                                                                          \
+  do {                                                                                                                     \
+    if (rm && rm_stats) k_bn_partial<1, V_, TY_, true><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_,           \
+                                                                        bn_rows(n, c), part, ty, mk_gamma, mk_beta);       \
+    else k_bn_partial<1, V_, TY_, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_,             \
+                                                                      bn_rows(n, c), part, ty, nullptr, nullptr);          \
+  } while (0)
   if (!(phases & 1)) {
   } else if (v8)
-    k_bn_partial<1, 8, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                   next_pow2(c / 8), bn_rows(n, c), part, ty, mk_gamma, mk_beta);
+    BN_PARTIAL1(8, false, next_pow2(c / 8));
   else if (v4 && any_bf)
-    k_bn_partial<1, 4, true><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                         next_pow2(c / 4), bn_rows(n, c), part, ty, mk_gamma, mk_beta);
+    BN_PARTIAL1(4, true, next_pow2(c / 4));
   else if (v4)
-    k_bn_partial<1, 4, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu,
-                                                          next_pow2(c / 4), bn_rows(n, c), part, ty, mk_gamma, mk_beta);
+    BN_PARTIAL1(4, false, next_pow2(c / 4));
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_backward: c=%d needs c %% 4 == 0 or c <= 256", c);
-    k_bn_partial<1, 1, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, next_pow2(c),
-                                                   bn_rows(n, c), part, ty, mk_gamma, mk_beta);
+    BN_PARTIAL1(1, false, next_pow2(c));
   }
+#undef BN_PARTIAL1
   if (phases & 1) {
     IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
     k_bn_finalize<1><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
@@ -608,23 +621,19 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   const float* sg = (phases == 2) ? all_sum_g : dbeta;
   const float* sgx = (phases == 2) ? all_sum_gx : dgamma;
   const float inv_count = (phases == 2) ? (all_count >= 1.0 ? (float)(1.0 / all_count) : 0.f) : 1.f / (float)n;
-  if (v8) {
-    const int qpad = next_pow2(c / 8);
-    k_bn_bwd_apply<8, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
-                                                               sgx, relu, dx, dresidual, ty, inv_count, count_dev, mk_beta);
-  } else if (v4 && any_bf) {
-    const int qpad = next_pow2(c / 4);
-    k_bn_bwd_apply<4, true><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
-                                                                     sgx, relu, dx, dresidual, ty, inv_count, count_dev, mk_beta);
-  } else if (v4) {
-    const int qpad = next_pow2(c / 4);
-    k_bn_bwd_apply<4, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
-                                                                      sgx, relu, dx, dresidual, ty, inv_count, count_dev, mk_beta);
-  } else {
-    const int qpad = next_pow2(c);
-    k_bn_bwd_apply<1, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, y, dy, n, c, qpad, mean, invstd, gamma, sg,
-                                                               sgx, relu, dx, dresidual, ty, inv_count, count_dev, mk_beta);
-  }
+#define BN_BWD_APPLY(V_, TY_, QP_)                                                                                         \
+  do {                                                                                                                     \
+    const int qpad = QP_;                                                                                                  \
+    if (rm) k_bn_bwd_apply<V_, TY_, true><<<row_grid(n, qpad), 256, 0, S(stream)>>>(                                       \
+        x, y, dy, n, c, qpad, mean, invstd, gamma, sg, sgx, relu, dx, dresidual, ty, inv_count, count_dev, mk_beta);       \
+    else k_bn_bwd_apply<V_, TY_, false><<<row_grid(n, qpad), 256, 0, S(stream)>>>(                                         \
+        x, y, dy, n, c, qpad, mean, invstd, gamma, sg, sgx, relu, dx, dresidual, ty, inv_count, count_dev, nullptr);       \
+  } while (0)
+  if (v8) BN_BWD_APPLY(8, false, next_pow2(c / 8));
+  else if (v4 && any_bf) BN_BWD_APPLY(4, true, next_pow2(c / 4));
+  else if (v4) BN_BWD_APPLY(4, false, next_pow2(c / 4));
+  else BN_BWD_APPLY(1, false, next_pow2(c));
+#undef BN_BWD_APPLY
   IRX_CHECK_LAUNCH("irx_bn_backward(apply)");
   return IRX_OK;
 }
