@@ -66,8 +66,14 @@ __host__ __device__ static inline int next_pow2(int v) {
 //   MODE 0: (sum x, sum x^2)
 //   MODE 1: (sum g, sum g*xhat), g = dy * (RELU ? y > 0 : 1), xhat = (x - mean) * invstd
 // V = vector width (4 when c % 4 == 0 else 1). part layout [blk][2][c].
+// threads per statistics workgroup: 512 (round 3, rocprofv3 same box: k_bn_partial<1> 15.7 / 14.5 / 16.2 us and k_bn_partial<0>
+// 7.2 / 7.0 / 8.3 us at 256 / 512 / 1024 — these launches have fewer workgroups than the chip has CUs, so more loads in
+// flight per workgroup help until the LDS fold grows); -DBN_PT=... for A/B builds
+#ifndef BN_PT
+#define BN_PT 512
+#endif
 template <int MODE, int V, bool TY, bool RM = false, bool RL = true>
-__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
+__global__ __launch_bounds__(BN_PT) void k_bn_partial(const float* __restrict__ x,
                                                     const float* __restrict__ y,
                                                     const float* __restrict__ dy, int n, int c,
                                                     const float* __restrict__ mean,
@@ -78,12 +84,12 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
   // again in round 3: 15.8 -> 21.8 us) with mk_gamma / mk_beta (MODE 1, relu, a layer WITHOUT a shortcut): the ReLU mask is recomputed from x —
   // y > 0  <=>  fma(x, invstd * gamma, fma(-mean, invstd * gamma, beta)) > 0, the very expression k_bn_apply evaluated — so y
   // is never read (a third of this pass's bytes)
-  __shared__ float s0[256 * V];
-  __shared__ float s1[256 * V];
+  __shared__ float s0[BN_PT * V];
+  __shared__ float s1[BN_PT * V];
   const int cq = c / V;
   const int qd = threadIdx.x % qpad;
   const int rg = threadIdx.x / qpad;
-  const int nrg = 256 / qpad;
+  const int nrg = BN_PT / qpad;
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block;
   if (r1 > n) r1 = n;
@@ -433,17 +439,17 @@ int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, floa
   rc = bn_bf_ok("irx_bn_stats", x_bf != 0, v4);
   if (rc) return rc;
   if (v4 && x_bf && c % 8 == 0)
-    k_bn_partial<0, 8, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+    k_bn_partial<0, 8, false><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
                                                    next_pow2(c / 8), bn_rows(n, c), part, ty, nullptr, nullptr);
   else if (v4 && x_bf)
-    k_bn_partial<0, 4, true><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+    k_bn_partial<0, 4, true><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
                                                          next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr);
   else if (v4)
-    k_bn_partial<0, 4, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+    k_bn_partial<0, 4, false><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
                                                           next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_stats: c=%d needs c %% 4 == 0 or c <= 256", c);
-    k_bn_partial<0, 1, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+    k_bn_partial<0, 1, false><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
                                                    next_pow2(c), bn_rows(n, c), part, ty, nullptr, nullptr);
   }
   IRX_CHECK_LAUNCH("irx_bn_stats(partial)");
@@ -469,11 +475,11 @@ extern "C" int irx_bn_sums(const float* x, int n, int c, double* sums, void* wor
   float* part = (float*)workspace;
   const BnTy ty = {0, 0, 0, 0, 0};
   if ((c % 4 == 0) && (((uintptr_t)x & 15) == 0))
-    k_bn_partial<0, 4, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+    k_bn_partial<0, 4, false><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
                                                           next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_sums: c=%d needs c %% 4 == 0 or c <= 256", c);
-    k_bn_partial<0, 1, false><<<nblk, 256, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+    k_bn_partial<0, 1, false><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
                                                           next_pow2(c), bn_rows(n, c), part, ty, nullptr, nullptr);
   }
   IRX_CHECK_LAUNCH("irx_bn_sums(partial)");
@@ -609,11 +615,11 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   static const bool rm_stats = getenv("IRX_BN_REMASK_STATS") && atoi(getenv("IRX_BN_REMASK_STATS")) != 0;   // dev A/B knob
 #define BN_PARTIAL1(V_, TY_, QP_)                                                                                          \
   do {                                                                                                                     \
-    if (rm && rm_stats) k_bn_partial<1, V_, TY_, true, true><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_,     \
+    if (rm && rm_stats) k_bn_partial<1, V_, TY_, true, true><<<nblk, BN_PT, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_,     \
                                                                         bn_rows(n, c), part, ty, mk_gamma, mk_beta);       \
-    else if (relu) k_bn_partial<1, V_, TY_, false, true><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_, \
+    else if (relu) k_bn_partial<1, V_, TY_, false, true><<<nblk, BN_PT, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_, \
                                                                       bn_rows(n, c), part, ty, nullptr, nullptr);          \
-    else k_bn_partial<1, V_, TY_, false, false><<<nblk, 256, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_,      \
+    else k_bn_partial<1, V_, TY_, false, false><<<nblk, BN_PT, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_,      \
                                                                       bn_rows(n, c), part, ty, nullptr, nullptr);          \
   } while (0)
   if (!(phases & 1)) {
