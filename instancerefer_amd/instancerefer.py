@@ -77,6 +77,11 @@ class InstanceRefer(nn.Module):
         pending = data_dict.pop('_scene_pending', None)
         if pending is not None:
             data_dict['lidar'].level().build_pyramid_finish(pending)
+            if self.training:
+                data_dict['lidar'].level().build_tables()      # kernel maps + tile order on the preparation stream
+        prep = data_dict.get('_attr_prepared')
+        if self.training and prep is not None and prep[0] is not None:
+            prep[0].level().build_tables()
         data_dict['_prepared'] = True
         return data_dict
 

@@ -143,6 +143,23 @@ class Level:
                 lv = out
         return lv
 
+    def build_tables(self, order_min_rows=None):
+        """Enqueue NOW, on the current stream, every table the encoder's convolutions will ask for: the 27-neighbour table
+        of each level of the (already built) pyramid and the tile launch order of the levels whose 3^3 convolutions run on
+        k_spconv2 with more than one round of tiles. Called by the input-preparation stage (its own stream, one step
+        ahead): built lazily these ten k_kmap_s1 launches and the ordering sat at the head of the encoders' streams."""
+        from . import encoder_fn
+        if order_min_rows is None:
+            order_min_rows = encoder_fn.TILE_ORDER_MIN_ROWS if encoder_fn.TILE_ORDER else None
+        lv, first = self, True
+        while lv is not None:
+            if lv.n > 0:
+                lv.nbr27()
+                if not first and order_min_rows is not None and lv.n >= order_min_rows:
+                    lv.order27()                     # (level 0 hosts the stem convolution: no k_spconv2 layer)
+            first = False
+            lv = lv._down.out_level if lv._down is not None else None
+
     def offsets(self):
         if self._offsets is None:
             self._offsets = F_.batch_offsets(self.coords, self.batch_size)
