@@ -9,6 +9,11 @@ import torch.nn as nn
 
 _PKG = __name__.rsplit('.', 1)[0]
 import os as _os
+# Kernel maps + tile orders enqueued by prepare_finish() on the preparation stream instead of lazily at the head of the
+# encoders' streams: OFF by default. Measured (round 3, alternating runs on one box): the resident-input loop of bench.py gains
+# 0.5 % (9.27-9.30 vs 9.31-9.35 ms/step), the end-to-end loop (tools/e2e_train_bench.py, whose preparation stream also carries
+# the next batches' input pipeline) LOSES 5-15 % (1425-1560 vs 1665-1693 scenes/s). IRX_PREP_TABLES=1 enables it.
+_PREP_TABLES = _os.environ.get('IRX_PREP_TABLES', '0') == '1'
 _ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
 
 
@@ -77,10 +82,10 @@ class InstanceRefer(nn.Module):
         pending = data_dict.pop('_scene_pending', None)
         if pending is not None:
             data_dict['lidar'].level().build_pyramid_finish(pending)
-            if self.training:
+            if self.training and _PREP_TABLES:
                 data_dict['lidar'].level().build_tables()      # kernel maps + tile order on the preparation stream
         prep = data_dict.get('_attr_prepared')
-        if self.training and prep is not None and prep[0] is not None:
+        if self.training and _PREP_TABLES and prep is not None and prep[0] is not None:
             prep[0].level().build_tables()
         data_dict['_prepared'] = True
         return data_dict

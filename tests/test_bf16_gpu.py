@@ -9,8 +9,8 @@ rounded layers (1e-7 -> 3e-5 -> 4e-4 -> ... -> the bf16 noise floor; emulate.py'
 arithmetic is therefore pinned in two ways:
   (a) LAYER BY LAYER ("teacher forced"): every layer of the executor, forward and backward, recomputed by the emulation
       from the executor's OWN stored inputs (bit-identical) — conv output, BatchNorm statistics, layer output, data-,
-      weight-, scale- and shift-gradients, shortcut gradient: <= 2e-4 relative L2 each (measured ~3e-5: only values within
-      fp32 round-off of a bf16 tie differ, by one bf16 ulp);
+      weight-, scale- and shift-gradients, shortcut gradient: <= 1e-3 relative L2 each (measured 2e-5 .. 2e-4: only values
+      within fp32 round-off of a bf16 tie differ, by one bf16 ulp; a misplaced rounding point shows up as 6e-3);
   (b) END TO END: HIP vs the emulation no further apart than the emulation is from ITSELF with another summation order
       (float64 accumulation) — median ratio <= 1.5 over all tensors, every tensor <= 4x — and closer to the emulation than
       to the fp32 oracle (measured on the encoder output: 6e-3 vs 1e-2)."""
@@ -59,9 +59,10 @@ def test_executor_bf16_layer_by_layer(lib, c0, mode):
     bf16 output and double rounding, k_wgrad_pairs reading x with a row stride and a separately typed dy), in both modes:
     the one-call executor runs forward + backward with its arenas traced (sparse/encoder_fn.TRACE); then each of the 13
     layers is recomputed on the CPU by the emulation from the executor's stored x_i / c_i / y_i / gy_i. Bars: bf16 storage
-    3e-4 relative L2 (measured <= 1.6e-4: one-ulp re-roundings of values within fp32 round-off of a tie); bf16 operands:
+    1e-3 relative L2 (measured 2e-5 .. 2.2e-4 over the four cases and two kernel schedules: one-ulp re-roundings of values
+    within fp32 round-off of a tie; the bf16 noise floor a wrong rounding point would produce is 6e-3); bf16 operands:
     forward quantities 2e-5 (the stored tensors are fp32 and rounding the SAME fp32 input is deterministic: measured 1e-7),
-    data- / weight-gradients 3e-4 (measured 4e-5)."""
+    data- / weight-gradients 1e-3 (measured 2e-5 .. 2.2e-4: d c_i is recomputed by both sides before it is rounded)."""
     import torch.nn.functional as TF
     import instancerefer_amd as irx
     from instancerefer_amd.sparse import encoder_fn
@@ -132,7 +133,7 @@ def test_executor_bf16_layer_by_layer(lib, c0, mode):
     # (operand mode: the forward quantities see bit-identical fp32 inputs; d c_i is not a stored tensor there, it is
     # recomputed from gy_i by both sides and THEN rounded at use, so the backward quantities carry one-ulp re-roundings too)
     fwd_keys = ("conv output c", "mean", "invstd", "layer output y", "d gamma", "d beta")
-    bad = {k: v for k, v in worst.items() if not v <= (2e-5 if (not st and k in fwd_keys) else 3e-4)}
+    bad = {k: v for k, v in worst.items() if not v <= (2e-5 if (not st and k in fwd_keys) else 1e-3)}
     assert not bad, bad
 
 

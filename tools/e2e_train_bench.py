@@ -95,8 +95,12 @@ for step in range(a.warmup + a.steps):
     opt.zero_grad()
     out = get_loss(model(cur), cfg)
     out["loss"].backward()
-    opt.backward_step()
-    cur = stage_finish(launched)
+    if os.environ.get("IRX_E2E_FINISH_EARLY") == "1":      # dev A/B: collect the level sizes (and enqueue the tables) before the optimizer
+        cur = stage_finish(launched)
+        opt.backward_step()
+    else:
+        opt.backward_step()
+        cur = stage_finish(launched)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 if a.json:
