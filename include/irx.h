@@ -70,6 +70,9 @@ int irx_device_props(int device, int* out8_host);
 
 /* keys[i] = (b<<48)|morton(x,y,z) for coords[i]. */
 int irx_coords_to_keys(const int32_t* coords, int n, uint64_t* keys, void* stream);
+/* ... and back: coords[i] = (x, y, z, b) of keys[i] (int32 [n][4]). The voxeliser takes the coordinate rows of its
+ * Morton-sorted voxels from the sorted keys (a streaming pass) instead of gathering them through the sort permutation. */
+int irx_keys_to_coords(const uint64_t* keys, int n, int32_t* coords, void* stream);
 
 /* Stable ascending radix sort (8-bit digits, LSD) of 64-bit keys by their bits [begin_bit, end_bit), with the permutation
  * it applies: keys_out[i] = keys[order_out[i]]. The ordering step of the voxeliser: rows of every SparseTensor are kept
@@ -89,7 +92,7 @@ int irx_sort_pairs_u64(const uint64_t* keys, int n, const int32_t* n_dev, uint64
  * kept) — replaces the `np.floor(coords / quantization_size)` step reached from
  * models/attribute_module.py:65-69 and lib/dataset.py:229-233,256-260.
  * xyz: [n][3] (float64 when xyz_is_f64 else float32), batch: int32 [n] or NULL (=0).
- * Writes coords int32 [n][4] and keys uint64 [n]. A point whose voxel coordinate falls outside [-32768, 32768) (or
+ * Writes coords int32 [n][4] (skipped when coords == NULL) and keys uint64 [n]. A point whose voxel coordinate falls outside [-32768, 32768) (or
  * whose batch index is outside [0, 32768), or that is NaN) cannot be keyed: it receives a poison key, and
  * irx_voxel_select reports it by returning a NEGATIVE count (sign bit set) — callers must treat that as an error. */
 int irx_quantize(const void* xyz, int xyz_is_f64, const int32_t* batch, int n,

@@ -24,6 +24,7 @@ _SIGNATURES = {
     "irx_last_error": (_c.c_char_p, []),
     "irx_device_props": (_I, [_I, _P]),
     "irx_coords_to_keys": (_I, [_P, _I, _P, _P]),
+    "irx_keys_to_coords": (_I, [_P, _I, _P, _P]),
     "irx_sort_workspace_bytes": (_Z, [_I]),
     "irx_sort_pairs_u64": (_I, [_P, _I, _P, _c.c_uint64, _I, _I, _P, _P, _P, _Z, _P]),
     "irx_tile_order_workspace_bytes": (_Z, [_I]),

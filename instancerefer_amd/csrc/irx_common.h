@@ -61,6 +61,17 @@ __host__ __device__ static inline uint64_t irx_make_key(int x, int y, int z, int
   return ((uint64_t)(uint32_t)b << 48) | (m & 0xFFFFFFFFFFFFull);
 }
 
+// inverse of irx_spread3: every third bit of a 48-bit interleave -> 16-bit value
+__host__ __device__ static inline uint32_t irx_compact3(uint64_t x) {
+  x &= 0x9249249249249249ull;
+  x = (x | (x >> 2)) & 0x30C30C30C30C30C3ull;
+  x = (x | (x >> 4)) & 0xF00F00F00F00F00Full;
+  x = (x | (x >> 8)) & 0x00FF0000FF0000FFull;
+  x = (x | (x >> 16)) & 0x00FF00000000FFFFull;
+  x = (x | (x >> 32)) & 0xFFFFull;
+  return (uint32_t)x;
+}
+
 // ---- open-addressing hash (linear probing, 64-bit keys) ---------------------------------
 __host__ __device__ static inline uint64_t irx_mix64(uint64_t k) {
   // murmur3 finaliser

@@ -52,6 +52,16 @@ __global__ void k_coords_to_keys(const int4* __restrict__ coords, int n, uint64_
   keys[i] = irx_make_key(c.x, c.y, c.z, c.w);
 }
 
+// a key holds its voxel: (x, y, z, batch) back out of the Morton interleave (rows of the sorted key array -> coordinate
+// rows, a streaming pass instead of a random 16-byte gather through the sort permutation)
+__global__ void k_keys_to_coords(const uint64_t* __restrict__ keys, int n, int4* __restrict__ coords) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i], m = key & 0xFFFFFFFFFFFFull;
+  coords[i] = make_int4((int)irx_compact3(m) - IRX_COORD_BIAS, (int)irx_compact3(m >> 1) - IRX_COORD_BIAS,
+                        (int)irx_compact3(m >> 2) - IRX_COORD_BIAS, (int)(key >> 48));
+}
+
 template <typename T>
 __global__ void k_quantize(const T* __restrict__ xyz, const int32_t* __restrict__ batch, int n,
                            double vx, double vy, double vz, int4* __restrict__ coords,
@@ -70,7 +80,7 @@ __global__ void k_quantize(const T* __restrict__ xyz, const int32_t* __restrict_
                   fy < (double)IRX_COORD_BIAS && fz >= -(double)IRX_COORD_BIAS && fz < (double)IRX_COORD_BIAS &&
                   b >= 0 && b < 32768;          // (NaN coordinates fail the comparisons too)
   int cx = ok ? (int)fx : 0, cy = ok ? (int)fy : 0, cz = ok ? (int)fz : 0;
-  coords[i] = make_int4(cx, cy, cz, b);
+  if (coords) coords[i] = make_int4(cx, cy, cz, b);
   keys[i] = ok ? irx_make_key(cx, cy, cz, b) : IRX_POISON_KEY;
 }
 
@@ -322,11 +332,20 @@ extern "C" int irx_coords_to_keys(const int32_t* coords, int n, uint64_t* keys, 
   return IRX_OK;
 }
 
+extern "C" int irx_keys_to_coords(const uint64_t* keys, int n, int32_t* coords, void* stream) {
+  IRX_REQUIRE(n >= 0, "irx_keys_to_coords: n < 0");
+  if (n == 0) return IRX_OK;
+  IRX_REQUIRE(coords && keys, "irx_keys_to_coords: null pointer");
+  k_keys_to_coords<<<irx_cdiv(n, 256), 256, 0, S(stream)>>>(keys, n, (int4*)coords);
+  IRX_CHECK_LAUNCH("irx_keys_to_coords");
+  return IRX_OK;
+}
+
 extern "C" int irx_quantize(const void* xyz, int xyz_is_f64, const int32_t* batch, int n, double vx,
                             double vy, double vz, int32_t* coords, uint64_t* keys, void* stream) {
   IRX_REQUIRE(n >= 0, "irx_quantize: n < 0");
   if (n == 0) return IRX_OK;
-  IRX_REQUIRE(xyz && coords && keys, "irx_quantize: null pointer");
+  IRX_REQUIRE(xyz && keys, "irx_quantize: null pointer");
   IRX_REQUIRE(vx > 0 && vy > 0 && vz > 0, "irx_quantize: voxel size must be > 0");
   if (xyz_is_f64)
     k_quantize<double><<<irx_cdiv(n, 256), 256, 0, S(stream)>>>((const double*)xyz, batch, n, vx, vy,

@@ -6,7 +6,7 @@
 // 2.5 tiles per slot (1270 tiles on 512 slots for the largest 128-channel level) list scheduling in Morton order ends 39 %
 // above the balanced makespan in a replay of the measured per-tile costs; longest-tile-first ends 18 % above it (and 9 %
 // instead of 23 % for the 64-channel level with 4045 tiles on 768 slots). So: one pass over the neighbour table computes a
-// cost class per tile, and a stable counting sort (one wave; <= a few thousand tiles) lists the tiles heaviest class first.
+// cost class per tile, and a stable counting sort (one workgroup; <= a few thousand tiles) lists the tiles heaviest class first.
 // The order changes WHEN a tile is computed, never what is computed: results are bit-identical with and without it.
 #include "irx_common.h"
 
@@ -35,11 +35,16 @@ __global__ __launch_bounds__(256) void k_tile_cost(const int32_t* __restrict__ n
   if (lane == 0) cls[t] = (unsigned char)(TS_NCLS - 1 - c);      // class 0 = heaviest
 }
 
-// stable counting sort of the tiles by class, one wave (ntiles / 64 chunks, twice)
-__global__ __launch_bounds__(64) void k_tile_order(const unsigned char* __restrict__ cls, int ntiles, int32_t* __restrict__ order) {
-  __shared__ int cnt[TS_NCLS];
-  const int lane = threadIdx.x;
-  cnt[lane] = 0;                                       // TS_NCLS == 64 == lanes
+// stable counting sort of the tiles by class: one workgroup of TO_WAVES waves, wave w owns the w-th contiguous segment of the
+// tile list (whole 64-tile chunks); per-wave class histograms in LDS, then position = (tiles of lighter-numbered classes) +
+// (same class in earlier waves) + (same class earlier in my wave). The single-wave version took 35-110 us per level.
+#define TO_WAVES 16
+__global__ __launch_bounds__(64 * TO_WAVES) void k_tile_order(const unsigned char* __restrict__ cls, int ntiles,
+                                                              int32_t* __restrict__ order) {
+  __shared__ int cnt[TO_WAVES][TS_NCLS];
+  __shared__ int cls_base[TS_NCLS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  cnt[wave][lane] = 0;                                 // TS_NCLS == 64 == lanes
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   auto peers_of = [&](unsigned c, bool valid) {
     unsigned long long m = __ballot(valid);
@@ -50,30 +55,45 @@ __global__ __launch_bounds__(64) void k_tile_order(const unsigned char* __restri
     }
     return valid ? m : 0ull;
   };
-  for (int base = 0; base < ntiles; base += 64) {
+  const int seg = ((ntiles + 64 * TO_WAVES - 1) / (64 * TO_WAVES)) * 64;
+  const int t0 = wave * seg, t1 = (t0 + seg < ntiles) ? t0 + seg : ntiles;
+  for (int base = t0; base < t1; base += 64) {
     const int t = base + lane;
-    const bool valid = t < ntiles;
+    const bool valid = t < t1;
     const unsigned c = valid ? cls[t] : 0u;
     const unsigned long long peers = peers_of(c, valid);
-    if (valid && (peers & lt) == 0ull) cnt[c] += __popcll(peers);
+    if (valid && (peers & lt) == 0ull) cnt[wave][c] += __popcll(peers);
   }
-  // exclusive scan over the 64 classes (lane == class)
-  int v = cnt[lane], incl = v;
+  __syncthreads();
+  // thread (wave, lane = class): tiles of my class in earlier waves; wave 0 also scans the class totals
+  int before = 0, total = 0;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int up = __shfl_up(incl, off);
-    if (lane >= off) incl += up;
+  for (int w = 0; w < TO_WAVES; ++w) {
+    const int h = cnt[w][lane];
+    before += (w < wave) ? h : 0;
+    total += h;
   }
-  cnt[lane] = incl - v;
-  for (int base = 0; base < ntiles; base += 64) {
+  if (wave == 0) {
+    int incl = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    cls_base[lane] = incl - total;
+  }
+  __syncthreads();
+  cnt[wave][lane] = cls_base[lane] + before;
+  __builtin_amdgcn_wave_barrier();
+  for (int base = t0; base < t1; base += 64) {
     const int t = base + lane;
-    const bool valid = t < ntiles;
+    const bool valid = t < t1;
     const unsigned c = valid ? cls[t] : 0u;
     const unsigned long long peers = peers_of(c, valid);
     int pos = 0;
-    if (valid) pos = cnt[c] + __popcll(peers & lt);
+    if (valid) pos = cnt[wave][c] + __popcll(peers & lt);
     __builtin_amdgcn_wave_barrier();
-    if (valid && (peers & lt) == 0ull) cnt[c] += __popcll(peers);
+    if (valid && (peers & lt) == 0ull) cnt[wave][c] += __popcll(peers);
     __builtin_amdgcn_wave_barrier();
     if (valid) order[pos] = t;
   }
@@ -93,7 +113,7 @@ extern "C" int irx_tile_order(const int32_t* nbr, int ld, int n_out, int K, int3
   while (((K * (TS_FIX + 4 * TS_GRP)) >> shift) >= TS_NCLS) ++shift;
   unsigned char* cls = (unsigned char*)workspace;
   k_tile_cost<<<irx_cdiv(ntiles, 4), 256, 0, S(stream)>>>(nbr, ld, n_out, K, ntiles, shift, cls);
-  k_tile_order<<<1, 64, 0, S(stream)>>>(cls, ntiles, order);
+  k_tile_order<<<1, 64 * TO_WAVES, 0, S(stream)>>>(cls, ntiles, order);
   IRX_CHECK_LAUNCH("irx_tile_order");
   return IRX_OK;
 }

@@ -51,6 +51,14 @@ def coords_to_keys(coords):
     return keys
 
 
+def keys_to_coords(keys):
+    """(n,) int64 Morton keys -> (n, 4) int32 coordinate rows (x, y, z, batch): irx_keys_to_coords."""
+    n = keys.shape[0]
+    coords = torch.empty((n, 4), dtype=_i32, device=keys.device)
+    _lib.call("irx_keys_to_coords", _lib.ptr(keys), n, _lib.ptr(coords), _stream())
+    return coords
+
+
 def sort_keys(keys, end_bit=63, n_dev=None, pad=None, begin_bit=0):
     """Stable ascending sort of int64 `keys` (non-negative) by bits [begin_bit, end_bit) -> (sorted keys, order int32) with
     sorted[i] = keys[order[i]]: irx_sort_pairs_u64 (csrc/irx_sort.hip), the build's own radix sort. n_dev (int32 device
@@ -78,12 +86,13 @@ def morton_bits(batch_size, with_pad=False):
     return 48 + max(top.bit_length(), 1)
 
 
-def quantize(xyz, batch, voxel):
-    """xyz (N,3) f32/f64 cuda, batch (N,) int32 or None, voxel: 3 floats -> coords (N,4) i32, keys (N,) i64."""
+def quantize(xyz, batch, voxel, want_coords=True):
+    """xyz (N,3) f32/f64 cuda, batch (N,) int32 or None, voxel: 3 floats -> coords (N,4) i32 (None when not wanted: the
+    voxeliser decodes the rows it keeps from their keys), keys (N,) i64."""
     n = xyz.shape[0]
     xyz = xyz.contiguous()
     assert xyz.dtype in (torch.float32, torch.float64)
-    coords = torch.empty((n, 4), dtype=_i32, device=xyz.device)
+    coords = torch.empty((n, 4), dtype=_i32, device=xyz.device) if want_coords else None
     keys = torch.empty(n, dtype=_i64, device=xyz.device)
     _lib.call("irx_quantize", _lib.ptr(xyz), int(xyz.dtype == torch.float64), _lib.ptr(batch), n,
               float(voxel[0]), float(voxel[1]), float(voxel[2]), _lib.ptr(coords), _lib.ptr(keys), _stream())

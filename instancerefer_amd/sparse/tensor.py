@@ -259,7 +259,7 @@ class SparseTensor:
         F = F.float()
         keys = F_.coords_to_keys(C)
         skeys, perm = F_.sort_keys(keys, F_.morton_bits(self._batch_size))
-        C = C.index_select(0, perm).contiguous()
+        C = F_.keys_to_coords(skeys)                     # a key holds its row: decoded (streaming), not gathered through perm
         F = F.index_select(0, perm)
         bs = self._batch_size if self._batch_size is not None else (int(C[-1, 3].item()) + 1 if C.shape[0] else 0)
         lv = Level(C, skeys, self.s, bs)

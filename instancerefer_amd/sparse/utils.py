@@ -25,12 +25,12 @@ def voxelize(xyz, feats, batch, voxel_size, batch_size):
     xyz (N,3) f32/f64 cuda; feats (N,C) cuda; batch (N,) int32 cuda or None; returns a canonical
     SparseTensor (rows in Morton order) at stride 1.
     """
-    coords, keys = F_.quantize(xyz, batch, _voxel3(voxel_size))
+    _, keys = F_.quantize(xyz, batch, _voxel3(voxel_size), want_coords=False)
     win = F_.voxel_unique(keys)
     wkeys = keys.index_select(0, win)
     skeys, order = F_.sort_keys(wkeys, F_.morton_bits(batch_size))
     idx = win.index_select(0, order)
-    C = coords.index_select(0, idx).contiguous()
+    C = F_.keys_to_coords(skeys)          # a key holds its voxel: no gather of coordinate rows through the permutation
     Fv = feats.index_select(0, idx).float().contiguous()
     lv = Level(C, skeys, 1, batch_size)
     return SparseTensor(Fv, C, 1, batch_size, lv)
@@ -60,7 +60,7 @@ class VoxelizePending:
 
 def voxelize_launch(xyz, feats, batch, voxel_size, batch_size, levels):
     """Sync-free voxelize + pyramid (see VoxelizePending). Same result as voxelize() followed by build_pyramid()."""
-    coords, keys = F_.quantize(xyz, batch, _voxel3(voxel_size))
+    _, keys = F_.quantize(xyz, batch, _voxel3(voxel_size), want_coords=False)
     n = keys.shape[0]
     win, count = F_.voxel_unique_launch(keys)                    # winners first, zeros behind; count on the device
     # rows behind the device-side count are padding: the sort reads the count itself and gives them the key
@@ -68,7 +68,7 @@ def voxelize_launch(xyz, feats, batch, voxel_size, batch_size, levels):
     skeys, order = F_.sort_keys(keys.index_select(0, win), F_.morton_bits(batch_size, True), n_dev=count,
                                 pad=int(batch_size) << 48)
     idx = win.index_select(0, order)
-    C = coords.index_select(0, idx).contiguous()
+    C = F_.keys_to_coords(skeys)          # (rows behind the count decode the padding key: sliced off in finish())
     Fv = feats.index_select(0, idx).float().contiguous()
     pyr = F_.pyramid_launch(skeys, C, 1, levels, n0_dev=count)
     return VoxelizePending(C, Fv, skeys, batch_size, pyr)

@@ -44,6 +44,30 @@ def test_voxelize_matches_sparse_quantize(lib, clouds):
     assert np.all(k[1:] > k[:-1]), "rows must be in strictly ascending Morton-key order"
 
 
+def test_keys_decode_back_to_their_coordinates(lib):
+    """irx_keys_to_coords is the inverse of irx_coords_to_keys over the whole keyable range (16 biased bits per axis, 15 bits
+    of batch index): the voxeliser and SparseTensor.canonical() take the coordinate rows of the sorted voxels from the sorted
+    keys instead of gathering them through the sort permutation."""
+    from instancerefer_amd.sparse import functional as F_
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    C = torch.cat([torch.randint(-32768, 32768, (100_003, 3), generator=g), torch.randint(0, 32768, (100_003, 1), generator=g)], 1)
+    C[0] = torch.tensor([-32768, -32768, -32768, 0])
+    C[1] = torch.tensor([32767, 32767, 32767, 32767])
+    C[2] = torch.tensor([0, -1, 1, 5])
+    C = C.int().to(dev)
+    assert torch.equal(F_.keys_to_coords(F_.coords_to_keys(C)), C)
+    assert F_.keys_to_coords(torch.empty(0, dtype=torch.int64, device=dev)).shape == (0, 4)
+    # canonical(): rows come out in Morton order with the coordinates that belong to their features
+    from instancerefer_amd.sparse import SparseTensor
+    Cs = torch.unique(torch.cat([torch.randint(-50, 50, (5000, 3), generator=g), torch.randint(0, 3, (5000, 1), generator=g)], 1), dim=0)
+    Cs = Cs[torch.randperm(Cs.shape[0], generator=g)].int().to(dev)
+    Fs = Cs.float() * 0.5
+    st = SparseTensor(Fs, Cs, 1, batch_size=3).canonical()
+    assert torch.equal(st.F, st.C.float() * 0.5)
+    assert torch.equal(torch.unique(st.C, dim=0), torch.unique(Cs, dim=0))
+
+
 def test_sparse_quantize_api(lib, clouds):
     from instancerefer_amd.sparse.utils import sparse_quantize
     from oracle.torchsparse.utils import sparse_quantize as oq
@@ -830,3 +854,21 @@ def test_tile_launch_order_is_a_cost_sorted_permutation(lib, clouds):
     cls = np.minimum(cost >> shift, 63)
     exp = np.argsort(-cls, kind="stable")
     assert np.array_equal(order, exp)
+    # thousands of tiles (every wave of the sorting workgroup owns a segment; ragged last tile / last segment): a synthetic
+    # table whose fill varies smoothly along the rows so that all cost classes occur
+    dev = tbl.device
+    g = torch.Generator().manual_seed(3)
+    for n in (64 * 1024 + 1, 200_001, 64 * 16 * 3, 1000):
+        ld = n + 7
+        fill = 0.05 + 0.9 * (0.5 + 0.5 * torch.sin(torch.arange(n) / 900.0))
+        tbl = torch.where(torch.rand(27, n, generator=g) < fill[None, :] * torch.rand(27, 1, generator=g),
+                          torch.randint(0, n, (27, n), generator=g), torch.tensor(-1))
+        full = torch.full((27, ld), -1, dtype=torch.int32)
+        full[:, :n] = tbl.int()
+        order = F_.tile_order(full.to(dev), ld, n, 27).cpu().numpy()
+        nt = (n + 63) // 64
+        v = np.pad((tbl >= 0).numpy(), ((0, 0), (0, nt * 64 - n))).reshape(27, nt, 64).sum(2)
+        cost = (3 * (v > 0) + 5 * ((v + 15) // 16)).sum(0)
+        cls = np.minimum(cost >> shift, 63)
+        assert nt < 100 or len(np.unique(cls)) > 8
+        assert np.array_equal(order, np.argsort(-cls, kind="stable")), n
