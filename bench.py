@@ -97,6 +97,17 @@ def build_model(args_ns, workload, device):
     return model.to(device).train()
 
 
+_SPIN_US = float(os.environ.get("IRX_BENCH_SPIN_US", "0"))
+_MARKS = None          # dev (IRX_BENCH_TIMELINE=1): list receiving (name, event on the main stream, host clock) per step
+
+
+def _mark(name):
+    if _MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        _MARKS.append((name, ev, time.perf_counter()))
+
+
 def fresh_batch(resident):
     """The next batch as a training loop would hand it over: a FRESH un-canonical scene SparseTensor (Morton sort, hash,
     kernel maps, pair lists are rebuilt every step) and no cached candidate selection."""
@@ -186,8 +197,14 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
     if state is not None and state.get("pipeline") and not at_bwd:
         # batch N+1: threaded -> the whole preparation runs beside this step; inline -> only its launch phase now
         prepare_next(model, resident, state, phase="launch")
+    _mark("step start")
     opt.zero_grad()
+    if _SPIN_US:                                         # dev: is the loop host- or GPU-paced? (host-only busy-wait)
+        t_end = time.perf_counter() + _SPIN_US * 1e-6
+        while time.perf_counter() < t_end:
+            pass
     dd = model(dd)
+    _mark("forward issued")
     if workload in ("full", "stress"):
         loss = get_loss(dd, step_fn.cfg)["loss"]
     else:
@@ -207,13 +224,76 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
         if w is None:
             w = state["worker"] = _Worker(torch.cuda.current_device())
         w.post(lambda: prepare_next(model, resident, state, phase="launch"))
+    _mark("loss issued")
     loss.backward()
+    _mark("backward returned")
     if at_bwd:
         state["worker"].wait()
     opt.backward_step()          # one cat -> one all-reduce (N > 1) -> one fused Adam launch
+    _mark("optimizer issued")
     if state is not None and state.get("pipeline") and not state.get("threaded", True):
         prepare_next(model, resident, state, phase="finish")   # level sizes arrived during the step: no wait
     return loss
+
+
+def timeline(model, resident, args, reducer, opt, state, F_, n=12):
+    """Dev (IRX_BENCH_TIMELINE=1): GPU-side clock of the REAL pipelined loop, no syncs added — main-stream events at the step's
+    phase boundaries plus the library's per-layer events of both encoders (IRX_ENC_PROF, recorded on the launch streams by
+    the asynchronous lanes) — printed to stderr relative to each step's start, averaged over the last n - 2 steps."""
+    global _MARKS
+    from instancerefer_amd.sparse import encoder_fn
+    encoder_fn.EVENT_POOL.extend(encoder_fn._new_event() for _ in range(n * 2 * 6 * 13))
+    torch.cuda.synchronize()
+    _MARKS, F_.PROFILE, encoder_fn.PROFILE_NO_COUNT = [], [], True
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step_fn(model, resident, args.workload, reducer, opt, state)
+    torch.cuda.synchronize()
+    log("timeline steps: %.2f ms/step" % ((time.perf_counter() - t0) * 1e3 / n))
+    marks, recs = _MARKS, F_.PROFILE
+    _MARKS, F_.PROFILE, encoder_fn.PROFILE_NO_COUNT = None, None, False
+    per = len(marks) // n
+    rper = len(recs) // n
+    rows = {}
+    for s in range(4, n):
+        m = marks[s * per:(s + 1) * per]
+        ev0, h0 = m[0][1], m[0][2]
+        nxt = marks[(s + 1) * per] if s + 1 < n else None
+        for name, ev, h in m:
+            rows.setdefault(("main", name), []).append((ev0.elapsed_time(ev), (h - h0) * 1e3))
+        if nxt is not None:
+            rows.setdefault(("main", "next step start"), []).append((ev0.elapsed_time(nxt[1]), (nxt[2] - h0) * 1e3))
+        r = recs[s * rper:(s + 1) * rper]
+        # encoders in issue order: a record stream of (kind, n_out, K, cin, cout, M, start, stop, esz); a new encoder pass
+        # begins at every "fwd" record whose input is a stem (cin <= 8 or > 128)
+        encs, cur = [], None
+        for rec in r:
+            if rec[0] == "fwd" and (rec[3] <= 8 or rec[3] > 128):
+                cur = []
+                encs.append(cur)
+            cur.append(rec)
+        for ei, e in enumerate(encs):
+            tag = "encoder %d (%d voxels)" % (ei, e[0][1])
+            f = [x for x in e if x[0] == "fwd"]
+            b = [x for x in e if x[0] != "fwd"]
+            rows.setdefault((tag, "forward first kernel starts"), []).append((ev0.elapsed_time(f[0][6]), None))
+            rows.setdefault((tag, "forward last conv ends"), []).append((ev0.elapsed_time(f[-1][7]), None))
+            bs = min(ev0.elapsed_time(x[6]) for x in b)
+            be = max(ev0.elapsed_time(x[7]) for x in b)
+            rows.setdefault((tag, "backward first conv starts"), []).append((bs, None))
+            rows.setdefault((tag, "backward last conv ends"), []).append((be, None))
+            big = [x for x in b if x[1] >= 50000 or (x[0] == "dgrad" and x[1] >= 50000)]
+            if big:
+                rows.setdefault((tag, "backward reaches the >= 50 k-row levels"), []).append((min(ev0.elapsed_time(x[6]) for x in big), None))
+    out = []
+    for (who, name), v in rows.items():
+        g = sum(a for a, _ in v) / len(v)
+        h = [b for _, b in v if b is not None]
+        out.append((g, who, name, sum(h) / len(h) if h else None))
+    out.sort()
+    log("timeline (ms after the step's start; GPU clock | host clock when issued):")
+    for g, who, name, h in out:
+        sys.stderr.write("  %8.3f  %-24s %-42s %s\n" % (g, who, name, "" if h is None else "host %.3f" % h))
 
 
 class _Worker:
@@ -572,6 +652,9 @@ def main():
         dt = float(t.item())
     final_loss = float(loss.item())
     log("timed region done: %.1f ms/step" % (1000.0 * dt / args.steps))
+
+    if rank == 0 and os.environ.get("IRX_BENCH_TIMELINE") == "1":
+        timeline(model, resident, args, reducer, opt, state, F_)
 
     # ---- the same loop with bf16 conv operands (BASELINE configs[2]-[4] dtype), reported beside the fp32 headline ----
     alt = None

@@ -214,11 +214,12 @@ int irx_pairs_build(const int32_t* nbr, int ld, int n_out, int K, int32_t* in_li
 int irx_pairs_build_multi(int n_tables, const int32_t* const* nbr, const int* ld, const int* n_out, const int* K,
                           int32_t* const* in_list, int32_t* const* out_list, const int* ldp, int32_t* const* counts,
                           void* workspace, size_t workspace_bytes, void* stream);
-/* Weight-gradient over pair lists in DENSE 64-pair MFMA stages (cin, cout in {32,64,128}); same result as
- * irx_spconv_wgrad up to fp32 summation order; deterministic. */
+/* Weight-gradient over pair lists in DENSE MFMA stages (cin, cout in {32,64,128}); same result as
+ * irx_spconv_wgrad up to fp32 summation order; deterministic. x: [n_in][cin], dy: [n_out][cout]; every entry of
+ * in_list must be < n_in (the fp32 kernel addresses both tensors with 32-bit byte offsets when they are below 2 GiB). */
 size_t irx_spconv_wgrad_pairs_workspace_bytes(int n_out, int K, int cin, int cout);
 int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int32_t* in_list, const int32_t* out_list,
-                           int ldp, const int32_t* counts, int n_out, int K, int cin, int cout, float* dw,
+                           int ldp, const int32_t* counts, int n_in, int n_out, int K, int cin, int cout, float* dw,
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- BatchNorm(+residual)(+ReLU) over voxel rows (spnn.BatchNorm / spnn.ReLU and the

@@ -192,7 +192,9 @@ int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr
 
 int irx_spconv_wgrad_pairs_impl(const float* x, const float* dy, const int32_t* in_list, const int32_t* out_list, int ldp,
                                 const int32_t* counts, int n_out, int K, int cin, int cout, float* dw, void* workspace,
-                                size_t workspace_bytes, void* stream, int bf_rows);
+                                size_t workspace_bytes, void* stream, int bf_rows, int n_in = 0);
+// (n_in: rows of x when the caller knows them — the fp32 second-generation kernel addresses x and dy with 32-bit byte
+//  offsets and is only taken when both tensors are known to stay below 2 GiB; 0 = unknown -> first-generation kernel)
 
 // ---- BatchNorm with per-tensor element types (irx_norm.hip; 0 = float32, 1 = bf16) — the executor's bf16 storage mode
 int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, float* mean, float* invstd,

@@ -205,7 +205,7 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
     if (pairs_path(L)) {
       IRX_REQUIRE(!st || i > 0, "irx_encoder_backward: bf16 storage expects a stem (Cin <= 8 or 129..136) as layer 0");
       rc = irx_spconv_wgrad_pairs_impl(L.x, dc_scratch, L.pair_in, L.pair_out, L.ld_pairs, L.pair_counts, L.n_out, L.K,
-                                       L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st);
+                                       L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st, L.n_in);
     } else {
       IRX_REQUIRE(!st || i == 0, "irx_encoder_backward: layer %d (%d -> %d channels) has no bf16-storage weight-gradient path",
                   i, L.cin, L.cout);

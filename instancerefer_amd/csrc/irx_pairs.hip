@@ -334,6 +334,192 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
       }
 }
 
+// ---- fp32 weight-gradient, second generation (round 3): ONE barrier per stage, nothing outside the MFMA chain -----------
+// k_wgrad_pairs above alternates "wait for the rows, write them to LDS, barrier" with the MFMA chain, and its ablation showed
+// the two parts simply ADD (MFMA alone 187 us, everything else alone 97 us, together 284 us at 128 x 128 on the 81 k level):
+// two resident workgroups whose phases drift freely overlap a chain with the other's non-MFMA phase only by chance (the
+// `phases` probe: 71 % of the MFMA peak at two workgroups per CU). Here the overlap is built into every wave instead:
+//   * stages of 32 pairs, the LDS tiles double-buffered (same 74 KB at 128 x 128 as one 64-pair stage: still two workgroups per CU);
+//   * during the chain over stage t (8 k-steps) a wave requests the rows of stage t + 2 (k-steps 0..3, into the register set
+//     that stage t's rows left) and writes the rows of stage t + 1 — requested one chain earlier — to the other LDS buffer
+//     (k-steps 4..7); the pair indices run three to four stages ahead through a 4-slot LDS ring;
+//   * the single barrier at the top of a stage publishes buffer t and retires the reads of buffer t - 1.
+// Same pair order, same 4-pair MFMA groups, same (split, offset) partials as k_wgrad_pairs: results are bit-identical
+// (missing pairs are zero rows; a partial last stage runs its full chain over zeros).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void k_wgrad_pairs2(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const int32_t* __restrict__ in_list,
+                                                         const int32_t* __restrict__ out_list, int ldp,
+                                                         const int32_t* __restrict__ counts, int K, int G, int smax,
+                                                         float* __restrict__ part, int ldx = CIN) {
+  constexpr int SP = 32;                                  // pairs per stage
+  constexpr int TC = CIN / 16, TN = COUT / 16;
+  constexpr int CW = (TC >= 4) ? TC / 4 : 1;             // c-tiles per wave
+  constexpr int NW = (TC >= 4) ? TN : TN / (4 / TC);     // n-tiles per wave
+  constexpr int LDX = CIN + 16, LDD = COUT + 16;         // consecutive pairs 16 banks apart
+  constexpr int LPX = CIN / 4, LPD = COUT / 4;           // lanes (float4) per row
+  constexpr int PX = 256 / LPX, PD = 256 / LPD;          // pairs per workgroup pass
+  constexpr int NX = SP / PX, ND = SP / PD;              // passes per stage (1, 2 or 4)
+  static_assert(NX >= 1 && NX <= 4 && ND >= 1 && ND <= 4, "stage passes");
+  __shared__ __attribute__((aligned(16))) float sX[2][SP * LDX];
+  __shared__ __attribute__((aligned(16))) float sD[2][SP * LDD];
+  __shared__ int sIdx[4][64];                             // ring of stages: [0, 32) input rows, [32, 64) output rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g4 = lane >> 4;
+  const int s = blockIdx.x, k = blockIdx.y;
+  const int ct0 = (TC >= 4) ? wave * CW : (wave % TC);
+  const int nt0 = (TC >= 4) ? 0 : (wave / TC) * NW;
+  const int cnt = counts[k];
+  const int nsplit = pairs_shares(counts, K, k, G, smax);
+  if (s >= nsplit) return;                               // block-uniform
+  // the share of this workgroup in 64-pair units (k_pairs_reduce and the v1 kernel count the same way), walked in 32-pair stages
+  const int nst = (cnt + 63) / 64;
+  const int st0 = (int)(((long long)nst * s) / nsplit), st1 = (int)(((long long)nst * (s + 1)) / nsplit);
+  // (always an even number of stages — the loop below runs them in unconditional pairs, one per register set / LDS buffer:
+  // with a conditional second half the compiler sinks the first half's row loads into it, out of the chain they are meant to
+  // hide behind; at most the last 32-pair stage of an offset's list is empty)
+  const int s0 = 2 * st0, s1 = 2 * st1;
+  const int n_it = s1 - s0;
+  const int xr = tid / LPX, xc = (tid % LPX) * 4;        // this thread's pair / column in an x pass
+  const int dr = tid / LPD, dc = (tid % LPD) * 4;
+
+  f32x4 acc[CW][NW];
+#pragma unroll
+  for (int a = 0; a < CW; ++a)
+#pragma unroll
+    for (int b = 0; b < NW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Every global read is a raw buffer load: an out-of-range offset returns zeros, so a missing pair needs neither a branch nor
+  // a select on the loaded value (with plain loads the compiler predicates them, and every branch inside the chain costs the
+  // exact vmcnt bookkeeping: it waits for ALL outstanding loads at the next LDS write). 32-bit offsets: the launcher checks
+  // that both tensors stay below 2 GiB and falls back to k_wgrad_pairs otherwise.
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)(in_list + (size_t)k * ldp), 0, cnt * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(out_list + (size_t)k * ldp), 0, cnt * 4, 0x00020000);
+  // lanes 0..31 of every wave: input row of pair j of a stage, lanes 32..63: its output row; -1 beyond the list / the share
+  // (all four waves fetch and later store the same 64 values: no wave-dependent branch in the chain)
+  // (the loaded words are combined one chain later: any use right behind the load would put a vmcnt wait — a global round
+  // trip — into the chain; three plain ints, because a struct captured by the stage lambda was promoted to LDS)
+#define WP2_LDIDX(stage_, vi_, vo_, inv_)                                              \
+  {                                                                                    \
+    const int p_ = (stage_) * SP + (lane & 31);                                        \
+    inv_ = ((stage_) < s1 && p_ < cnt) ? 0 : -1;                                       \
+    const unsigned off_ = inv_ ? OOB : (unsigned)p_ * 4u;                              \
+    vi_ = __builtin_amdgcn_raw_buffer_load_b32(rs_i, off_, 0, 0);                      \
+    vo_ = __builtin_amdgcn_raw_buffer_load_b32(rs_o, off_, 0, 0);                      \
+  }
+#define WP2_IDX(vi_, vo_, inv_) ((((lane & 32) ? (vo_) : (vi_))) | (inv_))
+  const unsigned xcb = (unsigned)xc * 4u, dcb = (unsigned)dc * 4u, ldxb = (unsigned)ldx * 4u;
+  auto x_off = [&](int slot, int i) __attribute__((always_inline)) -> unsigned {
+    const int idx = sIdx[slot][xr + i * PX];
+    return idx < 0 ? OOB : (unsigned)idx * ldxb + xcb;
+  };
+  auto d_off = [&](int slot, int i) __attribute__((always_inline)) -> unsigned {
+    const int idx = sIdx[slot][32 + dr + i * PD];
+    return idx < 0 ? OOB : (unsigned)idx * (unsigned)(COUT * 4) + dcb;
+  };
+  auto ldrow = [&](const __amdgpu_buffer_rsrc_t& r, unsigned off) __attribute__((always_inline)) -> float4 {
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return *reinterpret_cast<float4*>(&v);
+  };
+
+  float4 rx[2][NX], rd[2][ND];                            // register set q holds the rows of a stage of parity q
+  int nvi = -1, nvo = -1, ninv = -1;
+  if (n_it > 0) {
+    int a0, b0, c0, a1, b1, c1, a2, b2, c2;
+    WP2_LDIDX(s0, a0, b0, c0);
+    WP2_LDIDX(s0 + 1, a1, b1, c1);
+    WP2_LDIDX(s0 + 2, a2, b2, c2);
+    WP2_LDIDX(s0 + 3, nvi, nvo, ninv);
+    sIdx[0][lane] = WP2_IDX(a0, b0, c0);
+    sIdx[1][lane] = WP2_IDX(a1, b1, c1);
+    sIdx[2][lane] = WP2_IDX(a2, b2, c2);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NX; ++i) rx[0][i] = ldrow(rs_x, x_off(0, i));
+#pragma unroll
+    for (int i = 0; i < ND; ++i) rd[0][i] = ldrow(rs_d, d_off(0, i));
+#pragma unroll
+    for (int i = 0; i < NX; ++i) rx[1][i] = ldrow(rs_x, x_off(1, i));
+#pragma unroll
+    for (int i = 0; i < ND; ++i) rd[1][i] = ldrow(rs_d, d_off(1, i));
+#pragma unroll
+    for (int i = 0; i < NX; ++i) *reinterpret_cast<float4*>(&sX[0][(xr + i * PX) * LDX + xc]) = rx[0][i];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) *reinterpret_cast<float4*>(&sD[0][(dr + i * PD) * LDD + dc]) = rd[0][i];
+  }
+
+  // one stage: P = parity of the stage relative to s0 (LDS buffer read, register set refilled)
+  auto stage = [&](auto Pc, int rel) __attribute__((always_inline)) {
+    constexpr int P = decltype(Pc)::value, Q = P ^ 1;
+    sIdx[(rel + 3) & 3][lane] = WP2_IDX(nvi, nvo, ninv);   // requested one chain ago (the same value from every wave)
+    __syncthreads();                                       // buffer P and the ring slot are published; reads of buffer Q retired
+    const int slot2 = (rel + 2) & 3;
+    unsigned ox[NX], od[ND];                               // byte offsets of the rows of stage rel + 2
+#pragma unroll
+    for (int i = 0; i < NX; ++i) ox[i] = x_off(slot2, i);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) od[i] = d_off(slot2, i);
+    const float* bx = sX[P];
+    const float* bd = sD[P];
+    float a[CW], b[NW];
+#pragma unroll
+    for (int i = 0; i < CW; ++i) a[i] = bx[g4 * LDX + (ct0 + i) * 16 + m];     // A[m = c][kk = pair]
+#pragma unroll
+    for (int i = 0; i < NW; ++i) b[i] = bd[g4 * LDD + (nt0 + i) * 16 + m];     // B[kk = pair][n]
+#pragma unroll
+    for (int ks = 0; ks < SP / 4; ++ks) {
+      if (ks == 0) WP2_LDIDX(s0 + rel + 4, nvi, nvo, ninv);
+      if (ks < NX) rx[P][ks] = ldrow(rs_x, ox[ks]);        // rows of stage rel + 2
+      if (ks < ND) rd[P][ks] = ldrow(rs_d, od[ks]);
+      if (ks >= 4 && ks - 4 < NX)                          // rows of stage rel + 1 -> the other buffer
+        *reinterpret_cast<float4*>(&sX[Q][(xr + (ks - 4) * PX) * LDX + xc]) = rx[Q][ks - 4];
+      if (ks >= 4 && ks - 4 < ND)
+        *reinterpret_cast<float4*>(&sD[Q][(dr + (ks - 4) * PD) * LDD + dc]) = rd[Q][ks - 4];
+      float an[CW], bn[NW];
+      if (ks + 1 < SP / 4) {
+        const int pp = (ks + 1) * 4 + g4;
+#pragma unroll
+        for (int i = 0; i < CW; ++i) an[i] = bx[pp * LDX + (ct0 + i) * 16 + m];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) bn[i] = bd[pp * LDD + (nt0 + i) * 16 + m];
+      }
+#pragma unroll
+      for (int i = 0; i < CW; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NW; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < SP / 4) {
+#pragma unroll
+        for (int i = 0; i < CW; ++i) a[i] = an[i];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) b[i] = bn[i];
+      }
+    }
+  };
+  for (int rel = 0; rel < n_it; rel += 2) {
+    stage(std::integral_constant<int, 0>{}, rel);
+    stage(std::integral_constant<int, 1>{}, rel + 1);
+  }
+  float* out = part + ((size_t)s * K + k) * CIN * COUT;
+#pragma unroll
+  for (int i = 0; i < CW; ++i)
+#pragma unroll
+    for (int jn = 0; jn < NW; ++jn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = (ct0 + i) * 16 + g4 * 4 + r;
+        const int n = (nt0 + jn) * 16 + m;
+        out[(size_t)c * COUT + n] = acc[i][jn][r];
+      }
+}
+
+#undef WP2_LDIDX
+#undef WP2_IDX
+
 // dw[k] = sum of the shares of offset k in a fixed order (deterministic). One workgroup never straddles two offsets
 // (cin * cout is a multiple of 256 for the supported channel counts).
 __global__ __launch_bounds__(256) void k_pairs_reduce(const float* __restrict__ part, const int32_t* __restrict__ counts,
@@ -533,9 +719,16 @@ extern "C" size_t irx_spconv_wgrad_pairs_workspace_bytes(int n_out, int K, int c
   return (size_t)pairs_smax(n_out, K) * K * cin * cout * sizeof(float);
 }
 
+// dev A/B: IRX_WGRAD_V1=1 runs the fp32 weight-gradient on the first-generation kernel (bit-identical results)
+static bool wp_v1() {
+  const char* e = getenv("IRX_WGRAD_V1");          // read per call: the parity test flips it inside one process
+  return e && atoi(e) != 0;
+}
+
 template <int CIN>
 static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* il,
-                      const int32_t* ol, int ldp, const int32_t* counts, int K, int G, int smax, float* part, bool bf_rows) {
+                      const int32_t* ol, int ldp, const int32_t* counts, int K, int G, int smax, float* part, bool bf_rows,
+                      bool gen2) {
   irx_bracket_begin(st);
   if (irx_conv_bf16() && bf_rows) {
     if (cout == 128) k_wgrad_pairs<CIN, 128, true, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
@@ -545,10 +738,14 @@ static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const
     if (cout == 128) k_wgrad_pairs<CIN, 128, true, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
     else if (cout == 64) k_wgrad_pairs<CIN, 64, true, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
     else k_wgrad_pairs<CIN, 32, true, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-  } else {
+  } else if (!gen2 || wp_v1()) {
     if (cout == 128) k_wgrad_pairs<CIN, 128, false, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
     else if (cout == 64) k_wgrad_pairs<CIN, 64, false, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
     else k_wgrad_pairs<CIN, 32, false, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+  } else {
+    if (cout == 128) k_wgrad_pairs2<CIN, 128><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    else if (cout == 64) k_wgrad_pairs2<CIN, 64><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    else k_wgrad_pairs2<CIN, 32><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
   }
   irx_bracket_end(st);
 }
@@ -569,8 +766,10 @@ int irx_wgrad_pairs_wide_launch(const float* x, int ldx, const float* dy, const 
     k_wgrad_pairs<128, 32, true, false, true><<<grid, 256, 0, st>>>(x, dy, in_list, out_list, ldp, counts, K, G, smax, part, ldx);
   else if (irx_conv_bf16())
     k_wgrad_pairs<128, 32, true, false, false><<<grid, 256, 0, st>>>(x, dy, in_list, out_list, ldp, counts, K, G, smax, part, ldx);
-  else
+  else if (wp_v1() || (size_t)n_out * ldx * sizeof(float) >= ((size_t)1 << 31))       // (a stride-1 stem: rows of x = n_out)
     k_wgrad_pairs<128, 32, false, false, false><<<grid, 256, 0, st>>>(x, dy, in_list, out_list, ldp, counts, K, G, smax, part, ldx);
+  else
+    k_wgrad_pairs2<128, 32><<<grid, 256, 0, st>>>(x, dy, in_list, out_list, ldp, counts, K, G, smax, part, ldx);
   irx_bracket_end(st);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem, pairs)");
   const size_t elems = (size_t)K * 128 * cout;
@@ -583,8 +782,8 @@ extern "C" int irx_debug_occupancy_wp(int which) {
   int n = -1;
   hipError_t e = hipSuccess;
   switch (which) {
-    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wgrad_pairs<128, 128, false, false, false>, 256, 0); break;
-    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wgrad_pairs<64, 64, false, false, false>, 256, 0); break;
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wgrad_pairs2<128, 128>, 256, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wgrad_pairs2<64, 64>, 256, 0); break;
     case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wgrad_pairs<128, 128, true, true, true>, 256, 0); break;
     default: return -2;
   }
@@ -592,17 +791,18 @@ extern "C" int irx_debug_occupancy_wp(int which) {
 }
 
 extern "C" int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int32_t* in_list,
-                                      const int32_t* out_list, int ldp, const int32_t* counts, int n_out, int K,
+                                      const int32_t* out_list, int ldp, const int32_t* counts, int n_in, int n_out, int K,
                                       int cin, int cout, float* dw, void* workspace, size_t workspace_bytes,
                                       void* stream) {
+  IRX_REQUIRE(n_in >= 0, "irx_spconv_wgrad_pairs: n_in < 0");
   return irx_spconv_wgrad_pairs_impl(x, dy, in_list, out_list, ldp, counts, n_out, K, cin, cout, dw, workspace,
-                                     workspace_bytes, stream, 0);
+                                     workspace_bytes, stream, 0, n_in);
 }
 
 // bf_rows != 0 (executor, bf16 storage mode): x and dy are bf16 tensors
 int irx_spconv_wgrad_pairs_impl(const float* x, const float* dy, const int32_t* in_list, const int32_t* out_list, int ldp,
                                 const int32_t* counts, int n_out, int K, int cin, int cout, float* dw, void* workspace,
-                                size_t workspace_bytes, void* stream, int bf_rows) {
+                                size_t workspace_bytes, void* stream, int bf_rows, int n_in) {
   IRX_REQUIRE(!bf_rows || irx_conv_bf16(), "irx_spconv_wgrad_pairs: bf16 rows need the bf16 compute mode");
   IRX_REQUIRE(n_out >= 0 && K >= 1 && dw, "irx_spconv_wgrad_pairs: bad arguments");
   IRX_REQUIRE(irx_spconv2_supported(cin, cout), "irx_spconv_wgrad_pairs: channels (%d, %d) unsupported (32/64/128)", cin, cout);
@@ -621,9 +821,11 @@ int irx_spconv_wgrad_pairs_impl(const float* x, const float* dy, const int32_t* 
   }
   float* part = (float*)workspace;
   dim3 grid(smax, K);
-  if (cin == 128) launch_wp<128>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0);
-  else if (cin == 64) launch_wp<64>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0);
-  else launch_wp<32>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0);
+  const bool gen2 = n_in > 0 && (size_t)n_in * cin * sizeof(float) < ((size_t)1 << 31) &&
+                    (size_t)n_out * cout * sizeof(float) < ((size_t)1 << 31);
+  if (cin == 128) launch_wp<128>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2);
+  else if (cin == 64) launch_wp<64>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2);
+  else launch_wp<32>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad_pairs");
   k_pairs_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(part, counts, K, G, smax, (size_t)cin * cout, elems,
                                                                        dw);

@@ -362,6 +362,17 @@ class EncoderFn(torch.autograd.Function):
         return (dfeats, None, None) + tuple(grads)
 
 
+PROFILE_NO_COUNT = False     # timeline mode: only the events matter; no pair counting (it syncs)
+EVENT_POOL = []        # instantiated timing events (bench.py's timeline mode fills it ahead of the loop: creating 156 events per
+                       # step inside the loop costs the host ~2 ms and turns the loop host-paced)
+
+
+def _new_event():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()                                            # instantiates the HIP event; re-recorded by the library
+    return e
+
+
 def _profile_slots(layers, store):
     """bench.py's instrumented steps: six timing events per layer (start / stop around the dominant forward, data-gradient
     and weight-gradient kernel; recorded by the library on the launch stream: IRX_ENC_PROF) and the matching PROFILE
@@ -370,12 +381,11 @@ def _profile_slots(layers, store):
     nl = len(layers)
     evs, handles = [], (ctypes.c_void_p * (6 * nl))()
     for i, L in enumerate(layers):
-        row = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        row = [EVENT_POOL.pop() if EVENT_POOL else _new_event() for _ in range(6)]
         for j, e in enumerate(row):
-            e.record()                                    # instantiates the HIP event; re-recorded by the library
             handles[6 * i + j] = e.cuda_event
         evs.append(row)
-        m = F_._pairs(L.tbl, L.K, L.n_out)
+        m = 0 if PROFILE_NO_COUNT else F_._pairs(L.tbl, L.K, L.n_out)      # (a host sync per fresh table)
         esz = 2 if (store and i > 0) else 4
         F_.PROFILE.append(("fwd", L.n_out, L.K, L.cin, L.cout, m, row[0], row[1], esz))
         if i > 0:

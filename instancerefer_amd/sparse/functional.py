@@ -370,7 +370,7 @@ def spconv_wgrad_pairs(x, dy, pairs, n_out, K, cin, cout, m_for_profile=None):
         m = int(counts.sum().item())
         e0, e1 = _bracket()
     _lib.call("irx_spconv_wgrad_pairs", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_list), _lib.ptr(out_list), ldp,
-              _lib.ptr(counts), n_out, K, cin, cout, _lib.ptr(dw), _lib.ptr(ws), wsb, _stream())
+              _lib.ptr(counts), int(x.shape[0]), n_out, K, cin, cout, _lib.ptr(dw), _lib.ptr(ws), wsb, _stream())
     if PROFILE is not None:
         PROFILE.append(("wgrad", n_out, K, cin, cout, m, e0, e1))
     return dw

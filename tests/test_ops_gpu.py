@@ -1,6 +1,8 @@
 """GPU parity of every libirx operator against the CPU oracle (oracle/torchsparse, oracle/torch_geometric)
 on seeded inputs. Integer/index work must be bit-exact; fp32 arithmetic within the tolerance stated at
 each assert (north star: 1e-4 fp32). All calls go through the C-ABI (instancerefer_amd._lib -> libirx.so)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -381,6 +383,14 @@ def test_pair_lists_and_dense_stage_wgrad(lib, clouds):
             ref = F_.spconv_wgrad(x, dy, tbl, ld, n_out, K, cin, cout)
             got = F_.spconv_wgrad_pairs(x, dy, (il, ol, counts, ldp), n_out, K, cin, cout)
             assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (K, cin, cout)
+            # the second-generation fp32 kernel (32-pair stages, double-buffered LDS, buffer loads) walks the pairs in the
+            # same order through the same 4-pair MFMA groups as the first one: bit-identical
+            os.environ["IRX_WGRAD_V1"] = "1"
+            try:
+                v1 = F_.spconv_wgrad_pairs(x, dy, (il, ol, counts, ldp), n_out, K, cin, cout)
+            finally:
+                del os.environ["IRX_WGRAD_V1"]
+            assert torch.equal(got, v1), (K, cin, cout)
 
 
 def test_batched_pair_list_build_equals_per_table_builds(lib, clouds):
