@@ -653,6 +653,18 @@ def main():
     final_loss = float(loss.item())
     log("timed region done: %.1f ms/step" % (1000.0 * dt / args.steps))
 
+    if rank == 0 and os.environ.get("IRX_BENCH_CPROFILE") == "1":     # dev: host profile of the real pipelined loop
+        import cProfile, io, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(16):
+            step_fn(model, resident, args.workload, reducer, opt, state)
+        pr.disable()
+        torch.cuda.synchronize()
+        for key in ("cumulative", "tottime"):
+            buf = io.StringIO()
+            pstats.Stats(pr, stream=buf).sort_stats(key).print_stats(70)
+            sys.stderr.write("\n".join(l[:160] for l in buf.getvalue().splitlines()) + "\n(16 steps)\n")
     if rank == 0 and os.environ.get("IRX_BENCH_TIMELINE") == "1":
         timeline(model, resident, args, reducer, opt, state, F_)
 

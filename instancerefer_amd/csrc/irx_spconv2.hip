@@ -45,6 +45,9 @@ bool irx_conv_bf16() { return irx_mode_now() != 0; }
 bool irx_conv_bf16_storage() { return irx_mode_now() == 2; }
 
 #define S2_TM 64
+#ifndef IRX_S2_LDA_PAD
+#define IRX_S2_LDA_PAD 8      // dev A/B: -DIRX_S2_LDA_PAD=4 is the round-1/2 layout (two-way conflicts on the A-fragment reads)
+#endif
 
 // Dev-only per-phase cycle attribution of k_spconv2 (tools/conv_phase_prof.py builds a -DIRX_S2_PROF variant).
 #ifdef IRX_S2_PROF
@@ -264,7 +267,10 @@ void k_spconv2(const float* __restrict__ x, const float* __restrict__ wn, const 
   constexpr int NT = (COUT >= 128) ? 2 : 1;       // 16-column tiles per wave
   constexpr int NCS = COUT / (16 * NT);           // channel slices (waves along N)
   constexpr int NGP = 4 / NCS;                    // waves along the pair-group dimension
-  constexpr int LDA = CIN + 4;
+  // A-tile row stride: + 8 floats. A fragment is one ds_read_b128 per lane; the LDS serves a wave's b128 read in four groups
+  // of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) over 64 banks, and with a stride of Cin + 4 two lanes of
+  // every group shared a bank quad (rocprofv3: SQ_LDS_BANK_CONFLICT = 30 % of SQ_LDS_IDX_ACTIVE); Cin + 8 is conflict-free.
+  constexpr int LDA = CIN + IRX_S2_LDA_PAD;
   constexpr int LDO = COUT + 4;
   constexpr int LPR = CIN / 4;                    // lanes (float4) per gathered row
   constexpr int PPI = 64 / LPR;                   // pairs per wave-instruction
