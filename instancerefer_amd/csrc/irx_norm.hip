@@ -425,6 +425,14 @@ static int bn_bf_ok(const char* who, bool any_bf, bool v4) {
   return IRX_OK;
 }
 
+// Dev-only, TIMING ONLY (results wrong): IRX_BN_ABL bit 0 = no forward statistics pass, 1 = no forward apply pass,
+// 2 = no backward statistics pass, 3 = no backward apply pass — what a perfect fusion of that pass into a neighbouring
+// kernel could buy at most.
+static int bn_abl() {
+  static const int v = getenv("IRX_BN_ABL") ? atoi(getenv("IRX_BN_ABL")) : 0;
+  return v;
+}
+
 int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, float* mean, float* invstd,
                    float* running_mean, float* running_var, void* workspace, size_t workspace_bytes, void* stream,
                    int x_bf) {
@@ -438,7 +446,8 @@ int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, floa
   const BnTy ty = {x_bf, 0, 0, 0, 0};
   rc = bn_bf_ok("irx_bn_stats", x_bf != 0, v4);
   if (rc) return rc;
-  if (v4 && x_bf && c % 8 == 0)
+  if (bn_abl() & 1) {
+  } else if (v4 && x_bf && c % 8 == 0)
     k_bn_partial<0, 8, false><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
                                                    next_pow2(c / 8), bn_rows(n, c), part, ty, nullptr, nullptr);
   else if (v4 && x_bf)
@@ -530,6 +539,7 @@ int irx_bn_apply_t(const float* x, int n, int c, const float* mean, const float*
   const BnTy ty = {x_bf, y_bf, 0, 0, res_bf};
   int rc = bn_bf_ok("irx_bn_apply", (x_bf | res_bf | y_bf) != 0, v4);
   if (rc) return rc;
+  if (bn_abl() & 2) return IRX_OK;
   if (v4 && x_bf && y_bf && (!residual || res_bf) && c % 8 == 0) {
     const int qpad = next_pow2(c / 8);
     if (residual && relu) k_bn_apply<8, false, true, true><<<row_grid(n, qpad), 256, 0, S(stream)>>>(x, n, c, qpad, mean, invstd, gamma, beta, residual, relu, y, ty);
@@ -622,7 +632,7 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
     else k_bn_partial<1, V_, TY_, false, false><<<nblk, BN_PT, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_,      \
                                                                       bn_rows(n, c), part, ty, nullptr, nullptr);          \
   } while (0)
-  if (!(phases & 1)) {
+  if (!(phases & 1) || (bn_abl() & 4)) {
   } else if (v8)
     BN_PARTIAL1(8, false, next_pow2(c / 8));
   else if (v4 && any_bf)
@@ -640,7 +650,7 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
                                                             nullptr, nullptr);
     IRX_CHECK_LAUNCH("irx_bn_backward(finalize)");
   }
-  if (!(phases & 2)) return IRX_OK;
+  if (!(phases & 2) || (bn_abl() & 8)) return IRX_OK;
   const float* sg = (phases == 2) ? all_sum_g : dbeta;
   const float* sgx = (phases == 2) ? all_sum_gx : dgamma;
   const float inv_count = (phases == 2) ? (all_count >= 1.0 ? (float)(1.0 / all_count) : 0.f) : 1.f / (float)n;
