@@ -847,7 +847,9 @@ def end_to_end(args):
     its own, after this one's GPU work is done): reported beside `value`, which by contract times resident inputs."""
     import subprocess
     tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "e2e_train_bench.py")
-    cmd = [sys.executable, tool, "--json", "--steps", "40", "--warmup", "8", "--scans", "16",
+    # (a fresh process on a GPU that idled while it imported torch: 8 warm-up + 40 timed steps read 8-13 % low against three
+    #  back-to-back runs of the tool — 1488 vs 1624 / 1687 / 1721 scenes/s — so the leg now warms up 30 and times 100 steps)
+    cmd = [sys.executable, tool, "--json", "--steps", "100", "--warmup", "30", "--scans", "16",
            "--dtype", "bf16" if args.dtype == "bf16" else "f32", "--batch", str(args.batch or 16)]
     try:
         torch.cuda.synchronize()
