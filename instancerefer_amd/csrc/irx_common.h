@@ -190,6 +190,11 @@ int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr
                              int cin, int cout, int splits, int rps, float* part, hipStream_t st, int ldx = 0,
                              int dy_bf = 0);
 
+// data-gradient of a stride-2 convolution tiled by parent rows (irx_spconv2.hip, k_updgrad; fp32 only)
+bool irx_updgrad_supported(int cr, int co);
+int irx_updgrad_launch(const float* dy, const float* wn, const int32_t* child, int ldc, int n_parent, int cr, int co,
+                       float* dx, hipStream_t st);
+
 int irx_spconv_wgrad_pairs_impl(const float* x, const float* dy, const int32_t* in_list, const int32_t* out_list, int ldp,
                                 const int32_t* counts, int n_out, int K, int cin, int cout, float* dw, void* workspace,
                                 size_t workspace_bytes, void* stream, int bf_rows, int n_in = 0);

@@ -224,8 +224,19 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
       ty.y = st;                                  // gy of layer i - 1 (never the last layer)
       ty.order = (L.tbl_b == L.tbl) ? L.order : nullptr;   // stride-1: the forward table with flipped offsets, same tile costs
       if (L.prof) irx_profile_next_kernel(L.prof[2], L.prof[3]);
-      rc = irx_spconv_fwd_impl(dc_scratch, L.w, L.tbl_b, L.ld_b, L.n_in, L.K, L.cout, L.cin, L.flip_b, 1, dx, acc, wimg[i],
-                               ws_c, r.conv, stream, ty);
+      // a 2^3 / stride-2 layer in fp32: tiled by parent rows over the FORWARD (child) table (irx_spconv2.hip, k_updgrad)
+      // IRX_UPDGRAD=0 switches it off, IRX_UPDGRAD_MIN overrides the size threshold (dev A/B and the bit-identity test; read per
+      // call, twice per encoder pass)
+      const bool updgrad = !(getenv("IRX_UPDGRAD") && atoi(getenv("IRX_UPDGRAD")) == 0);
+      const int updgrad_min = getenv("IRX_UPDGRAD_MIN") ? atoi(getenv("IRX_UPDGRAD_MIN")) : 40000;
+      // (from 40 k parents = 625 workgroups on: measured 120 -> 79 us at 259 k parents, 92 -> 58 at 489 k fine rows, 36 -> 29 at
+      //  51 k, but 31 -> 38 at 29 k and 24 -> 39 at 9 k parents, where 64-parent tiles leave most CUs without a workgroup)
+      if (updgrad && L.tbl_b != L.tbl && L.K == 8 && !st && !irx_conv_bf16() && !acc && wimg[i] && L.n_out >= updgrad_min &&
+          irx_updgrad_supported(L.cout, L.cin))
+        rc = irx_updgrad_launch(dc_scratch, wimg[i], L.tbl, L.ld, L.n_out, L.cout, L.cin, dx, (hipStream_t)stream);
+      else
+        rc = irx_spconv_fwd_impl(dc_scratch, L.w, L.tbl_b, L.ld_b, L.n_in, L.K, L.cout, L.cin, L.flip_b, 1, dx, acc, wimg[i],
+                                 ws_c, r.conv, stream, ty);
       if (rc) return rc;
     }
   }

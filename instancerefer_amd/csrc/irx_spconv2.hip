@@ -715,6 +715,180 @@ int irx_spconv2_launch(const float* x, const float* wn, const int32_t* nbr, int 
   return IRX_OK;
 }
 
+// ---- data-gradient of a stride-2 (2^3) convolution, tiled by PARENT rows (round 3) ------------------------------------
+// dx[q] = dy[parent(q)] . W[koff(q)]^T: every fine row q has exactly one (parent, offset) pair. Through k_spconv2 (tiles of 64
+// fine rows over the transposed child table) a tile's 8 offsets hold ~8 pairs each: eight half-empty 16-row MFMA groups and
+// eight weight slices per 64 output rows, and an LDS output tile that is only ever written once per row.
+// Here a workgroup owns 64 consecutive PARENT rows: their dy rows are one contiguous block (loaded once, coalesced, into the
+// LDS A tile — no gather), offset k pairs the 15-32 parents that have a child k with that child's row (one ballot compaction
+// of child[k][p0 .. p0+63]), the MFMA groups read their A fragments straight from the tile through the compacted parent
+// list, and the results go from the accumulators to dx (each row written exactly once: no LDS output tile, no
+// read-modify-write, one barrier per workgroup). Per output row: 2.5 x fewer weight-slice loads and ~30 % fewer MFMA rows.
+// Same weight image, same reduction order as k_spconv2: bit-identical results. fp32 only (the bf16 modes keep the old path).
+template <int CR, int CO, int NJ, int NT, int LDA, int WN, bool PF>
+__device__ __forceinline__ void ud_group(const float* __restrict__ sA, const unsigned char* __restrict__ sel,
+                                         const int* __restrict__ dst, int g, int cnt, int m, int g4, int n_base,
+                                         const float4 (&wc)[WN], float4 (&wx)[WN], const float4* __restrict__ wnk,
+                                         float* __restrict__ dx) {
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int pi = 16 * g + m;
+  const int row = pi < cnt ? (int)sel[pi] : 0;                     // padded pairs re-read row 0; their results are dropped
+  const float4* pa = reinterpret_cast<const float4*>(&sA[row * LDA + 4 * g4]);
+  int orow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) orow[r] = (16 * g + 4 * g4 + r < cnt) ? dst[16 * g + 4 * g4 + r] : -1;
+  float4 a_nxt = pa[0];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const float4 a4 = a_nxt;
+    if (j + 1 < NJ) a_nxt = pa[4 * (j + 1)];
+    if (PF) {                                                        // this step's share of the next offset's weight slice
+#pragma unroll
+      for (int i = j * NT; i < (j + 1) * NT; ++i) wx[i] = wnk[(size_t)i * 64];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wc[j * NT + t].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wc[j * NT + t].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wc[j * NT + t].z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wc[j * NT + t].w, acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // D layout: col = lane & 15, row = 4 * (lane >> 4) + r -> pair 16 g + 4 g4 + r -> fine row orow[r]
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (orow[r] >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dx[(size_t)orow[r] * CO + n_base + 16 * t + m] = acc[t][r];
+    }
+}
+
+template <int CR, int CO>
+__global__ __launch_bounds__(256, 2) void k_updgrad(const float* __restrict__ dy, const float* __restrict__ wn,
+                                                    const int32_t* __restrict__ child, int ldc, int n_parent,
+                                                    float* __restrict__ dx) {
+  constexpr int NT = (CO >= 128) ? 2 : 1;
+  constexpr int NCS = CO / (16 * NT);
+  constexpr int NGP = 4 / NCS;
+  constexpr int NJ = CR / 16;
+  constexpr int WN = NJ * NT;
+  constexpr int LDA = CR + 8;
+  constexpr int LPR = CR / 4;                     // lanes (float4) per dy row
+  constexpr int RPP = 256 / LPR;                  // rows per load pass
+  static_assert(NCS * NGP == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float sA[64 * LDA];
+  __shared__ int sDst[8 * 64];
+  __shared__ unsigned char sSel[8 * 64];
+  __shared__ int sCnt[8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g4 = lane >> 4;
+  const int cs = wave % NCS, gp = wave / NCS;
+  const int n_base = cs * 16 * NT;
+  const int p0 = blockIdx.x * 64;
+  // pairs of offset k: the parents of this tile that have a child k (wave w compacts offsets w and w + 4)
+  {
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = wave + 4 * i;
+      const int e = (p0 + lane < n_parent) ? child[(size_t)k * ldc + p0 + lane] : -1;
+      const unsigned long long valid = __ballot(e >= 0);
+      if (e >= 0) {
+        const int d = __popcll(valid & lt);
+        sSel[k * 64 + d] = (unsigned char)lane;
+        sDst[k * 64 + d] = e;
+      }
+      if (lane == 0) sCnt[k] = __popcll(valid);
+    }
+  }
+  // the tile's dy rows: one contiguous block
+#pragma unroll
+  for (int it = 0; it < 64 / RPP; ++it) {
+    const int row = tid / LPR + it * RPP, c4 = (tid % LPR) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p0 + row < n_parent) v = *reinterpret_cast<const float4*>(dy + (size_t)(p0 + row) * CR + c4);
+    *reinterpret_cast<float4*>(&sA[row * LDA + c4]) = v;
+  }
+  __syncthreads();
+  unsigned act;
+  {
+    const int c = (lane < 8) ? sCnt[lane] : 0;
+    act = (unsigned)__ballot(c > 0) & 0xFFu;
+  }
+  if (!act) return;
+  const float4* wn4 = reinterpret_cast<const float4*>(wn);
+  float4 W[2][WN];
+  int kk[2] = {-1, -1};
+  auto slice = [&](int k) __attribute__((always_inline)) { return wn4 + (((size_t)k * NCS + cs) * WN) * 64 + lane; };
+  kk[0] = __builtin_ctz(act);
+  act &= act - 1;
+  {
+    const float4* w0 = slice(kk[0]);
+#pragma unroll
+    for (int i = 0; i < WN; ++i) W[0][i] = w0[(size_t)i * 64];
+  }
+  auto item = [&](auto C_, auto T_) __attribute__((always_inline)) {
+    constexpr int C = decltype(C_)::value, T = decltype(T_)::value;
+    const int k = kk[C];
+    const int cnt = __builtin_amdgcn_readfirstlane(sCnt[k]);
+    int kn = -1;
+    if (act) {
+      kn = __builtin_ctz(act);
+      act &= act - 1;
+    }
+    kk[T] = kn;
+    const float4* wnk = slice(kn < 0 ? k : kn);
+    const unsigned char* sel = sSel + k * 64;
+    const int* dst = sDst + k * 64;
+    int g = gp;
+    if (g * 16 < cnt) {
+      if (kn >= 0) ud_group<CR, CO, NJ, NT, LDA, WN, true>(sA, sel, dst, g, cnt, m, g4, n_base, W[C], W[T], wnk, dx);
+      else ud_group<CR, CO, NJ, NT, LDA, WN, false>(sA, sel, dst, g, cnt, m, g4, n_base, W[C], W[T], wnk, dx);
+      for (g += NGP; g * 16 < cnt; g += NGP)
+        ud_group<CR, CO, NJ, NT, LDA, WN, false>(sA, sel, dst, g, cnt, m, g4, n_base, W[C], W[T], wnk, dx);
+    } else if (kn >= 0) {                          // a wave without a group in this item still fetches its next slice
+#pragma unroll
+      for (int i = 0; i < WN; ++i) W[T][i] = wnk[(size_t)i * 64];
+    }
+  };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  while (true) {
+    item(J0{}, J1{});
+    if (kk[1] < 0) break;
+    item(J1{}, J0{});
+    if (kk[0] < 0) break;
+  }
+}
+
+bool irx_updgrad_supported(int cr, int co) { return (cr == 64 || cr == 128) && (co == 32 || co == 64 || co == 128); }
+
+// dx [n_child][co] = data-gradient of a 2^3 / stride-2 convolution from dy [n_parent][cr]; child: the forward table
+// [8][ldc] (child row of parent p at offset k, or -1); wn: the data-gradient weight image (k_permute_w, transposed).
+int irx_updgrad_launch(const float* dy, const float* wn, const int32_t* child, int ldc, int n_parent, int cr, int co,
+                       float* dx, hipStream_t st) {
+  IRX_REQUIRE(irx_updgrad_supported(cr, co), "irx_updgrad: channels (%d, %d) unsupported", cr, co);
+  if (n_parent <= 0) return IRX_OK;
+  const dim3 grid(irx_cdiv(n_parent, 64));
+  irx_bracket_begin(st);
+#define UD(CR_, CO_) k_updgrad<CR_, CO_><<<grid, 256, 0, st>>>(dy, wn, child, ldc, n_parent, dx)
+  if (cr == 128 && co == 128) UD(128, 128);
+  else if (cr == 128 && co == 64) UD(128, 64);
+  else if (cr == 128 && co == 32) UD(128, 32);
+  else if (cr == 64 && co == 128) UD(64, 128);
+  else if (cr == 64 && co == 64) UD(64, 64);
+  else UD(64, 32);
+#undef UD
+  irx_bracket_end(st);
+  IRX_CHECK_LAUNCH("irx_updgrad");
+  return IRX_OK;
+}
+
 // All layers of an encoder in ONE launch (the per-layer permutes were 54 launches of ~5 us per training step).
 __global__ void k_permute_w_multi(IrxPermuteJobs J, int trans_w, int bf16) {
   const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

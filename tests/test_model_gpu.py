@@ -98,7 +98,10 @@ def test_encoder_executor_equals_per_layer_path(lib):
     torch.manual_seed(1)
     enc = SparseConvEncoder(7).cuda().train()
     res = {}
-    for mode in ("fused", "layers"):
+    # "fused_up": the executor with the parent-tiled stride-2 data-gradient (k_updgrad) forced on at this small size — in
+    # production it takes over from 40 k parent rows; same weight image, same reduction order, one pair per output row
+    for mode in ("fused", "layers", "fused_up"):
+        os.environ["IRX_UPDGRAD_MIN"] = "0" if mode == "fused_up" else "1000000000"
         enc.zero_grad()
         for m in enc.modules():
             if isinstance(m, torch.nn.BatchNorm1d):
@@ -115,12 +118,14 @@ def test_encoder_executor_equals_per_layer_path(lib):
         out.F.backward(g)
         res[mode] = (out.F.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in enc.named_parameters()},
                      {n: b.clone() for n, b in enc.named_buffers()})
-    assert torch.equal(res["fused"][0], res["layers"][0])
-    assert torch.equal(res["fused"][1], res["layers"][1])
-    for n in res["fused"][2]:
-        assert torch.equal(res["fused"][2][n], res["layers"][2][n]), n
-    for n in res["fused"][3]:
-        assert torch.equal(res["fused"][3][n], res["layers"][3][n]), n
+    del os.environ["IRX_UPDGRAD_MIN"]
+    for other in ("layers", "fused_up"):
+        assert torch.equal(res["fused"][0], res[other][0])
+        assert torch.equal(res["fused"][1], res[other][1]), other
+        for n in res["fused"][2]:
+            assert torch.equal(res["fused"][2][n], res[other][2][n]), (other, n)
+        for n in res["fused"][3]:
+            assert torch.equal(res["fused"][3][n], res[other][3][n]), (other, n)
 
 
 def _oracle_and_product(cfg, seed, c0=7):
