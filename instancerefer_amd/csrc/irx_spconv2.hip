@@ -647,13 +647,20 @@ bool irx_spconv2_supported(int cin, int cout) {
   return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128);
 }
 
+// dev knob: IRX_S2_EXTRA_LDS = bytes of dynamic LDS added to every k_spconv2 launch — fewer resident workgroups per CU, to
+// measure how much a resident workgroup is worth
+static size_t s2_extra_lds() {
+  static const size_t v = getenv("IRX_S2_EXTRA_LDS") ? (size_t)atol(getenv("IRX_S2_EXTRA_LDS")) : 0;
+  return v;
+}
+
 template <int CIN, bool BF, bool ST>
 static void launch_fwd2(int cout, dim3 grid, hipStream_t st, const float* x, const float* wn, const int32_t* nbr,
                         int ld, int n_out, int K, int flip_k, float* y, int kps, int acc, int ldx, int y_bf,
                         const int32_t* ord) {
-  if (cout == 128) k_spconv2<CIN, 128, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ord);
-  else if (cout == 64) k_spconv2<CIN, 64, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ord);
-  else k_spconv2<CIN, 32, BF, ST><<<grid, 256, 0, st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ord);
+  if (cout == 128) k_spconv2<CIN, 128, BF, ST><<<grid, 256, s2_extra_lds(), st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ord);
+  else if (cout == 64) k_spconv2<CIN, 64, BF, ST><<<grid, 256, s2_extra_lds(), st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ord);
+  else k_spconv2<CIN, 32, BF, ST><<<grid, 256, s2_extra_lds(), st>>>(x, wn, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, ord);
 }
 
 // Output rows per workgroup: 64.  128-row tiles stream half the weight bytes per useful FLOP but MEASURED SLOWER twice:
