@@ -249,7 +249,10 @@ class SparseTensor:
                 t.record_stream(stream)
 
     def canonical(self):
-        """Rows re-ordered to ascending Morton key (device tensors). No-op when already canonical."""
+        """Rows re-ordered to ascending Morton key (device tensors). No-op when already canonical.
+        Precondition (not checked here — a check would be a host sync on the hot path): voxel coordinates in [-32768, 32768)
+        and batch indices in [0, 32768), the range a key holds; the voxeliser entry points (sparse/utils.py), which see raw
+        point coordinates, do check it and raise."""
         if self._level is not None:
             return self
         F, C = self._as_torch()
