@@ -196,6 +196,17 @@ int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr, int ld, i
                    int K, int cin, int cout, int flip_k, int trans_w, float* y, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* irx_spconv_fwd with the element types of x and y stated (0 = float32, 1 = bf16 stored as uint16; a bf16 tensor needs
+ * irx_set_compute_dtype(1 | 2)) — the convolution of the encoder executor's bf16 STORAGE mode as a single operator
+ * (BASELINE configs[2]-[4]; reference dtype fp32, models/basic_blocks.py:10-95). x: [n_in][cin], y: [n_out][cout];
+ * accumulate != 0: y += result. A bf16 x with channel counts in {32,64,128} (cin*cout >= 2048) and n_in*cin*2 < 2 GiB
+ * takes the third-generation kernel (irx_spconv3.hip: 128-row output tiles with register accumulators, rows gathered
+ * straight into v_mfma_f32_32x32x16_bf16 operands, W[k] double-buffered in LDS); IRX_SPCONV3=0 keeps it on the second
+ * generation. Same workspace query as irx_spconv_fwd. */
+int irx_spconv_fwd_t(const void* x, const float* w, const int32_t* nbr, int ld, int n_in, int n_out, int K, int cin,
+                     int cout, int flip_k, int trans_w, void* y, int accumulate, int x_bf, int y_bf, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* dw[k][ci][co] = sum_q x[nbr[k][q]][ci] * dy[q][co].  Deterministic two-stage reduction
  * through `workspace` (irx_spconv_wgrad_workspace_bytes). */
 size_t irx_spconv_wgrad_workspace_bytes(int n_out, int K, int cin, int cout);
@@ -271,6 +282,14 @@ int irx_bn_backward_apply(const float* x, const float* y, const float* dy, int n
  * split-reduce helpers that share the call) is bracketed with the two caller-owned HIP events on its launch stream.
  * One-shot: cleared after that kernel. Pass NULL, NULL to cancel. */
 int irx_profile_next_kernel(void* ev_start, void* ev_stop);
+
+/* Dev / test knobs. Each knob takes its default from an environment variable read ONCE (first use) and can then be changed
+ * only through this setter (atomic; safe against the library's lane threads): "spconv3" (IRX_SPCONV3, 1: bf16-input convs
+ * on the third-generation kernel), "updgrad" (IRX_UPDGRAD, 1) / "updgrad_min" (IRX_UPDGRAD_MIN, 40000: k_updgrad and its
+ * size threshold), "wgrad_v1" (IRX_WGRAD_V1, 0: fp32 pair-list weight-gradient on the first-generation kernel).
+ * irx_debug_get_knob returns the value in force (-1: unknown name). Not part of the reference-facing surface. */
+int irx_debug_set_knob(const char* name, long value);
+long irx_debug_get_knob(const char* name);
 
 /* ---- whole-encoder executor ------------------------------------------------------------
  * SparseConvEncoder.forward / BEVEncoder.forward (models/basic_blocks.py:59-95,136-171) and their backward as ONE

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "irx_get_compute_dtype": (_I, []),
     "irx_spconv_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "irx_spconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    "irx_spconv_fwd_t": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _Z, _P]),
     "irx_spconv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "irx_spconv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "irx_pairs_workspace_bytes": (_Z, [_I, _I]),
@@ -60,6 +61,8 @@ _SIGNATURES = {
     "irx_bn_backward_sums": (_I, [_P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _Z, _P]),
     "irx_bn_backward_apply": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _D, _P, _P, _P, _P]),
     "irx_profile_next_kernel": (_I, [_P, _P]),
+    "irx_debug_set_knob": (_I, [_c.c_char_p, _c.c_long]),
+    "irx_debug_get_knob": (_c.c_long, [_c.c_char_p]),
     "irx_encoder_workspace_bytes": (_Z, [_P, _P, _I, _I]),
     "irx_encoder_forward": (_I, [_P, _P, _I, _P, _Z, _P]),
     "irx_encoder_backward": (_I, [_P, _P, _I, _P, _P, _P, _Z, _P]),
@@ -149,6 +152,15 @@ def call(name: str, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError("%s failed (status %d): %s" % (name, rc, last_error()))
+
+
+def set_knob(name: str, value: int):
+    """Dev / test knob of the library (include/irx.h irx_debug_set_knob)."""
+    call("irx_debug_set_knob", name.encode(), int(value))
+
+
+def get_knob(name: str) -> int:
+    return int(load().irx_debug_get_knob(name.encode()))
 
 
 def hash_capacity(n: int) -> int:

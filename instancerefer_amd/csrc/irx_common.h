@@ -132,7 +132,15 @@ static inline size_t irx_esz(int bf) { return bf ? 2 : 4; }
 struct IrxStore {
   int x = 0, y = 0;
   const int32_t* order = nullptr;   // launch order of the 64-row output tiles (irx_tile_order) or NULL = blockIdx order
+  long long x_rows = 0;             // rows of x when the caller knows them (the third-generation bf16 kernel addresses rows with
+                                    // 32-bit byte offsets and is only taken for a known size below 2 GiB); 0 = unknown
 };
+
+// ---- dev / test knobs (irx_debug_set_knob, include/irx.h): each is read from its environment variable ONCE, on first use, and
+// can afterwards only be changed through the setter (an atomic store) — a per-call getenv() from library lane threads raced
+// with tests that mutate os.environ from the Python thread.
+enum IrxKnob { IRX_KNOB_SPCONV3 = 0, IRX_KNOB_UPDGRAD, IRX_KNOB_UPDGRAD_MIN, IRX_KNOB_WGRAD_V1, IRX_KNOB_COUNT };
+long irx_knob(int id);
 
 // ---- measurement aid (irx_profile_next_kernel, include/irx.h): brackets the next DOMINANT sparse-conv kernel of this
 // host thread (k_spconv2 / k_wgrad_pairs / k_spconv2_wgrad / k_stem_*) with two caller-owned events, excluding the small helper
@@ -189,6 +197,16 @@ bool irx_spconv_fast_path(const void* x, const void* w, const void* y, int cin, 
 int irx_spconv2_wgrad_launch(const float* x, const float* dy, const int32_t* nbr, int ld, int n_out, int K,
                              int cin, int cout, int splits, int rps, float* part, hipStream_t st, int ldx = 0,
                              int dy_bf = 0);
+
+// ---- third-generation forward / data-gradient for bf16 inputs (irx_spconv3.hip) ------------------------------------------
+bool irx_spconv3_supported(int cin, int cout);
+bool irx_spconv3_enabled();
+bool irx_spconv3_use(int cin, int cout, int x_bf, long long x_rows, int ldx);
+int irx_spconv3_splits(int n_out, int K);
+int irx_permute_w3_launch(const float* w, int K, int cin, int cout, int trans_w, float* dst, hipStream_t st);
+int irx_permute_w3_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStream_t st);
+int irx_spconv3_launch(const float* x, const float* wimg, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
+                       int flip_k, float* y, int splits, int accumulate, hipStream_t st, int ldx, int y_bf);
 
 // data-gradient of a stride-2 convolution tiled by parent rows (irx_spconv2.hip, k_updgrad; fp32 only)
 bool irx_updgrad_supported(int cr, int co);

@@ -96,26 +96,33 @@ extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int
   // fragment-major weight images of every fast-path layer: one launch
   const float* wimg[64] = {nullptr};
   IRX_REQUIRE(n_layers <= 16, "irx_encoder_forward: more than 16 layers");
+  const int st = (int)desc[IRX_ENC_STORE];
   {
-    IrxPermuteJobs J;
-    J.n = 0;
+    IrxPermuteJobs J, J3;                         // second- / third-generation images (the latter: bf16 inputs, irx_spconv3.hip)
+    J.n = J3.n = 0;
     char* p = ws_b + r.bn;
     size_t run = 0;
     for (int i = 0; i < n_layers; ++i) {
       const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
       if (L.n_out > 0 && !irx_stem_supported(L.K, L.cin, L.cout) && irx_spconv_fast_path(L.x, L.w, L.c, L.cin, L.cout, 0)) {
-        const int j = J.n++;
-        J.w[j] = L.w; J.dst[j] = (float*)p; J.K[j] = L.K; J.cin[j] = L.cin; J.cout[j] = L.cout;
-        run += (size_t)L.K * L.cin * L.cout / 4;
-        J.end4[j] = run;
+        if (irx_spconv3_use(L.cin, L.cout, (st && i > 0) ? 1 : 0, L.n_in, 0)) {
+          const int j = J3.n++;
+          J3.w[j] = L.w; J3.dst[j] = (float*)p; J3.K[j] = L.K; J3.cin[j] = L.cin; J3.cout[j] = L.cout;
+        } else {
+          const int j = J.n++;
+          J.w[j] = L.w; J.dst[j] = (float*)p; J.K[j] = L.K; J.cin[j] = L.cin; J.cout[j] = L.cout;
+          run += (size_t)L.K * L.cin * L.cout / 4;
+          J.end4[j] = run;
+        }
         wimg[i] = (const float*)p;
       }
       p += align256((size_t)L.K * L.cin * L.cout * sizeof(float));
     }
     int rc = irx_permute_w_multi_launch(J, 0, (hipStream_t)stream);
     if (rc) return rc;
+    rc = irx_permute_w3_multi_launch(J3, 0, (hipStream_t)stream);
+    if (rc) return rc;
   }
-  const int st = (int)desc[IRX_ENC_STORE];
   IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_forward: bf16 storage needs a bf16 compute mode in IRX_ENC_MODE");
   for (int i = 0; i < n_layers; ++i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
@@ -125,6 +132,7 @@ extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int
     ty.x = (st && i > 0) ? 1 : 0;                 // the encoder's input features are fp32
     ty.y = st;                                    // conv output c
     ty.order = L.order;
+    ty.x_rows = L.n_in;
     const int y_bf = (st && i < n_layers - 1) ? 1 : 0;   // the encoder's output stays fp32
     if (L.prof) irx_profile_next_kernel(L.prof[0], L.prof[1]);
     int rc = irx_spconv_fwd_impl(L.x, L.w, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, 0, 0, L.c, 0, wimg[i], ws_c, r.conv,
@@ -159,23 +167,31 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
   const float* wimg[64] = {nullptr};
   IRX_REQUIRE(n_layers <= 16, "irx_encoder_backward: more than 16 layers");
   {
-    IrxPermuteJobs J;
-    J.n = 0;
+    IrxPermuteJobs J, J3;
+    J.n = J3.n = 0;
+    const int st_ = (int)desc[IRX_ENC_STORE];
     char* p = ws_b + r.bn;
     size_t run = 0;
     for (int i = 0; i < n_layers; ++i) {
       const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
       const float* dxp = (i > 0) ? (const float*)desc[(size_t)(i - 1) * IRX_ENC_NFIELDS + IRX_ENC_GY] : dx0;
       if (dxp && L.n_in > 0 && irx_spconv_fast_path(dc_scratch, L.w, dxp, L.cout, L.cin, 1)) {
-        const int j = J.n++;
-        J.w[j] = L.w; J.dst[j] = (float*)p; J.K[j] = L.K; J.cin[j] = L.cout; J.cout[j] = L.cin;
-        run += (size_t)L.K * L.cin * L.cout / 4;
-        J.end4[j] = run;
+        if (irx_spconv3_use(L.cout, L.cin, st_, L.n_out, 0)) {      // x = d c [n_out][cout] in bf16
+          const int j = J3.n++;
+          J3.w[j] = L.w; J3.dst[j] = (float*)p; J3.K[j] = L.K; J3.cin[j] = L.cout; J3.cout[j] = L.cin;
+        } else {
+          const int j = J.n++;
+          J.w[j] = L.w; J.dst[j] = (float*)p; J.K[j] = L.K; J.cin[j] = L.cout; J.cout[j] = L.cin;
+          run += (size_t)L.K * L.cin * L.cout / 4;
+          J.end4[j] = run;
+        }
         wimg[i] = (const float*)p;
       }
       p += align256((size_t)L.K * L.cin * L.cout * sizeof(float));
     }
     int rc = irx_permute_w_multi_launch(J, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = irx_permute_w3_multi_launch(J3, 1, (hipStream_t)stream);
     if (rc) return rc;
   }
   // a layer whose OUTPUT feeds a later layer's shortcut receives that share (dresidual) first; the main-path
@@ -223,12 +239,13 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
       ty.x = st;                                  // dc
       ty.y = st;                                  // gy of layer i - 1 (never the last layer)
       ty.order = (L.tbl_b == L.tbl) ? L.order : nullptr;   // stride-1: the forward table with flipped offsets, same tile costs
+      ty.x_rows = L.n_out;
       if (L.prof) irx_profile_next_kernel(L.prof[2], L.prof[3]);
       // a 2^3 / stride-2 layer in fp32: tiled by parent rows over the FORWARD (child) table (irx_spconv2.hip, k_updgrad)
-      // IRX_UPDGRAD=0 switches it off, IRX_UPDGRAD_MIN overrides the size threshold (dev A/B and the bit-identity test; read per
-      // call, twice per encoder pass)
-      const bool updgrad = !(getenv("IRX_UPDGRAD") && atoi(getenv("IRX_UPDGRAD")) == 0);
-      const int updgrad_min = getenv("IRX_UPDGRAD_MIN") ? atoi(getenv("IRX_UPDGRAD_MIN")) : 40000;
+      // IRX_UPDGRAD=0 switches it off, IRX_UPDGRAD_MIN overrides the size threshold (dev A/B; the bit-identity test uses
+      // irx_debug_set_knob)
+      const bool updgrad = irx_knob(IRX_KNOB_UPDGRAD) != 0;
+      const long updgrad_min = irx_knob(IRX_KNOB_UPDGRAD_MIN);
       // (from 40 k parents = 625 workgroups on: measured 120 -> 79 us at 259 k parents, 92 -> 58 at 489 k fine rows, 36 -> 29 at
       //  51 k, but 31 -> 38 at 29 k and 24 -> 39 at 9 k parents, where 64-parent tiles leave most CUs without a workgroup)
       if (updgrad && L.tbl_b != L.tbl && L.K == 8 && !st && !irx_conv_bf16() && !acc && wimg[i] && L.n_out >= updgrad_min &&

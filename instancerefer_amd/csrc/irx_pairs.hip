@@ -720,10 +720,7 @@ extern "C" size_t irx_spconv_wgrad_pairs_workspace_bytes(int n_out, int K, int c
 }
 
 // dev A/B: IRX_WGRAD_V1=1 runs the fp32 weight-gradient on the first-generation kernel (bit-identical results)
-static bool wp_v1() {
-  const char* e = getenv("IRX_WGRAD_V1");          // read per call: the parity test flips it inside one process
-  return e && atoi(e) != 0;
-}
+static bool wp_v1() { return irx_knob(IRX_KNOB_WGRAD_V1) != 0; }   // (the parity test flips it with irx_debug_set_knob)
 
 template <int CIN>
 static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* il,

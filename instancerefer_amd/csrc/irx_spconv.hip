@@ -285,6 +285,44 @@ __global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t ele
 }
 
 // ---------------------------------------------------------------------------- host side -----
+#include <atomic>
+#include <string.h>
+namespace {
+struct KnobDef { const char* name; const char* env; long def; };
+const KnobDef kKnobs[IRX_KNOB_COUNT] = {
+    {"spconv3", "IRX_SPCONV3", 1},               // bf16-input convs on the third-generation kernel (irx_spconv3.hip)
+    {"updgrad", "IRX_UPDGRAD", 1},               // fp32 stride-2 data-gradient tiled by parent rows (k_updgrad)
+    {"updgrad_min", "IRX_UPDGRAD_MIN", 40000},   // ... from this many parent rows on
+    {"wgrad_v1", "IRX_WGRAD_V1", 0},             // fp32 pair-list weight-gradient on the first-generation kernel
+};
+std::atomic<long> g_knob_val[IRX_KNOB_COUNT];
+std::atomic<int> g_knob_set[IRX_KNOB_COUNT];
+}  // namespace
+long irx_knob(int id) {
+  if (id < 0 || id >= IRX_KNOB_COUNT) return 0;
+  if (!g_knob_set[id].load(std::memory_order_acquire)) {
+    const char* e = getenv(kKnobs[id].env);
+    g_knob_val[id].store(e ? atol(e) : kKnobs[id].def, std::memory_order_relaxed);
+    g_knob_set[id].store(1, std::memory_order_release);
+  }
+  return g_knob_val[id].load(std::memory_order_relaxed);
+}
+extern "C" int irx_debug_set_knob(const char* name, long value) {
+  IRX_REQUIRE(name != nullptr, "irx_debug_set_knob: null name");
+  for (int i = 0; i < IRX_KNOB_COUNT; ++i)
+    if (!strcmp(name, kKnobs[i].name)) {
+      g_knob_val[i].store(value, std::memory_order_relaxed);
+      g_knob_set[i].store(1, std::memory_order_release);
+      return IRX_OK;
+    }
+  IRX_REQUIRE(false, "irx_debug_set_knob: unknown knob '%s'", name);
+}
+extern "C" long irx_debug_get_knob(const char* name) {
+  for (int i = 0; name && i < IRX_KNOB_COUNT; ++i)
+    if (!strcmp(name, kKnobs[i].name)) return irx_knob(i);
+  return -1;
+}
+
 static thread_local hipEvent_t g_br_start = nullptr, g_br_stop = nullptr;
 extern "C" int irx_profile_next_kernel(void* ev_start, void* ev_stop) {
   g_br_start = (hipEvent_t)ev_start;
@@ -365,7 +403,11 @@ extern "C" size_t irx_spconv_fwd_workspace_bytes(int n_out, int K, int cin, int 
            (splits > 1 ? (size_t)splits * n_out * cout * sizeof(float) : 0);
   }
   if (!irx_spconv2_supported(cin, cout)) return 0;
-  const int splits = irx_spconv2_splits(n_out, K);
+  int splits = irx_spconv2_splits(n_out, K);
+  if (irx_spconv3_supported(cin, cout) && irx_spconv3_enabled()) {   // a bf16 input takes the third-generation kernel
+    const int s3 = irx_spconv3_splits(n_out, K);
+    if (s3 > splits) splits = s3;
+  }
   return fwd_ws_weights(K, cin, cout) + (splits > 1 ? (size_t)splits * n_out * cout * sizeof(float) : 0);
 }
 
@@ -374,6 +416,18 @@ extern "C" int irx_spconv_fwd(const float* x, const float* w, const int32_t* nbr
                               void* workspace, size_t workspace_bytes, void* stream) {
   return irx_spconv_fwd_impl(x, w, nbr, ld, n_out, K, cin, cout, flip_k, trans_w, y, 0, nullptr, workspace,
                              workspace_bytes, stream);
+}
+
+extern "C" int irx_spconv_fwd_t(const void* x, const float* w, const int32_t* nbr, int ld, int n_in, int n_out, int K,
+                                int cin, int cout, int flip_k, int trans_w, void* y, int accumulate, int x_bf, int y_bf,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  IRX_REQUIRE(!(x_bf || y_bf) || irx_conv_bf16(), "irx_spconv_fwd_t: bf16 tensors need irx_set_compute_dtype(1 | 2)");
+  IrxStore ty;
+  ty.x = x_bf ? 1 : 0;
+  ty.y = y_bf ? 1 : 0;
+  ty.x_rows = n_in;
+  return irx_spconv_fwd_impl((const float*)x, w, nbr, ld, n_out, K, cin, cout, flip_k, trans_w, (float*)y, accumulate,
+                             nullptr, workspace, workspace_bytes, stream, ty);
 }
 
 bool irx_spconv_fast_path(const void* x, const void* w, const void* y, int cin, int cout, int trans_w) {
@@ -397,16 +451,23 @@ int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int 
       irx_set_error("irx_spconv_fwd: workspace %zu < %zu", workspace_bytes, need);
       return IRX_ERR_WORKSPACE;
     }
-    const int splits = irx_spconv2_splits(n_out, K);
+    // a bf16 input of known size: third-generation kernel (irx_spconv3.hip) with its own weight image and offset splits
+    const bool v3 = irx_spconv3_use(cin, cout, ty.x, ty.x_rows, 0);
+    const int splits = v3 ? irx_spconv3_splits(n_out, K) : irx_spconv2_splits(n_out, K);
     float* slabs = (float*)((char*)workspace + fwd_ws_weights(K, cin, cout));
     int rc = IRX_OK;
     if (!wimg) {
-      rc = irx_permute_w_launch(w, K, cin, cout, trans_w, (float*)workspace, S(stream));
+      rc = v3 ? irx_permute_w3_launch(w, K, cin, cout, trans_w, (float*)workspace, S(stream))
+              : irx_permute_w_launch(w, K, cin, cout, trans_w, (float*)workspace, S(stream));
       if (rc) return rc;
       wimg = (const float*)workspace;
     }
-    rc = irx_spconv2_launch(x, wimg, nbr, ld, n_out, K, cin, cout, flip_k,
-                            splits > 1 ? slabs : y, splits, accumulate, S(stream), 0, ty);
+    if (v3)
+      rc = irx_spconv3_launch(x, wimg, nbr, ld, n_out, K, cin, cout, flip_k, splits > 1 ? slabs : y, splits,
+                              splits > 1 ? 0 : accumulate, S(stream), 0, splits > 1 ? 0 : ty.y);
+    else
+      rc = irx_spconv2_launch(x, wimg, nbr, ld, n_out, K, cin, cout, flip_k,
+                              splits > 1 ? slabs : y, splits, accumulate, S(stream), 0, ty);
     if (rc) return rc;
     if (splits > 1) {
       const size_t elems = (size_t)n_out * cout;

@@ -1,0 +1,429 @@
+// irx_spconv3.hip — third-generation sparse-conv forward / data-gradient for the bf16 STORAGE mode (irx_set_compute_dtype(2):
+// x is a bf16 tensor in HBM, BASELINE configs[2]-[4]).  Reference semantics: models/basic_blocks.py:10-95 (spnn.Conv3d).
+//
+// k_spconv2 in bf16 is the fp32 design with narrower operands: per (64-row tile, offset) it compacts pairs, stages the
+// gathered rows in LDS, runs 16-pair MFMA groups and read-modify-writes an fp32 LDS output tile — round 3's ablation
+// priced that skeleton at 52 of 131 us on the largest 128-channel level with 4 us of matrix-core time.  At 2.5 PFLOP/s the
+// matrix core is the one resource this path has to spare, so this kernel spends it to delete the skeleton:
+//   * workgroup = NW waves, wave w owns 32 consecutive (Morton-ordered) output rows x ALL output channels; its fp32
+//     accumulators (COUT/32 x 16 VGPRs) stay in registers for the whole offset loop: no LDS output tile, no
+//     read-modify-write, no pair compaction, no pair lists;
+//   * A operand: lane l gathers 16 bytes of row nbr[k][row l & 31] straight into the A-fragment layout of
+//     v_mfma_f32_32x32x16_bf16 (8 reduction channels per lane and step) with raw BUFFER loads — a missing neighbour is an
+//     out-of-range offset and returns zeros without a memory access, the wasted MFMA rows are free;  a wave whose 32 rows
+//     have no neighbour at an offset skips that offset's MFMAs altogether (wave-uniform bit test);
+//   * B operand: W[k] as a bf16 image in B-fragment order ([step][column block][lane][8]: one ds_read_b128 per fragment,
+//     conflict-free, shared by all waves), DOUBLE-buffered in LDS: offset k+1's image is requested at the top of offset k's
+//     MFMA chain and written behind it; one barrier per offset;
+//   * epilogue: the wave transposes its accumulators through LDS once per tile and stores whole rows (16 B per lane);
+//   * small levels split the offsets over blockIdx.y (fp32 slabs summed by k_wgrad_reduce), as k_spconv2 does.
+#include <stdlib.h>
+#include <type_traits>
+#include "irx_common.h"
+
+typedef __bf16 s3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float s3_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned s3_u32x4 __attribute__((ext_vector_type(4)));
+
+// dev ablation (timing only, results wrong): 1 = no A gather (offsets all out of range), 2 = no MFMA, 4 = no W staging,
+// 8 = no B-fragment LDS reads, 16 = no W instructions at all (loads and LDS stores), 32 = no row-load instructions,
+// 64 = no per-offset barrier
+#ifndef IRX_S3_ABL
+#define IRX_S3_ABL 0
+#endif
+// channel -> (step s, lane half h, element j) of the A / B fragments: 0: c = 16 s + 8 h + j (the two halves of a row read
+// adjacent 16-byte pieces), 1: c = (CIN/2) h + 8 s + j (each lane reads its own contiguous CIN bytes over the steps)
+#ifndef IRX_S3_AMAP
+#define IRX_S3_AMAP 0
+#endif
+
+template <int CIN>
+__host__ __device__ constexpr int s3_chan(int s, int h, int j) {
+  return IRX_S3_AMAP ? (CIN / 2) * h + 8 * s + j : 16 * s + 8 * h + j;
+}
+
+#define S3_OOB 0x80000000u
+#ifndef IRX_S3_SKIP
+#define IRX_S3_SKIP 1
+#endif
+
+// s_waitcnt vmcnt(n) with expcnt / lgkmcnt untouched (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4)
+template <int N>
+__device__ __forceinline__ void s3_wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+template <int CIN, int COUT, int NW>
+__global__ __launch_bounds__(64 * NW, (NW <= 4 ? 2 : 1))   // NW = 4: two workgroups per CU; 8: one
+void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ wimg, const int32_t* __restrict__ nbr,
+               int ld, int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate, int ldx,
+               int y_bf) {
+  constexpr int TM = 32 * NW, NTH = 64 * NW;
+  constexpr int NS = CIN / 16, NCB = COUT / 32;
+  constexpr int WP = CIN * COUT * 2 / 16;           // 16-byte pieces of one offset's image
+  constexpr int WPT = (WP + NTH - 1) / NTH;         // ... per thread (the last pass may cover only the leading waves)
+  constexpr bool WFULL = (WP % NTH) == 0;
+  static_assert(WP % 64 == 0, "a staging pass is whole waves");
+  constexpr int KMAX = 27;
+  constexpr int LDO = 32 + 4;                       // epilogue: one 32-column block per pass
+  constexpr int SM_MAIN = 2 * WP * 16 + KMAX * TM * 4;
+  constexpr int SM_EPI = NW * 32 * LDO * 4;
+  constexpr int SM = SM_MAIN > SM_EPI ? SM_MAIN : SM_EPI;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+  __shared__ unsigned sMask;
+  s3_u32x4* sW = reinterpret_cast<s3_u32x4*>(smem);                          // [2][WP]
+  unsigned* sOff = reinterpret_cast<unsigned*>(smem + 2 * WP * 16);    // [nk][TM] byte offsets into x, S3_OOB = none
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q0 = blockIdx.x * TM;
+  const int kb = blockIdx.y * k_per_split;
+  const int ke = (kb + k_per_split < K) ? kb + k_per_split : K;
+  const int nk = ke - kb;
+  y += (size_t)blockIdx.y * n_out * COUT;           // offset-split slabs (fp32; y_bf and accumulate are 0 then)
+  const unsigned rowbytes = (unsigned)ldx * 2u;
+
+  // ---- setup: the tile's table columns as byte offsets; per-wave and per-tile activity masks ----
+  for (int e = tid; e < nk * TM; e += NTH) {
+    const int kk = e / TM, r = e % TM;
+    const int k = kb + kk;
+    const int kt = flip_k ? (K - 1 - k) : k;
+    const int idx = (q0 + r < n_out) ? nbr[(size_t)kt * ld + q0 + r] : -1;
+    sOff[e] = (idx >= 0 && !(IRX_S3_ABL & 1)) ? (unsigned)idx * rowbytes : S3_OOB;
+  }
+  if (tid == 0) sMask = 0;
+  __syncthreads();
+  unsigned wm = 0;                                   // offsets at which this wave's 32 rows have a neighbour
+  for (int kk = 0; kk < nk; ++kk) {
+    const unsigned o = sOff[kk * TM + wave * 32 + (lane & 31)];
+    if (__ballot(o != S3_OOB) != 0ull) wm |= 1u << kk;
+  }
+  if (IRX_S3_ABL & 1) wm = (1u << nk) - 1u;
+  wm = __builtin_amdgcn_readfirstlane(wm);
+  if (lane == 0 && wm) atomicOr(&sMask, wm);
+  __syncthreads();
+  unsigned act = __builtin_amdgcn_readfirstlane(sMask);
+
+  s3_f32x16 acc[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+
+  if (act) {
+    // Every global read of the offset loop is a raw BUFFER load issued unconditionally: a missing neighbour, a wave without
+    // pairs at the next offset and "no next offset" are all an out-of-range offset (zeros, no memory access).  With no load
+    // behind a branch the number of loads in flight is exact at every point, so the two explicit s_waitcnt below are all
+    // the vector-memory waits of the loop (a conditional prefetch made the compiler wait for the loads it had just issued).
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)wimg, 0, (unsigned)K * (unsigned)(WP * 16), 0x00020000);
+    const unsigned ahalf = IRX_S3_AMAP ? (unsigned)(lane >> 5) * (unsigned)CIN : (unsigned)(lane >> 5) * 16u;
+    constexpr unsigned ASTEP = IRX_S3_AMAP ? 16u : 32u;
+    const unsigned* myoff = sOff + wave * 32 + (lane & 31);
+    const unsigned wlane = (unsigned)tid * 16u;
+    s3_u32x4 A[2][NS];
+    s3_u32x4 wreg[WPT];
+    // kkn_ < 0: nothing to fetch (offsets forced out of range)
+#define S3_LOAD_A(T, kkn_, kk_)                                                                                       \
+    do {                                                                                                                \
+      const unsigned off_ = (myoff[((kkn_) < 0 ? (kk_) : (kkn_)) * TM] + ahalf) | ((kkn_) < 0 ? S3_OOB : 0u);           \
+      if (!(IRX_S3_ABL & 32)) {                                                                                         \
+        _Pragma("unroll") for (int s = 0; s < NS; ++s)                                                                  \
+          A[T][s] = __builtin_bit_cast(s3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off_ + s * ASTEP, 0, 0));  \
+      }                                                                                                                 \
+    } while (0)
+    // piece i_ of offset kkn_'s image -> wreg[i_]
+#define S3_LOAD_W(kkn_, i_)                                                                                           \
+    do {                                                                                                                \
+      const unsigned voff_ =                                                                                            \
+          wlane | (((kkn_) < 0 || (IRX_S3_ABL & 4) || (!WFULL && tid + (i_) * NTH >= WP)) ? S3_OOB : 0u);               \
+      const unsigned soff_ = (unsigned)(kb + ((kkn_) < 0 ? 0 : (kkn_))) * (unsigned)(WP * 16);                          \
+      if (!(IRX_S3_ABL & 16))                                                                                           \
+        wreg[i_] = __builtin_bit_cast(s3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff_, soff_ + (i_) * NTH * 16, 0)); \
+    } while (0)
+#define S3_STORE_W(b_, i_)                                                                                            \
+    do {                                                                                                                \
+      if (!(IRX_S3_ABL & 16) && (WFULL || tid + (i_) * NTH < WP)) sW[(b_) * WP + tid + (i_) * NTH] = wreg[i_];          \
+    } while (0)
+#define S3_BARRIER()                                                                                                  \
+    do {                                                                                                                \
+      if (!(IRX_S3_ABL & 64)) __syncthreads();                                                                          \
+    } while (0)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto pop = [&]() __attribute__((always_inline)) {
+      int k = -1;
+      if (act) { k = __builtin_ctz(act); act &= act - 1; }
+      return k;
+    };
+    if (IRX_S3_ABL & (16 | 32)) {
+#pragma unroll
+      for (int i = 0; i < WPT; ++i) wreg[i] = (s3_u32x4){1u, 2u, 3u, 4u};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) A[0][s] = A[1][s] = (s3_u32x4){(unsigned)lane, 2u, 3u, 4u};
+    }
+
+    // Software pipeline over the tile's active offsets k_0, k_1, ...; item i has parity C = i & 1, T = C ^ 1:
+    //   on entry  sW[C] = image of k_i (visible: barrier), A[C] = rows for k_i and wreg = image of k_i+1 in flight (requested
+    //             during item i - 1);
+    //   the item  waits for them, requests A[T] = rows for k_i+1, writes its pieces of wreg to sW[T] (last read in item i - 1,
+    //             behind a barrier) and requests the same pieces of k_i+2's image into the registers it has just stored (an
+    //             in-place ring: one register set, and every request has one whole item to land), then runs the MFMA chain
+    //             over sW[C];  one barrier ends the offset.
+    int kk = pop();
+    int kkn = pop();
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) S3_LOAD_W(kk, i);
+    S3_LOAD_A(0, kk, kk);
+    s3_wait_vmcnt<(IRX_S3_ABL & 32) ? 0 : NS>();
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      S3_STORE_W(0, i);
+      S3_LOAD_W(kkn, i);
+    }
+    s3_wait_vmcnt<0>();                               // once per tile: the per-step waits below count from a clean slate
+    S3_BARRIER();
+
+    auto item = [&](auto C_, auto T_, int kk, int kkn, int kkn2) __attribute__((always_inline)) {
+      constexpr int C = decltype(C_)::value, T = decltype(T_)::value;
+      // The 2 NS .. NS + WPT vector-memory instructions of the item are spread over the MFMA chain, one or two per step: a
+      // wave that issues them back to back sits in the texture-address queue (~20 cycles per 1 KiB instruction and CU) with
+      // its MFMA pipe idle — measured: the row loads and the image loads then ADD 27 us each to a 55 us kernel.
+      // IRX_S3_SKIP: a wave whose 32 rows have no neighbour at this offset skips the MFMAs (per step, wave-uniform).
+      const unsigned offA = (myoff[(kkn < 0 ? 0 : kkn) * TM] + ahalf) | (kkn < 0 ? S3_OOB : 0u);
+      const bool live = kk >= 0 && (!IRX_S3_SKIP || ((wm >> kk) & 1u));
+      const s3_u32x4* bw = sW + C * WP + lane;
+      // B fragments of step s + 1 are requested before the MFMAs of step s
+      s3_u32x4 bq[2][NCB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bq[0][cb] = (IRX_S3_ABL & 8) ? A[C][cb % NS] : bw[cb * 64];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const s3_bf16x8 a = __builtin_bit_cast(s3_bf16x8, A[C][s]);
+        if (s + 1 < NS) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+            bq[(s + 1) & 1][cb] = (IRX_S3_ABL & 8) ? A[C][(s + 1 + cb) % NS] : bw[((s + 1) * NCB + cb) * 64];
+        }
+        // exact wait: A[C][s] and wreg[s] were requested at step s of the previous item; the loads issued since then — the rest
+        // of that item and steps 0 .. s-1 of this one — stay in flight (every request has one whole item to land)
+        if (!(IRX_S3_ABL & 48)) {
+          if (s < WPT) s3_wait_vmcnt<NS + WPT - 2>();
+          else s3_wait_vmcnt<NS + WPT - 1>();
+        }
+        if (s < WPT) {
+          S3_STORE_W(T, s);
+          S3_LOAD_W(kkn2, s);
+        }
+        if (!(IRX_S3_ABL & 32))
+          A[T][s] = __builtin_bit_cast(s3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, offA + s * ASTEP, 0, 0));
+        __builtin_amdgcn_sched_barrier(0);            // (keeps this step's memory instructions between the MFMA blocks)
+        if (live) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) {
+            if constexpr ((IRX_S3_ABL & 2) != 0) {
+              acc[cb][0] += __uint_as_float(bq[s & 1][cb][0] ^ A[C][s][0]);
+            } else {
+              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(s3_bf16x8, bq[s & 1][cb]), acc[cb], 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      S3_BARRIER();
+    };
+    // Items go in pairs (register-set parity is a compile-time constant) and the loop has ONE exit, at the bottom: an odd number
+    // of offsets ends with an empty item (kk < 0: no MFMAs, all requests out of range).  A mid-loop exit made the compiler
+    // route a never-taken edge from the first item back to the loop header, and its waitcnt pass then waited at the header
+    // for the loads the first item had just issued.
+    const int npairs = (__builtin_popcount(act) + (kkn >= 0 ? 3 : 2)) >> 1;      // act: the offsets behind kk and kkn
+    for (int ip = 0; ip < npairs; ++ip) {
+      int kkn2 = pop();
+      item(I0{}, I1{}, kk, kkn, kkn2);
+      kk = kkn; kkn = kkn2;
+      kkn2 = pop();
+      item(I1{}, I0{}, kk, kkn, kkn2);
+      kk = kkn; kkn = kkn2;
+    }
+    s3_wait_vmcnt<0>();
+    if (IRX_S3_ABL & (16 | 32)) {
+#pragma unroll
+      for (int i = 0; i < WPT; ++i) acc[0][i] += __uint_as_float(wreg[i][0]);
+    }
+  }
+
+  // ---- epilogue: D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  One 32-column block at a time through
+  // the wave's OWN LDS region (no workgroup barrier: the loop's last barrier is behind every read of sW / sOff), then whole
+  // 32-column row pieces go out with 16 B (fp32) / 8 B (bf16) per lane ----
+  float* so = reinterpret_cast<float*>(smem) + wave * 32 * LDO;
+  const int col = lane & 31, r4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) so[((reg & 3) + 8 * (reg >> 2) + r4) * LDO + col] = acc[cb][reg];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int f = lane + 64 * it;                  // 32 rows x 8 float4
+      const int row = f >> 3, cc = (f & 7) * 4;
+      const int gr = q0 + wave * 32 + row;
+      if (gr < n_out) {
+        float4 o = *reinterpret_cast<const float4*>(&so[row * LDO + cc]);
+        const size_t off = (size_t)gr * COUT + cb * 32 + cc;
+        if (accumulate) {
+          const float4 e = irx_ld4(y, off, y_bf);
+          o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+        }
+        irx_st4(y, off, y_bf, o);
+      }
+    }
+  }
+}
+
+// ---- weight image: [K][NS][NCB][64 lanes][8 bf16]; lane l of fragment (s, cb) holds W[k][c = chan(s, l >> 5, j)][n = 32 cb + (l & 31)]
+//   forward      : W[k][c][n] = w[(k*cin + c)*cout + n]
+//   data-gradient: W[k][c][n] = w[(k*cout + n)*cin + c]      (kernel-relative cin = reduction, cout = outputs)
+__device__ __forceinline__ void s3_image_piece(const float* __restrict__ w, int cin, int cout, int trans_w, size_t piece,
+                                               uint4* __restrict__ dst) {
+  const int ncb = cout / 32, ns = cin / 16;
+  const int lane = (int)(piece & 63);
+  size_t r = piece >> 6;
+  const int cb = (int)(r % ncb); r /= ncb;
+  const int s = (int)(r % ns); r /= ns;
+  const int k = (int)r;
+  const int n = cb * 32 + (lane & 31), h = lane >> 5;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = IRX_S3_AMAP ? (cin / 2) * h + 8 * s + j : 16 * s + 8 * h + j;
+    v[j] = trans_w ? w[((size_t)k * cout + n) * cin + c] : w[((size_t)k * cin + c) * cout + n];
+  }
+  dst[piece] = make_uint4(irx_pk_bf16(v[0], v[1]), irx_pk_bf16(v[2], v[3]), irx_pk_bf16(v[4], v[5]), irx_pk_bf16(v[6], v[7]));
+}
+
+__global__ void k_permute_w3(const float* __restrict__ w, int K, int cin, int cout, int trans_w, uint4* __restrict__ dst) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (size_t)K * cin * cout / 8) return;
+  s3_image_piece(w, cin, cout, trans_w, p, dst);
+}
+
+// all third-generation layers of an encoder pass in one launch (end4 counts float4 = 4 weights; a piece holds 8)
+__global__ void k_permute_w3_multi(IrxPermuteJobs J, int trans_w) {
+  const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int j = 0;
+  size_t begin = 0;
+  while (j < J.n) {
+    const size_t pieces = (size_t)J.K[j] * J.cin[j] * J.cout[j] / 8;
+    if (f < begin + pieces) break;
+    begin += pieces;
+    ++j;
+  }
+  if (j >= J.n) return;
+  s3_image_piece(J.w[j], J.cin[j], J.cout[j], trans_w, f - begin, reinterpret_cast<uint4*>(J.dst[j]));
+}
+
+// Dev: resident workgroups per CU the runtime reports (tools/micro/occupancy.py)
+extern "C" int irx_debug_occupancy_s3(int which) {
+  int n = -1;
+  hipError_t e = hipSuccess;
+  switch (which) {
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<128, 128, 4>, 256, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<64, 64, 4>, 256, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<128, 128, 8>, 512, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<64, 128, 4>, 256, 0); break;
+    default: return -2;
+  }
+  return e == hipSuccess ? n : -1;
+}
+
+// ---------------------------------------------------------------------------- host side -----
+bool irx_spconv3_supported(int cin, int cout) {
+  auto ok = [](int c) { return c == 32 || c == 64 || c == 128; };
+  return ok(cin) && ok(cout) && cin * cout >= 2048;
+}
+
+// IRX_SPCONV3=0 / irx_debug_set_knob("spconv3", 0): the bf16-storage convs go back to k_spconv2 (A/B and the equality test)
+bool irx_spconv3_enabled() { return irx_knob(IRX_KNOB_SPCONV3) != 0; }
+
+// x_rows: rows of the bf16 input tensor (0 = unknown -> not taken: rows are addressed with 32-bit byte offsets)
+bool irx_spconv3_use(int cin, int cout, int x_bf, long long x_rows, int ldx) {
+  if (!x_bf || !irx_spconv3_enabled() || !irx_spconv3_supported(cin, cout) || x_rows <= 0) return false;
+  if (ldx <= 0) ldx = cin;
+  return x_rows * (long long)ldx * 2 < 0x7FFFFFF0ll;
+}
+
+// waves per workgroup (32 output rows each): dev knob IRX_S3_NW = 4 | 8
+static int s3_nw() {
+  static const int v = getenv("IRX_S3_NW") ? atoi(getenv("IRX_S3_NW")) : 4;
+  return v == 8 ? 8 : 4;
+}
+int irx_spconv3_tile() { return 32 * s3_nw(); }
+
+// offsets are split over workgroups when a level has too few 128-row tiles to fill the 256 CUs twice
+int irx_spconv3_splits(int n_out, int K) {
+  static const char* e = getenv("IRX_SPCONV3_KSPLIT");
+  if (e) { int s = atoi(e); return s < 1 ? 1 : (s > K ? K : s); }
+  const int tiles = irx_cdiv(n_out, irx_spconv3_tile());
+  static const int full = getenv("IRX_SPCONV3_SPLIT_BELOW") ? atoi(getenv("IRX_SPCONV3_SPLIT_BELOW")) : 384;
+  if (tiles >= full || K < 4) return 1;
+  static const int target = getenv("IRX_SPCONV3_SPLIT_TARGET") ? atoi(getenv("IRX_SPCONV3_SPLIT_TARGET")) : 640;
+  int s = irx_cdiv(target, tiles);
+  if (s > 9) s = 9;
+  if (s > K) s = K;
+  const int kps = irx_cdiv(K, s);
+  return irx_cdiv(K, kps);
+}
+
+int irx_permute_w3_launch(const float* w, int K, int cin, int cout, int trans_w, float* dst, hipStream_t st) {
+  const size_t pieces = (size_t)K * cin * cout / 8;
+  k_permute_w3<<<irx_cdiv((long long)pieces, 256), 256, 0, st>>>(w, K, cin, cout, trans_w, reinterpret_cast<uint4*>(dst));
+  IRX_CHECK_LAUNCH("irx_spconv_fwd(permute v3)");
+  return IRX_OK;
+}
+
+int irx_permute_w3_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStream_t st) {
+  if (jobs.n == 0) return IRX_OK;
+  size_t pieces = 0;
+  for (int j = 0; j < jobs.n; ++j) pieces += (size_t)jobs.K[j] * jobs.cin[j] * jobs.cout[j] / 8;
+  k_permute_w3_multi<<<irx_cdiv((long long)pieces, 256), 256, 0, st>>>(jobs, trans_w);
+  IRX_CHECK_LAUNCH("irx_encoder(permute v3)");
+  return IRX_OK;
+}
+
+template <int CIN, int NW>
+static void launch3(int cout, dim3 grid, hipStream_t st, const unsigned short* x, const uint4* wimg, const int32_t* nbr, int ld,
+                    int n_out, int K, int flip_k, float* y, int kps, int acc, int ldx, int y_bf) {
+  if (cout == 128) k_spconv3<CIN, 128, NW><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+  else if (cout == 64) k_spconv3<CIN, 64, NW><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+  else if constexpr (CIN >= 64) k_spconv3<CIN, 32, NW><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+}
+
+// x: bf16 [rows][ldx]; wimg: irx_permute_w3* image; y: result (splits == 1; accumulate adds to it; y_bf = bf16 tensor) or
+// `splits` fp32 slabs [n_out][cout]
+int irx_spconv3_launch(const float* x, const float* wimg, const int32_t* nbr, int ld, int n_out, int K, int cin, int cout,
+                       int flip_k, float* y, int splits, int accumulate, hipStream_t st, int ldx, int y_bf) {
+  if (ldx <= 0) ldx = cin;
+  IRX_REQUIRE(irx_spconv3_supported(cin, cout), "irx_spconv3: channels (%d, %d) unsupported", cin, cout);
+  IRX_REQUIRE(K <= 27, "irx_spconv3: K = %d > 27", K);
+  IRX_REQUIRE(splits == 1 || (!accumulate && !y_bf), "irx_spconv3: offset-split slabs are plain fp32");
+  const dim3 grid(irx_cdiv(n_out, irx_spconv3_tile()), splits);
+  const int kps = irx_cdiv(K, splits);
+  const unsigned short* xb = reinterpret_cast<const unsigned short*>(x);
+  const uint4* wi = reinterpret_cast<const uint4*>(wimg);
+  irx_bracket_begin(st);
+#define S3_GO(CIN_, NW_) launch3<CIN_, NW_>(cout, grid, st, xb, wi, nbr, ld, n_out, K, flip_k, y, kps, accumulate, ldx, y_bf)
+  if (s3_nw() == 8) {
+    if (cin == 128) S3_GO(128, 8);
+    else if (cin == 64) S3_GO(64, 8);
+    else S3_GO(32, 4);
+  } else {
+    if (cin == 128) S3_GO(128, 4);
+    else if (cin == 64) S3_GO(64, 4);
+    else S3_GO(32, 4);
+  }
+#undef S3_GO
+  irx_bracket_end(st);
+  IRX_CHECK_LAUNCH("irx_spconv_fwd(v3)");
+  return IRX_OK;
+}

@@ -298,6 +298,25 @@ def spconv_gather_gemm(x, w, tbl, ld, n_out, K, cin, cout, flip_k, trans_w):
     return y
 
 
+def spconv_gather_gemm_t(x, w, tbl, ld, n_out, K, cin, cout, flip_k, trans_w, y_dtype=_f32, accumulate_into=None):
+    """irx_spconv_fwd_t: the convolution with typed tensors — x float32 or bfloat16 [n_in][cin], result float32 or bfloat16
+    (the encoder executor's bf16 storage mode as a single operator; needs set_compute_dtype('bf16' | 'bf16_operands') for
+    bf16 tensors). accumulate_into: y tensor that the result is added to."""
+    x_bf = x.dtype == torch.bfloat16
+    y = accumulate_into if accumulate_into is not None else torch.empty((n_out, cout), dtype=y_dtype, device=x.device)
+    y_bf = y.dtype == torch.bfloat16
+    wsb = int(_lib.load().irx_spconv_fwd_workspace_bytes(n_out, K, cin, cout, int(trans_w)))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    if PROFILE is not None:
+        m = _pairs(tbl, K, n_out)
+        e0, e1 = _bracket()
+    _lib.call("irx_spconv_fwd_t", _lib.ptr(x), _lib.ptr(w), _lib.ptr(tbl), ld, x.shape[0], n_out, K, cin, cout, int(flip_k),
+              int(trans_w), _lib.ptr(y), int(accumulate_into is not None), int(x_bf), int(y_bf), _lib.ptr(ws), wsb, _stream())
+    if PROFILE is not None:
+        PROFILE.append(("dgrad" if trans_w else "fwd", n_out, K, cin, cout, m, e0, e1))
+    return y
+
+
 def spconv_wgrad(x, dy, tbl, ld, n_out, K, cin, cout):
     dw = torch.empty((K, cin, cout), dtype=_f32, device=x.device)
     wsb = int(_lib.load().irx_spconv_wgrad_workspace_bytes(n_out, K, cin, cout))

@@ -100,8 +100,10 @@ def test_encoder_executor_equals_per_layer_path(lib):
     res = {}
     # "fused_up": the executor with the parent-tiled stride-2 data-gradient (k_updgrad) forced on at this small size — in
     # production it takes over from 40 k parent rows; same weight image, same reduction order, one pair per output row
+    from instancerefer_amd import _lib
+    updgrad_min = _lib.get_knob("updgrad_min")
     for mode in ("fused", "layers", "fused_up"):
-        os.environ["IRX_UPDGRAD_MIN"] = "0" if mode == "fused_up" else "1000000000"
+        _lib.set_knob("updgrad_min", 0 if mode == "fused_up" else 1000000000)
         enc.zero_grad()
         for m in enc.modules():
             if isinstance(m, torch.nn.BatchNorm1d):
@@ -118,7 +120,7 @@ def test_encoder_executor_equals_per_layer_path(lib):
         out.F.backward(g)
         res[mode] = (out.F.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in enc.named_parameters()},
                      {n: b.clone() for n, b in enc.named_buffers()})
-    del os.environ["IRX_UPDGRAD_MIN"]
+    _lib.set_knob("updgrad_min", updgrad_min)
     for other in ("layers", "fused_up"):
         assert torch.equal(res["fused"][0], res[other][0])
         assert torch.equal(res["fused"][1], res[other][1]), other

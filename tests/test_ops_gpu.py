@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from helpers import align, device_batch, oracle_batch, pack_coords, surface_cloud
+from instancerefer_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -385,11 +386,11 @@ def test_pair_lists_and_dense_stage_wgrad(lib, clouds):
             assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (K, cin, cout)
             # the second-generation fp32 kernel (32-pair stages, double-buffered LDS, buffer loads) walks the pairs in the
             # same order through the same 4-pair MFMA groups as the first one: bit-identical
-            os.environ["IRX_WGRAD_V1"] = "1"
+            _lib.set_knob("wgrad_v1", 1)
             try:
                 v1 = F_.spconv_wgrad_pairs(x, dy, (il, ol, counts, ldp), n_out, K, cin, cout)
             finally:
-                del os.environ["IRX_WGRAD_V1"]
+                _lib.set_knob("wgrad_v1", 0)
             assert torch.equal(got, v1), (K, cin, cout)
 
 

@@ -13,7 +13,7 @@ def short(name):
 acc = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel -> counter -> values of its biggest grid
 grid_of = {}
 for path in sys.argv[2:]:
-    rows = [r for r in csv.DictReader(open(path)) if short(r["Kernel_Name"]).startswith(("k_spconv2", "k_wgrad_pairs"))]
+    rows = [r for r in csv.DictReader(open(path)) if short(r["Kernel_Name"]).startswith(("k_spconv2", "k_spconv3", "k_wgrad_pairs"))]
     for r in rows:
         k = short(r["Kernel_Name"])
         g = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
