@@ -54,17 +54,20 @@ __device__ __forceinline__ void s3_wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
-template <int CIN, int COUT, int NW>
-__global__ __launch_bounds__(64 * NW, (NW <= 4 ? 2 : 1))   // NW = 4: two workgroups per CU; 8: one
+// KH: an offset's reduction dimension is processed in KH items of CIN / KH channels (KH = 2 for 128 x 128: a 16 KB half image
+// per item -> 46 KB of LDS and, with half the row / image registers, <= 168 VGPRs: THREE resident workgroups per CU)
+template <int CIN, int COUT, int NW, int KH>
+__global__ __launch_bounds__(64 * NW, (NW <= 4 ? (KH > 1 ? 3 : 2) : 1))
 void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ wimg, const int32_t* __restrict__ nbr,
                int ld, int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate, int ldx,
                int y_bf) {
   constexpr int TM = 32 * NW, NTH = 64 * NW;
-  constexpr int NS = CIN / 16, NCB = COUT / 32;
-  constexpr int WP = CIN * COUT * 2 / 16;           // 16-byte pieces of one offset's image
+  constexpr int NS = CIN / 16 / KH, NCB = COUT / 32;    // MFMA steps of one item
+  constexpr int WPK = CIN * COUT * 2 / 16;          // 16-byte pieces of one offset's image
+  constexpr int WP = WPK / KH;                      // ... of one item's part of it (steps are the image's major index)
   constexpr int WPT = (WP + NTH - 1) / NTH;         // ... per thread (the last pass may cover only the leading waves)
   constexpr bool WFULL = (WP % NTH) == 0;
-  static_assert(WP % 64 == 0, "a staging pass is whole waves");
+  static_assert(WP % 64 == 0 && (CIN / 16) % KH == 0, "a staging pass is whole waves");
   constexpr int KMAX = 27;
   constexpr int LDO = 32 + 4;                       // epilogue: one 32-column block per pass
   constexpr int SM_MAIN = 2 * WP * 16 + KMAX * TM * 4;
@@ -118,28 +121,32 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
     // the vector-memory waits of the loop (a conditional prefetch made the compiler wait for the loads it had just issued).
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w =
-        __builtin_amdgcn_make_buffer_rsrc((void*)wimg, 0, (unsigned)K * (unsigned)(WP * 16), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)wimg, 0, (unsigned)K * (unsigned)(WPK * 16), 0x00020000);
     const unsigned ahalf = IRX_S3_AMAP ? (unsigned)(lane >> 5) * (unsigned)CIN : (unsigned)(lane >> 5) * 16u;
     constexpr unsigned ASTEP = IRX_S3_AMAP ? 16u : 32u;
     const unsigned* myoff = sOff + wave * 32 + (lane & 31);
     const unsigned wlane = (unsigned)tid * 16u;
     s3_u32x4 A[2][NS];
     s3_u32x4 wreg[WPT];
-    // kkn_ < 0: nothing to fetch (offsets forced out of range)
-#define S3_LOAD_A(T, kkn_, kk_)                                                                                       \
-    do {                                                                                                                \
-      const unsigned off_ = (myoff[((kkn_) < 0 ? (kk_) : (kkn_)) * TM] + ahalf) | ((kkn_) < 0 ? S3_OOB : 0u);           \
-      if (!(IRX_S3_ABL & 32)) {                                                                                         \
-        _Pragma("unroll") for (int s = 0; s < NS; ++s)                                                                  \
-          A[T][s] = __builtin_bit_cast(s3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off_ + s * ASTEP, 0, 0));  \
-      }                                                                                                                 \
-    } while (0)
-    // piece i_ of offset kkn_'s image -> wreg[i_]
-#define S3_LOAD_W(kkn_, i_)                                                                                           \
+    // an item = (offset kk, part h of its reduction channels); kk < 0: nothing (requests forced out of range)
+    struct Cur { int kk, h; };
+    auto pop = [&]() __attribute__((always_inline)) {
+      int k = -1;
+      if (act) { k = __builtin_ctz(act); act &= act - 1; }
+      return k;
+    };
+    auto next = [&](Cur c) __attribute__((always_inline)) {
+      Cur n;
+      if (KH > 1 && c.kk >= 0 && c.h + 1 < KH) { n.kk = c.kk; n.h = c.h + 1; }
+      else { n.kk = pop(); n.h = 0; }
+      return n;
+    };
+    // piece i_ of item c_'s image -> wreg[i_]
+#define S3_LOAD_W(c_, i_)                                                                                             \
     do {                                                                                                                \
       const unsigned voff_ =                                                                                            \
-          wlane | (((kkn_) < 0 || (IRX_S3_ABL & 4) || (!WFULL && tid + (i_) * NTH >= WP)) ? S3_OOB : 0u);               \
-      const unsigned soff_ = (unsigned)(kb + ((kkn_) < 0 ? 0 : (kkn_))) * (unsigned)(WP * 16);                          \
+          wlane | (((c_).kk < 0 || (IRX_S3_ABL & 4) || (!WFULL && tid + (i_) * NTH >= WP)) ? S3_OOB : 0u);              \
+      const unsigned soff_ = ((unsigned)(kb + ((c_).kk < 0 ? 0 : (c_).kk)) * (unsigned)KH + (unsigned)(c_).h) * (unsigned)(WP * 16); \
       if (!(IRX_S3_ABL & 16))                                                                                           \
         wreg[i_] = __builtin_bit_cast(s3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff_, soff_ + (i_) * NTH * 16, 0)); \
     } while (0)
@@ -147,17 +154,13 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
     do {                                                                                                                \
       if (!(IRX_S3_ABL & 16) && (WFULL || tid + (i_) * NTH < WP)) sW[(b_) * WP + tid + (i_) * NTH] = wreg[i_];          \
     } while (0)
+#define S3_OFF_A(c_) ((myoff[((c_).kk < 0 ? 0 : (c_).kk) * TM] + ahalf + (unsigned)(c_).h * (NS * ASTEP)) | ((c_).kk < 0 ? S3_OOB : 0u))
 #define S3_BARRIER()                                                                                                  \
     do {                                                                                                                \
       if (!(IRX_S3_ABL & 64)) __syncthreads();                                                                          \
     } while (0)
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    auto pop = [&]() __attribute__((always_inline)) {
-      int k = -1;
-      if (act) { k = __builtin_ctz(act); act &= act - 1; }
-      return k;
-    };
     if (IRX_S3_ABL & (16 | 32)) {
 #pragma unroll
       for (int i = 0; i < WPT; ++i) wreg[i] = (s3_u32x4){1u, 2u, 3u, 4u};
@@ -165,35 +168,43 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
       for (int s = 0; s < NS; ++s) A[0][s] = A[1][s] = (s3_u32x4){(unsigned)lane, 2u, 3u, 4u};
     }
 
-    // Software pipeline over the tile's active offsets k_0, k_1, ...; item i has parity C = i & 1, T = C ^ 1:
-    //   on entry  sW[C] = image of k_i (visible: barrier), A[C] = rows for k_i and wreg = image of k_i+1 in flight (requested
+    // Software pipeline over the tile's items u_0, u_1, ...; item i has parity C = i & 1, T = C ^ 1:
+    //   on entry  sW[C] = image of u_i (visible: barrier), A[C] = rows for u_i and wreg = image of u_i+1 in flight (requested
     //             during item i - 1);
-    //   the item  waits for them, requests A[T] = rows for k_i+1, writes its pieces of wreg to sW[T] (last read in item i - 1,
-    //             behind a barrier) and requests the same pieces of k_i+2's image into the registers it has just stored (an
-    //             in-place ring: one register set, and every request has one whole item to land), then runs the MFMA chain
-    //             over sW[C];  one barrier ends the offset.
-    int kk = pop();
-    int kkn = pop();
+    //   step s    waits for exactly A[C][s] and wreg[s], writes wreg[s] to sW[T] (last read in item i - 1, behind a barrier),
+    //             requests the same piece of u_i+2's image into the register it has just stored (an in-place ring: one
+    //             register set) and A[T][s] = its piece of the rows for u_i+1 — every request has one whole item to land —
+    //             then runs the step's MFMAs over sW[C];  one barrier ends the item.
+    const int n_off = __builtin_popcount(act);
+    Cur cur = next(Cur{-1, 0});
+    Cur nx = next(cur);
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) S3_LOAD_W(kk, i);
-    S3_LOAD_A(0, kk, kk);
+    for (int i = 0; i < WPT; ++i) S3_LOAD_W(cur, i);
+    {
+      const unsigned off0 = S3_OFF_A(cur);
+      if (!(IRX_S3_ABL & 32)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          A[0][s] = __builtin_bit_cast(s3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off0 + s * ASTEP, 0, 0));
+      }
+    }
     s3_wait_vmcnt<(IRX_S3_ABL & 32) ? 0 : NS>();
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       S3_STORE_W(0, i);
-      S3_LOAD_W(kkn, i);
+      S3_LOAD_W(nx, i);
     }
     s3_wait_vmcnt<0>();                               // once per tile: the per-step waits below count from a clean slate
     S3_BARRIER();
 
-    auto item = [&](auto C_, auto T_, int kk, int kkn, int kkn2) __attribute__((always_inline)) {
+    auto item = [&](auto C_, auto T_, Cur c, Cur cn, Cur cn2) __attribute__((always_inline)) {
       constexpr int C = decltype(C_)::value, T = decltype(T_)::value;
-      // The 2 NS .. NS + WPT vector-memory instructions of the item are spread over the MFMA chain, one or two per step: a
-      // wave that issues them back to back sits in the texture-address queue (~20 cycles per 1 KiB instruction and CU) with
-      // its MFMA pipe idle — measured: the row loads and the image loads then ADD 27 us each to a 55 us kernel.
-      // IRX_S3_SKIP: a wave whose 32 rows have no neighbour at this offset skips the MFMAs (per step, wave-uniform).
-      const unsigned offA = (myoff[(kkn < 0 ? 0 : kkn) * TM] + ahalf) | (kkn < 0 ? S3_OOB : 0u);
-      const bool live = kk >= 0 && (!IRX_S3_SKIP || ((wm >> kk) & 1u));
+      // The NS .. NS + WPT vector-memory instructions of the item are spread over the MFMA chain, one or two per step: a wave
+      // that issues them back to back sits in the texture-address queue (~25 cycles per 1 KiB instruction and CU) with its
+      // MFMA pipe idle.  IRX_S3_SKIP: a wave whose 32 rows have no neighbour at this offset skips the MFMAs (per step,
+      // wave-uniform; the requests stay unconditional so that the counts below are exact).
+      const unsigned offA = S3_OFF_A(cn);
+      const bool live = c.kk >= 0 && (!IRX_S3_SKIP || ((wm >> c.kk) & 1u));
       const s3_u32x4* bw = sW + C * WP + lane;
       // B fragments of step s + 1 are requested before the MFMAs of step s
       s3_u32x4 bq[2][NCB];
@@ -215,7 +226,7 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
         }
         if (s < WPT) {
           S3_STORE_W(T, s);
-          S3_LOAD_W(kkn2, s);
+          S3_LOAD_W(cn2, s);
         }
         if (!(IRX_S3_ABL & 32))
           A[T][s] = __builtin_bit_cast(s3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, offA + s * ASTEP, 0, 0));
@@ -235,17 +246,17 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
       S3_BARRIER();
     };
     // Items go in pairs (register-set parity is a compile-time constant) and the loop has ONE exit, at the bottom: an odd number
-    // of offsets ends with an empty item (kk < 0: no MFMAs, all requests out of range).  A mid-loop exit made the compiler
+    // of items ends with an empty one (kk < 0: no MFMAs, all requests out of range).  A mid-loop exit made the compiler
     // route a never-taken edge from the first item back to the loop header, and its waitcnt pass then waited at the header
     // for the loads the first item had just issued.
-    const int npairs = (__builtin_popcount(act) + (kkn >= 0 ? 3 : 2)) >> 1;      // act: the offsets behind kk and kkn
+    const int npairs = (n_off * KH + 1) >> 1;
     for (int ip = 0; ip < npairs; ++ip) {
-      int kkn2 = pop();
-      item(I0{}, I1{}, kk, kkn, kkn2);
-      kk = kkn; kkn = kkn2;
-      kkn2 = pop();
-      item(I1{}, I0{}, kk, kkn, kkn2);
-      kk = kkn; kkn = kkn2;
+      Cur nx2 = next(nx);
+      item(I0{}, I1{}, cur, nx, nx2);
+      cur = nx; nx = nx2;
+      nx2 = next(nx);
+      item(I1{}, I0{}, cur, nx, nx2);
+      cur = nx; nx = nx2;
     }
     s3_wait_vmcnt<0>();
     if (IRX_S3_ABL & (16 | 32)) {
@@ -328,10 +339,10 @@ extern "C" int irx_debug_occupancy_s3(int which) {
   int n = -1;
   hipError_t e = hipSuccess;
   switch (which) {
-    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<128, 128, 4>, 256, 0); break;
-    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<64, 64, 4>, 256, 0); break;
-    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<128, 128, 8>, 512, 0); break;
-    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<64, 128, 4>, 256, 0); break;
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<128, 128, 4, 2>, 256, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<64, 64, 4, 1>, 256, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<128, 128, 4, 1>, 256, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spconv3<64, 128, 4, 1>, 256, 0); break;
     default: return -2;
   }
   return e == hipSuccess ? n : -1;
@@ -367,7 +378,7 @@ int irx_spconv3_splits(int n_out, int K) {
   const int tiles = irx_cdiv(n_out, irx_spconv3_tile());
   static const int full = getenv("IRX_SPCONV3_SPLIT_BELOW") ? atoi(getenv("IRX_SPCONV3_SPLIT_BELOW")) : 384;
   if (tiles >= full || K < 4) return 1;
-  static const int target = getenv("IRX_SPCONV3_SPLIT_TARGET") ? atoi(getenv("IRX_SPCONV3_SPLIT_TARGET")) : 640;
+  static const int target = getenv("IRX_SPCONV3_SPLIT_TARGET") ? atoi(getenv("IRX_SPCONV3_SPLIT_TARGET")) : 448;
   int s = irx_cdiv(target, tiles);
   if (s > 9) s = 9;
   if (s > K) s = K;
@@ -391,12 +402,14 @@ int irx_permute_w3_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStre
   return IRX_OK;
 }
 
-template <int CIN, int NW>
+template <int CIN, int NW, int KH>
 static void launch3(int cout, dim3 grid, hipStream_t st, const unsigned short* x, const uint4* wimg, const int32_t* nbr, int ld,
                     int n_out, int K, int flip_k, float* y, int kps, int acc, int ldx, int y_bf) {
-  if (cout == 128) k_spconv3<CIN, 128, NW><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-  else if (cout == 64) k_spconv3<CIN, 64, NW><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-  else if constexpr (CIN >= 64) k_spconv3<CIN, 32, NW><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+  if (cout == 128) k_spconv3<CIN, 128, NW, KH><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+  else if constexpr (KH == 1) {
+    if (cout == 64) k_spconv3<CIN, 64, NW, 1><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    else if constexpr (CIN >= 64) k_spconv3<CIN, 32, NW, 1><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+  }
 }
 
 // x: bf16 [rows][ldx]; wimg: irx_permute_w3* image; y: result (splits == 1; accumulate adds to it; y_bf = bf16 tensor) or
@@ -412,15 +425,18 @@ int irx_spconv3_launch(const float* x, const float* wimg, const int32_t* nbr, in
   const unsigned short* xb = reinterpret_cast<const unsigned short*>(x);
   const uint4* wi = reinterpret_cast<const uint4*>(wimg);
   irx_bracket_begin(st);
-#define S3_GO(CIN_, NW_) launch3<CIN_, NW_>(cout, grid, st, xb, wi, nbr, ld, n_out, K, flip_k, y, kps, accumulate, ldx, y_bf)
+#define S3_GO(CIN_, NW_, KH_) launch3<CIN_, NW_, KH_>(cout, grid, st, xb, wi, nbr, ld, n_out, K, flip_k, y, kps, accumulate, ldx, y_bf)
+  // 128 -> 128: the reduction in two half-items (three resident workgroups per CU); dev knob IRX_S3_KH=1: whole offsets
+  static const int kh_env = getenv("IRX_S3_KH") ? atoi(getenv("IRX_S3_KH")) : 2;
   if (s3_nw() == 8) {
-    if (cin == 128) S3_GO(128, 8);
-    else if (cin == 64) S3_GO(64, 8);
-    else S3_GO(32, 4);
+    if (cin == 128) S3_GO(128, 8, 1);
+    else if (cin == 64) S3_GO(64, 8, 1);
+    else S3_GO(32, 4, 1);
   } else {
-    if (cin == 128) S3_GO(128, 4);
-    else if (cin == 64) S3_GO(64, 4);
-    else S3_GO(32, 4);
+    if (cin == 128 && cout == 128 && kh_env == 2) S3_GO(128, 4, 2);
+    else if (cin == 128) S3_GO(128, 4, 1);
+    else if (cin == 64) S3_GO(64, 4, 1);
+    else S3_GO(32, 4, 1);
   }
 #undef S3_GO
   irx_bracket_end(st);

@@ -394,6 +394,75 @@ def test_pair_lists_and_dense_stage_wgrad(lib, clouds):
             assert torch.equal(got, v1), (K, cin, cout)
 
 
+@pytest.mark.parametrize("cin,cout,ks,stride", [(128, 128, 3, 1), (64, 64, 3, 1), (32, 64, 2, 2), (64, 128, 2, 2), (128, 64, 3, 1),
+                                                (64, 32, 3, 1), (128, 32, 3, 1), (32, 128, 3, 1)])
+def test_conv_bf16_storage_operator_third_generation(lib, clouds, cin, cout, ks, stride):
+    """irx_spconv_fwd_t with a bf16 x (the encoder executor's bf16 STORAGE mode as one operator, include/irx.h): the
+    third-generation kernel (csrc/irx_spconv3.hip — 128-row tiles, register accumulators, rows gathered straight into
+    v_mfma_f32_32x32x16_bf16 operands, W[k] double-buffered in LDS) against the CPU oracle's per-offset gather -> mm ->
+    index_add (oracle/torchsparse/nn/functional, models/basic_blocks.py:14-19 through spnn.Conv3d) evaluated on the
+    SAME bf16 values: forward and data-gradient (flipped offsets / transposed weights for stride 1, the transposed child
+    table for stride 2), fp32 and bf16 outputs, gradient accumulation (the level sizes of the fixture take the offset-split path). Only the fp32
+    summation order differs: 1e-5 relative for fp32 outputs; bf16 outputs are the fp32 result rounded once (the bar is one
+    bf16 ulp of the value). The second-generation kernel (knob spconv3 = 0) must agree with it to the same bar."""
+    import instancerefer_amd as irx
+    import oracle.torchsparse.nn.functional as OF
+    from instancerefer_amd.sparse import functional as F_
+
+    def r(t):
+        return t.bfloat16().float()
+    torch.manual_seed(cin * 131 + cout * 7 + ks)
+    d = device_batch(clouds, 0.05)
+    lv = d.level()
+    if stride == 1:
+        tbl, ld = lv.nbr27()
+        n_in = n_out = lv.n
+        K = 27
+    else:
+        dm = lv.down()
+        tbl, ld, n_in, n_out, K = dm.child, dm.ld, lv.n, dm.out_level.n, 8
+    t = tbl[:K, :n_out].cpu().long()
+    maps = []
+    for k in range(K):
+        v = torch.nonzero(t[k] >= 0).flatten()
+        maps.append((t[k][v], v))
+    x = r(torch.randn(n_in, cin))
+    w = torch.randn(K, cin, cout) * 0.1
+    g = r(torch.randn(n_out, cout))
+    y0 = r(torch.randn(n_out, cout))
+    xo = x.clone().requires_grad_(True)
+    yo = OF.sparseconv_op(xo, r(w), maps, n_out)      # the oracle's per-offset gather -> mm -> index_add
+    yo.backward(g)
+    dxo = xo.grad
+    xb, gb, wd = x.cuda().bfloat16(), g.cuda().bfloat16(), w.cuda()
+    if stride == 1:
+        tbl_b, ld_b, flip = tbl, ld, 1
+    else:
+        tbl_b, ld_b, flip = F_.kmap_down_transpose(dm.parent, dm.koff), max(n_in, 1), 0
+    res = {}
+    irx.set_compute_dtype("bf16")
+    try:
+        for gen in (3, 2):
+            _lib.set_knob("spconv3", 1 if gen == 3 else 0)
+            yf = F_.spconv_gather_gemm_t(xb, wd, tbl, ld, n_out, K, cin, cout, 0, 0)
+            yb = F_.spconv_gather_gemm_t(xb, wd, tbl, ld, n_out, K, cin, cout, 0, 0, y_dtype=torch.bfloat16)
+            ya = F_.spconv_gather_gemm_t(xb, wd, tbl, ld, n_out, K, cin, cout, 0, 0, accumulate_into=y0.cuda().bfloat16())
+            dx = F_.spconv_gather_gemm_t(gb, wd, tbl_b, ld_b, n_in, K, cout, cin, flip, 1)
+            res[gen] = [v.float().cpu() for v in (yf, yb, ya, dx)]
+    finally:
+        _lib.set_knob("spconv3", 1)
+        irx.set_compute_dtype("fp32")
+    exp = yo.detach()
+    ulp = 2.0 ** -8
+    for gen, (yf, yb, ya, dx) in res.items():
+        assert (yf - exp).abs().max().item() <= 1e-5 * max(exp.abs().max().item(), 1.0), ("forward", gen)
+        assert ((yb - exp).abs() <= ulp * exp.abs() + 1e-6).all(), ("bf16 output", gen)
+        ea = exp + y0
+        assert ((ya - ea).abs() <= ulp * ea.abs() + 2e-5).all(), ("accumulate", gen)
+        assert (dx - dxo).abs().max().item() <= 1e-5 * max(dxo.abs().max().item(), 1.0), ("dgrad", gen)
+    assert (res[3][0] - res[2][0]).abs().max().item() <= 2e-5 * max(exp.abs().max().item(), 1.0)
+
+
 def test_batched_pair_list_build_equals_per_table_builds(lib, clouds):
     """irx_pairs_build_multi over every table of a pyramid == irx_pairs_build table by table (bit-exact)."""
     from instancerefer_amd.sparse import functional as F_

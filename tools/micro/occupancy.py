@@ -9,5 +9,5 @@ for i, n in enumerate(("k_spconv2<128,128> fp32", "k_spconv2<64,64> fp32", "k_sp
     print("%-36s %d workgroups of 256 threads per CU" % (n, L.irx_debug_occupancy(i)))
 for i, n in enumerate(("k_wgrad_pairs<128,128> fp32", "k_wgrad_pairs<64,64> fp32", "k_wgrad_pairs<128,128> bf16 storage")):
     print("%-36s %d workgroups of 256 threads per CU" % (n, L.irx_debug_occupancy_wp(i)))
-for i, n in enumerate(("k_spconv3<128,128,4>", "k_spconv3<64,64,4>", "k_spconv3<128,128,8> (512 threads)", "k_spconv3<64,128,4>")):
+for i, n in enumerate(("k_spconv3<128,128,4,KH=2>", "k_spconv3<64,64,4>", "k_spconv3<128,128,4,KH=1>", "k_spconv3<64,128,4>")):
     print("%-36s %d workgroups per CU" % (n, L.irx_debug_occupancy_s3(i)))
