@@ -112,9 +112,40 @@ class DynamicEdgeConv(nn.Module):
             counts = torch.bincount(batch_index, minlength=nb)
             support_offsets = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
         nbr = F_.knn_batched(support_xyz, support_offsets, query_xyz, query_batch.int(), self.k)  # (nq,k)
+        if not self.fused_supported(features.shape[1]):
+            return self.forward_unfused(support_xyz, filtered_index, features, nbr)
         return EdgeConvMaxFn.apply(features, support_xyz, filtered_index, nbr, self.num_classes,
                                    self.weight[0].weight, self.weight[0].bias, self.weight[2].weight, self.weight[2].bias,
                                    self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias)
+
+
+    # limits of the fused kernels (csrc/irx_edgeconv.hip: one 16-row MFMA tile of edges per query, the edge-input gradient in a
+    # tile of F_out columns); `k` is a YAML knob of the reference (config/InstanceRefer.yaml, models/relation_module.py:13-25)
+    FUSED_MAX_K = 16
+
+    def fused_supported(self, f_in):
+        hid, f_out = self.weight[0].out_features, self.mlp[2].out_features
+        return (self.k <= self.FUSED_MAX_K and hid <= 128 and 3 + 2 * self.num_classes <= f_out and f_in >= self.num_classes
+                and self.mlp[0].out_features == f_out)
+
+    def forward_unfused(self, support_xyz, filtered_index, features, nbr):
+        """The same function on the (n_query, k) neighbour grid of irx_knn_batched with ATen ops (rocBLAS GEMMs), for graphs
+        the fused kernel does not take (k > 16): message(i <- j) = mlp([x_i, weight([pos_j - pos_i, cls_i, cls_j]), x_j])
+        (reference models/basic_blocks.py:126-133), max over the valid neighbours, 0 for a query without any (torch_scatter's
+        fill, as the fused op)."""
+        nq, k = nbr.shape
+        nc = self.num_classes
+        valid = nbr >= 0
+        j = nbr.clamp(min=0).long().view(-1)
+        x_i = torch.index_select(features, 0, filtered_index).unsqueeze(1).expand(nq, k, features.shape[1])
+        x_j = torch.index_select(features, 0, j).view(nq, k, -1)
+        pos_i = torch.index_select(support_xyz, 0, filtered_index).unsqueeze(1)
+        pos_j = torch.index_select(support_xyz, 0, j).view(nq, k, 3)
+        ew = self.weight(torch.cat([pos_j - pos_i, x_i[..., -nc:], x_j[..., -nc:]], -1))
+        msg = self.mlp(torch.cat([x_i, ew, x_j], -1))
+        msg = msg.masked_fill(~valid.unsqueeze(-1), float("-inf"))
+        out = msg.max(1).values
+        return torch.where(valid.any(1, keepdim=True), out, torch.zeros_like(out))
 
 
 class EdgeConvMaxFn(torch.autograd.Function):

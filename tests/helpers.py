@@ -56,3 +56,53 @@ def device_batch(clouds, voxel):
     feats = torch.from_numpy(np.concatenate(clouds, 0)).float().to(dev)
     batch = torch.from_numpy(np.concatenate([np.full(len(pc), i, np.int32) for i, pc in enumerate(clouds)])).to(dev)
     return voxelize(xyz, feats, batch, voxel, len(clouds))
+
+
+def kink_free_state_dict(sd, shift=6.0):
+    """A state dict with `shift` added to every BatchNorm shift of the two sparse encoders (attribute.net.*, scene.net.*): their
+    ReLU inputs then sit ~6 sigma above zero, so no activation is within fp32 round-off of its kink and two correct fp32
+    implementations take the same branch everywhere — which is what makes an ELEMENT-WISE gradient comparison meaningful
+    (a single flipped ReLU moves every shallower gradient by ~2e-3)."""
+    out = dict(sd)
+    for k in out:
+        if k.startswith(("attribute.net.", "scene.net.")) and k.endswith(("net.1.bias", "net.4.bias")):
+            out[k] = out[k] + shift
+    return out
+
+
+# Parameters whose gradient is MATHEMATICALLY zero: a Linear / Conv2d bias that feeds a train-mode BatchNorm (the batch mean
+# removes any per-channel shift: reference models/attribute_module.py:31, relation_module.py:26, scene_module.py:36,42) and the
+# biases of the attention logits (softmax is shift invariant: models/lang_module.py:61-83). Both implementations return pure
+# cancellation noise there (~1e-5 from sums of O(1) terms), so the bar cannot be relative to the entry. The rule only applies to a
+# listed name whose ORACLE gradient is itself below zero_bar * top (a Linear bias in front of a LayerNorm is not zero and is
+# compared like every other parameter).
+ZERO_GRAD_SUFFIXES = ("lang_emb_fc.0.bias", "vis_emb_fc.0.bias", "vis_emb_fc1.0.bias", "cls.0.bias", "fc_a.bias", "fc_cls.bias",
+                      "fc_rel.bias", "fc_scene.bias", "lang_fc.bias", "conv1.0.bias", "conv1.3.bias")
+
+
+def elementwise_grad_report(named_got, named_exp, rel=1e-3, floor=1e-6, zero_suffixes=ZERO_GRAD_SUFFIXES, zero_bar=1e-4):
+    """Per parameter: max |got - exp| against rel * max(max|exp|, floor * top) with top = the largest entry of any gradient;
+    parameters named in zero_suffixes (mathematically zero gradients) must stay below zero_bar * top on both sides instead.
+    Returns (bad: {name: (err, max|exp|)}, worst ratio err / bar over the ordinary parameters, report lines)."""
+    top = max(float(p.grad.abs().max()) for p in named_exp.values() if p.grad is not None)
+    bad, worst, lines = {}, 0.0, []
+    for n, p in named_exp.items():
+        g = named_got[n].grad
+        if p.grad is None:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        assert g is not None and g.shape == p.grad.shape, n
+        e = float((g.detach().cpu().double() - p.grad.double()).abs().max())
+        m = float(p.grad.abs().max())
+        if n.endswith(zero_suffixes) and m <= zero_bar * top:
+            mg = float(g.abs().max())
+            lines.append("%-52s zero-gradient: |exp| %.1e |got| %.1e (top %.1e)" % (n, m, mg, top))
+            if not mg <= zero_bar * top:
+                bad[n] = (mg, m)
+            continue
+        bar = rel * max(m, floor * top)
+        worst = max(worst, e / bar)
+        lines.append("%-52s err %.1e  max|exp| %.1e  err/bar %.3f" % (n, e, m, e / bar))
+        if not e <= bar:
+            bad[n] = (e, m)
+    return bad, worst, lines

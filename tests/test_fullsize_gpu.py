@@ -281,7 +281,7 @@ def test_stress_full_model_bf16_within_the_reordering_distance(lib, stress_batch
     TB.check_model_against_emulation(model, dd, runs, "stress 200k x 64, C0 = 135, bf16")
 
 
-@pytest.mark.parametrize("which", ["full", "attr_only"])
+@pytest.mark.parametrize("which", ["full", "attr_only", "full_elementwise"])
 def test_whole_model_at_baseline_size_vs_oracle(lib, which):
     """BASELINE configs[2] / configs[1] shapes through the WHOLE model, not only the encoders: 16 scenes x 50 k points, 8
     instances, 4 candidates each (64 candidates), 30-token utterances, fp32, training mode — language module, candidate
@@ -289,7 +289,13 @@ def test_whole_model_at_baseline_size_vs_oracle(lib, which):
     (pinned to the reference's own models/instancerefer.py:37-70 output by tests/test_oracle_cpu.py). "attr_only" is
     configs[1]'s model: relation_module = scene_module = None (reference models/instancerefer.py:24-34,56-68).
     Forward tensors <= 1e-4 absolute (the north star's bar); loss terms <= 1e-4; gradient norms 2e-3 per parameter
-    (floor: 1e-3 of the total), total 1e-3."""
+    (floor: 1e-3 of the total), total 1e-3. "full_elementwise": the full model with the encoders' ReLUs kept away from their
+    kinks (helpers.kink_free_state_dict) and EVERY parameter gradient compared element by element: 1e-3 of the tensor's
+    largest entry (floor 1e-6 of the largest entry of any gradient)."""
+    from helpers import elementwise_grad_report, kink_free_state_dict
+    elementwise = which == "full_elementwise"
+    if elementwise:
+        which = "full"
     from instancerefer_amd import synthetic as S
     from instancerefer_amd.instancerefer import InstanceRefer
     from instancerefer_amd.loss_helper import DatasetConfig, compute_lang_classification_loss, get_loss
@@ -301,6 +307,8 @@ def test_whole_model_at_baseline_size_vs_oracle(lib, which):
         args.scene_module = None
     model = InstanceRefer(7, args)
     sd = S.seeded_state_dict(model, 2024)
+    if elementwise:
+        sd = kink_free_state_dict(sd)
     model.load_state_dict(sd)
     oracle = OracleModel(7, args)
     oracle.load_state_dict(sd)
@@ -329,6 +337,14 @@ def test_whole_model_at_baseline_size_vs_oracle(lib, which):
     ld.backward()
     lo.backward()
     gp = dict(model.named_parameters())
+    if elementwise:
+        bad, worst_ratio, lines = elementwise_grad_report(gp, dict(oracle.named_parameters()))
+        import os
+        os.makedirs('gpurun_out', exist_ok=True)
+        open('gpurun_out/elementwise_fullsize.txt', 'w').write('\n'.join(lines) + '\n')
+        print("element-wise gradients at 16 x 50 k: worst error / bar = %.3f" % worst_ratio)
+        assert not bad, bad
+        return
     tot_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in oracle.parameters() if p.grad is not None)))
     tot_d = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
     assert abs(tot_d - tot_o) <= 1e-3 * tot_o, (tot_d, tot_o)
