@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--no-prep-at-backward", action="store_true",
                     help="default: the launch phase of the next batch's input preparation is issued by a persistent helper "
                          "thread WHILE the autograd engine runs this step's backward (the Python thread is parked in "
-                         "loss.backward() and the engine's C++ nodes do not hold the GIL): +5 % in the host-bound bf16 "
+                         "loss.backward() and the engine's C++ nodes do not hold the GIL): +5 %% in the host-bound bf16 "
                          "mode (2127 -> 2239 scenes/s). This flag issues it inline before the forward instead")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do the input preparation of each step inline instead of on a side stream during the previous backward")
@@ -342,6 +342,20 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    """Host CPU model string (/proc/cpuinfo) + the logical core count of the machine (the baseline itself runs on `cores`)."""
+    name = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return "%s (%d logical cores on the host)" % (name or "unknown", os.cpu_count() or 0)
+
+
 def cpu_baseline_worker(points, instances, candidates, tokens, n_scenes, threads, multiview=0):
     """Runs in a child process: the oracle (CPU restatement of the reference path; kind 'port') on a
     bounded sample of the workload. Prints one JSON line."""
@@ -399,8 +413,23 @@ def cpu_baseline_worker(points, instances, candidates, tokens, n_scenes, threads
         c_note = "; C/OpenMP port (oracle/csrc/spconv_cpu.c, the two sparse encoders fwd+bwd only, kernel maps included): %.2f scenes/s" % c_rate
     except Exception as e:   # the C port is optional strengthening; never lose the PyTorch-CPU number over it
         c_note = "; C/OpenMP port unavailable (%r)" % (e,)
+    # the same C port on ONE thread (2 scenes: a bounded sample; scenes/s scales with the scene count)
+    one_thread = None
+    try:
+        if c_rate is not None and n >= 2:
+            ms = cs[:, 3] < 2
+            ma = ca[:, 3] < 2 * candidates
+            t0 = time.perf_counter()
+            cpu_port.encoder_fwd_bwd(np.ascontiguousarray(cs[ms]), np.ascontiguousarray(fs[ms]), 2, ps, gs[:2], 1)
+            cpu_port.encoder_fwd_bwd(np.ascontiguousarray(ca[ma]), np.ascontiguousarray(fa[ma]), 2 * candidates, pa,
+                                     ga[:2 * candidates], 1)
+            one_thread = 2 / (time.perf_counter() - t0)
+    except Exception:
+        one_thread = None
     value = max(torch_rate, c_rate or 0.0)
-    print(json.dumps({"value": value, "unit": "scenes/s", "cores": threads, "kind": "port",
+    print(json.dumps({"value": value, "unit": "scenes/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+                      "one_thread": {"value": one_thread, "unit": "scenes/s", "cores": 1,
+                                     "what": "C/OpenMP port, the two sparse encoders fwd+bwd, 1 thread, 2 scenes"},
                       "sample": "%d scenes x %d pts; the faster of: oracle/model_ref.py (CPU PyTorch gather-GEMM-scatter "
                                 "restatement of the reference path, full model fwd+bwd, %d threads): %.2f scenes/s%s; scene "
                                 "voxelisation (%.2fs) excluded as in the reference's dataloader"
@@ -752,6 +781,14 @@ def main():
                        "host_binding_rank0": binding},
             "roofline": roof if roof_error is None else {"error": roof_error},
         }
+        for blk, ms_step in ((out["roofline"], out["ms_per_step"]), ((alt or {}).get("roofline"), (alt or {}).get("ms_per_step"))):
+            if isinstance(blk, dict) and "bound_ms_total" in blk and ms_step:
+                # whole-step figure: the time the sparse-conv kernels of ONE step would take at their rooflines (sum of the
+                # per-kernel bounds of the instrumented steps / their count) over the measured step — what launch overhead,
+                # small kernels, the dense heads and host stalls leave of the machine
+                b = blk.pop("bound_ms_total") / max(args.profile_steps, 1)
+                blk["step_frac_of_conv_roofline"] = b / ms_step
+                blk["conv_roofline_ms_per_step"] = b
         if alt is not None:
             out["alt_dtype"] = alt
         if world == 1 and args.workload != "attr" and not args.no_cpu_baseline:   # (quick runs skip the auxiliary legs)
@@ -839,7 +876,7 @@ def traffic_for(roof, pmc, bf16):
     key = roof["kernel"].replace(",", ", ")
     if key.startswith(("k_spconv2<", "k_wgrad_pairs<")):           # template flags: <..., bf16 operands, bf16 storage>
         key = key[:-1] + (", true, true>" if bf16 else ", false, false>")
-    hit = [k for k in pmc if k == key or k.startswith(key[:-1] + ",")]
+    hit = [k for k in pmc if k == key or k.startswith(key[:-1] + ",")]     # (k_spconv3<cin, cout, waves, K parts>)
     if hit:
         roof["traffic"] = pmc[hit[0]]
         roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py on this box (2 steps, serial issue)"
@@ -941,10 +978,17 @@ def summarise_roofline(recs, bf16=False):
     binding resource) / sum(measured time); the events bracket the dominant kernel only (irx_profile_next_kernel)."""
     agg = {}
 
-    def klass(kind, cin, cout):
+    try:
+        from instancerefer_amd import _lib
+        v3 = bool(_lib.get_knob("spconv3"))
+    except Exception:
+        v3 = False
+
+    def klass(kind, cin, cout, e=4.0):
         if kind in ("fwd", "dgrad"):
             if cin in (32, 64, 128) and cout in (32, 64, 128):
-                return "k_spconv2<%d,%d>" % (cin, cout)
+                # a bf16 INPUT (bf16 storage inside the executor) runs on the third-generation kernel (csrc/irx_spconv3.hip)
+                return ("k_spconv3<%d,%d>" if (bf16 and e == 2.0 and v3 and cin * cout >= 2048) else "k_spconv2<%d,%d>") % (cin, cout)
             if 128 < cin <= 136 and cout == 32 and kind == "fwd":
                 return "wide stem fwd (k_stem_fwd + k_spconv2<128,32>)"
             return "k_stem_fwd" if (cin <= 8 and cout == 32) else "k_spconv_fwd(generic)"
@@ -967,13 +1011,13 @@ def summarise_roofline(recs, bf16=False):
             byts = e * M * (cin + cout) + 4.0 * K * cin * cout + 8.0 * M
         else:
             byts = e * (M * cin + n_out * cout) + ew * K * cin * cout + 8.0 * M
-        kl = klass(kind, cin, cout)
+        kl = klass(kind, cin, cout, e)
         a = agg.setdefault(kl, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, bound_ms=0.0))
         a["ms"] += ms
         a["flops"] += flops
         a["bytes"] += byts
         a["launches"] += 1
-        a["peak_tf"] = peak_tf = PEAK_BF16_TFLOPS if (bf16 and kl.startswith(("k_spconv2<", "k_wgrad_pairs<"))) else PEAK_F32_TFLOPS
+        a["peak_tf"] = peak_tf = PEAK_BF16_TFLOPS if (bf16 and kl.startswith(("k_spconv2<", "k_spconv3<", "k_wgrad_pairs<"))) else PEAK_F32_TFLOPS
         b_ms = max(byts / (PEAK_HBM_GBS * 1e9), flops / (peak_tf * 1e12)) * 1e3
         a["bound_ms"] += b_ms
         tot["ms"] += ms
@@ -1021,7 +1065,7 @@ def summarise_roofline(recs, bf16=False):
             "traffic": traffic, "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
             "algorithmic_flops_per_launch": a["flops"] / a["launches"],
             "avg_launch_us": 1e3 * a["ms"] / a["launches"], "launches": a["launches"],
-            "path_frac_of_roofline": tot["bound_ms"] / tot["ms"], "per_kernel": per_kernel}
+            "path_frac_of_roofline": tot["bound_ms"] / tot["ms"], "bound_ms_total": tot["bound_ms"], "per_kernel": per_kernel}
 
 
 if __name__ == "__main__":

@@ -71,6 +71,8 @@ class Solver:
                  out_dir=None, verbose=20, device=None, use_checkpoint=None, sync_bn=False):
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.model = model.to(self.device)
+        self.sync_bn = bool(sync_bn)
+        self.sync_bn_skipped = 0                   # steps dropped by sync_bn_guard (same count on every rank)
         if sync_bn:                                # world > 1: BatchNorm statistics over all ranks (syncbn.py)
             from .syncbn import convert_sync_batchnorm
             convert_sync_batchnorm(self.model)
@@ -143,11 +145,41 @@ class Solver:
     def _forward(self, data_dict):
         return get_loss(self.model(to_device(data_dict, self.device)), self.config)
 
+    def has_scored_candidates(self, data_dict):
+        """Host-side: does this rank's shard hold a scene with >= 2 instances of the target class (the condition under which
+        the candidate encoder and the attribute / relation heads run at all, reference models/attribute_module.py:75-76)?
+        Known before the forward only when the target class is the ground-truth one (`use_gt_lang`, the training default)."""
+        args = getattr(self.model, "args", None)
+        if args is not None and not getattr(args, "use_gt_lang", True):
+            return True                            # arg-max of lang_scores: not known on the host before the forward
+        cats = [int(c) for c in torch.as_tensor(data_dict["object_cat"]).reshape(-1).tolist()]
+        return any(sum(int(c) == cat for c in cls) >= 2 for cls, cat in zip(data_dict["instance_class"], cats))
+
+    def sync_bn_guard(self, data_dict):
+        """Sync-BatchNorm contract (syncbn.py): every rank runs every BatchNorm layer in every step. A shard without scored
+        candidates would skip the candidate encoder and the heads' BatchNorm1d layers and leave the other ranks waiting in
+        their collectives. One 4-byte all-reduce (MIN) before the forward makes the decision the same everywhere: the step
+        runs only if EVERY rank can run every layer, otherwise all ranks drop this batch (counted in sync_bn_skipped)."""
+        if not (self.sync_bn and self.world > 1):
+            return True
+        flag = torch.tensor([1 if self.has_scored_candidates(data_dict) else 0], dtype=torch.int32,
+                            device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item()) == 1
+        if not ok:
+            self.sync_bn_skipped += 1
+            if self.sync_bn_skipped in (1, 10, 100) or self.sync_bn_skipped % 1000 == 0:
+                self._say("sync-BN: batch dropped on all ranks (a shard has no scene with >= 2 candidates); %d so far"
+                          % self.sync_bn_skipped)
+        return ok
+
     def train_epoch(self, epoch):
         self.model.train()
         self.optimizer.lr = scheduled_lr(self.base_lr, epoch, self.lr_decay_step, self.lr_decay_rate)
         t0, seen = time.perf_counter(), 0
         for data_dict in self.dataloader["train"]:
+            if not self.sync_bn_guard(data_dict):
+                continue
             self.optimizer.zero_grad()
             data_dict = self._forward(data_dict)
             data_dict["loss"].backward()

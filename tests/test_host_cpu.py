@@ -141,6 +141,40 @@ def test_flat_adam_reducer_gloo_world2():
     assert out["segments_0"] == out["segments_1"] == ([(4, 176, 208)], [(0, 176), (208, 256)])
 
 
+def _guard_worker(rank, world, port, out):
+    import types
+    import torch.distributed as dist
+    from instancerefer_amd.solver import Solver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sv = object.__new__(Solver)                # the guard needs no model weights: only the flags and the host lists
+    sv.sync_bn, sv.world, sv.rank, sv.device, sv.sync_bn_skipped, sv.out_dir = True, world, rank, torch.device("cpu"), 0, None
+    sv.model = types.SimpleNamespace(args=types.SimpleNamespace(use_gt_lang=True))
+    good = dict(object_cat=torch.tensor([4, 7]), instance_class=[[4, 4, 1], [7, 2, 7]])
+    lone = dict(object_cat=torch.tensor([4, 7]), instance_class=[[4, 3, 1], [7, 2, 5]])      # one candidate per scene
+    res = []
+    for step, batches in enumerate([(good, good), (good, lone), (lone, good), (good, good)]):
+        res.append(sv.sync_bn_guard(batches[rank]))
+    out["guard_%d" % rank] = (res, sv.sync_bn_skipped, sv.has_scored_candidates(lone), sv.has_scored_candidates(good))
+    sv.model.args.use_gt_lang = False          # target class = arg-max of lang_scores: unknown before the forward
+    out["nogt_%d" % rank] = sv.has_scored_candidates(lone)
+    dist.destroy_process_group()
+
+
+def test_solver_sync_bn_guard_drops_a_batch_on_every_rank_or_none():
+    """Sync-BatchNorm's contract is "every rank runs every BatchNorm layer in every step"; a shard whose scenes have fewer than
+    two candidates would skip the candidate encoder (reference models/attribute_module.py:75-76) and deadlock the others.
+    Solver.sync_bn_guard decides with one MIN all-reduce: gloo, world 2 — the decision is identical on both ranks, a batch
+    is dropped when EITHER rank lacks candidates, and the counter agrees."""
+    mp.set_start_method("spawn", force=True)
+    out = mp.Manager().dict()
+    port = 27000 + os.getpid() % 2000
+    mp.spawn(_guard_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out["guard_0"] == out["guard_1"] == ([True, False, False, True], 2, False, True)
+    assert out["nogt_0"] is True and out["nogt_1"] is True
+
+
 def test_flat_adam_state_dict_is_torch_adam_layout():
     """checkpoint.tar["optimizer_state_dict"] (reference scripts/train.py:114-119 feeds it to
     torch.optim.Adam.load_state_dict): FlatAdam.state_dict() loads into torch.optim.Adam over the same parameter list

@@ -158,6 +158,73 @@ def test_two_ranks_share_one_gpu_product_path(lib, tmp_path):
     assert float((r0["g_ab"] - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+def _many_worker(rank, world, port, out_dir):
+    """Scenario A of _worker for any world size: per-rank seeds, ranks r % 3 == 1 hold no scene with >= 2 candidates (for
+    world 8 that is ranks 1, 4 and 7: three EMPTY ranks), three optimizer steps through the product path."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from instancerefer_amd import _build, _lib, synthetic as S
+    from instancerefer_amd.optim import FlatAdam
+    _build.build_lib()
+    _lib.load()
+    res = {}
+    model = _model(500 + rank, dev).train()
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, module=model)
+    res["p_init"] = opt.flat_p.clone().cpu()
+    empty = rank % 3 == 1
+    cands = [1, 0] if empty else [3, 2 + rank % 2]
+    losses = []
+    for it in range(3):
+        batch = S.make_batch(2, seed=700 + 10 * it + 2 * rank, num_candidates=cands, **KW)
+        loss, g = _step(model, opt, batch, dev)
+        losses.append(loss)
+        if it == 0:
+            res["g_first"] = g.cpu()
+            res["delivered"] = len(opt._direct)
+    torch.cuda.synchronize()
+    res.update(losses=losses, p_final=opt.flat_p.clone().cpu(), steps=list(opt.steps), empty=empty)
+    index = {id(p): n for n, p in model.named_parameters()}
+    res["skipped"] = [index[id(p)] for p, s_ in zip(opt.params, opt.steps) if s_ != 3]
+    torch.save(res, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_ranks_share_one_gpu(lib, tmp_path, world):
+    """BASELINE configs[3]'s world size (8) — and 4 — with the hardware there is: `world` ranks on cuda:0 over gloo through
+    the product path (FlatAdam sinks, lanes, early all-reduce of the encoder ranges). More than one rank has no candidates
+    (ranks 1, 4, 7), so the collective sequence must not depend on the data: every rank ends with bit-identical parameters,
+    nobody skips a parameter another rank had a gradient for, and the empty ranks delivered the scene encoder only."""
+    mp.set_start_method("spawn", force=True)
+    port = 33000 + (os.getpid() * 11 + int(time.time())) % 2000
+    ctx = mp.start_processes(_many_worker, args=(world, port, str(tmp_path)), nprocs=world, join=False, start_method="spawn")
+    deadline = time.time() + 600
+    try:
+        while not ctx.join(timeout=5):
+            if time.time() > deadline:
+                raise TimeoutError("%d-rank run exceeded 600 s" % world)
+    finally:
+        for p in ctx.processes:              # exact PIDs we started, never a pattern
+            if p.is_alive():
+                p.kill()
+    rs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    assert sum(r["empty"] for r in rs) >= (2 if world >= 5 else 1)
+    for r in rs[1:]:
+        assert torch.equal(r["p_init"], rs[0]["p_init"])
+        assert torch.equal(r["g_first"], rs[0]["g_first"])
+        assert torch.equal(r["p_final"], rs[0]["p_final"])
+        assert r["steps"] == rs[0]["steps"] and r["skipped"] == rs[0]["skipped"]
+    assert all(np.isfinite(r["losses"]).all() for r in rs)
+    assert bool(torch.isfinite(rs[0]["p_final"]).all()) and not torch.equal(rs[0]["p_final"], rs[0]["p_init"])
+    assert all(r["delivered"] == (39 if r["empty"] else 78) for r in rs), [r["delivered"] for r in rs]
+    assert not [n for n in rs[0]["skipped"] if n.startswith(("attribute.", "relation.", "scene.", "lang."))], rs[0]["skipped"]
+
+
 def _rccl_worker(rank, world, port, out_dir):
     """One rank, backend nccl (= RCCL): every collective of the product path is issued for real (FlatAdam._force_collectives)
     and the result must equal the run without a process group bit for bit (a one-rank sum is the identity)."""

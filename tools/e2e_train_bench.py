@@ -60,16 +60,24 @@ side = torch.cuda.Stream()
 main = torch.cuda.current_stream()
 
 
+RESIDENT = None      # second leg: the sampled batch of the last end-to-end step, reused as a resident input
+
+
 def stage_launch(step):
     """On the side stream: collect batch step+1's input (enqueued one step ago: its read-back has long arrived), enqueue
     its model-side preparation (candidate voxelisation, pyramids, labels), then enqueue the input pipeline of batch
-    step+2. Nothing here waits for the GPU."""
+    step+2. Nothing here waits for the GPU. Resident leg: the same model-side preparation on a fixed sampled batch."""
     global pend
     with torch.cuda.stream(side):
-        dd = finish(pend)
+        if RESIDENT is not None:
+            dd = dict(RESIDENT)
+            dd["_host"] = dict(RESIDENT["_host"])
+        else:
+            dd = finish(pend)
         dd = model.prepare_launch(dd)
         dd["_loss_prepared"] = prepare_labels(dd, cfg, dev) if "_attr_prepared" in dd else None
-        pend = make_pending(step + 2)
+        if RESIDENT is None:
+            pend = make_pending(step + 2)
     return dd
 
 
@@ -78,31 +86,42 @@ def stage_finish(dd):
         return model.prepare_finish(dd)
 
 
+def loop(cur, n_warm, n_steps):
+    t0, out = None, None
+    for step in range(n_warm + n_steps):
+        if step == n_warm:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        main.wait_stream(side)
+        model.hand_over(cur, main)
+        for t in list(cur.values()) + [cur["irx"].xyz64, cur["irx"].pts32, cur["irx"].centres]:   # made on the side stream
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(main)
+        launched = stage_launch(step)
+        opt.zero_grad()
+        out = get_loss(model(cur), cfg)
+        out["loss"].backward()
+        if os.environ.get("IRX_E2E_FINISH_EARLY") == "1":      # dev A/B: collect the level sizes (and enqueue the tables) before the optimizer
+            cur = stage_finish(launched)
+            opt.backward_step()
+        else:
+            opt.backward_step()
+            cur = stage_finish(launched)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, out, cur
+
+
 with torch.cuda.stream(side):
     pend = make_pending(0)
     cur = model.prepare(finish(pend))
     pend = make_pending(1)
-t0 = None
-for step in range(a.warmup + a.steps):
-    if step == a.warmup:
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-    main.wait_stream(side)
-    model.hand_over(cur, main)
-    for t in list(cur.values()) + [cur["irx"].xyz64, cur["irx"].pts32, cur["irx"].centres]:   # made on the side stream
-        if isinstance(t, torch.Tensor) and t.is_cuda:
-            t.record_stream(main)
-    launched = stage_launch(step)
-    opt.zero_grad()
-    out = get_loss(model(cur), cfg)
-    out["loss"].backward()
-    if os.environ.get("IRX_E2E_FINISH_EARLY") == "1":      # dev A/B: collect the level sizes (and enqueue the tables) before the optimizer
-        cur = stage_finish(launched)
-        opt.backward_step()
-    else:
-        opt.backward_step()
-        cur = stage_finish(launched)
+dt, out, cur = loop(cur, a.warmup, a.steps)
+# the SAME process, model and scene statistics with the input pipeline taken out of the loop (a fixed sampled batch; candidate
+# voxelisation, Morton sort, pyramids and labels still redone every step, as in bench.py's resident-input loop): the ratio
+# of the two is what the input pipeline costs, free of box-to-box and process-to-process differences
+with torch.cuda.stream(side):
+    RESIDENT = finish(pend)
 torch.cuda.synchronize()
-dt = time.perf_counter() - t0
+dt_res, _, _ = loop(cur, max(5, a.warmup // 3), a.steps)
 if a.json:
     import json
     print(json.dumps({"value": B * a.steps / dt, "unit": "scenes/s", "ms_per_step": 1e3 * dt / a.steps, "steps": a.steps,
@@ -110,7 +129,13 @@ if a.json:
                       "resident_scans": a.scans, "vertices_per_scan": a.vertices, "augment": bool(a.augment),
                       "what": "every step builds its batch from scans resident in HBM with the device-side input pipeline "
                               "(sampling, instance split, boxes, both voxelisations), then forward + loss + backward + Adam; "
-                              "nothing cached between steps", "loss": float(out["loss"])}))
+                              "nothing cached between steps", "loss": float(out["loss"]),
+                      "resident_same_process": {"value": B * a.steps / dt_res, "ms_per_step": 1e3 * dt_res / a.steps,
+                                                "what": "same process / model / scenes with one sampled batch reused as a resident "
+                                                        "input (model-side preparation still redone every step)"},
+                      "ratio_to_resident": dt_res / dt}))
 else:
     print("end to end (%s, B=%d, %d pts from %d-vertex scans, input pipeline in the loop): %.1f scenes/s, %.2f ms/step, loss %.4f"
           % (a.dtype, B, a.points, a.vertices, B * a.steps / dt, 1e3 * dt / a.steps, float(out["loss"])))
+    print("  same process, resident sampled batch: %.1f scenes/s, %.2f ms/step -> end to end / resident = %.3f"
+          % (B * a.steps / dt_res, 1e3 * dt_res / a.steps, dt_res / dt))
