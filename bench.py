@@ -694,6 +694,13 @@ def main():
             buf = io.StringIO()
             pstats.Stats(pr, stream=buf).sort_stats(key).print_stats(70)
             sys.stderr.write("\n".join(l[:160] for l in buf.getvalue().splitlines()) + "\n(16 steps)\n")
+    if rank == 0 and os.environ.get("IRX_BENCH_TORCHPROF") == "1":     # dev: per-operator / per-autograd-node host time of the loop
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU]) as prof:
+            for _ in range(8):
+                step_fn(model, resident, args.workload, reducer, opt, state)
+        torch.cuda.synchronize()
+        sys.stderr.write(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=70, max_name_column_width=70) + "\n(8 steps)\n")
     if rank == 0 and os.environ.get("IRX_BENCH_TIMELINE") == "1":
         timeline(model, resident, args, reducer, opt, state, F_)
 

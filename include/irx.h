@@ -498,6 +498,21 @@ int irx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 int irx_knn_batched(const float* sup_xyz, const int32_t* sup_offsets, const float* qry_xyz,
                     const int32_t* qry_batch, int nq, int k, int32_t* nbr_idx, void* stream);
 
+/* The two-layer head MLPs  y = W2 . D(relu(N(W1 x + b1))) + b2  (reference models/attribute_module.py:26-34, relation_module.py:18-27,
+ * scene_module.py:38-42: nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, [Dropout], Linear)) as one operator each way.
+ * x [rows][din], w1 [dh][din], w2 [dout][dh] (nn.Linear layouts); norm: 1 = BatchNorm1d with batch statistics (running_mean /
+ * running_var, when given, are updated with `momentum` and the unbiased variance), 2 = BatchNorm1d with the running statistics,
+ * 3 = LayerNorm over dh; drop_p > 0: dropout of the hidden activations, decided by a counter-based hash of (seed, element).
+ * saved: irx_mlp2_saved_floats(rows, dh) floats the backward reads back (h, a, statistics). Backward: dhid = scratch
+ * [rows][dh]; dx may be NULL; drop_scale = 1 / (1 - drop_p). fp32 FMA tiles, deterministic, any row count. */
+size_t irx_mlp2_saved_floats(int rows, int dh);
+int irx_mlp2_fwd(const float* x, int rows, int din, int dh, int dout, const float* w1, const float* b1, int norm,
+                 const float* gamma, const float* beta, float eps, float* running_mean, float* running_var, float momentum,
+                 float drop_p, unsigned long long seed, const float* w2, const float* b2, float* saved, float* y, void* stream);
+int irx_mlp2_bwd(const float* x, const float* dy, int rows, int din, int dh, int dout, const float* w1, int norm,
+                 const float* gamma, const float* w2, const float* saved, float drop_scale, float* dhid, float* dx, float* dw1,
+                 float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, void* stream);
+
 /* ---- language-instance matching scores ---------------------------------------------------
  * models/attribute_module.py:122-126 (normalize + normalize + row dot), relation_module.py:104-105 and
  * scene_module.py:104-106 (cosine_similarity): score[i] = <a_i, b_j> / (max(|a_i|, eps) * max(|b_j|, eps)) with

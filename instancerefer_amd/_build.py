@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("IRX_LIB_PATH") or os.path.join(CSRC, "libirx.so")   # override: dev-only instrumented builds
-SOURCES = ["irx_coords.hip", "irx_sort.hip", "irx_sched.hip", "irx_spconv.hip", "irx_spconv2.hip", "irx_spconv3.hip", "irx_pairs.hip", "irx_encoder.hip", "irx_stem.hip", "irx_norm.hip", "irx_pool.hip", "irx_match.hip", "irx_input.hip", "irx_gru.hip", "irx_optim.hip", "irx_labels.hip", "irx_project.hip", "irx_edgeconv.hip"]
+SOURCES = ["irx_coords.hip", "irx_sort.hip", "irx_sched.hip", "irx_spconv.hip", "irx_spconv2.hip", "irx_spconv3.hip", "irx_pairs.hip", "irx_encoder.hip", "irx_stem.hip", "irx_norm.hip", "irx_pool.hip", "irx_match.hip", "irx_mlp.hip", "irx_input.hip", "irx_gru.hip", "irx_optim.hip", "irx_labels.hip", "irx_project.hip", "irx_edgeconv.hip"]
 HEADERS = ["irx_common.h", os.path.join("..", "..", "include", "irx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-pthread"]

@@ -13,7 +13,7 @@ import torch.nn as nn
 from .basic_blocks import SparseConvEncoder
 from .data import idx_tensor, selection_on_device, upload_instances
 from .sparse.encoder_fn import lane_of, lane_wait
-from .dense import cosine_rows
+from .dense import cosine_rows, mlp2
 from .sparse import nn as spnn
 from .sparse.utils import voxelize, voxelize_launch
 
@@ -89,7 +89,7 @@ class AttributeModule(nn.Module):
 
     def forward(self, data_dict):
         lang_feats = data_dict['lang_attr_feats']
-        lang_feats = self.lang_emb_fc(lang_feats)                             # (B, h_dim)
+        lang_feats = mlp2(self.lang_emb_fc, lang_feats)                       # (B, h_dim)
 
         if '_attr_prepared' in data_dict:
             st, sel = data_dict.pop('_attr_prepared')
@@ -115,7 +115,7 @@ class AttributeModule(nn.Module):
         lane_wait(lane_of(self.net))                      # the encoder may be issued by a library thread
         feats = self.pooling(feats)                       # (Nc, 128)
         data_dict['obj_feats'] = feats
-        feats = self.vis_emb_fc(feats)
+        feats = mlp2(self.vis_emb_fc, feats)
         sd = selection_on_device(sel, upload_instances(data_dict), dev)
         data_dict['_sel_dev'] = sd                         # the scene head reuses cand_scene
         # normalize(vis) . normalize(lang)[scene of the candidate]  ==  a clamped cosine (F.normalize eps = 1e-12)

@@ -1,0 +1,378 @@
+// irx_mlp.hip — the two-layer head MLPs of the matching modules as ONE operator each way:
+//     y = W2 . D( relu( N( W1 x + b1 ) ) ) + b2,     N = BatchNorm1d (train / eval) or LayerNorm, D = dropout (optional)
+// (reference models/attribute_module.py:26-34 lang_emb_fc / vis_emb_fc, relation_module.py:18-27, scene_module.py:38-42
+// vis_emb_fc1 / lang_emb_fc / cls: nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, [Dropout], Linear) on (B, 256) or
+// (Nc, 128) rows).  Through ATen each of the seven is ~8 forward and ~25 backward operator dispatches on tensors of a few
+// KB — with the bf16 step host-bound that is ~1 ms per step of pure dispatch.  Here: 2 launches forward, 2 (BatchNorm) or 3
+// (LayerNorm) backward, issued by one C-ABI call each; deterministic (no atomics); any row count.
+//
+// The GEMMs are 16..512 rows x 128..256: far too small for the matrix core to matter (8 MFLOP), so they run as LDS-tiled
+// fp32 FMA loops; a workgroup owns a block of 32 hidden (or output) columns for ALL rows, which makes every per-column
+// reduction over the rows (BatchNorm statistics, d gamma, d beta, d bias) local to one workgroup.
+#include "irx_common.h"
+
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+#define ML_TR 64   // rows per tile
+#define ML_TC 32   // columns per tile
+#define ML_TK 32   // reduction chunk
+
+// C[i][j] (i < 64, j < 32) += sum_k A(i, k) * B(j, k) for k in [0, K): both operands are functors staged through LDS in
+// chunks of 32; thread t owns column j = t & 31 and rows (t >> 5) + 8 m.  acc[m] accumulates; all 256 threads take part.
+template <typename FA, typename FB>
+__device__ __forceinline__ void ml_tile(FA A, FB B, int K, float (&acc)[8], float (*sA)[ML_TK + 1], float (*sB)[ML_TK + 1]) {
+  const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
+  for (int k0 = 0; k0 < K; k0 += ML_TK) {
+    __syncthreads();
+    for (int e = t; e < ML_TR * ML_TK; e += 256) {
+      const int i = e / ML_TK, k = e % ML_TK;
+      sA[i][k] = (k0 + k < K) ? A(i, k0 + k) : 0.f;
+    }
+    for (int e = t; e < ML_TC * ML_TK; e += 256) {
+      const int jj = e / ML_TK, k = e % ML_TK;
+      sB[jj][k] = (k0 + k < K) ? B(jj, k0 + k) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < ML_TK; ++k) {
+      const float b = sB[j][k];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[m] = fmaf(sA[i0 + 8 * m][k], b, acc[m]);
+    }
+  }
+}
+
+// block-wide column sums: v[m] of thread (j, i0) for rows i0 + 8 m -> total over the 64 rows of the tile, valid in threads
+// with i0 == 0 (returned to every thread through LDS)
+__device__ __forceinline__ float ml_colsum(float part, float (*red)[ML_TC]) {
+  const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
+  __syncthreads();
+  red[i0][j] = part;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s += red[q][j];
+  return s;
+}
+
+enum { ML_BN_TRAIN = 1, ML_BN_EVAL = 2, ML_LN = 3 };
+
+// Dropout without a mask tensor: element o of call `seed` is kept iff a counter-based hash of (seed, o) falls above p — the
+// same decision wherever it is evaluated (forward 1 / forward 2 recompute it), scaled by 1 / (1 - p) like F.dropout. The
+// backward never needs it again: a kept, positive activation is a > 0.  (Another random stream than torch's Philox: dropout
+// has no parity requirement beyond its distribution; tests run with p = 0.)
+__device__ __forceinline__ float ml_drop(float v, float p, float scale, unsigned long long seed, size_t o) {
+  if (p <= 0.f) return v;
+  const unsigned u = (unsigned)(irx_mix64(seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(o + 1))) >> 40);   // 24 bits
+  return ((float)u * (1.0f / 16777216.0f) >= p) ? v * scale : 0.f;
+}
+
+// ---- forward 1: h = x W1^T + b1 for this block's 32 hidden columns, all rows; BatchNorm: statistics + a = D(relu(N(h))) ----
+__global__ __launch_bounds__(256) void k_mlp_fwd1(const float* __restrict__ x, int rows, int din, int dh,
+                                                  const float* __restrict__ w1, const float* __restrict__ b1, int norm,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                  float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                                  float drop_p, unsigned long long seed, float* __restrict__ h,
+                                                  float* __restrict__ stat, float* __restrict__ a) {
+  __shared__ float sA[ML_TR][ML_TK + 1], sB[ML_TC][ML_TK + 1], red[8][ML_TC];
+  const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
+  const int c = blockIdx.x * ML_TC + j;
+  const bool cv = c < dh;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r0 = 0; r0 < rows; r0 += ML_TR) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ml_tile([&](int i, int k) { return (r0 + i < rows) ? x[(size_t)(r0 + i) * din + k] : 0.f; },
+            [&](int jj, int k) { const int cc = blockIdx.x * ML_TC + jj; return cc < dh ? w1[(size_t)cc * din + k] : 0.f; },
+            din, acc, sA, sB);
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int r = r0 + i0 + 8 * m;
+      if (r < rows && cv) {
+        const float v = acc[m] + b1[c];
+        h[(size_t)r * dh + c] = v;
+        p1 += v;
+        p2 = fmaf(v, v, p2);
+      }
+    }
+    if (norm == ML_BN_TRAIN) {
+      s1 += (double)ml_colsum(p1, red);
+      s2 += (double)ml_colsum(p2, red);
+    }
+  }
+  if (norm == ML_LN) return;                          // row statistics need the whole row: forward 2
+  float mean, invstd;
+  if (norm == ML_BN_TRAIN) {
+    // two-pass variance over this block's own h (E[x^2] - mean^2 loses everything when two rows are nearly equal)
+    const double m = s1 / rows;
+    float pv = 0.f;
+    if (cv)
+      for (int r = i0; r < rows; r += 8) {             // (the entries of h this thread stored above)
+        const float d = h[(size_t)r * dh + c] - (float)m;
+        pv = fmaf(d, d, pv);
+      }
+    const double var = (double)ml_colsum(pv, red) / rows;
+    (void)s2;
+    mean = (float)m;
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (cv && i0 == 0 && rmean) {                     // nn.BatchNorm1d: running statistics with the unbiased variance
+      const double unb = rows > 1 ? var * rows / (rows - 1) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = cv ? rmean[c] : 0.f;
+    invstd = cv ? rsqrtf(rvar[c] + eps) : 0.f;
+  }
+  if (cv && i0 == 0) {
+    stat[c] = mean;
+    stat[dh + c] = invstd;
+  }
+  if (!cv) return;
+  const float g = gamma[c] * invstd, bsh = beta[c] - mean * g;
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int r = i0; r < rows; r += 8) {                // (rows i0 + 8 m: exactly the entries of h this thread stored above)
+    const size_t o = (size_t)r * dh + c;
+    a[o] = ml_drop(fmaxf(fmaf(h[o], g, bsh), 0.f), drop_p, dscale, seed, o);
+  }
+}
+
+// ---- forward 2: y = a W2^T + b2 for this block's 32 output columns; LayerNorm: row statistics and a are made here ----
+__global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, int rows, int dh, int dout, int norm,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                  float drop_p, unsigned long long seed, const float* __restrict__ w2,
+                                                  const float* __restrict__ b2, float* __restrict__ stat,
+                                                  float* __restrict__ a, float* __restrict__ y) {
+  __shared__ float sA[ML_TR][ML_TK + 1], sB[ML_TC][ML_TK + 1];
+  __shared__ float sMean[ML_TR], sInv[ML_TR];
+  const int t = threadIdx.x, j = t & 31, i0 = t >> 5, lane = t & 63, wave = t >> 6;
+  const int c = blockIdx.x * ML_TC + j;
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int r0 = 0; r0 < rows; r0 += ML_TR) {
+    if (norm == ML_LN) {                              // every block recomputes the tile's row statistics (dh <= 512 floats a row)
+      __syncthreads();
+      for (int i = wave; i < ML_TR; i += 4) {
+        const int r = r0 + i;
+        float p1 = 0.f, p2 = 0.f;
+        if (r < rows)
+          for (int k = lane; k < dh; k += 64) { const float v = h[(size_t)r * dh + k]; p1 += v; p2 = fmaf(v, v, p2); }
+        for (int off = 32; off > 0; off >>= 1) { p1 += __shfl_xor(p1, off); p2 += __shfl_xor(p2, off); }
+        if (lane == 0) {
+          const float m = p1 / dh, var = fmaxf(p2 / dh - m * m, 0.f);
+          sMean[i] = m;
+          sInv[i] = rsqrtf(var + eps);
+          if (blockIdx.x == 0 && r < rows) { stat[2 * r] = m; stat[2 * r + 1] = sInv[i]; }
+        }
+      }
+      __syncthreads();
+      if (blockIdx.x == 0) {                          // a (needed by the backward) is written once
+        for (int e = t; e < ML_TR * dh; e += 256) {
+          const int i = e / dh, k = e % dh, r = r0 + i;
+          if (r < rows) {
+            const size_t o = (size_t)r * dh + k;
+            a[o] = ml_drop(fmaxf(fmaf((h[o] - sMean[i]) * sInv[i], gamma[k], beta[k]), 0.f), drop_p, dscale, seed, o);
+          }
+        }
+      }
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ml_tile([&](int i, int k) {
+              const int r = r0 + i;
+              if (r >= rows) return 0.f;
+              const size_t o = (size_t)r * dh + k;
+              if (norm != ML_LN) return a[o];
+              return ml_drop(fmaxf(fmaf((h[o] - sMean[i]) * sInv[i], gamma[k], beta[k]), 0.f), drop_p, dscale, seed, o);
+            },
+            [&](int jj, int k) { const int cc = blockIdx.x * ML_TC + jj; return cc < dout ? w2[(size_t)cc * dh + k] : 0.f; },
+            dh, acc, sA, sB);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int r = r0 + i0 + 8 * m;
+      if (r < rows && c < dout) y[(size_t)r * dout + c] = acc[m] + b2[c];
+    }
+  }
+}
+
+// ---- backward 1 (block = 32 hidden columns, all rows): da = dy W2, dz = relu'/dropout, d gamma, d beta, dW2 rows, db2;
+//      BatchNorm: dh complete; LayerNorm: g = dz * gamma is left in dh for backward 2 ----
+__global__ __launch_bounds__(256) void k_mlp_bwd1(const float* __restrict__ dy, int rows, int dh, int dout, int norm,
+                                                  const float* __restrict__ gamma, const float* __restrict__ w2,
+                                                  const float* __restrict__ h, const float* __restrict__ stat,
+                                                  const float* __restrict__ a, float drop_scale, float* __restrict__ dhid,
+                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                  float* __restrict__ dw2, float* __restrict__ db2) {
+  __shared__ float sA[ML_TR][ML_TK + 1], sB[ML_TC][ML_TK + 1], red[8][ML_TC];
+  const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
+  const int c = blockIdx.x * ML_TC + j;
+  const bool cv = c < dh;
+  const float mean_c = (norm != ML_LN && cv) ? stat[c] : 0.f, inv_c = (norm != ML_LN && cv) ? stat[dh + c] : 0.f;
+  float sg = 0.f, sb = 0.f;
+  for (int r0 = 0; r0 < rows; r0 += ML_TR) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ml_tile([&](int i, int k) { return (r0 + i < rows) ? dy[(size_t)(r0 + i) * dout + k] : 0.f; },
+            [&](int jj, int k) { const int cc = blockIdx.x * ML_TC + jj; return cc < dh ? w2[(size_t)k * dh + cc] : 0.f; },
+            dout, acc, sA, sB);
+    float pg = 0.f, pb = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int r = r0 + i0 + 8 * m;
+      if (r < rows && cv) {
+        const size_t o = (size_t)r * dh + c;
+        const float dz = a[o] > 0.f ? acc[m] * drop_scale : 0.f;
+        const float xh = (norm == ML_LN) ? (h[o] - stat[2 * r]) * stat[2 * r + 1] : (h[o] - mean_c) * inv_c;
+        pg = fmaf(dz, xh, pg);
+        pb += dz;
+        dhid[o] = (norm == ML_LN) ? dz * gamma[c] : dz;      // (BatchNorm: finished below)
+      }
+    }
+    sg += ml_colsum(pg, red);
+    sb += ml_colsum(pb, red);
+  }
+  if (cv && i0 == 0) {
+    dgamma[c] = sg;
+    dbeta[c] = sb;
+  }
+  if (norm != ML_LN && cv) {                          // (rows i0 + 8 m: this thread's own dhid entries)
+    const float gi = gamma[c] * inv_c;
+    const float kb = (norm == ML_BN_TRAIN) ? sb / rows : 0.f, kg = (norm == ML_BN_TRAIN) ? sg / rows : 0.f;
+    for (int r = i0; r < rows; r += 8) {
+      const size_t o = (size_t)r * dh + c;
+      const float xh = (h[o] - mean_c) * inv_c;
+      dhid[o] = gi * (dhid[o] - kb - xh * kg);
+    }
+  }
+  // dW2[o][c] = sum_r dy[r][o] a[r][c] for this block's columns c, every output o (tiles of 64 outputs, reduction over rows)
+  for (int o0 = 0; o0 < dout; o0 += ML_TR) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ml_tile([&](int i, int k) { return (o0 + i < dout) ? dy[(size_t)k * dout + o0 + i] : 0.f; },
+            [&](int jj, int k) { const int cc = blockIdx.x * ML_TC + jj; return cc < dh ? a[(size_t)k * dh + cc] : 0.f; },
+            rows, acc, sA, sB);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int o = o0 + i0 + 8 * m;
+      if (o < dout && cv) dw2[(size_t)o * dh + c] = acc[m];
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int o = t; o < dout; o += 256) {
+      float s = 0.f;
+      for (int r = 0; r < rows; ++r) s += dy[(size_t)r * dout + o];
+      db2[o] = s;
+    }
+}
+
+// ---- backward 2 (LayerNorm): one wave per row: dh = invstd (g - mean(g) - xhat mean(g xhat)) ----
+__global__ __launch_bounds__(256) void k_mlp_bwd2_ln(int rows, int dh, const float* __restrict__ h, const float* __restrict__ stat,
+                                                     float* __restrict__ dhid) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float m = stat[2 * r], inv = stat[2 * r + 1];
+  float p1 = 0.f, p2 = 0.f;
+  for (int k = lane; k < dh; k += 64) {
+    const size_t o = (size_t)r * dh + k;
+    const float g = dhid[o], xh = (h[o] - m) * inv;
+    p1 += g;
+    p2 = fmaf(g, xh, p2);
+  }
+  for (int off = 32; off > 0; off >>= 1) { p1 += __shfl_xor(p1, off); p2 += __shfl_xor(p2, off); }
+  p1 /= dh;
+  p2 /= dh;
+  for (int k = lane; k < dh; k += 64) {
+    const size_t o = (size_t)r * dh + k;
+    const float xh = (h[o] - m) * inv;
+    dhid[o] = inv * (dhid[o] - p1 - xh * p2);
+  }
+}
+
+// ---- backward 3: blocks [0, nW): dW1 tile (64 hidden rows x 32 input columns, reduction over rows) + db1;
+//      blocks [nW, nW + nX): dx tile (64 rows x 32 input columns, reduction over hidden) ----
+__global__ __launch_bounds__(256) void k_mlp_bwd3(const float* __restrict__ x, int rows, int din, int dh,
+                                                  const float* __restrict__ w1, const float* __restrict__ dhid,
+                                                  float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dx,
+                                                  int nW) {
+  __shared__ float sA[ML_TR][ML_TK + 1], sB[ML_TC][ML_TK + 1];
+  const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
+  const int kblocks = (din + ML_TC - 1) / ML_TC;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if ((int)blockIdx.x < nW) {
+    const int c0 = ((int)blockIdx.x / kblocks) * ML_TR, k0 = ((int)blockIdx.x % kblocks) * ML_TC;
+    ml_tile([&](int i, int r) { return (c0 + i < dh) ? dhid[(size_t)r * dh + c0 + i] : 0.f; },
+            [&](int jj, int r) { return (k0 + jj < din) ? x[(size_t)r * din + k0 + jj] : 0.f; },
+            rows, acc, sA, sB);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int c = c0 + i0 + 8 * m;
+      if (c < dh && k0 + j < din) dw1[(size_t)c * din + k0 + j] = acc[m];
+    }
+    if (k0 == 0)
+      for (int c = c0 + t; c < c0 + ML_TR && c < dh; c += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += dhid[(size_t)r * dh + c];
+        db1[c] = s;
+      }
+  } else if (dx) {
+    const int b = (int)blockIdx.x - nW;
+    const int r0 = (b / kblocks) * ML_TR, k0 = (b % kblocks) * ML_TC;
+    ml_tile([&](int i, int c) { return (r0 + i < rows) ? dhid[(size_t)(r0 + i) * dh + c] : 0.f; },
+            [&](int jj, int c) { return (k0 + jj < din) ? w1[(size_t)c * din + k0 + jj] : 0.f; },
+            dh, acc, sA, sB);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int r = r0 + i0 + 8 * m;
+      if (r < rows && k0 + j < din) dx[(size_t)r * din + k0 + j] = acc[m];
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------- host ---
+extern "C" size_t irx_mlp2_saved_floats(int rows, int dh) {
+  // h [rows][dh], a [rows][dh], stat (2 dh for BatchNorm, 2 rows for LayerNorm: the larger is reserved)
+  return (size_t)2 * rows * dh + (size_t)2 * (rows > dh ? rows : dh);
+}
+
+extern "C" int irx_mlp2_fwd(const float* x, int rows, int din, int dh, int dout, const float* w1, const float* b1, int norm,
+                            const float* gamma, const float* beta, float eps, float* running_mean, float* running_var,
+                            float momentum, float drop_p, unsigned long long seed, const float* w2, const float* b2,
+                            float* saved, float* y, void* stream) {
+  IRX_REQUIRE(rows >= 0 && din >= 1 && dh >= 1 && dout >= 1, "irx_mlp2_fwd: bad sizes");
+  IRX_REQUIRE(norm >= ML_BN_TRAIN && norm <= ML_LN, "irx_mlp2_fwd: norm %d is not 1 (BatchNorm train), 2 (eval) or 3 (LayerNorm)", norm);
+  if (rows == 0) return IRX_OK;
+  IRX_REQUIRE(x && w1 && b1 && gamma && beta && w2 && b2 && saved && y, "irx_mlp2_fwd: null pointer");
+  IRX_REQUIRE(norm != ML_BN_EVAL || (running_mean && running_var), "irx_mlp2_fwd: BatchNorm eval needs the running statistics");
+  IRX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "irx_mlp2_fwd: dropout probability %f outside [0, 1)", (double)drop_p);
+  IRX_REQUIRE(norm != ML_BN_TRAIN || rows > 1, "irx_mlp2_fwd: train-mode BatchNorm1d needs more than one row");
+  float* h = saved;
+  float* a = saved + (size_t)rows * dh;
+  float* stat = a + (size_t)rows * dh;
+  k_mlp_fwd1<<<irx_cdiv(dh, ML_TC), 256, 0, S(stream)>>>(x, rows, din, dh, w1, b1, norm, gamma, beta, eps, running_mean,
+                                                          running_var, momentum, drop_p, seed, h, stat, a);
+  IRX_CHECK_LAUNCH("irx_mlp2_fwd(1)");
+  k_mlp_fwd2<<<irx_cdiv(dout, ML_TC), 256, 0, S(stream)>>>(h, rows, dh, dout, norm, gamma, beta, eps, drop_p, seed, w2, b2, stat, a, y);
+  IRX_CHECK_LAUNCH("irx_mlp2_fwd(2)");
+  return IRX_OK;
+}
+
+// dhid: scratch [rows][dh]. dx may be NULL (no input gradient wanted).
+extern "C" int irx_mlp2_bwd(const float* x, const float* dy, int rows, int din, int dh, int dout, const float* w1, int norm,
+                            const float* gamma, const float* w2, const float* saved, float drop_scale, float* dhid, float* dx,
+                            float* dw1, float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, void* stream) {
+  IRX_REQUIRE(rows >= 1 && din >= 1 && dh >= 1 && dout >= 1, "irx_mlp2_bwd: bad sizes");
+  IRX_REQUIRE(norm >= ML_BN_TRAIN && norm <= ML_LN, "irx_mlp2_bwd: bad norm %d", norm);
+  IRX_REQUIRE(x && dy && w1 && gamma && w2 && saved && dhid && dw1 && db1 && dgamma && dbeta && dw2 && db2,
+              "irx_mlp2_bwd: null pointer");
+  const float* h = saved;
+  const float* a = saved + (size_t)rows * dh;
+  const float* stat = a + (size_t)rows * dh;
+  k_mlp_bwd1<<<irx_cdiv(dh, ML_TC), 256, 0, S(stream)>>>(dy, rows, dh, dout, norm, gamma, w2, h, stat, a, drop_scale, dhid, dgamma,
+                                                          dbeta, dw2, db2);
+  IRX_CHECK_LAUNCH("irx_mlp2_bwd(1)");
+  if (norm == ML_LN) {
+    k_mlp_bwd2_ln<<<irx_cdiv(rows, 4), 256, 0, S(stream)>>>(rows, dh, h, stat, dhid);
+    IRX_CHECK_LAUNCH("irx_mlp2_bwd(2)");
+  }
+  const int kblocks = irx_cdiv(din, ML_TC);
+  const int nW = irx_cdiv(dh, ML_TR) * kblocks, nX = dx ? irx_cdiv(rows, ML_TR) * kblocks : 0;
+  k_mlp_bwd3<<<nW + nX, 256, 0, S(stream)>>>(x, rows, din, dh, w1, dhid, dw1, db1, dx, nW);
+  IRX_CHECK_LAUNCH("irx_mlp2_bwd(3)");
+  return IRX_OK;
+}

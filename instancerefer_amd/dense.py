@@ -5,6 +5,8 @@
 `gru_packed(gru, x, lengths)` reproduces `pad_packed_sequence(gru(pack_padded_sequence(x, lengths)))` of an
 `nn.GRU(batch_first=True)` (reference models/lang_module.py:53-57) using that module's own parameters
 (state-dict keys unchanged)."""
+import os
+
 import torch
 
 from . import _lib
@@ -140,3 +142,113 @@ class ContrastiveFn(torch.autograd.Function):
                   _lib.stream_ptr())
         return ds, ds, ds, None, None, None, None, None
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The head MLPs nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, [Dropout], Linear) as ONE autograd node (csrc/irx_mlp.hip)
+class MLP2Fn(torch.autograd.Function):
+    """y = W2 . D(relu(N(W1 x + b1))) + b2 — irx_mlp2_fwd / irx_mlp2_bwd (include/irx.h): one C-ABI call each way instead of
+    ~8 forward and ~25 backward ATen dispatches. norm: 1 BatchNorm1d (batch statistics), 2 BatchNorm1d (running statistics),
+    3 LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, gamma, beta, w2, b2, norm, eps, rmean, rvar, momentum, drop_p, seed):
+        x = x.contiguous().float()
+        rows, din = x.shape
+        dh, dout = w1.shape[0], w2.shape[0]
+        y = torch.empty((rows, dout), dtype=_f32, device=x.device)
+        saved = torch.empty(int(_lib.load().irx_mlp2_saved_floats(rows, dh)), dtype=_f32, device=x.device)
+        _lib.call("irx_mlp2_fwd", _lib.ptr(x), rows, din, dh, dout, _lib.ptr(w1), _lib.ptr(b1), norm, _lib.ptr(gamma),
+                  _lib.ptr(beta), float(eps), _lib.ptr(rmean), _lib.ptr(rvar), float(momentum), float(drop_p), int(seed),
+                  _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(saved), _lib.ptr(y), _lib.stream_ptr())
+        ctx.save_for_backward(x, w1, gamma, w2, saved)
+        ctx.cfg = (norm, float(drop_p))
+        params = (w1, b1, gamma, beta, w2, b2)
+        ctx.params = params if all(getattr(p, "_irx_sink", None) is not None for p in params) else None
+        ctx.key = ("mlp2", id(w1))
+        ctx.stream = torch.cuda.current_stream()
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, gamma, w2, saved = ctx.saved_tensors
+        norm, drop_p = ctx.cfg
+        rows, din = x.shape
+        dh, dout = w1.shape[0], w2.shape[0]
+        dy = dy.contiguous().float()
+        want_dx = ctx.needs_input_grad[0]
+        # Gradient sink (optim.FlatAdam): the six parameter gradients go straight into the optimizer's flat gradient buffer —
+        # no AccumulateGrad nodes, no .grad tensors, no copy at gather time. Only when this node runs on the optimizer's
+        # stream (the heads do: autograd replays them on the main stream) and every parameter is the optimizer's.
+        slots = None
+        sink = getattr(w1, "_irx_sink", None)
+        if sink is not None and ctx.params is not None and torch.cuda.current_stream() == ctx.stream:
+            slots = sink[0].sink_slots(ctx.key, ctx.params)
+        scratch = torch.empty(rows * (dh + (din if want_dx else 0)), dtype=_f32, device=x.device)
+        base = scratch.data_ptr()
+        dx_ptr = base + 4 * rows * dh if want_dx else None
+        if slots is not None:
+            gp = [t.data_ptr() for t in slots]           # order of ctx.params: w1, b1, gamma, beta, w2, b2
+            grads = (None,) * 6
+        else:
+            sizes = (dh * din, dh, dh, dh, dout * dh, dout)
+            buf = torch.empty(sum(sizes), dtype=_f32, device=x.device)
+            gp, grads, off = [], [], 0
+            for n, shape in zip(sizes, ((dh, din), (dh,), (dh,), (dh,), (dout, dh), (dout,))):
+                gp.append(buf.data_ptr() + 4 * off)
+                grads.append(buf[off:off + n].view(shape))
+                off += n
+        _lib.call("irx_mlp2_bwd", x.data_ptr(), dy.data_ptr(), rows, din, dh, dout, w1.data_ptr(), norm, gamma.data_ptr(),
+                  w2.data_ptr(), saved.data_ptr(), 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0, base, dx_ptr,
+                  gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], _lib.stream_ptr())
+        if slots is not None:
+            sink[0].sink_delivered_inline(ctx.key, ctx.params)
+        dx = scratch[rows * dh:].view(rows, din) if want_dx else None
+        return (dx,) + tuple(grads) + (None,) * 7
+
+
+FUSED_MLP2 = os.environ.get("IRX_FUSED_MLP2", "1") != "0"      # dev A/B switch
+
+
+def _dropout_seed(device):
+    """A 64-bit key for one dropout call, drawn host-side from the device's default generator: (seed, Philox offset), and the
+    offset is advanced like a real dropout kernel would — so torch.manual_seed() reproduces the masks, two calls never share
+    one, and no GPU work or sync is involved."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    off = gen.get_offset()
+    gen.set_offset(off + 4)
+    return (gen.initial_seed() * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03 + 1) & 0xFFFFFFFFFFFFFFFF
+
+
+def mlp2(seq, x):
+    """Apply a head MLP `seq` = nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, [Dropout], Linear) to (rows, C) device rows
+    through the fused operator; anything else (host tensors, another layout, sync-BatchNorm over more than one rank, a
+    single row in training) goes through the module itself. Same parameters, buffers and state-dict keys either way."""
+    import torch.nn as nn
+    mods = list(seq)
+    ok = (FUSED_MLP2 and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and len(mods) in (4, 5) and isinstance(mods[0], nn.Linear)
+          and isinstance(mods[1], (nn.BatchNorm1d, nn.LayerNorm)) and isinstance(mods[2], nn.ReLU) and isinstance(mods[-1], nn.Linear)
+          and (len(mods) == 4 or isinstance(mods[3], nn.Dropout)) and mods[0].bias is not None and mods[-1].bias is not None)
+    if ok and isinstance(mods[1], nn.BatchNorm1d):
+        bn = mods[1]
+        if getattr(bn, "_irx_sync", False):
+            import torch.distributed as dist
+            ok = not (bn.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        ok = ok and bn.affine and bn.track_running_stats and bn.momentum is not None and not (bn.training and x.shape[0] < 2)
+    elif ok:
+        ln = mods[1]
+        ok = ln.elementwise_affine and len(ln.normalized_shape) == 1
+    if not ok:
+        return seq(x)
+    lin1, nrm, lin2 = mods[0], mods[1], mods[-1]
+    drop_p = mods[3].p if (len(mods) == 5 and mods[3].training) else 0.0
+    if isinstance(nrm, nn.BatchNorm1d):
+        norm = 1 if nrm.training else 2
+        rmean, rvar, momentum = nrm.running_mean, nrm.running_var, nrm.momentum
+        if nrm.training:
+            nrm.num_batches_tracked += 1
+    else:
+        norm, rmean, rvar, momentum = 3, None, None, 0.0
+    seed = _dropout_seed(x.device) if drop_p > 0 else 0
+    return MLP2Fn.apply(x, lin1.weight, lin1.bias, nrm.weight, nrm.bias, lin2.weight, lin2.bias, norm, nrm.eps, rmean, rvar,
+                        momentum, drop_p, seed)

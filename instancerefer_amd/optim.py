@@ -155,6 +155,13 @@ class FlatAdam:
         except KeyError:
             return None
 
+    def sink_delivered_inline(self, key, params):
+        """sink_delivered for a producer that enqueued its kernels on the CURRENT stream and whose stream is the one
+        gather_grads() / the optimizer will run on (the heads' fused MLP nodes: autograd replays them on the main stream): the
+        stream order already guarantees the slots are written before they are read — no event, nothing pending."""
+        self._direct_groups.add(key)
+        self._direct.update(self._index[id(p)] for p in params)
+
     def sink_delivered(self, key, params, lane=None):
         """Called by the producer right after it enqueued the kernels that write the slots (on ITS current stream, which
         for the scene encoder is not the optimizer's): an event makes gather_grads() wait for them. (Autograd only

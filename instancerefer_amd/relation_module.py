@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from .basic_blocks import DynamicEdgeConv
 from .data import idx_tensor, selection_on_device, upload_instances
-from .dense import cosine_rows
+from .dense import cosine_rows, mlp2
 from .sparse import functional as F_
 
 
@@ -60,7 +60,7 @@ class RelationModule(nn.Module):
         return data_dict
 
     def forward(self, data_dict):
-        lang_feats = self.lang_emb_fc(data_dict['lang_rel_feats'])           # (B, h_dim)
+        lang_feats = mlp2(self.lang_emb_fc, data_dict['lang_rel_feats'])     # (B, h_dim)
         if '_rel_prepared' in data_dict:
             prep = data_dict.pop('_rel_prepared')[0]
         else:
@@ -76,6 +76,6 @@ class RelationModule(nn.Module):
         sel, sd, centres, feats = prep
         # batch ids of the support rows are renumbered over the kept scenes (contiguous segments)
         feats = self.gcn(centres, sd['support_seg'], sd['query_in_support'], feats, support_offsets=sd['support_offsets'])
-        feats = self.vis_emb_fc(feats)
+        feats = mlp2(self.vis_emb_fc, feats)
         data_dict['relation_scores'] = cosine_rows(feats, lang_feats, sd['cand_scene'])      # F.cosine_similarity, eps 1e-8
         return data_dict

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .basic_blocks import BEVEncoder, SparseCrop, ToDenseBEVConvolution, batchnorm_rows, conv2d_rows
 from .data import idx_tensor
-from .dense import cosine_rows
+from .dense import cosine_rows, mlp2
 from .sparse.encoder_fn import lane_of, lane_wait
 from .sparse import nn as spnn
 
@@ -76,13 +76,13 @@ class SceneModule(nn.Module):
         rows = conv2d_rows(self.vis_emb_fc[4], rows, batch_size, nx - 2, ny - 2)  # -> (B*11*21, D)
         h, w = nx - 4, ny - 4
         feats = rows.view(batch_size, h * w, self.h_dim)                        # (B, n_vis, D)
-        lang_feats = self.lang_emb_fc(lang_feats).unsqueeze(2)
+        lang_feats = mlp2(self.lang_emb_fc, lang_feats).unsqueeze(2)
         atten = torch.bmm(feats, lang_feats) / math.sqrt(feats.shape[2])
         atten = torch.softmax(atten.squeeze(2), dim=1)
         data_dict['vis_atten'] = atten.reshape(batch_size, h, w)
 
         scene_feats = torch.sum(feats * atten.unsqueeze(2), dim=1)
-        data_dict['seg_scores'] = self.cls(scene_feats)
+        data_dict['seg_scores'] = mlp2(self.cls, scene_feats)
 
         cand_scene = [i for i in range(batch_size) for _ in range(len(pred_obb_batch[i]))
                       if len(pred_obb_batch[i]) >= 2]
@@ -91,6 +91,6 @@ class SceneModule(nn.Module):
             return data_dict
         sd = data_dict.get('_sel_dev')
         cs = sd['cand_scene'] if sd is not None else idx_tensor(cand_scene, scene_feats.device)
-        obj = self.vis_emb_fc1(obj_feats_flatten)
+        obj = mlp2(self.vis_emb_fc1, obj_feats_flatten)
         data_dict['scene_scores'] = cosine_rows(obj, scene_feats, cs)                        # F.cosine_similarity, eps 1e-8
         return data_dict

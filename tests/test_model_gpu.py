@@ -475,7 +475,8 @@ def test_gradient_sink_equals_autograd_accumulation(lib):
         delivered = len(opt._direct)
         torch.cuda.synchronize()
         out[mode] = (losses, opt.flat_p.clone(), delivered)
-    assert out["sink"][2] == 78 and out["autograd"][2] == 0          # 2 encoders x 13 layers x (kernel, gamma, beta)
+    # 2 encoders x 13 layers x (kernel, gamma, beta) + the 7 fused head MLPs x (2 Linear + 1 norm) x (weight, bias)
+    assert out["sink"][2] == 78 + 42 and out["autograd"][2] == 0
     assert out["sink"][0] == out["autograd"][0], (out["sink"][0], out["autograd"][0])
     assert torch.equal(out["sink"][1], out["autograd"][1])
 

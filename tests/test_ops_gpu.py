@@ -402,6 +402,85 @@ def test_lang_module_constructor_variants_vs_reference_fixture(lib, variant):
         assert abs(float(np.linalg.norm(g.astype(np.float64))) - en) <= 1e-4 * max(en, 1e-4 * top), n
 
 
+@pytest.mark.parametrize("rows,din,dh,dout,norm,train", [(16, 256, 256, 256, "bn", True), (64, 128, 256, 256, "ln", True),
+                                                         (200, 128, 128, 128, "ln", True), (16, 128, 128, 9, "bn", True),
+                                                         (33, 256, 128, 128, "bn", False), (2, 256, 256, 256, "bn", True),
+                                                         (1, 128, 128, 128, "ln", True), (513, 128, 128, 128, "bn", True)])
+def test_fused_head_mlp_equals_the_sequential_module(lib, rows, din, dh, dout, norm, train):
+    """The head MLPs nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, Dropout, Linear) (reference
+    models/attribute_module.py:26-34, relation_module.py:18-27, scene_module.py:38-42) through the fused operator
+    (dense.mlp2 -> irx_mlp2_fwd / _bwd, csrc/irx_mlp.hip) against the SAME module evaluated by PyTorch on the CPU: output
+    1e-5, input gradient and all six parameter gradients 1e-4 of each tensor's largest entry (floor 1e-6: the first Linear's
+    bias has a mathematically zero gradient in front of a train-mode BatchNorm), BatchNorm running statistics and
+    num_batches_tracked identical (1e-6). Row counts: one tile, ragged tiles, > 8 tiles, 2 rows (BatchNorm's minimum), 1 row."""
+    import copy
+    import torch.nn as nn
+    from instancerefer_amd import dense
+    torch.manual_seed(rows * 7 + din + dout)
+    nrm = nn.BatchNorm1d(dh) if norm == "bn" else nn.LayerNorm(dh)
+    ref = nn.Sequential(nn.Linear(din, dh), nrm, nn.ReLU(), nn.Dropout(0.0), nn.Linear(dh, dout))
+    with torch.no_grad():
+        nrm.weight.uniform_(0.5, 1.5); nrm.bias.uniform_(-0.5, 0.5)
+        if norm == "bn":
+            nrm.running_mean.uniform_(-0.2, 0.2); nrm.running_var.uniform_(0.5, 1.5)
+    ref.train(train)
+    mod = copy.deepcopy(ref).cuda()
+    x = torch.randn(rows, din)
+    g = torch.randn(rows, dout)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g)
+    xd = x.clone().cuda().requires_grad_(True)
+    assert dense.FUSED_MLP2
+    yd = dense.mlp2(mod, xd)
+    assert type(yd.grad_fn).__name__ == "MLP2FnBackward", type(yd.grad_fn).__name__
+    yd.backward(g.cuda())
+
+    def close(a, b, tol, what, floor=1e-6):
+        a, b = a.detach().cpu(), b.detach()
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), floor), (what, float((a - b).abs().max()), float(b.abs().max()))
+    close(yd, yr, 1e-5, "output", 1.0)
+    close(xd.grad, xr.grad, 1e-4, "dx")
+    for (n, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad, 1e-4, n, 1e-2 * float(max(t.grad.abs().max() for t in ref.parameters())))
+    for (n, b), (_, c) in zip(mod.named_buffers(), ref.named_buffers()):
+        assert float((b.detach().cpu().double() - c.double()).abs().max()) <= 1e-6, n
+
+
+def test_fused_head_mlp_dropout_and_fallbacks(lib):
+    """Dropout inside the fused MLP: about p of the hidden units are dropped and the rest scaled by 1 / (1 - p) (the output's
+    kept ones equal the clean activation / (1 - p)), a different call draws a different mask, eval mode is deterministic and
+    equals the clean activations. Shapes the operator does not take (one row in train-mode BatchNorm, host tensors) go
+    through the module."""
+    import torch.nn as nn
+    from instancerefer_amd import dense
+    torch.manual_seed(5)
+    p = 0.3
+    mod = nn.Sequential(nn.Linear(64, 128), nn.LayerNorm(128), nn.ReLU(), nn.Dropout(p), nn.Linear(128, 128)).cuda().train()
+    with torch.no_grad():                                 # second Linear = identity: the output shows the hidden activations
+        mod[4].weight.copy_(torch.eye(128)); mod[4].bias.zero_()
+    x = torch.randn(4000, 64, device="cuda")
+    y1 = dense.mlp2(mod, x)
+    y2 = dense.mlp2(mod, x)
+    clean = torch.relu(mod[1](mod[0](x)))
+    pos = clean > 1e-6
+    kept1 = (y1 > 0) & pos
+    frac = float(kept1.sum()) / float(pos.sum())
+    assert abs(frac - (1 - p)) < 0.01, frac
+    assert float((y1[kept1] - clean[kept1] / (1 - p)).abs().max()) <= 1e-5 * float(clean.abs().max())
+    assert float(y1[pos & ~kept1].abs().max()) == 0.0
+    assert not torch.equal(y1 > 0, y2 > 0)
+    mod.eval()
+    assert torch.equal(dense.mlp2(mod, x), dense.mlp2(mod, x))
+    assert float((dense.mlp2(mod, x) - clean).abs().max()) <= 1e-5 * float(clean.abs().max())
+    # fallbacks
+    bn = nn.Sequential(nn.Linear(8, 16), nn.BatchNorm1d(16), nn.ReLU(), nn.Linear(16, 4)).train()
+    out = dense.mlp2(bn, torch.randn(5, 8))               # host tensors: the module itself
+    assert type(out.grad_fn).__name__ != "MLP2FnBackward"
+    with pytest.raises(ValueError):
+        dense.mlp2(bn.cuda(), torch.randn(1, 8, device="cuda"))     # nn.BatchNorm1d's own error for one training row
+
+
 def test_flat_adam_matches_torch_adam(lib):
     from instancerefer_amd.optim import FlatAdam
     torch.manual_seed(0)
