@@ -15,7 +15,12 @@ region; per step everything the reference does inside forward/backward is redone
 sort + hash + kernel maps of the scene tensor, candidate voxelisation, 26 sparse convs, BN, heads, loss,
 backward, all-reduce, Adam.
 
-Also in the line (N = 1): `alt_dtype` (the same loop in BASELINE configs[2]'s bf16 with its own roofline), `dense_path`
+Default dtype: bf16 (operands + activation / gradient storage inside the two sparse encoders, fp32 accumulation, statistics,
+parameters and heads) — the dtype BASELINE configs[2]-[4] name for this metric; the reference's own fp32 (the dtype of the 1e-4
+parity gate) runs in the same process and is reported, with its own roofline, under `alt_dtype` (`--dtype f32` makes it the
+headline and bf16 the alternative).
+
+Also in the line (N = 1): `alt_dtype` (the same loop in the other dtype with its own roofline), `dense_path`
 (language encoder alone against the MFMA peak) and `end_to_end` (tools/e2e_train_bench.py in its own process: the per-sample
 input pipeline inside the loop, nothing resident but the raw scans).
 """
@@ -51,12 +56,14 @@ def parse():
     ap.add_argument("--multiview", type=int, default=None, help="extra ENet feature channels per point (128 in the stress config)")
     ap.add_argument("--tokens", type=int, default=30)
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "bf16op"],
-                    help="compute dtype of the sparse encoders: f32 (default: the reference's dtype, exact); bf16 (BASELINE "
+                    help="compute dtype of the sparse encoders: bf16 (default for the full / stress workloads = BASELINE "
                          "configs[2]-[4]: bf16 operands / fp32 accumulation AND bf16 storage of the activations and gradients "
-                         "inside the encoders; BatchNorm statistics, parameters, heads fp32); bf16op (bf16 operands only, "
-                         "every tensor fp32 in HBM)")
+                         "inside the encoders; BatchNorm statistics, parameters, heads fp32); f32 (the reference's own dtype, "
+                         "the 1e-4 parity gate; default for --workload attr = configs[1]); bf16op (bf16 operands only, every "
+                         "tensor fp32 in HBM)")
     ap.add_argument("--no-alt-dtype", action="store_true",
-                    help="skip the extra bf16 leg (N = 1, --dtype f32 only) reported under 'alt_dtype'")
+                    help="skip the extra leg in the OTHER dtype (N = 1: fp32 beside a bf16 headline, bf16 beside fp32) "
+                         "reported under 'alt_dtype'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--cpu-timeout", type=int, default=150)
@@ -77,9 +84,11 @@ def parse():
     args = ap.parse_args()
     stress = args.workload == "stress"
     for k, full, st in (("points", 50000, 200000), ("instances", 8, 64), ("candidates", 4, 16), ("multiview", 0, 128),
-                        ("dtype", "f32", "bf16")):
+                        ("dtype", "bf16", "bf16")):
         if getattr(args, k) is None:
             setattr(args, k, st if stress else full)
+    if args.workload == "attr" and "--dtype" not in sys.argv:
+        args.dtype = "f32"                       # BASELINE configs[1] names fp32
     if stress and args.cpu_scenes == 16:
         args.cpu_scenes = 2                      # bounded CPU sample: these scenes are 4x the size
     return args
@@ -704,10 +713,11 @@ def main():
     if rank == 0 and os.environ.get("IRX_BENCH_TIMELINE") == "1":
         timeline(model, resident, args, reducer, opt, state, F_)
 
-    # ---- the same loop with bf16 conv operands (BASELINE configs[2]-[4] dtype), reported beside the fp32 headline ----
+    # ---- the same loop in the other dtype (fp32 = the reference's / bf16 = BASELINE configs[2]-[4]'s), reported beside the headline ----
     alt = None
-    if world == 1 and args.dtype == "f32" and not args.no_alt_dtype:
-        irx.set_compute_dtype("bf16")
+    other = {"f32": "bf16", "bf16": "f32"}.get(args.dtype)
+    if world == 1 and other is not None and not args.no_alt_dtype:
+        irx.set_compute_dtype("bf16" if other == "bf16" else "fp32")
         try:
             for _ in range(max(3, min(args.warmup, 20))):
                 step_fn(model, resident, args.workload, reducer, opt, state)
@@ -721,13 +731,15 @@ def main():
                 step_fn(model, resident, args.workload, reducer, opt, state)
             barrier()
             adt = time.perf_counter() - t0
-            alt = {"dtype": "bf16", "value": B * ak / adt, "unit": "scenes/s", "ms_per_step": 1000.0 * adt / ak,
+            alt = {"dtype": other, "value": B * ak / adt, "unit": "scenes/s", "ms_per_step": 1000.0 * adt / ak,
                    "steps": ak, "warmup": max(3, min(args.warmup, 20)),
-                   "what": "same loop, irx_set_compute_dtype(2) = BASELINE configs[2]-[4] dtype: bf16 operands / fp32 "
-                           "accumulation in the 32/64/128-channel sparse convs (fwd, dgrad, wgrad) and bf16 STORAGE of every "
-                           "activation / gradient tensor inside the two encoders; BatchNorm statistics, parameters and their "
-                           "gradients, stems' inputs, encoder outputs, heads fp32. Not the headline: the 1e-4 parity gate is "
-                           "proven for fp32; tolerance of this mode vs the fp32 fixture: tests/test_model_gpu.py"}
+                   "what": ("same loop, irx_set_compute_dtype(2) = BASELINE configs[2]-[4] dtype: bf16 operands / fp32 "
+                            "accumulation in the 32/64/128-channel sparse convs (fwd, dgrad, wgrad) and bf16 STORAGE of every "
+                            "activation / gradient tensor inside the two encoders; BatchNorm statistics, parameters and their "
+                            "gradients, stems' inputs, encoder outputs, heads fp32; parity: tests/test_bf16_gpu.py, "
+                            "tests/test_fullsize_gpu.py::test_baseline_config2_full_model_bf16_vs_emulation") if other == "bf16" else
+                           ("same loop in the REFERENCE's own dtype, fp32 everywhere (exact fp32 MFMA in the sparse convs): the "
+                            "dtype of the north star's 1e-4 parity gate (tests/test_model_gpu.py, tests/test_fullsize_gpu.py)")}
             try:                                       # its own roofline (HBM-bound: algorithmic bytes at 2 B / element)
                 F_.PROFILE = []
                 with serial_issue(model):
@@ -735,15 +747,15 @@ def main():
                         step_fn(model, resident, args.workload, reducer, opt)
                     torch.cuda.synchronize()
                 recs, F_.PROFILE = F_.PROFILE, None
-                alt["roofline"] = summarise_roofline(recs, True)
+                alt["roofline"] = summarise_roofline(recs, other == "bf16")
             except Exception as e:
                 F_.PROFILE = None
                 alt["roofline"] = {"error": repr(e)}
         except Exception as e:                         # the extra leg must never take the headline down with it
-            alt = {"dtype": "bf16", "error": repr(e)}
+            alt = {"dtype": other, "error": repr(e)}
         finally:
-            irx.set_compute_dtype("fp32")
-        log("bf16 leg done: %s" % (alt.get("ms_per_step", alt.get("error")),))
+            irx.set_compute_dtype({"f32": "fp32", "bf16": "bf16", "bf16op": "bf16_operands"}[args.dtype])
+        log("%s leg done: %s" % (other, alt.get("ms_per_step", alt.get("error")),))
 
     # ---- instrumented steps: per-launch events on the launch stream for the sparse-conv kernels ----
     roof = None
@@ -819,14 +831,14 @@ def main():
             if isinstance(pmc, dict) and "error" in pmc:
                 out["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic*.json (live PMC pass failed: %s)" % pmc["error"]
             if alt is not None and isinstance(alt.get("roofline"), dict) and "kernel" in alt["roofline"]:
-                traffic_for(alt["roofline"], measure_pmc_traffic(args, True), True)
+                traffic_for(alt["roofline"], measure_pmc_traffic(args, other == "bf16", other), other == "bf16")
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.barrier(device_ids=None if share else [device.index])
         dist.destroy_process_group()
 
 
-def measure_pmc_traffic(args, bf16=False):
+def measure_pmc_traffic(args, bf16=False, dtype=None):
     """HBM bytes per launch of every k_* kernel, measured NOW on this box: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE —
     separate runs, with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes) over a short child run of this
     same script (2 steps, serial issue so that dispatches are attributed cleanly), folded per kernel:
@@ -841,7 +853,7 @@ def measure_pmc_traffic(args, bf16=False):
     if not os.path.exists(rp):
         return {"error": "rocprofv3 not found"}
     child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-pipeline", "--no-cpu-baseline",
-             "--no-alt-dtype", "--profile-steps", "0", "--workload", args.workload, "--dtype", "bf16" if bf16 else args.dtype]
+             "--no-alt-dtype", "--profile-steps", "0", "--workload", args.workload, "--dtype", dtype or ("bf16" if bf16 else args.dtype)]
     if args.batch:
         child += ["--batch", str(args.batch)]
     sums = {}
