@@ -583,6 +583,8 @@ def main():
     if os.environ.get("IRX_BENCH_VERBOSE"):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("IRX_BENCH_DUMP_AFTER", "90")), repeat=True, file=sys.stderr)
+    if os.environ.get("IRX_BENCH_AUTOGRAD_ST") == "1":    # dev A/B: backward on the calling thread (no engine-thread hand-over)
+        torch.autograd.set_multithreading_enabled(False)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
