@@ -12,6 +12,28 @@
 // Rows per thread: the kernel is bound by its LDS weight reads (one ds_read_b128 per (offset, channel) per wave costs 8
 // LDS cycles whether or not the lanes read the same address), so every weight fragment read is reused for ST_R rows.
 #define ST_R 4
+
+// One input row (CIN <= 8 floats, rows only 4-byte aligned: ldx = 7 for xyz + rgb + height) as TWO 16-byte loads — elements
+// [0, 4) and [CIN - 4, CIN) — instead of CIN dword loads (16-byte global loads at dword alignment run at full speed on gfx950,
+// tools/micro/unaligned_load.hip; both loads stay inside the row). Round 4: measured NEUTRAL on the forward (124.9 vs 124.6 us on
+// the 489 k-voxel level): the kernel executes every offset at which ANY of a wave's 32 row slots has a neighbour — nearly all
+// 27 — so its 28 FMAs per (slot, offset) run 5x more often than there are pairs (27 N x 7 x 32 x 2 = 5.9 GFLOP = 38 us at the
+// fp32 vector peak); what would move it is a dense im2col tile in LDS + fp32 MFMA as k_stem_wgrad does (same 38 us floor at
+// full MFMA efficiency), or bf16 operands for the stem (a numerics change the emulation oracle would have to follow).
+template <int CIN>
+__device__ __forceinline__ void st_load_row(const float* __restrict__ xr, float (&v)[CIN]) {
+  if constexpr (CIN >= 4) {
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const f4u lo = *reinterpret_cast<const f4u*>(xr);
+    const f4u hi = *reinterpret_cast<const f4u*>(xr + (CIN - 4));
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) v[c] = c < 4 ? lo[c] : hi[c - (CIN - 4)];
+  } else {
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) v[c] = xr[c];
+  }
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const int32_t* __restrict__ nbr, int ld, int n_out, int K,
@@ -38,8 +60,9 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, c
 #pragma unroll
     for (int j = 0; j < ST_R; ++j) {
       const float* xr = x + (size_t)(idx[j] < 0 ? 0 : idx[j]) * ldx;  // missing neighbour: row 0, masked below
+      st_load_row<CIN>(xr, xv[j]);
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) xv[j][c] = idx[j] >= 0 ? xr[c] : 0.f;
+      for (int c = 0; c < CIN; ++c) xv[j][c] = idx[j] >= 0 ? xv[j][c] : 0.f;
     }
 #pragma unroll
     for (int c = 0; c < CIN; ++c) {
@@ -113,8 +136,9 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
         const float* xr = x + (size_t)(idx[e] < 0 ? 0 : idx[e]) * ldx;
+        st_load_row<CIN>(xr, v[e]);
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) v[e][c] = idx[e] >= 0 ? xr[c] : 0.f;
+        for (int c = 0; c < CIN; ++c) v[e][c] = idx[e] >= 0 ? v[e][c] : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
