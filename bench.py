@@ -915,7 +915,10 @@ def traffic_for(roof, pmc, bf16):
     hit = [k for k in pmc if k == key or k.startswith(key[:-1] + ",")]     # (k_spconv3<cin, cout, waves, K parts>)
     if hit:
         roof["traffic"] = pmc[hit[0]]
-        roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py on this box (2 steps, serial issue)"
+        roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py on this box (2 steps, serial "
+                                  "issue); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB — the factor 2 is gfx950's half-count of wide "
+                                  "(16 B per lane) read streams, which is what this kernel's row / image loads are; it would "
+                                  "overstate kernels with narrow or scalar reads, for which no traffic figure is reported")
 
 
 def end_to_end(args):

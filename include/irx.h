@@ -81,7 +81,11 @@ int irx_keys_to_coords(const uint64_t* keys, int n, int32_t* coords, void* strea
  * of sampled points by instance slot in the device-side input pipeline (lib/dataset.py:207-213: np.nonzero per instance id).
  * n_dev != NULL: only the first *n_dev elements are real (the count lives on the device: no host sync); the remaining
  * n - *n_dev elements are treated as the key `pad` (must compare above every real key within the sorted bits) and come out
- * behind the real ones. Deterministic (no global atomics). workspace: irx_sort_workspace_bytes(n). */
+ * behind the real ones. Deterministic (no global atomics). workspace: irx_sort_workspace_bytes(n).
+ * NOTE (whole digits): the sort runs ceil((end_bit - begin_bit) / 8) passes of 8 bits, so it orders by bits
+ * [begin_bit, begin_bit + 8 * passes) — key bits between end_bit and that digit boundary TAKE PART in the ordering (unlike
+ * CUB's begin/end-bit semantics). Callers keep those bits zero in real keys (the in-tree ones do: Morton keys carry nothing
+ * above their batch field) or want them sorted too (the `pad` key). */
 size_t irx_sort_workspace_bytes(int n);
 int irx_sort_pairs_u64(const uint64_t* keys, int n, const int32_t* n_dev, uint64_t pad, int begin_bit, int end_bit,
                        uint64_t* keys_out, int32_t* order_out, void* workspace, size_t workspace_bytes, void* stream);
@@ -303,7 +307,11 @@ enum {
   IRX_ENC_K = 0, IRX_ENC_CIN, IRX_ENC_COUT, IRX_ENC_N_IN, IRX_ENC_N_OUT,
   IRX_ENC_RES,                      /* index of the layer whose OUTPUT is added before the ReLU, or -1 */
   IRX_ENC_TBL, IRX_ENC_LD,          /* forward table int32 [K][ld]: nbr27 (stride 1) or child (2^3 stride 2) */
-  IRX_ENC_TBL_B, IRX_ENC_LD_B, IRX_ENC_FLIP_B,   /* data-gradient table: same table + flip (stride 1) or child_T */
+  IRX_ENC_TBL_B, IRX_ENC_LD_B, IRX_ENC_FLIP_B,   /* data-gradient table: same table + flip (stride 1) or child_T.
+                                     * PRECONDITION for a 2^3 / stride-2 layer (TBL_B != TBL, K == 8): every input row is the child of
+                                     * exactly one output row (true for irx_downsample / irx_pyramid_build maps). The fp32 parent-tiled
+                                     * data-gradient (k_updgrad) writes each input-gradient row from its parent and does not zero rows
+                                     * no parent references. */
   IRX_ENC_PAIR_IN, IRX_ENC_PAIR_OUT, IRX_ENC_PAIR_COUNTS, IRX_ENC_LD_PAIRS,   /* irx_pairs_build lists, or 0 */
   IRX_ENC_W, IRX_ENC_GAMMA, IRX_ENC_BETA, IRX_ENC_RUNNING_MEAN, IRX_ENC_RUNNING_VAR,
   IRX_ENC_X, IRX_ENC_C, IRX_ENC_Y,  /* layer input [n_in][cin], conv output and layer output [n_out][cout] */
