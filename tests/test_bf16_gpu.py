@@ -308,6 +308,9 @@ def check_model_against_emulation(model, dd, runs, tag):
     print("%s: HIP-emu %s | emu-emu64 %s | pooled bar %.1e" % (tag, {k: "%.0e" % v for k, v in pe.items()},
           {k: "%.0e" % v for k, v in ee.items()}, bar))
     assert all(v <= bar for v in pe.values()), (pe, bar)
+    # ... and an ABSOLUTE cap beside the self-calibrated bar: whatever the emulation's own reordering distance is
+    # on this batch, no score tensor may sit further than 1.5e-2 (in units of max(1, |expected|max)) from the emulation
+    assert max(pe.values()) <= 1.5e-2, pe
     assert all(pe[k] <= 5.0 * ee[k] + 2e-4 for k in SCORE_KEYS), (pe, ee)
 
     def gnorm(m):
