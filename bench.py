@@ -69,7 +69,8 @@ def parse():
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented (serially issued) steps behind the timed region; 0 = none")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1: BatchNorm statistics over all ranks (instancerefer_amd.syncbn; "
-                    "the encoders then run layer by layer, one small all-reduce per BatchNorm layer and direction)")
+                    "the encoders stay in the one-call executor, which calls back for one small all-reduce per BatchNorm layer "
+                    "and direction)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (input pipeline in the loop, own process)")
     ap.add_argument("--prep-thread", action="store_true",
                     help="run the input preparation on a helper thread instead of inline behind the step (same speed: "

@@ -346,6 +346,21 @@ int irx_encoder_forward(const int64_t* desc, const double* fdesc, int n_layers, 
  * dx0 [n_in0][cin0]; GY of the other layers and dc_scratch [max n_out*cout] are scratch. */
 int irx_encoder_backward(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch, float* dx0,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Sync BatchNorm inside the one-call executor (torch.nn.SyncBatchNorm's contract — the reference has no multi-GPU
+ * path): the same passes with the cross-rank fold of every layer's statistics done by the CALLER through `allreduce`, which the
+ * library calls on the calling thread between a layer's statistics and apply pass (forward: 2 cout + 1 float64 = sum x, sum x^2,
+ * row count; backward: 2 cout float32 = sum g, sum g xhat): it must enqueue an in-place SUM over the ranks of buf[0..n) on
+ * `stream` (or complete it) and return 0. sums: device [n_layers][IRX_ENC_SYNC_STRIDE] float64, written by the forward and read
+ * back by the backward (the folded row counts); gsums: device [n_layers][IRX_ENC_SYNC_STRIDE] float32 scratch. Parameter
+ * gradients stay this rank's own sums. Every rank must call with the same layer list. Not available through irx_encoder_submit. */
+#define IRX_ENC_SYNC_STRIDE 264
+typedef int (*irx_allreduce_fn)(void* user, void* buf, int n, int is_double, void* stream);
+int irx_encoder_forward_sync(const int64_t* desc, const double* fdesc, int n_layers, void* workspace, size_t workspace_bytes,
+                             void* stream, double* sums, irx_allreduce_fn allreduce, void* user);
+int irx_encoder_backward_sync(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch, float* dx0,
+                              void* workspace, size_t workspace_bytes, void* stream, double* sums, float* gsums,
+                              irx_allreduce_fn allreduce, void* user);
+
 /* Asynchronous issue of the two calls above: a lane (0..3) is a library thread that performs the call from a copy of
  * the descriptor table while the caller's thread goes on issuing independent work (Python: the ctypes call returns at
  * once). backward == 0: irx_encoder_forward (dc_scratch / dx0 ignored). Jobs of a lane run in submission order. The

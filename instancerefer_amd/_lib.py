@@ -66,6 +66,8 @@ _SIGNATURES = {
     "irx_encoder_workspace_bytes": (_Z, [_P, _P, _I, _I]),
     "irx_encoder_forward": (_I, [_P, _P, _I, _P, _Z, _P]),
     "irx_encoder_backward": (_I, [_P, _P, _I, _P, _P, _P, _Z, _P]),
+    "irx_encoder_forward_sync": (_I, [_P, _P, _I, _P, _Z, _P, _P, _P, _P]),
+    "irx_encoder_backward_sync": (_I, [_P, _P, _I, _P, _P, _P, _Z, _P, _P, _P, _P, _P]),
     "irx_encoder_submit": (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _Z, _P]),
     "irx_encoder_wait": (_I, [_I]),
     "irx_segment_max": (_I, [_P, _P, _I, _I, _P, _P, _P]),

@@ -233,6 +233,10 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
                       const float* all_sum_gx = nullptr, double all_count = 0.0, const double* count_dev = nullptr,
                       const float* beta = nullptr);
 
+int irx_bn_sums_t(const float* x, int n, int c, double* sums, void* workspace, size_t workspace_bytes, void* stream, int x_bf,
+                  double* count_slot);
+int irx_bn_pack_sums(const float* sum_g, const float* sum_gx, int c, float* out, void* stream);
+
 // ---- stem (small-Cin) launchers (irx_stem.hip) ------------------------------------------------------
 bool irx_stem_supported(int K, int cin, int cout);
 int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin,

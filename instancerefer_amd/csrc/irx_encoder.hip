@@ -82,8 +82,47 @@ extern "C" size_t irx_encoder_workspace_bytes(const int64_t* desc, const double*
   return r.conv + r.wgrad + r.bn + r.wimg + 256;
 }
 
+namespace {
+// Sync BatchNorm inside the one-call executor (include/irx.h irx_encoder_forward_sync): the fold over the ranks is the CALLER's
+// (torch.distributed), reached through a callback between the statistics and the apply pass of every layer.
+struct EncSync {
+  irx_allreduce_fn cb = nullptr;
+  void* user = nullptr;
+  double* sums = nullptr;    // [n_layers][IRX_ENC_SYNC_STRIDE] float64: sum x | sum x^2 | row count   (kept for the backward)
+  float* gsums = nullptr;    // [n_layers][IRX_ENC_SYNC_STRIDE] float32: sum g | sum g xhat (backward)
+};
+int encoder_forward_impl(const int64_t* desc, const double* fdesc, int n_layers, void* workspace, size_t workspace_bytes,
+                         void* stream, const EncSync& sync);
+int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch, float* dx0, void* workspace,
+                          size_t workspace_bytes, void* stream, const EncSync& sync);
+}  // namespace
+
 extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int n_layers, void* workspace,
                                    size_t workspace_bytes, void* stream) {
+  return encoder_forward_impl(desc, fdesc, n_layers, workspace, workspace_bytes, stream, EncSync());
+}
+
+extern "C" int irx_encoder_forward_sync(const int64_t* desc, const double* fdesc, int n_layers, void* workspace,
+                                        size_t workspace_bytes, void* stream, double* sums, irx_allreduce_fn allreduce,
+                                        void* user) {
+  IRX_REQUIRE(sums && allreduce, "irx_encoder_forward_sync: null sums buffer / callback");
+  EncSync sy;
+  sy.cb = allreduce; sy.user = user; sy.sums = sums;
+  return encoder_forward_impl(desc, fdesc, n_layers, workspace, workspace_bytes, stream, sy);
+}
+
+extern "C" int irx_encoder_backward_sync(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch, float* dx0,
+                                         void* workspace, size_t workspace_bytes, void* stream, double* sums, float* gsums,
+                                         irx_allreduce_fn allreduce, void* user) {
+  IRX_REQUIRE(sums && gsums && allreduce, "irx_encoder_backward_sync: null buffers / callback");
+  EncSync sy;
+  sy.cb = allreduce; sy.user = user; sy.sums = sums; sy.gsums = gsums;
+  return encoder_backward_impl(desc, fdesc, n_layers, dc_scratch, dx0, workspace, workspace_bytes, stream, sy);
+}
+
+namespace {
+int encoder_forward_impl(const int64_t* desc, const double* fdesc, int n_layers, void* workspace, size_t workspace_bytes,
+                         void* stream, const EncSync& sync) {
   IRX_REQUIRE(desc && fdesc && n_layers > 0, "irx_encoder_forward: empty descriptor table");
   const int mode = (int)desc[IRX_ENC_MODE];
   IRX_REQUIRE(mode >= 0 && mode <= 2, "irx_encoder_forward: IRX_ENC_MODE = %d", mode);
@@ -138,8 +177,20 @@ extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int
     int rc = irx_spconv_fwd_impl(L.x, L.w, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, 0, 0, L.c, 0, wimg[i], ws_c, r.conv,
                                  stream, ty);
     if (rc) return rc;
-    rc = irx_bn_stats_t(L.c, L.n_out, L.cout, L.eps, L.momentum, L.mean, L.invstd, L.running_mean, L.running_var, ws_b,
-                        r.bn, stream, st);
+    if (sync.cb) {
+      // this rank's float64 sums and row count -> the caller's all-reduce -> mean / invstd from the folded sums (the global count
+      // stays on the device: sums[2 cout])
+      IRX_REQUIRE(L.cout <= (IRX_ENC_SYNC_STRIDE - 2) / 2, "irx_encoder_forward_sync: %d channels exceed the sums stride", L.cout);
+      double* sl = sync.sums + (size_t)i * IRX_ENC_SYNC_STRIDE;
+      rc = irx_bn_sums_t(L.c, L.n_out, L.cout, sl, ws_b, r.bn, stream, st, sl + 2 * L.cout);
+      if (rc) return rc;
+      rc = sync.cb(sync.user, sl, 2 * L.cout + 1, 1, stream);
+      IRX_REQUIRE(rc == 0, "irx_encoder_forward_sync: the all-reduce callback failed (%d) at layer %d", rc, i);
+      rc = irx_bn_stats_from_sums(sl, 0.0, L.cout, L.eps, L.momentum, L.mean, L.invstd, L.running_mean, L.running_var, stream);
+    } else {
+      rc = irx_bn_stats_t(L.c, L.n_out, L.cout, L.eps, L.momentum, L.mean, L.invstd, L.running_mean, L.running_var, ws_b,
+                          r.bn, stream, st);
+    }
     if (rc) return rc;
     const float* res = nullptr;
     if (L.res >= 0) res = (const float*)desc[(size_t)L.res * IRX_ENC_NFIELDS + IRX_ENC_Y];
@@ -148,11 +199,18 @@ extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int
   }
   return IRX_OK;
 }
+}  // namespace
 
 // gy of the last layer holds d(loss)/d(output) on entry.  On return dw / dgamma / dbeta of every layer are written and,
 // when dx0 != NULL, dx0 [n_in0][cin0] = d(loss)/d(input features).  gy of the other layers is scratch.
 extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch,
                                     float* dx0, void* workspace, size_t workspace_bytes, void* stream) {
+  return encoder_backward_impl(desc, fdesc, n_layers, dc_scratch, dx0, workspace, workspace_bytes, stream, EncSync());
+}
+
+namespace {
+int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch, float* dx0, void* workspace,
+                          size_t workspace_bytes, void* stream, const EncSync& sync) {
   IRX_REQUIRE(desc && fdesc && n_layers > 0 && dc_scratch, "irx_encoder_backward: bad arguments");
   const int mode = (int)desc[IRX_ENC_MODE];
   IRX_REQUIRE(mode >= 0 && mode <= 2, "irx_encoder_backward: IRX_ENC_MODE = %d", mode);
@@ -213,9 +271,28 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
     // c: st | y, gy: fp32 for the last layer | dc scratch and the shortcut gradient (never the last layer's): st
     // a layer without a shortcut hands over beta: its ReLU mask is recomputed from c and y is not read (irx_norm.hip)
     static const bool remask = !(getenv("IRX_BN_REMASK") && atoi(getenv("IRX_BN_REMASK")) == 0);   // dev A/B knob
-    int rc = irx_bn_backward_t(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, dc_scratch, L.dgamma,
-                               L.dbeta, dres, ws_b, r.bn, stream, st, (st && !last) ? 1 : 0, (st && !last) ? 1 : 0, st, st,
-                               3, nullptr, nullptr, 0.0, nullptr, (L.res < 0 && remask) ? L.beta : nullptr);
+    int rc;
+    const float* mk_beta = (L.res < 0 && remask) ? L.beta : nullptr;
+    if (sync.cb) {
+      // this rank's sums (= the parameter gradients d beta, d gamma, which the gradient all-reduce folds like every other) ->
+      // folded copies through the caller's all-reduce -> the apply pass with the folded sums and the global row count
+      float* gl = sync.gsums + (size_t)i * IRX_ENC_SYNC_STRIDE;
+      const double* cnt = sync.sums + (size_t)i * IRX_ENC_SYNC_STRIDE + 2 * L.cout;
+      rc = irx_bn_backward_t(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, nullptr, L.dgamma, L.dbeta, nullptr,
+                             ws_b, r.bn, stream, st, (st && !last) ? 1 : 0, (st && !last) ? 1 : 0, st, st, 1);
+      if (rc) return rc;
+      rc = irx_bn_pack_sums(L.dbeta, L.dgamma, L.cout, gl, stream);
+      if (rc) return rc;
+      rc = sync.cb(sync.user, gl, 2 * L.cout, 0, stream);
+      IRX_REQUIRE(rc == 0, "irx_encoder_backward_sync: the all-reduce callback failed (%d) at layer %d", rc, i);
+      rc = irx_bn_backward_t(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, dc_scratch, nullptr, nullptr, dres,
+                             nullptr, 0, stream, st, (st && !last) ? 1 : 0, (st && !last) ? 1 : 0, st, st, 2, gl, gl + L.cout,
+                             0.0, cnt, mk_beta);
+    } else {
+      rc = irx_bn_backward_t(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, dc_scratch, L.dgamma,
+                             L.dbeta, dres, ws_b, r.bn, stream, st, (st && !last) ? 1 : 0, (st && !last) ? 1 : 0, st, st,
+                             3, nullptr, nullptr, 0.0, nullptr, mk_beta);
+    }
     if (rc) return rc;
     if (L.prof) irx_profile_next_kernel(L.prof[4], L.prof[5]);
     if (pairs_path(L)) {
@@ -259,6 +336,7 @@ extern "C" int irx_encoder_backward(const int64_t* desc, const double* fdesc, in
   }
   return IRX_OK;
 }
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Asynchronous issue (irx_encoder_submit / irx_encoder_wait): the ~50 (forward) / ~100 (backward) kernel launches of one

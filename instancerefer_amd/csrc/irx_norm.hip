@@ -498,6 +498,51 @@ extern "C" int irx_bn_sums(const float* x, int n, int c, double* sums, void* wor
   return IRX_OK;
 }
 
+// irx_bn_sums with an element type for x (0 = float32, 1 = bf16) — the executor's sync-BatchNorm path; count_slot != NULL:
+// the row count n is stored there as a double (the caller folds it with the sums: sums[2 c])
+__global__ void k_set_double(double* p, double v) { *p = v; }
+__global__ void k_copy2_f32(const float* __restrict__ a, const float* __restrict__ b, int c, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c) { out[i] = a[i]; out[c + i] = b[i]; }
+}
+int irx_bn_sums_t(const float* x, int n, int c, double* sums, void* workspace, size_t workspace_bytes, void* stream, int x_bf,
+                  double* count_slot) {
+  int rc = bn_check("irx_bn_sums", n, c, workspace, workspace_bytes);
+  if (rc) return rc;
+  IRX_REQUIRE(sums, "irx_bn_sums: null pointer");
+  if (count_slot) {
+    k_set_double<<<1, 1, 0, S(stream)>>>(count_slot, (double)n);
+    IRX_CHECK_LAUNCH("irx_bn_sums(count)");
+  }
+  if (n == 0) {
+    IRX_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), S(stream)), "irx_bn_sums(memset)");
+    return IRX_OK;
+  }
+  if (!x_bf) return irx_bn_sums(x, n, c, sums, workspace, workspace_bytes, stream);
+  const int nblk = irx_cdiv(n, bn_rows(n, c));
+  float* part = (float*)workspace;
+  const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  const BnTy ty = {1, 0, 0, 0, 0};
+  rc = bn_bf_ok("irx_bn_sums", true, v4);
+  if (rc) return rc;
+  if (c % 8 == 0)
+    k_bn_partial<0, 8, false><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+                                                          next_pow2(c / 8), bn_rows(n, c), part, ty, nullptr, nullptr);
+  else
+    k_bn_partial<0, 4, true><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
+                                                         next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr);
+  IRX_CHECK_LAUNCH("irx_bn_sums(partial)");
+  k_bn_finalize<2><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(
+      part, nblk, n, c, 0.f, 0.f, reinterpret_cast<float*>(sums), reinterpret_cast<float*>(sums + c), nullptr, nullptr);
+  IRX_CHECK_LAUNCH("irx_bn_sums(finalize)");
+  return IRX_OK;
+}
+int irx_bn_pack_sums(const float* sum_g, const float* sum_gx, int c, float* out, void* stream) {
+  k_copy2_f32<<<irx_cdiv(c, 128), 128, 0, S(stream)>>>(sum_g, sum_gx, c, out);
+  IRX_CHECK_LAUNCH("irx_bn_backward(pack sums)");
+  return IRX_OK;
+}
+
 extern "C" int irx_bn_stats_from_sums(const double* sums, double count, int c, float eps, float momentum, float* mean,
                                       float* invstd, float* running_mean, float* running_var, void* stream) {
   IRX_REQUIRE(sums && mean && invstd && c >= 1, "irx_bn_stats_from_sums: bad arguments");

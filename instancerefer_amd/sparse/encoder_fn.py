@@ -144,6 +144,40 @@ ASYNC = os.environ.get("IRX_ENCODER_ASYNC", "1") != "0"
 _HELD = {}            # lane -> device buffers that must outlive the queued jobs
 
 
+# ---- sync BatchNorm inside the one-call executor (irx_encoder_forward_sync / _backward_sync, include/irx.h) ----------------
+# The library calls back between a layer's statistics and apply pass; the fold over the ranks is torch.distributed's. The pass
+# runs inline on the calling thread (no lane): the callback needs the interpreter and the collective's stream is torch's current one.
+SYNC_IN_EXECUTOR = os.environ.get("IRX_SYNC_BN_EXECUTOR", "1") != "0"
+SYNC_STRIDE = 264                                      # IRX_ENC_SYNC_STRIDE
+SYNC_CALLS = [0, 0]                                    # forward / backward passes that went through the sync executor (tests)
+_SYNC_CTX = {}
+_SYNC_ERR = []
+
+
+def _allreduce_cb(user, buf, n, is_double, stream):
+    try:
+        import torch.distributed as dist
+        sums, gsums, group = _SYNC_CTX[int(user)]
+        t = sums if is_double else gsums
+        off = (int(buf) - t.data_ptr()) // t.element_size()
+        dist.all_reduce(t.view(-1)[off:off + int(n)], op=dist.ReduceOp.SUM, group=group)
+        return 0
+    except Exception as e:                             # never let an exception cross the C frame
+        _SYNC_ERR.append(repr(e))
+        return 1
+
+
+import ctypes as _ct
+_ALLREDUCE_C = _ct.CFUNCTYPE(_ct.c_int, _ct.c_void_p, _ct.c_void_p, _ct.c_int, _ct.c_int, _ct.c_void_p)(_allreduce_cb)
+
+
+def _sync_group_for(layers):
+    """The process group the encoder's BatchNorm layers fold their statistics over, or None (not converted / one rank)."""
+    if not SYNC_IN_EXECUTOR or not any(getattr(L.bn, "_irx_sync", False) for L in layers):
+        return None
+    return F_.sync_group()
+
+
 def lane_of(encoder):
     return encoder.__dict__.get("_irx_lane") if ASYNC else None
 
@@ -242,7 +276,23 @@ class EncoderFn(torch.autograd.Function):
         nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 0)
         ws = _ws(nbytes, dev)
         lane = lane_of(encoder)
-        if lane is not None:
+        group = _sync_group_for(layers)
+        ctx.sync = None
+        if group is not None:
+            lane = None
+            sums = torch.zeros(nl * SYNC_STRIDE, dtype=torch.float64, device=dev)
+            key = id(sums)
+            _SYNC_CTX[key] = (sums, None, group)
+            try:
+                rc = lib.irx_encoder_forward_sync(desc.ctypes.data, fdesc.ctypes.data, nl, ws.data_ptr(), nbytes,
+                                                  _lib.stream_ptr(), sums.data_ptr(), _ALLREDUCE_C, key)
+            finally:
+                del _SYNC_CTX[key]
+            if rc and _SYNC_ERR:
+                raise RuntimeError("sync BatchNorm all-reduce inside the encoder executor failed: %s" % _SYNC_ERR.pop())
+            ctx.sync = (sums, group)
+            SYNC_CALLS[0] += 1
+        elif lane is not None:
             rc = lib.irx_encoder_submit(lane, 0, desc.ctypes.data, fdesc.ctypes.data, nl, None, None, ws.data_ptr(),
                                         nbytes, _lib.stream_ptr())
             _HELD.setdefault(lane, []).append((ws, x0, arena, stats, prof))
@@ -333,6 +383,33 @@ class EncoderFn(torch.autograd.Function):
         fdesc = ctx.fdesc
         nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 1)
         ws = _ws(nbytes, dev)
+        if ctx.sync is not None:
+            sums, group = ctx.sync
+            gsums = torch.empty(nl * SYNC_STRIDE, dtype=_f32, device=dev)
+            key = id(gsums)
+            _SYNC_CTX[key] = (sums, gsums, group)
+            try:
+                rc = lib.irx_encoder_backward_sync(desc.ctypes.data, fdesc.ctypes.data, nl, gbase + dc_off,
+                                                   dfeats.data_ptr() if need_dx0 else None, ws.data_ptr(), nbytes,
+                                                   _lib.stream_ptr(), sums.data_ptr(), gsums.data_ptr(), _ALLREDUCE_C, key)
+            finally:
+                del _SYNC_CTX[key]
+            if rc:
+                if _SYNC_ERR:
+                    raise RuntimeError("sync BatchNorm all-reduce inside the encoder executor failed: %s" % _SYNC_ERR.pop())
+                _lib.check(rc, "irx_encoder_backward_sync")
+            SYNC_CALLS[1] += 1
+            if slots is not None:
+                owner.sink_delivered(ctx.sink[1], sparams)
+                return (dfeats, None, None) + (None,) * (3 * nl)
+            grads = []
+            po = poffs // 4
+            for i, L in enumerate(layers):
+                o = po[i]
+                grads.append(pgrad[o[0]:o[0] + L.K * L.cin * L.cout].view(L.K, L.cin, L.cout))
+                grads.append(pgrad[o[1]:o[1] + L.cout])
+                grads.append(pgrad[o[2]:o[2] + L.cout])
+            return (dfeats, None, None) + tuple(grads)
         if ctx.lane is not None and slots is not None and not need_dx0:
             # nothing autograd will touch depends on this pass: a library thread issues it; the optimizer waits for the
             # lane before it records the delivery event (FlatAdam.gather_grads)
@@ -414,8 +491,9 @@ def can_fuse(encoder):
         return False
     if not all(bn.training for _, bn, _, _ in _skeleton(encoder)):
         return False                                   # frozen BatchNorm layers: the per-layer path handles eval statistics
-    if any(getattr(bn, "_irx_sync", False) for _, bn, _, _ in _skeleton(encoder)) and F_.sync_group() is not None:
-        return False                                   # sync BatchNorm: a collective between statistics and apply (syncbn.py)
+    if not SYNC_IN_EXECUTOR and any(getattr(bn, "_irx_sync", False) for _, bn, _, _ in _skeleton(encoder)) \
+            and F_.sync_group() is not None:
+        return False                                   # sync BatchNorm layer by layer (IRX_SYNC_BN_EXECUTOR=0: the round-2/3 path)
     ok = encoder.__dict__.get("_irx_fusable")          # structural part: decided once per encoder instance
     if ok is None:
         ok = True

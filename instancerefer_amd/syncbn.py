@@ -5,7 +5,9 @@ torch.nn.SyncBatchNorm's: `convert_sync_batchnorm(model)` once, before the optim
 BatchNorm layer in every step. All BatchNorm layers of the model go through the irx kernels then (the sparse encoders'
 layers, the scene head's BatchNorm2d rows, and the heads' BatchNorm1d): sparse/functional.BatchNormActFn folds this rank's
 float64 sums over the default process group (one small all-reduce per layer and direction), include/irx.h "Sync BatchNorm".
-The encoders run layer by layer in this mode (sparse/encoder_fn.can_fuse): the one-call executor has no collective inside.
+The two sparse encoders stay in the one-call executor (round 4: irx_encoder_forward_sync / _backward_sync — the library calls back
+into torch.distributed between every layer's statistics and apply pass, sparse/encoder_fn.py; the pass then runs inline on the
+calling thread instead of a library lane; IRX_SYNC_BN_EXECUTOR=0 restores the layer-by-layer path of rounds 2-3).
 Every rank must run every BatchNorm layer in every step (a shard with no scene of >= 2 candidates skips the candidate
 encoder and would leave the other ranks waiting in its collectives): Solver / bench.py use shards that all hold candidates.
 A converted layer that cannot take the synchronised path raises in multi-rank training instead of using per-rank statistics.

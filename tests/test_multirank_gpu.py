@@ -302,6 +302,8 @@ def _syncbn_worker(rank, world, port, out_dir):
     res["g_2rank"] = (g2 / world).cpu()
     res["running_mean"] = model.scene.net.stem[0].net[1].running_mean.clone().cpu()
     res["sync_layers"] = sum(1 for m in model.modules() if getattr(m, "_irx_sync", False))
+    from instancerefer_amd.sparse import encoder_fn
+    res["executor_sync_calls"] = list(encoder_fn.SYNC_CALLS)
     dist.barrier()
     if rank == 0:
         model1 = _model(1201, dev).train()
@@ -324,7 +326,12 @@ def _syncbn_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sync_batchnorm_two_ranks_equal_one_rank_on_the_whole_batch(lib, tmp_path):
+@pytest.mark.parametrize("path", ["executor", "per_layer"])
+def test_sync_batchnorm_two_ranks_equal_one_rank_on_the_whole_batch(lib, tmp_path, monkeypatch, path):
+    """"executor": both encoders stay in the one-call executor (irx_encoder_forward_sync / _backward_sync: the library calls
+    back into torch.distributed between every layer's statistics and apply pass); "per_layer" (IRX_SYNC_BN_EXECUTOR=0): the
+    round-2/3 path, one Python autograd node per BatchNorm layer. Same assertions."""
+    monkeypatch.setenv("IRX_SYNC_BN_EXECUTOR", "1" if path == "executor" else "0")
     mp.set_start_method("spawn", force=True)
     port = 33000 + (os.getpid() * 11 + int(time.time())) % 2000
     ctx = mp.start_processes(_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=False, start_method="spawn")
@@ -339,6 +346,8 @@ def test_sync_batchnorm_two_ranks_equal_one_rank_on_the_whole_batch(lib, tmp_pat
                 p.kill()
     r0, r1 = (torch.load(os.path.join(str(tmp_path), "sync%d.pt" % r), weights_only=False) for r in range(2))
     assert r0["sync_layers"] >= 30                       # both encoders (13 + 13), the scene head, the heads' BatchNorm1d
+    # two encoders, forward and backward, through the sync executor — or none of them
+    assert r0["executor_sync_calls"] == r1["executor_sync_calls"] == ([2, 2] if path == "executor" else [0, 0])
     assert torch.equal(r0["g_2rank"], r1["g_2rank"])
     assert torch.equal(r0["running_mean"], r1["running_mean"])           # one set of statistics for both ranks
     g2, g1 = r0["g_2rank"], r0["g_1rank"]
