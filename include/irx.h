@@ -236,6 +236,13 @@ size_t irx_spconv_wgrad_pairs_workspace_bytes(int n_out, int K, int cin, int cou
 int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int32_t* in_list, const int32_t* out_list,
                            int ldp, const int32_t* counts, int n_in, int n_out, int K, int cin, int cout, float* dw,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* irx_spconv_wgrad_pairs with the element type of x AND dy stated (rows_bf: 0 = float32, 1 = bf16 stored as uint16, needs
+ * irx_set_compute_dtype(2)) — the weight gradient of the encoder executor's bf16 STORAGE mode as a single operator. bf16
+ * rows with cin, cout in {64,128} take k_wgrad3 (rows stay bf16 in LDS, ds_read_b64_tr_b16 operand reads,
+ * v_mfma_f32_32x32x16_bf16; IRX_WGRAD3=0 keeps the widening kernel); dw is float32 either way. */
+int irx_spconv_wgrad_pairs_t(const void* x, const void* dy, const int32_t* in_list, const int32_t* out_list, int ldp,
+                             const int32_t* counts, int n_in, int n_out, int K, int cin, int cout, float* dw, int rows_bf,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- BatchNorm(+residual)(+ReLU) over voxel rows (spnn.BatchNorm / spnn.ReLU and the
  *      residual add at models/basic_blocks.py:20-21,37-38,44,52,55) ----------------------- */
@@ -290,7 +297,9 @@ int irx_profile_next_kernel(void* ev_start, void* ev_stop);
 /* Dev / test knobs. Each knob takes its default from an environment variable read ONCE (first use) and can then be changed
  * only through this setter (atomic; safe against the library's lane threads): "spconv3" (IRX_SPCONV3, 1: bf16-input convs
  * on the third-generation kernel), "updgrad" (IRX_UPDGRAD, 1) / "updgrad_min" (IRX_UPDGRAD_MIN, 40000: k_updgrad and its
- * size threshold), "wgrad_v1" (IRX_WGRAD_V1, 0: fp32 pair-list weight-gradient on the first-generation kernel).
+ * size threshold), "wgrad_v1" (IRX_WGRAD_V1, 0: fp32 pair-list weight-gradient on the first-generation kernel), "wgrad3"
+ * (IRX_WGRAD3, 1: bf16-row pair-list weight-gradient on k_wgrad3), "wgrad3_units" (IRX_WGRAD3_UNITS, 448: workgroups of its
+ * XCD-segment mapping), "wgrad3_xcd_min" (IRX_WGRAD3_XCD_MIN, 200000: table entries n_out * K from which that mapping is used).
  * irx_debug_get_knob returns the value in force (-1: unknown name). Not part of the reference-facing surface. */
 int irx_debug_set_knob(const char* name, long value);
 long irx_debug_get_knob(const char* name);

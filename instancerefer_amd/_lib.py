@@ -52,6 +52,7 @@ _SIGNATURES = {
     "irx_pairs_build_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "irx_spconv_wgrad_pairs_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "irx_spconv_wgrad_pairs": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    "irx_spconv_wgrad_pairs_t": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "irx_bn_workspace_bytes": (_Z, [_I, _I]),
     "irx_bn_stats": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "irx_bn_apply": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),

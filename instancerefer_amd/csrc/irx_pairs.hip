@@ -81,12 +81,23 @@ __global__ __launch_bounds__(256) void k_pairs_write(const int32_t* __restrict__
 // device memory): with G workgroups for T = sum_k ceil(cnt_k / 64) stages, offset k is cut into
 // ceil(nst_k / ceil(T / G)) shares (1 .. smax), so every workgroup gets about the same number of 64-pair stages.
 // (Equal splits per offset made the centre offset's workgroups the critical path at ~2.8x the average work.)
-__device__ __forceinline__ int pairs_shares(const int32_t* __restrict__ counts, int K, int k, int G, int smax) {
+// xcd != 0 (k_wgrad3 on levels with enough rows): the share count is a multiple of 8 — every list is first cut into 8
+// equal segments, one per XCD (the lists are in ascending output-row order, so segment x of every offset covers about
+// the same rows), and a segment into m shares (pairs_xcd_m); the kernel maps workgroup b to XCD segment b % 8.
+__device__ __forceinline__ int pairs_xcd_m(int nst, int tgt, int smax) {
+  int m = (nst + 4 * tgt) / (8 * tgt);                   // nst / (8 tgt), rounded to nearest
+  const int cap = smax >> 3;
+  if (m > cap) m = cap;
+  if (m < 1) m = 1;
+  return m;
+}
+__device__ __forceinline__ int pairs_shares(const int32_t* __restrict__ counts, int K, int k, int G, int smax, int xcd = 0) {
   int T = 0;
   for (int j = 0; j < K; ++j) T += (counts[j] + 63) >> 6;
   int tgt = (T + G - 1) / G;
   if (tgt < 1) tgt = 1;
   const int nst = (counts[k] + 63) >> 6;
+  if (xcd) return 8 * pairs_xcd_m(nst, tgt, smax);
   int sp = (nst + tgt - 1) / tgt;
   if (sp < 1) sp = 1;
   if (sp > smax) sp = smax;
@@ -524,11 +535,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs2(const float* __restrict
 // (cin * cout is a multiple of 256 for the supported channel counts).
 __global__ __launch_bounds__(256) void k_pairs_reduce(const float* __restrict__ part, const int32_t* __restrict__ counts,
                                                       int K, int G, int smax, size_t per_offset, size_t elems,
-                                                      float* __restrict__ dw) {
+                                                      float* __restrict__ dw, int xcd = 0) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   // block-uniform offset index -> the share count is computed with scalar loads by every wave (no LDS round trip)
   const int k = (int)(((size_t)blockIdx.x * blockDim.x) / per_offset);
-  const int n = pairs_shares(counts, K, k, G, smax);
+  const int n = pairs_shares(counts, K, k, G, smax, xcd);
   if (i >= elems) return;
   float s = 0.f;                                  // loads in batches of 8, adds in the original order (bit-identical)
   int j = 0;
@@ -704,6 +715,259 @@ extern "C" int irx_pairs_build_multi(int n_tables, const int32_t* const* nbr, co
   return IRX_OK;
 }
 
+// ---- bf16 weight-gradient, third generation (round 4): bf16 rows stay bf16, transposing LDS reads, 32x32x16 MFMA ---------
+// k_wgrad_pairs in bf16 storage mode is the fp32 design fed narrower rows: it widens them to fp32 when it writes the LDS
+// tiles, reads every fragment element with its own ds_read_b32, packs pairs of them back to bf16 and runs the half-rate
+// 16x16x16 MFMA — 40 LDS reads and 20 packs per 16 MFMAs, two barriers and a full vector-memory drain per 64-pair stage
+// (161 us for the 0.79 M pairs of the largest 128-channel level: 6 % of the matrix-core peak).  Both operands of the weight
+// gradient have the PAIRS as their reduction dimension, i.e. a lane's 8 reduction elements come from 8 different rows — the
+// one access pattern gfx950 has an instruction for:
+//   * rows are gathered with raw buffer loads (16 B per lane, a missing pair is an out-of-range offset = zeros) and written
+//     to LDS as they are: bf16, [pair][channel], 64-byte windows XOR-swizzled by the pair's low bits instead of padded;
+//   * ds_read_b64_tr_b16 hands a lane 4 consecutive pairs of ITS channel (a 16-lane group reads a [4 pairs][16 channels]
+//     block); two of them are one operand of v_mfma_f32_32x32x16_bf16 — 1 LDS read per MFMA at 128 x 128 (wave tile 64 x 64),
+//     no packs, no conversion; the swizzle makes the four pair rows of a read land in four different 16-bank windows;
+//   * the row buffers are double-buffered: ONE barrier per stage; stage t+2's rows are requested from inside stage t's MFMA
+//     chain into one register set and written behind the next barrier; the index lists run four stages ahead through a
+//     three-slot LDS ring, so no load ever waits for another load inside the loop;
+//   * fp32 accumulators in registers for the whole share, same (share, offset) partials and reduce as k_wgrad_pairs.
+typedef __bf16 w3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short w3_s16x4 __attribute__((ext_vector_type(4)));
+typedef short w3_s16x8 __attribute__((ext_vector_type(8)));
+typedef float w3_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned w3_u32x4 __attribute__((ext_vector_type(4)));
+#define W3_OOB 0x80000000u
+// dev ablation (timing only, results wrong): 1 = no row loads, 2 = no MFMA, 4 = no fragment reads, 8 = no LDS row writes,
+// 16 = no partial-sum stores
+#ifndef IRX_W3_ABL
+#define IRX_W3_ABL 0
+#endif
+
+// 64-byte window swizzle of a row image with RB bytes per row: the four rows of an aligned group of four pairs must occupy
+// four different 16-bank windows of the 64-bank LDS for the transposing read to be conflict-free
+template <int RB>
+__device__ __forceinline__ int w3_swz(int row) {
+  constexpr int WPR = RB / 64;                       // windows per row
+  return (((row & 3) * WPR) >> 2) & (WPR - 1);       // 4 windows: row & 3; 2 windows: bit 1 of the row; 1 window: 0
+}
+
+__device__ __forceinline__ w3_bf16x8 w3_frag(const unsigned char* lds, int byte_off_lo, int byte_off_hi) {
+  typedef __attribute__((address_space(3))) w3_s16x4* lp;
+  const w3_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds + byte_off_lo));
+  const w3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds + byte_off_hi));
+  const w3_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(w3_bf16x8, v);
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void k_wgrad3(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                   const int32_t* __restrict__ in_list, const int32_t* __restrict__ out_list,
+                                                   int ldp, const int32_t* __restrict__ counts, int K, int G, int smax,
+                                                   float* __restrict__ part, int ldx, int xcd) {
+  static_assert((CIN == 64 || CIN == 128) && (COUT == 64 || COUT == 128), "wave tiles are (CIN/2) x (COUT/2)");
+  constexpr int RBX = CIN * 2, RBD = COUT * 2;           // bytes of a row image
+  constexpr int LPX = RBX / 16, LPD = RBD / 16;          // lanes (16 B) per row
+  constexpr int PX = 256 / LPX, PD = 256 / LPD;          // rows per staging pass
+  constexpr int NX = 64 / PX, ND = 64 / PD;              // passes per 64-pair stage
+  constexpr int CB = CIN / 64, NB = COUT / 64;           // 32 x 32 blocks per wave, each way
+  constexpr int BX = 64 * RBX, BD = 64 * RBD;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BX + BD)];
+  __shared__ __attribute__((aligned(16))) unsigned sIdx[8][4][64];   // byte offsets of stage u's rows in slot u & 7: [0] x, [1] dy
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int s, k, nsplit;
+  if (xcd) {
+    // 1-D grid: workgroup b belongs to XCD b % 8 (the dispatcher deals consecutive workgroups round-robin over the XCDs) and
+    // takes the (b / 8)-th unit of that XCD's list — offset by offset, the m_k shares of list k's segment b % 8.  The units
+    // of one XCD therefore walk the same eighth of the level's rows, all at the same time (the grid fits the chip at once):
+    // a row fetched for one offset is an L2 hit for the other 26 instead of 27 trips to the fabric.
+    const int xseg = blockIdx.x & 7, r = blockIdx.x >> 3;
+    int T = 0;
+    for (int j = 0; j < K; ++j) T += (counts[j] + 63) >> 6;
+    int tgt = (T + G - 1) / G;
+    if (tgt < 1) tgt = 1;
+    int cum = 0;
+    k = -1; s = 0; nsplit = 8;
+    for (int j = 0; j < K; ++j) {
+      const int m = pairs_xcd_m((counts[j] + 63) >> 6, tgt, smax);
+      if (k < 0 && r < cum + m) { k = j; s = xseg * m + (r - cum); nsplit = 8 * m; }
+      cum += m;
+    }
+    if (k < 0) return;                                   // block-uniform
+  } else {
+    s = blockIdx.x; k = blockIdx.y;
+    nsplit = pairs_shares(counts, K, k, G, smax);
+    if (s >= nsplit) return;                             // block-uniform
+  }
+  const int cnt = counts[k];
+  const int nst = (cnt + 63) / 64;
+  const int st0 = (int)(((long long)nst * s) / nsplit), st1 = (int)(((long long)nst * (s + 1)) / nsplit);
+  const int32_t* il = in_list + (size_t)k * ldp;
+  const int32_t* ol = out_list + (size_t)k * ldp;
+  const unsigned rbx_g = (unsigned)ldx * 2u;             // bytes of a row of x in HBM
+
+  w3_f32x16 acc[CB][NB];
+#pragma unroll
+  for (int a = 0; a < CB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  if (st0 < st1) {
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, 0x7FFFFFF0, 0x00020000);
+    // staging role of this thread: row xr (+ i * PX) / 16-byte piece xc of the x image, the same for dy
+    const int xr = tid / LPX, xc = tid % LPX;
+    const int dr = tid / LPD, dc = tid % LPD;
+    const int xw = xr * RBX + ((((xc >> 2) ^ w3_swz<RBX>(xr))) << 6) + (xc & 3) * 16;      // (PX, PD are multiples of 4: the
+    const int dw_ = BX + dr * RBD + ((((dc >> 2) ^ w3_swz<RBD>(dr))) << 6) + (dc & 3) * 16; //  swizzle is the same every pass)
+    // fragment role: lane l of a 16-lane group reads pair (l >> 2) & 3 of a [4 pairs][16 channels] block, 8 bytes at channel
+    // 4 (l & 3); lanes 16..31 take the block's upper 16 channels, lanes 32..63 the pairs 8..15 of the 16-pair step
+    const int li = lane & 15, g16 = (lane >> 4) & 1, kg = lane >> 5, pr = li >> 2;
+    const int wc = wave >> 1, wn = wave & 1;
+    int aoff[CB], boff[NB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int cbyte = ((wc * CB + i) * 32 + 16 * g16 + 4 * (li & 3)) * 2;
+      aoff[i] = (8 * kg + pr) * RBX + (((cbyte >> 6) ^ w3_swz<RBX>(pr)) << 6) + (cbyte & 63);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int cbyte = ((wn * NB + j) * 32 + 16 * g16 + 4 * (li & 3)) * 2;
+      boff[j] = BX + (8 * kg + pr) * RBD + (((cbyte >> 6) ^ w3_swz<RBD>(pr)) << 6) + (cbyte & 63);
+    }
+    // index role: wave 0 fetches input rows, wave 1 output rows, FOUR stages (256 indices, 16 B per lane) per load; waves 2, 3
+    // run the same instructions on an out-of-range offset (no memory access): no load of the loop sits behind a branch and
+    // every wait count is exact.  Lane l holds indices 4 (l & 15) .. + 3 of the chunk's stage l >> 4.
+    const __amdgpu_buffer_rsrc_t rs_i =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(wave == 0 ? il : ol), 0, (unsigned)ldp * 4u, 0x00020000);
+    const unsigned rb_mine = wave == 0 ? rbx_g : (unsigned)RBD;
+    auto fetch_chunk = [&](int u0) __attribute__((always_inline)) -> w3_u32x4 {      // stages u0 .. u0 + 3
+      const unsigned o = wave < 2 ? (unsigned)(u0 * 64 + lane * 4) * 4u : W3_OOB;
+      return __builtin_amdgcn_raw_buffer_load_b128(rs_i, o, 0, 0);
+    };
+    // ring of 8 stage slots: [slot][list: 0 x, 1 dy, (2, 3 unused)][64] byte offsets, W3_OOB = no such pair
+    auto store_chunk = [&](w3_u32x4 raw, int u0) __attribute__((always_inline)) {
+      const int u = u0 + (lane >> 4);
+      const int p = u * 64 + (lane & 15) * 4;
+      w3_u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (u < st1 && p + e < cnt) ? raw[e] * rb_mine : W3_OOB;
+      *reinterpret_cast<w3_u32x4*>(&sIdx[u & 7][wave][(lane & 15) * 4]) = o;
+    };
+    w3_u32x4 rx[2][NX], rd[2][ND];                        // rows of stage u in set u & 1 (relative to st0: chunks start even)
+    auto request_x = [&](int set, int u, int i) __attribute__((always_inline)) {
+      const unsigned o = (IRX_W3_ABL & 1) ? W3_OOB : sIdx[u & 7][0][xr + i * PX];
+      rx[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, o + (unsigned)xc * 16u, 0, 0);
+    };
+    auto request_d = [&](int set, int u, int i) __attribute__((always_inline)) {
+      const unsigned o = (IRX_W3_ABL & 1) ? W3_OOB : sIdx[u & 7][1][dr + i * PD];
+      rd[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, o + (unsigned)dc * 16u, 0, 0);
+    };
+    auto request_quarter = [&](int set, int u, int q) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if ((i * 4) / NX == q) request_x(set, u, i);
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+        if ((i * 4) / ND == q) request_d(set, u, i);
+    };
+    auto write_rows = [&](int set, int buf) __attribute__((always_inline)) {
+      if (IRX_W3_ABL & 8) return;
+      unsigned char* b = smem + buf * (BX + BD);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) *reinterpret_cast<w3_u32x4*>(b + xw + i * PX * RBX) = rx[set][i];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) *reinterpret_cast<w3_u32x4*>(b + dw_ + i * PD * RBD) = rd[set][i];
+    };
+
+    // Stage u (absolute) lives in LDS buffer (u - st0) & 1 and its rows travel in register set (u - st0) & 1; its indices
+    // sit in ring slot u & 7.  Timeline of iteration t (MFMAs of stage t):
+    //   rows(t+1) [requested at t-2]  registers -> the other buffer          rows(t+3) requested into the set just freed
+    //   first iteration of a chunk of 4: indices of stages c+4..c+7 [requested at c-4] registers -> ring, c+8..c+11 requested
+    // so a row load has two whole iterations and an index load four to land before anything waits for it.
+    // ---- prologue: the first 8 stages' indices in one round trip, the first three stages' rows in the next ----
+    // (first iteration of chunk c: indices c+4..c+7 registers -> ring, c+8..c+11 requested)
+    w3_u32x4 ic;                                          // indices of stages c+4 .. c+7 while chunk c runs
+    {
+      const w3_u32x4 ic0 = fetch_chunk(st0);
+      ic = fetch_chunk(st0 + 4);
+      store_chunk(ic0, st0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) request_quarter(0, st0, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) request_quarter(1, st0 + 1, q);
+    write_rows(0, 0);                                     // (waits for stage st0's rows only)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) request_quarter(0, st0 + 2, q);
+    __syncthreads();
+    for (int c = st0; c < st1; c += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = c + j;
+        const unsigned char* b = smem + (j & 1) * (BX + BD);
+        w3_bf16x8 fa[2][CB], fb[2][NB];
+        auto frags = [&](int ks) __attribute__((always_inline)) {
+          if (IRX_W3_ABL & 4) return;
+#pragma unroll
+          for (int i = 0; i < CB; ++i) fa[ks & 1][i] = w3_frag(b, aoff[i] + (16 * ks) * RBX, aoff[i] + (16 * ks + 4) * RBX);
+#pragma unroll
+          for (int jn = 0; jn < NB; ++jn) fb[ks & 1][jn] = w3_frag(b, boff[jn] + (16 * ks) * RBD, boff[jn] + (16 * ks + 4) * RBD);
+        };
+        auto mfmas = [&](int ks) __attribute__((always_inline)) {
+          if (IRX_W3_ABL & 2) return;
+#pragma unroll
+          for (int i = 0; i < CB; ++i)
+#pragma unroll
+            for (int jn = 0; jn < NB; ++jn)
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][jn], acc[i][jn], 0, 0, 0);
+        };
+        // (stages past the share's end — a chunk is always run to its 4th stage — have out-of-range rows: zeros, no memory
+        //  access; their MFMAs add nothing)
+        frags(0);
+        frags(1);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        write_rows((j + 1) & 1, (j + 1) & 1);
+        if (j == 0) {
+          store_chunk(ic, c + 4);
+          ic = fetch_chunk(c + 8);
+        }
+        request_quarter((j + 1) & 1, t + 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(2);
+        mfmas(1);
+        request_quarter((j + 1) & 1, t + 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(3);
+        mfmas(2);
+        request_quarter((j + 1) & 1, t + 3, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(3);
+        request_quarter((j + 1) & 1, t + 3, 3);
+        __syncthreads();
+      }
+    }
+  }
+  float* out = part + ((size_t)s * K + k) * CIN * COUT;
+  {
+    const int kg = lane >> 5, wc = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          const int n = (wn * NB + j) * 32 + (lane & 31);
+          if (!(IRX_W3_ABL & 16) || acc[i][j][r] == 12345.f) out[(size_t)c * COUT + n] = acc[i][j][r];
+        }
+  }
+}
+
 static int pairs_budget(int n_out, int K) {
   static const int target = getenv("IRX_PAIRS_BUDGET") ? atoi(getenv("IRX_PAIRS_BUDGET")) : 1024;   // dev A/B knob
   int s = irx_cdiv(target, K);
@@ -725,8 +989,19 @@ static bool wp_v1() { return irx_knob(IRX_KNOB_WGRAD_V1) != 0; }   // (the parit
 template <int CIN>
 static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const float* dy, const int32_t* il,
                       const int32_t* ol, int ldp, const int32_t* counts, int K, int G, int smax, float* part, bool bf_rows,
-                      bool gen2) {
+                      bool gen2, int xcd) {
   irx_bracket_begin(st);
+  if constexpr (CIN >= 64) {
+    if (irx_conv_bf16() && bf_rows && gen2 && cout >= 64 && irx_knob(IRX_KNOB_WGRAD3) != 0) {
+      const unsigned short* xb = reinterpret_cast<const unsigned short*>(x);
+      const unsigned short* db = reinterpret_cast<const unsigned short*>(dy);
+      const dim3 g3 = xcd ? dim3(8 * (G / 8 + K + 1)) : grid;
+      if (cout == 128) k_wgrad3<CIN, 128><<<g3, 256, 0, st>>>(xb, db, il, ol, ldp, counts, K, G, smax, part, CIN, xcd);
+      else k_wgrad3<CIN, 64><<<g3, 256, 0, st>>>(xb, db, il, ol, ldp, counts, K, G, smax, part, CIN, xcd);
+      irx_bracket_end(st);
+      return;
+    }
+  }
   if (irx_conv_bf16() && bf_rows) {
     if (cout == 128) k_wgrad_pairs<CIN, 128, true, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
     else if (cout == 64) k_wgrad_pairs<CIN, 64, true, true><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
@@ -796,6 +1071,14 @@ extern "C" int irx_spconv_wgrad_pairs(const float* x, const float* dy, const int
                                      workspace_bytes, stream, 0, n_in);
 }
 
+extern "C" int irx_spconv_wgrad_pairs_t(const void* x, const void* dy, const int32_t* in_list, const int32_t* out_list,
+                                        int ldp, const int32_t* counts, int n_in, int n_out, int K, int cin, int cout,
+                                        float* dw, int rows_bf, void* workspace, size_t workspace_bytes, void* stream) {
+  IRX_REQUIRE(n_in >= 0, "irx_spconv_wgrad_pairs_t: n_in < 0");
+  return irx_spconv_wgrad_pairs_impl((const float*)x, (const float*)dy, in_list, out_list, ldp, counts, n_out, K, cin, cout,
+                                     dw, workspace, workspace_bytes, stream, rows_bf != 0, n_in);
+}
+
 // bf_rows != 0 (executor, bf16 storage mode): x and dy are bf16 tensors
 int irx_spconv_wgrad_pairs_impl(const float* x, const float* dy, const int32_t* in_list, const int32_t* out_list, int ldp,
                                 const int32_t* counts, int n_out, int K, int cin, int cout, float* dw, void* workspace,
@@ -810,7 +1093,8 @@ int irx_spconv_wgrad_pairs_impl(const float* x, const float* dy, const int32_t* 
   }
   IRX_REQUIRE(x && dy && in_list && out_list && counts, "irx_spconv_wgrad_pairs: null pointer");
   IRX_REQUIRE(((((uintptr_t)x | (uintptr_t)dy)) & 15) == 0, "irx_spconv_wgrad_pairs: x / dy must be 16-byte aligned");
-  const int G = pairs_budget(n_out, K), smax = pairs_smax(n_out, K);
+  int G = pairs_budget(n_out, K);
+  const int smax = pairs_smax(n_out, K);
   const size_t need = irx_spconv_wgrad_pairs_workspace_bytes(n_out, K, cin, cout);
   if (workspace == nullptr || workspace_bytes < need) {
     irx_set_error("irx_spconv_wgrad_pairs: workspace %zu < %zu", workspace_bytes, need);
@@ -820,12 +1104,20 @@ int irx_spconv_wgrad_pairs_impl(const float* x, const float* dy, const int32_t* 
   dim3 grid(smax, K);
   const bool gen2 = n_in > 0 && (size_t)n_in * cin * sizeof(float) < ((size_t)1 << 31) &&
                     (size_t)n_out * cout * sizeof(float) < ((size_t)1 << 31);
-  if (cin == 128) launch_wp<128>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2);
-  else if (cin == 64) launch_wp<64>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2);
-  else launch_wp<32>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2);
+  // k_wgrad3 on a level with enough work: XCD-segment units (pairs_shares) — few enough that the whole grid is resident at
+  // once (2 workgroups per CU) and that the fp32 partials, 4 * cin * cout bytes per unit each way, stay a small part of the job
+  int xcd = 0;
+  if (irx_conv_bf16() && bf_rows && gen2 && cin >= 64 && cout >= 64 && irx_knob(IRX_KNOB_WGRAD3) != 0 && smax >= 8 &&
+      (long)n_out * K >= irx_knob(IRX_KNOB_WGRAD3_XCD_MIN)) {
+    const long units = irx_knob(IRX_KNOB_WGRAD3_UNITS);
+    if (units >= 8) { xcd = 1; G = (int)units; }
+  }
+  if (cin == 128) launch_wp<128>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2, xcd);
+  else if (cin == 64) launch_wp<64>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2, xcd);
+  else launch_wp<32>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2, xcd);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad_pairs");
   k_pairs_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(part, counts, K, G, smax, (size_t)cin * cout, elems,
-                                                                       dw);
+                                                                       dw, xcd);
   IRX_CHECK_LAUNCH("irx_spconv_wgrad_pairs(reduce)");
   return IRX_OK;
 }

@@ -294,6 +294,9 @@ const KnobDef kKnobs[IRX_KNOB_COUNT] = {
     {"updgrad", "IRX_UPDGRAD", 1},               // fp32 stride-2 data-gradient tiled by parent rows (k_updgrad)
     {"updgrad_min", "IRX_UPDGRAD_MIN", 40000},   // ... from this many parent rows on
     {"wgrad_v1", "IRX_WGRAD_V1", 0},             // fp32 pair-list weight-gradient on the first-generation kernel
+    {"wgrad3", "IRX_WGRAD3", 1},                 // bf16-row pair-list weight-gradient on k_wgrad3 (transposing LDS reads)
+    {"wgrad3_units", "IRX_WGRAD3_UNITS", 448},   // ... work units (workgroups) of its XCD-segment mapping
+    {"wgrad3_xcd_min", "IRX_WGRAD3_XCD_MIN", 200000},   // ... used from this many table entries (n_out * K) on
 };
 std::atomic<long> g_knob_val[IRX_KNOB_COUNT];
 std::atomic<int> g_knob_set[IRX_KNOB_COUNT];

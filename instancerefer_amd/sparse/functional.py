@@ -381,6 +381,7 @@ _PAIR_CHANNELS = (32, 64, 128)
 
 
 def spconv_wgrad_pairs(x, dy, pairs, n_out, K, cin, cout, m_for_profile=None):
+    """irx_spconv_wgrad_pairs_t: x, dy both float32 or both bfloat16 (bf16 storage mode; set_compute_dtype('bf16'))"""
     in_list, out_list, counts, ldp = pairs
     dw = torch.empty((K, cin, cout), dtype=_f32, device=x.device)
     wsb = int(_lib.load().irx_spconv_wgrad_pairs_workspace_bytes(n_out, K, cin, cout))
@@ -388,8 +389,11 @@ def spconv_wgrad_pairs(x, dy, pairs, n_out, K, cin, cout, m_for_profile=None):
     if PROFILE is not None:
         m = int(counts.sum().item())
         e0, e1 = _bracket()
-    _lib.call("irx_spconv_wgrad_pairs", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_list), _lib.ptr(out_list), ldp,
-              _lib.ptr(counts), int(x.shape[0]), n_out, K, cin, cout, _lib.ptr(dw), _lib.ptr(ws), wsb, _stream())
+    bf = x.dtype == torch.bfloat16
+    if bf != (dy.dtype == torch.bfloat16):
+        raise ValueError("spconv_wgrad_pairs: x and dy must have the same element type")
+    _lib.call("irx_spconv_wgrad_pairs_t", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_list), _lib.ptr(out_list), ldp,
+              _lib.ptr(counts), int(x.shape[0]), n_out, K, cin, cout, _lib.ptr(dw), int(bf), _lib.ptr(ws), wsb, _stream())
     if PROFILE is not None:
         PROFILE.append(("wgrad", n_out, K, cin, cout, m, e0, e1))
     return dw

@@ -601,6 +601,63 @@ def test_conv_bf16_storage_operator_third_generation(lib, clouds, cin, cout, ks,
     assert (res[3][0] - res[2][0]).abs().max().item() <= 2e-5 * max(exp.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("cin,cout,ks,stride", [(128, 128, 3, 1), (64, 64, 3, 1), (64, 128, 2, 2), (128, 64, 3, 1), (32, 64, 2, 2)])
+def test_wgrad_bf16_storage_operator_third_generation(lib, clouds, cin, cout, ks, stride):
+    """irx_spconv_wgrad_pairs_t with bf16 rows (the weight gradient of the encoder executor's bf16 STORAGE mode as one
+    operator, include/irx.h): k_wgrad3 (csrc/irx_pairs.hip — rows stay bf16 in LDS, ds_read_b64_tr_b16 operand reads,
+    v_mfma_f32_32x32x16_bf16, two register sets of rows in flight) against the weight gradient of the CPU oracle's
+    per-offset gather -> mm -> index_add (oracle/torchsparse/nn/functional; models/basic_blocks.py:14-19 through
+    spnn.Conv3d) evaluated on the SAME bf16 values. Only the fp32 summation order differs: 2e-5 relative. Runs the
+    share mapping of small levels, the XCD-segment mapping of large ones (forced with the knobs: the fixture is small)
+    and the widening kernel (knob wgrad3 = 0; 32-channel inputs always take it), which must all agree to that bar."""
+    import instancerefer_amd as irx
+    import oracle.torchsparse.nn.functional as OF
+    from instancerefer_amd.sparse import functional as F_
+
+    def r(t):
+        return t.bfloat16().float()
+    torch.manual_seed(cin * 17 + cout * 3 + ks)
+    d = device_batch(clouds, 0.05)
+    lv = d.level()
+    if stride == 1:
+        tbl, ld = lv.nbr27()
+        n_in = n_out = lv.n
+        K = 27
+    else:
+        dm = lv.down()
+        tbl, ld, n_in, n_out, K = dm.child, dm.ld, lv.n, dm.out_level.n, 8
+    t = tbl[:K, :n_out].cpu().long()
+    maps = []
+    for k in range(K):
+        v = torch.nonzero(t[k] >= 0).flatten()
+        maps.append((t[k][v], v))
+    x = r(torch.randn(n_in, cin))
+    g = r(torch.randn(n_out, cout))
+    wo = torch.zeros(K, cin, cout, requires_grad=True)
+    OF.sparseconv_op(x, wo, maps, n_out).backward(g)
+    exp = wo.grad
+    pairs = F_.pairs_build(tbl, ld, n_out, K)
+    xb, gb = x.cuda().bfloat16(), g.cuda().bfloat16()
+    got = {}
+    irx.set_compute_dtype("bf16")
+    saved = {n: _lib.get_knob(n) for n in ("wgrad3", "wgrad3_units", "wgrad3_xcd_min")}
+    try:
+        for name, knobs in (("shares", {"wgrad3": 1, "wgrad3_xcd_min": 1 << 40}),
+                            ("xcd segments", {"wgrad3": 1, "wgrad3_xcd_min": 0, "wgrad3_units": 64}),
+                            ("xcd segments, many units", {"wgrad3": 1, "wgrad3_xcd_min": 0, "wgrad3_units": 448}),
+                            ("widening kernel", {"wgrad3": 0})):
+            for n, v in knobs.items():
+                _lib.set_knob(n, v)
+            got[name] = F_.spconv_wgrad_pairs(xb, gb, pairs, n_out, K, cin, cout).cpu()
+    finally:
+        for n, v in saved.items():
+            _lib.set_knob(n, v)
+        irx.set_compute_dtype("fp32")
+    bar = 2e-5 * max(exp.abs().max().item(), 1.0)
+    for name, dw in got.items():
+        assert (dw - exp).abs().max().item() <= bar, (name, (dw - exp).abs().max().item(), bar)
+
+
 def test_batched_pair_list_build_equals_per_table_builds(lib, clouds):
     """irx_pairs_build_multi over every table of a pyramid == irx_pairs_build table by table (bit-exact)."""
     from instancerefer_amd.sparse import functional as F_
