@@ -74,5 +74,47 @@ def _build_locked(objdir, verbose):
     return LIB_PATH
 
 
+# ---- C++ autograd nodes over the C-ABI (csrc/torch_nodes.cpp -> csrc/_irx_nodes.so) ----------------------------------------
+# A Python extension module compiled against the torch headers with g++ (host code only: it calls libirx through function
+# addresses and never touches HIP). In-tree like libirx.so, so it travels to the GPU box with the snapshot.
+NODES_SRC = os.path.join(CSRC, "torch_nodes.cpp")
+NODES_PATH = os.path.join(CSRC, "_irx_nodes.so")
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_nodes(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/torch_nodes.cpp into csrc/_irx_nodes.so (torch C++ extension, ~1 min). Returns the module path."""
+    if not force and os.path.exists(NODES_PATH) and os.path.getmtime(NODES_PATH) >= os.path.getmtime(NODES_SRC):
+        return NODES_PATH
+    import fcntl
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    lock = open(os.path.join(objdir, ".lock_nodes"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and os.path.exists(NODES_PATH) and os.path.getmtime(NODES_PATH) >= os.path.getmtime(NODES_SRC):
+            return NODES_PATH
+        tlib = ce.library_paths()[0]
+        cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-DTORCH_EXTENSION_NAME=_irx_nodes", "-DTORCH_API_INCLUDE_EXTENSION_H",
+               "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+        cmd += ["-I" + d for d in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"]]
+        tmp = NODES_PATH + ".tmp.%d" % os.getpid()
+        cmd += [NODES_SRC, "-o", tmp, "-L" + tlib, "-Wl,-rpath," + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building _irx_nodes failed:\n%s\n%s" % (r.stdout, r.stderr))
+        os.replace(tmp, NODES_PATH)
+        return NODES_PATH
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_nodes(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,33 @@
+"""Loader of csrc/_irx_nodes.so — the C++ autograd nodes over libirx's C-ABI (csrc/torch_nodes.cpp).
+
+The module is handed the ADDRESSES of the entry points of the library instance _lib.py loaded (it links nothing itself), so
+a dev build selected with IRX_LIB_PATH is the one the nodes call. IRX_CPP_NODES=0 keeps every head on its Python / ATen path.
+"""
+import ctypes
+import importlib.util
+import os
+
+from . import _build, _lib
+
+ENABLED = os.environ.get("IRX_CPP_NODES", "1") != "0"
+_ENTRY_POINTS = ("irx_mlp2_saved_floats", "irx_mlp2_fwd", "irx_mlp2_bwd", "irx_last_error")
+_mod = None
+_tried = False
+
+
+def load():
+    """The extension module, bound to libirx — or None when it is switched off or has not been built (the callers then use
+    their Python autograd.Function: same kernels, more interpreter time; nothing here is a CPU fallback)."""
+    global _mod, _tried
+    if _tried:
+        return _mod
+    _tried = True
+    if not ENABLED or not os.path.exists(_build.NODES_PATH):
+        return None
+    spec = importlib.util.spec_from_file_location("_irx_nodes", _build.NODES_PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = _lib.load()
+    mod.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in _ENTRY_POINTS})
+    _mod = mod
+    return mod

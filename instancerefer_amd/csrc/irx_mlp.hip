@@ -15,29 +15,59 @@ static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
 #define ML_TR 64   // rows per tile
 #define ML_TC 32   // columns per tile
-#define ML_TK 32   // reduction chunk
+#define ML_TK 128  // reduction chunk
 
 // C[i][j] (i < 64, j < 32) += sum_k A(i, k) * B(j, k) for k in [0, K): both operands are functors staged through LDS in
-// chunks of 32; thread t owns column j = t & 31 and rows (t >> 5) + 8 m.  acc[m] accumulates; all 256 threads take part.
+// chunks of 128; thread t owns column j = t & 31 and rows (t >> 5) + 8 m.  acc[m] accumulates; all 256 threads take part.
+// These kernels are a handful of workgroups running a chain of dependent global round trips, so the chunk is as long as the
+// static LDS budget allows (K <= 128: ONE round trip per tile, K = 256: two) and a chunk's 48 loads per thread are all in
+// flight before the first one is stored (register staging), the next chunk's loads are issued before the current chunk is
+// multiplied, and the multiply reads its operands as float4 (9 LDS reads per 32 FMAs instead of per 8): with 32-wide chunks
+// filled by load-then-store loops every chunk paid its own round trip, 8 per tile — 34 us per launch for 8 MFLOP.
+#define ML_LD (ML_TK + 4)   // LDS row stride in floats: rows stay 16-byte aligned for the float4 fragment reads
 template <typename FA, typename FB>
-__device__ __forceinline__ void ml_tile(FA A, FB B, int K, float (&acc)[8], float (*sA)[ML_TK + 1], float (*sB)[ML_TK + 1]) {
+__device__ __forceinline__ void ml_tile(FA A, FB B, int K, float (&acc)[8], float (*sA)[ML_LD], float (*sB)[ML_LD]) {
   const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
+  constexpr int NA = ML_TR * ML_TK / 256, NB = ML_TC * ML_TK / 256;
+  float ra[NA], rb[NB];
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int e = t + 256 * q, i = e / ML_TK, k = e % ML_TK;
+      ra[q] = (k0 + k < K) ? A(i, k0 + k) : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int e = t + 256 * q, jj = e / ML_TK, k = e % ML_TK;
+      rb[q] = (k0 + k < K) ? B(jj, k0 + k) : 0.f;
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < K; k0 += ML_TK) {
     __syncthreads();
-    for (int e = t; e < ML_TR * ML_TK; e += 256) {
-      const int i = e / ML_TK, k = e % ML_TK;
-      sA[i][k] = (k0 + k < K) ? A(i, k0 + k) : 0.f;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int e = t + 256 * q;
+      sA[e / ML_TK][e % ML_TK] = ra[q];
     }
-    for (int e = t; e < ML_TC * ML_TK; e += 256) {
-      const int jj = e / ML_TK, k = e % ML_TK;
-      sB[jj][k] = (k0 + k < K) ? B(jj, k0 + k) : 0.f;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int e = t + 256 * q;
+      sB[e / ML_TK][e % ML_TK] = rb[q];
     }
     __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < ML_TK; ++k) {
-      const float b = sB[j][k];
+    if (k0 + ML_TK < K) fetch(k0 + ML_TK);            // the next chunk travels while this one is multiplied
+    const int kn = (K - k0 < ML_TK) ? K - k0 : ML_TK;  // (columns kn .. of the chunk hold zeros: whole float4 steps are safe)
+    for (int k = 0; k < kn; k += 4) {
+      const float4 b = *reinterpret_cast<const float4*>(&sB[j][k]);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) acc[m] = fmaf(sA[i0 + 8 * m][k], b, acc[m]);
+      for (int m = 0; m < 8; ++m) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&sA[i0 + 8 * m][k]);
+        acc[m] = fmaf(a4.x, b.x, acc[m]);
+        acc[m] = fmaf(a4.y, b.y, acc[m]);
+        acc[m] = fmaf(a4.z, b.z, acc[m]);
+        acc[m] = fmaf(a4.w, b.w, acc[m]);
+      }
     }
   }
 }
@@ -74,22 +104,26 @@ __global__ __launch_bounds__(256) void k_mlp_fwd1(const float* __restrict__ x, i
                                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                                   float drop_p, unsigned long long seed, float* __restrict__ h,
                                                   float* __restrict__ stat, float* __restrict__ a) {
-  __shared__ float sA[ML_TR][ML_TK + 1], sB[ML_TC][ML_TK + 1], red[8][ML_TC];
+  __shared__ __attribute__((aligned(16))) float sA[ML_TR][ML_LD], sB[ML_TC][ML_LD], red[8][ML_TC];
   const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
   const int c = blockIdx.x * ML_TC + j;
   const bool cv = c < dh;
   double s1 = 0.0, s2 = 0.0;
+  float hv[8];
   for (int r0 = 0; r0 < rows; r0 += ML_TR) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     ml_tile([&](int i, int k) { return (r0 + i < rows) ? x[(size_t)(r0 + i) * din + k] : 0.f; },
             [&](int jj, int k) { const int cc = blockIdx.x * ML_TC + jj; return cc < dh ? w1[(size_t)cc * din + k] : 0.f; },
             din, acc, sA, sB);
     float p1 = 0.f, p2 = 0.f;
+    const float bias = cv ? b1[c] : 0.f;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int r = r0 + i0 + 8 * m;
+      hv[m] = 0.f;
       if (r < rows && cv) {
-        const float v = acc[m] + b1[c];
+        const float v = acc[m] + bias;
+        hv[m] = v;
         h[(size_t)r * dh + c] = v;
         p1 += v;
         p2 = fmaf(v, v, p2);
@@ -101,16 +135,26 @@ __global__ __launch_bounds__(256) void k_mlp_fwd1(const float* __restrict__ x, i
     }
   }
   if (norm == ML_LN) return;                          // row statistics need the whole row: forward 2
+  // (one row tile — every head of the model: 16 or 64 rows — keeps this thread's h values in registers, so the second pass
+  //  of the variance and the activation below do not wait for the stores above to come back from memory)
+  const bool one_tile = rows <= ML_TR;
   float mean, invstd;
   if (norm == ML_BN_TRAIN) {
     // two-pass variance over this block's own h (E[x^2] - mean^2 loses everything when two rows are nearly equal)
     const double m = s1 / rows;
     float pv = 0.f;
-    if (cv)
-      for (int r = i0; r < rows; r += 8) {             // (the entries of h this thread stored above)
-        const float d = h[(size_t)r * dh + c] - (float)m;
-        pv = fmaf(d, d, pv);
+    if (cv) {
+      if (one_tile) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (i0 + 8 * q < rows) { const float d = hv[q] - (float)m; pv = fmaf(d, d, pv); }
+      } else {
+        for (int r = i0; r < rows; r += 8) {           // (the entries of h this thread stored above)
+          const float d = h[(size_t)r * dh + c] - (float)m;
+          pv = fmaf(d, d, pv);
+        }
       }
+    }
     const double var = (double)ml_colsum(pv, red) / rows;
     (void)s2;
     mean = (float)m;
@@ -131,6 +175,17 @@ __global__ __launch_bounds__(256) void k_mlp_fwd1(const float* __restrict__ x, i
   if (!cv) return;
   const float g = gamma[c] * invstd, bsh = beta[c] - mean * g;
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  if (one_tile) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = i0 + 8 * q;
+      if (r < rows) {
+        const size_t o = (size_t)r * dh + c;
+        a[o] = ml_drop(fmaxf(fmaf(hv[q], g, bsh), 0.f), drop_p, dscale, seed, o);
+      }
+    }
+    return;
+  }
   for (int r = i0; r < rows; r += 8) {                // (rows i0 + 8 m: exactly the entries of h this thread stored above)
     const size_t o = (size_t)r * dh + c;
     a[o] = ml_drop(fmaxf(fmaf(h[o], g, bsh), 0.f), drop_p, dscale, seed, o);
@@ -143,21 +198,24 @@ __global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, i
                                                   float drop_p, unsigned long long seed, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ stat,
                                                   float* __restrict__ a, float* __restrict__ y) {
-  __shared__ float sA[ML_TR][ML_TK + 1], sB[ML_TC][ML_TK + 1];
+  __shared__ __attribute__((aligned(16))) float sA[ML_TR][ML_LD], sB[ML_TC][ML_LD];
   __shared__ float sMean[ML_TR], sInv[ML_TR];
-  const int t = threadIdx.x, j = t & 31, i0 = t >> 5, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
   const int c = blockIdx.x * ML_TC + j;
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int r0 = 0; r0 < rows; r0 += ML_TR) {
     if (norm == ML_LN) {                              // every block recomputes the tile's row statistics (dh <= 512 floats a row)
       __syncthreads();
-      for (int i = wave; i < ML_TR; i += 4) {
-        const int r = r0 + i;
+      {
+        // four threads per row, all 64 rows of the tile at once (one wave per row, 16 rows in sequence, was 16 dependent
+        // round trips); thread q of a row sums elements q, q + 4, ... — the four partial sums are combined in a fixed order
+        const int i = t >> 2, q = t & 3, r = r0 + i;
         float p1 = 0.f, p2 = 0.f;
         if (r < rows)
-          for (int k = lane; k < dh; k += 64) { const float v = h[(size_t)r * dh + k]; p1 += v; p2 = fmaf(v, v, p2); }
-        for (int off = 32; off > 0; off >>= 1) { p1 += __shfl_xor(p1, off); p2 += __shfl_xor(p2, off); }
-        if (lane == 0) {
+          for (int k = q; k < dh; k += 4) { const float v = h[(size_t)r * dh + k]; p1 += v; p2 = fmaf(v, v, p2); }
+        p1 += __shfl_xor(p1, 1); p2 += __shfl_xor(p2, 1);
+        p1 += __shfl_xor(p1, 2); p2 += __shfl_xor(p2, 2);
+        if (q == 0) {
           const float m = p1 / dh, var = fmaxf(p2 / dh - m * m, 0.f);
           sMean[i] = m;
           sInv[i] = rsqrtf(var + eps);
@@ -201,10 +259,35 @@ __global__ __launch_bounds__(256) void k_mlp_bwd1(const float* __restrict__ dy, 
                                                   const float* __restrict__ a, float drop_scale, float* __restrict__ dhid,
                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                   float* __restrict__ dw2, float* __restrict__ db2) {
-  __shared__ float sA[ML_TR][ML_TK + 1], sB[ML_TC][ML_TK + 1], red[8][ML_TC];
+  __shared__ __attribute__((aligned(16))) float sA[ML_TR][ML_LD], sB[ML_TC][ML_LD], red[8][ML_TC];
   const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
   const int c = blockIdx.x * ML_TC + j;
   const bool cv = c < dh;
+  if (blockIdx.y > 0) {
+    // dW2[o][c] = sum_r dy[r][o] a[r][c] for this block's columns c and the 64 outputs of tile blockIdx.y - 1 (reduction over
+    // the rows); it only reads forward-saved tensors, so it runs beside the data-gradient blocks instead of behind them
+    const int o0 = ((int)blockIdx.y - 1) * ML_TR;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ml_tile([&](int i, int k) { return (o0 + i < dout) ? dy[(size_t)k * dout + o0 + i] : 0.f; },
+            [&](int jj, int k) { const int cc = blockIdx.x * ML_TC + jj; return cc < dh ? a[(size_t)k * dh + cc] : 0.f; },
+            rows, acc, sA, sB);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int o = o0 + i0 + 8 * m;
+      if (o < dout && cv) dw2[(size_t)o * dh + c] = acc[m];
+    }
+    if (blockIdx.x == 0)                                // db2 of this tile's outputs: 4 threads per output, fixed order
+      for (int e = t; e < 4 * ML_TR; e += 256) {
+        const int o = o0 + (e >> 2), q = e & 3;
+        float sdb = 0.f;
+        if (o < dout)
+          for (int r = q; r < rows; r += 4) sdb += dy[(size_t)r * dout + o];
+        sdb += __shfl_xor(sdb, 1);
+        sdb += __shfl_xor(sdb, 2);
+        if (q == 0 && o < dout) db2[o] = sdb;
+      }
+    return;
+  }
   const float mean_c = (norm != ML_LN && cv) ? stat[c] : 0.f, inv_c = (norm != ML_LN && cv) ? stat[dh + c] : 0.f;
   float sg = 0.f, sb = 0.f;
   for (int r0 = 0; r0 < rows; r0 += ML_TR) {
@@ -241,24 +324,6 @@ __global__ __launch_bounds__(256) void k_mlp_bwd1(const float* __restrict__ dy, 
       dhid[o] = gi * (dhid[o] - kb - xh * kg);
     }
   }
-  // dW2[o][c] = sum_r dy[r][o] a[r][c] for this block's columns c, every output o (tiles of 64 outputs, reduction over rows)
-  for (int o0 = 0; o0 < dout; o0 += ML_TR) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    ml_tile([&](int i, int k) { return (o0 + i < dout) ? dy[(size_t)k * dout + o0 + i] : 0.f; },
-            [&](int jj, int k) { const int cc = blockIdx.x * ML_TC + jj; return cc < dh ? a[(size_t)k * dh + cc] : 0.f; },
-            rows, acc, sA, sB);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int o = o0 + i0 + 8 * m;
-      if (o < dout && cv) dw2[(size_t)o * dh + c] = acc[m];
-    }
-  }
-  if (blockIdx.x == 0)
-    for (int o = t; o < dout; o += 256) {
-      float s = 0.f;
-      for (int r = 0; r < rows; ++r) s += dy[(size_t)r * dout + o];
-      db2[o] = s;
-    }
 }
 
 // ---- backward 2 (LayerNorm): one wave per row: dh = invstd (g - mean(g) - xhat mean(g xhat)) ----
@@ -290,7 +355,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd3(const float* __restrict__ x, i
                                                   const float* __restrict__ w1, const float* __restrict__ dhid,
                                                   float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dx,
                                                   int nW) {
-  __shared__ float sA[ML_TR][ML_TK + 1], sB[ML_TC][ML_TK + 1];
+  __shared__ __attribute__((aligned(16))) float sA[ML_TR][ML_LD], sB[ML_TC][ML_LD];
   const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
   const int kblocks = (din + ML_TC - 1) / ML_TC;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -363,7 +428,7 @@ extern "C" int irx_mlp2_bwd(const float* x, const float* dy, int rows, int din, 
   const float* h = saved;
   const float* a = saved + (size_t)rows * dh;
   const float* stat = a + (size_t)rows * dh;
-  k_mlp_bwd1<<<irx_cdiv(dh, ML_TC), 256, 0, S(stream)>>>(dy, rows, dh, dout, norm, gamma, w2, h, stat, a, drop_scale, dhid, dgamma,
+  k_mlp_bwd1<<<dim3(irx_cdiv(dh, ML_TC), 1 + irx_cdiv(dout, ML_TR)), 256, 0, S(stream)>>>(dy, rows, dh, dout, norm, gamma, w2, h, stat, a, drop_scale, dhid, dgamma,
                                                           dbeta, dw2, db2);
   IRX_CHECK_LAUNCH("irx_mlp2_bwd(1)");
   if (norm == ML_LN) {

@@ -1,0 +1,145 @@
+// torch_nodes.cpp — C++ autograd nodes over the C-ABI of libirx (include/irx.h) for the dense heads.
+//
+// The training step of the bf16 headline configuration is HOST-bound: the GPU finishes a step in ~4.3 ms
+// while the interpreter needs ~5.8 ms to issue it. A torch.autograd.Function written in Python costs 30 us (forward) to 100 us
+// (backward, entered from the C++ engine through the GIL) of interpreter time per node — more than the handful of ATen
+// dispatches a fused head operator replaces (the round-4 negative result of dense.MLP2Fn). The same operators behind
+// torch::autograd::Function cost a few microseconds: tensors are allocated with ATen, the kernels are the C-ABI entry points
+// of libirx (handed over as addresses by _lib.py — this module does not link the library, so IRX_LIB_PATH builds keep
+// working), parameter gradients go straight into the optimizer's flat gradient buffer (the gradient-sink protocol of
+// optim.FlatAdam: slot addresses in, one delivered flag per producer out — no AccumulateGrad nodes).
+//
+// This file is binding plumbing: no arithmetic happens here. Reference semantics of the operators: models/attribute_module.py:26-34,
+// relation_module.py:18-27, scene_module.py:38-42 (nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, [Dropout], Linear)).
+#include <torch/extension.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+namespace {
+
+typedef size_t (*saved_floats_fn)(int, int);
+typedef int (*mlp2_fwd_fn)(const float*, int, int, int, int, const float*, const float*, int, const float*, const float*, float,
+                           float*, float*, float, float, unsigned long long, const float*, const float*, float*, float*, void*);
+typedef int (*mlp2_bwd_fn)(const float*, const float*, int, int, int, int, const float*, int, const float*, const float*,
+                           const float*, float, float*, float*, float*, float*, float*, float*, float*, float*, void*);
+typedef const char* (*last_error_fn)();
+
+struct Api {
+  saved_floats_fn mlp2_saved_floats = nullptr;
+  mlp2_fwd_fn mlp2_fwd = nullptr;
+  mlp2_bwd_fn mlp2_bwd = nullptr;
+  last_error_fn last_error = nullptr;
+} g_api;
+
+void check(int rc, const char* what) {
+  if (rc == 0) return;
+  const char* msg = g_api.last_error ? g_api.last_error() : "";       // (thread-local in libirx: read on the failing thread)
+  throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + (msg ? msg : ""));
+}
+
+inline const float* fp(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+inline float* fpm(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+
+// y = W2 . D(relu(N(W1 x + b1))) + b2, irx_mlp2_fwd / irx_mlp2_bwd.  slot_ptrs: addresses of the six gradient slots
+// (w1, b1, gamma, beta, w2, b2) in the optimizer's flat buffer, or empty; flag: host int32 the backward sets to 1 when it
+// delivered there (the optimizer reads it at gather time); a second backward before the flags are cleared, or a backward
+// without slots, returns ordinary gradient tensors.
+struct MLP2Node : public torch::autograd::Function<MLP2Node> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w1, const Tensor& b1, const Tensor& gamma,
+                        const Tensor& beta, const Tensor& w2, const Tensor& b2, int64_t norm, double eps,
+                        const c10::optional<Tensor>& rmean, const c10::optional<Tensor>& rvar, double momentum, double drop_p,
+                        int64_t seed, int64_t stream, std::vector<int64_t> slot_ptrs, int64_t flag) {
+    const Tensor x = x_in.contiguous().to(torch::kFloat32);
+    const int rows = (int)x.size(0), din = (int)x.size(1), dh = (int)w1.size(0), dout = (int)w2.size(0);
+    Tensor y = torch::empty({rows, dout}, x.options());
+    Tensor saved = torch::empty({(int64_t)g_api.mlp2_saved_floats(rows, dh)}, x.options());
+    check(g_api.mlp2_fwd(fp(x), rows, din, dh, dout, fp(w1), fp(b1), (int)norm, fp(gamma), fp(beta), (float)eps,
+                         rmean.has_value() ? fpm(*rmean) : nullptr, rvar.has_value() ? fpm(*rvar) : nullptr, (float)momentum,
+                         (float)drop_p, (unsigned long long)seed, fp(w2), fp(b2), fpm(saved), fpm(y), (void*)stream),
+          "irx_mlp2_fwd");
+    ctx->save_for_backward({x, w1, gamma, w2, saved});
+    ctx->saved_data["norm"] = norm;
+    ctx->saved_data["drop_p"] = drop_p;
+    ctx->saved_data["stream"] = stream;          // (the engine replays the node on its forward stream)
+    ctx->saved_data["flag"] = flag;
+    ctx->saved_data["slots"] = slot_ptrs;
+    return y;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    const auto sv = ctx->get_saved_variables();
+    const Tensor &x = sv[0], &w1 = sv[1], &gamma = sv[2], &w2 = sv[3], &saved = sv[4];
+    const int rows = (int)x.size(0), din = (int)x.size(1), dh = (int)w1.size(0), dout = (int)w2.size(0);
+    const int64_t norm = ctx->saved_data["norm"].toInt();
+    const double drop_p = ctx->saved_data["drop_p"].toDouble();
+    void* stream = (void*)ctx->saved_data["stream"].toInt();
+    int32_t* flag = (int32_t*)ctx->saved_data["flag"].toInt();
+    const auto slots = ctx->saved_data["slots"].toIntVector();
+    const Tensor dy = grad_out[0].contiguous().to(torch::kFloat32);
+    const bool want_dx = ctx->needs_input_grad(0);
+    Tensor scratch = torch::empty({(int64_t)rows * (dh + (want_dx ? din : 0))}, x.options());
+    float* base = scratch.data_ptr<float>();
+    float* dx_ptr = want_dx ? base + (size_t)rows * dh : nullptr;
+    const bool deliver = slots.size() == 6 && flag != nullptr && *flag == 0;
+    float* gp[6];
+    variable_list out(17);
+    if (deliver) {
+      for (int i = 0; i < 6; ++i) gp[i] = (float*)slots[i];
+    } else {
+      const int64_t sizes[6] = {(int64_t)dh * din, dh, dh, dh, (int64_t)dout * dh, dout};
+      int64_t total = 0;
+      for (int i = 0; i < 6; ++i) total += sizes[i];
+      Tensor buf = torch::empty({total}, x.options());
+      int64_t off = 0;
+      for (int i = 0; i < 6; ++i) {
+        gp[i] = buf.data_ptr<float>() + off;
+        Tensor v = buf.narrow(0, off, sizes[i]);
+        out[1 + i] = (i == 0) ? v.view({dh, din}) : (i == 4 ? v.view({dout, dh}) : v);
+        off += sizes[i];
+      }
+    }
+    check(g_api.mlp2_bwd(fp(x), fp(dy), rows, din, dh, dout, fp(w1), (int)norm, fp(gamma), fp(w2), fp(saved),
+                         drop_p > 0 ? (float)(1.0 / (1.0 - drop_p)) : 1.f, base, dx_ptr, gp[0], gp[1], gp[2], gp[3], gp[4], gp[5],
+                         stream),
+          "irx_mlp2_bwd");
+    if (deliver) *flag = 1;
+    if (want_dx) out[0] = scratch.narrow(0, (int64_t)rows * dh, (int64_t)rows * din).view({rows, din});
+    return out;
+  }
+};
+
+Tensor mlp2(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& gamma, const Tensor& beta, const Tensor& w2,
+            const Tensor& b2, int64_t norm, double eps, const c10::optional<Tensor>& rmean, const c10::optional<Tensor>& rvar,
+            double momentum, double drop_p, int64_t seed, int64_t stream, std::vector<int64_t> slot_ptrs, int64_t flag) {
+  TORCH_CHECK(g_api.mlp2_fwd && g_api.mlp2_bwd && g_api.mlp2_saved_floats, "irx nodes: bind() has not been called");
+  return MLP2Node::apply(x, w1, b1, gamma, beta, w2, b2, norm, eps, rmean, rvar, momentum, drop_p, seed, stream,
+                         std::move(slot_ptrs), flag);
+}
+
+// addresses of the C-ABI entry points, taken from the library instance _lib.py loaded
+void bind(const std::unordered_map<std::string, uint64_t>& addr) {
+  auto get = [&](const char* name) -> uint64_t {
+    auto it = addr.find(name);
+    TORCH_CHECK(it != addr.end() && it->second != 0, "irx nodes: missing entry point ", name);
+    return it->second;
+  };
+  g_api.mlp2_saved_floats = (saved_floats_fn)get("irx_mlp2_saved_floats");
+  g_api.mlp2_fwd = (mlp2_fwd_fn)get("irx_mlp2_fwd");
+  g_api.mlp2_bwd = (mlp2_bwd_fn)get("irx_mlp2_bwd");
+  g_api.last_error = (last_error_fn)get("irx_last_error");
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "C++ autograd nodes over libirx's C-ABI (dense heads)";
+  m.def("bind", &bind);
+  m.def("mlp2", &mlp2);
+}

@@ -207,12 +207,27 @@ class MLP2Fn(torch.autograd.Function):
         return (dx,) + tuple(grads) + (None,) * 7
 
 
-# OFF by default — a measured negative result (round 4, pinned host, bf16 B = 16, two alternating pairs): 6.49 / 6.50 ms per step
-# with the seven head MLPs on this operator against 6.15 / 6.13 ms through ATen. The step is host-bound there, and a Python
-# autograd.Function node costs more host time (31 us forward + 97 us backward per MLP in torch.profiler) than the ~8 + ~25 ATen
-# dispatches it replaces, which run inside the C++ engine without the interpreter. The operator stays (tests cover it; a C++
-# autograd node would change the balance); IRX_FUSED_MLP2=1 switches it on.
-FUSED_MLP2 = os.environ.get("IRX_FUSED_MLP2", "0") == "1"
+# Two ways to run the operator. As the Python node above it is a measured NEGATIVE result (round 4, pinned host, bf16 B = 16,
+# two alternating pairs: 6.49 / 6.50 ms per step with the seven head MLPs on it against 6.15 / 6.13 ms through ATen): the step
+# is host-bound there, and a Python autograd.Function costs more interpreter time (31 us forward + 97 us backward per MLP in
+# torch.profiler) than the ~8 + ~25 ATen dispatches it replaces, which run inside the C++ engine without the interpreter.
+# As a C++ autograd node (csrc/torch_nodes.cpp, loaded by _nodes.py) the same two C-ABI calls cost a few microseconds each
+# way, so that is the default whenever the extension has been built; IRX_FUSED_MLP2=0 keeps ATen, =1 forces the operator
+# (through the Python node if the extension is missing), IRX_MLP2_BACKEND=py selects the Python node for tests.
+FUSED_MLP2 = {"0": False, "1": True}.get(os.environ.get("IRX_FUSED_MLP2", "auto"))     # None: on iff the C++ node is there
+MLP2_BACKEND = os.environ.get("IRX_MLP2_BACKEND", "auto")
+
+
+def _mlp2_backend():
+    """-> the C++ extension module, "py" (MLP2Fn) or None (ATen modules)"""
+    if FUSED_MLP2 is False:
+        return None
+    if MLP2_BACKEND != "py":
+        from . import _nodes
+        mod = _nodes.load()
+        if mod is not None:
+            return mod
+    return "py" if FUSED_MLP2 else None
 
 
 def _dropout_seed(device):
@@ -231,7 +246,8 @@ def mlp2(seq, x):
     single row in training) goes through the module itself. Same parameters, buffers and state-dict keys either way."""
     import torch.nn as nn
     mods = list(seq)
-    ok = (FUSED_MLP2 and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and len(mods) in (4, 5) and isinstance(mods[0], nn.Linear)
+    backend = _mlp2_backend()
+    ok = (backend is not None and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and len(mods) in (4, 5) and isinstance(mods[0], nn.Linear)
           and isinstance(mods[1], (nn.BatchNorm1d, nn.LayerNorm)) and isinstance(mods[2], nn.ReLU) and isinstance(mods[-1], nn.Linear)
           and (len(mods) == 4 or isinstance(mods[3], nn.Dropout)) and mods[0].bias is not None and mods[-1].bias is not None)
     if ok and isinstance(mods[1], nn.BatchNorm1d):
@@ -255,5 +271,17 @@ def mlp2(seq, x):
     else:
         norm, rmean, rvar, momentum = 3, None, None, 0.0
     seed = _dropout_seed(x.device) if drop_p > 0 else 0
+    if backend != "py":
+        # C++ node: the optimizer's slot addresses (gradient sink) are looked up once per MLP and travel as integers
+        slots, flag = (), 0
+        if torch.is_grad_enabled():
+            sink = getattr(lin1.weight, "_irx_sink", None)
+            if sink is not None:
+                ent = sink[0].native_sink(("mlp2", id(lin1.weight)),
+                                          (lin1.weight, lin1.bias, nrm.weight, nrm.bias, lin2.weight, lin2.bias))
+                if ent is not None:
+                    slots, flag = ent
+        return backend.mlp2(x, lin1.weight, lin1.bias, nrm.weight, nrm.bias, lin2.weight, lin2.bias, norm, nrm.eps, rmean, rvar,
+                            momentum, drop_p, seed if seed < (1 << 63) else seed - (1 << 64), _lib.stream_ptr(), slots, flag)
     return MLP2Fn.apply(x, lin1.weight, lin1.bias, nrm.weight, nrm.bias, lin2.weight, lin2.bias, norm, nrm.eps, rmean, rvar,
                         momentum, drop_p, seed)

@@ -18,6 +18,7 @@ gather instead, so the sequence of collectives never depends on the data.
 
 Buffer management, gather, all-reduce, broadcast and the state dict work on any device (the world-size-2 gloo test
 runs them on CPU tensors); `step()` is the HIP kernel and raises without a HIP device — there is no CPU optimizer."""
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -90,6 +91,10 @@ class FlatAdam:
         self._index = {id(p): i for i, p in enumerate(self.params)}
         for p, slot in zip(self.params, self._slots):
             p._irx_sink = (self, slot)
+        # ... and the C++ autograd nodes (csrc/torch_nodes.cpp): they get the slot ADDRESSES at forward time and raise one host
+        # flag per producer when their backward wrote them (no interpreter on that path); gather_grads() folds the flags in
+        self._native_flags = np.zeros(256, dtype=np.int32)
+        self._native = {}               # producer key -> (flag index, parameter indices, slot addresses, flag address)
         self._direct = set()            # parameter indices whose slot already holds this step's gradient
         self._direct_groups = set()     # producer keys that delivered since the last zero_grad()
         self._gather_cache = {}
@@ -143,6 +148,8 @@ class FlatAdam:
         self._direct.clear()
         self._direct_groups.clear()
         self._reduced.clear()
+        if self._native:
+            self._native_flags[:len(self._native)] = 0
 
     # ---- gradient-sink protocol (see __init__) ----
     def sink_slots(self, key, params):
@@ -154,6 +161,24 @@ class FlatAdam:
             return [self._slots[self._index[id(p)]] for p in params]
         except KeyError:
             return None
+
+    def native_sink(self, key, params):
+        """-> (slot addresses, address of the producer's delivered flag) for a C++ node that computes all gradients of
+        `params` on the stream gather_grads() runs on, or None when a parameter is not ours. The node writes the slots and
+        sets the flag in its backward if the flag is still 0 (a second backward before zero_grad() returns ordinary
+        gradients, which gather_grads() adds)."""
+        ent = self._native.get(key)
+        if ent is None:
+            try:
+                idx = [self._index[id(p)] for p in params]
+            except KeyError:
+                return None
+            j = len(self._native)
+            if j >= self._native_flags.shape[0]:
+                return None
+            ent = (j, idx, [self._slots[i].data_ptr() for i in idx], self._native_flags.ctypes.data + 4 * j)
+            self._native[key] = ent
+        return ent[2], ent[3]
 
     def sink_delivered_inline(self, key, params):
         """sink_delivered for a producer that enqueued its kernels on the CURRENT stream and whose stream is the one
@@ -224,6 +249,12 @@ class FlatAdam:
                 elif stream != cur:
                     cur.wait_stream(stream)
             self._pending.clear()
+        if self._native:
+            flags = self._native_flags
+            for k, (j, idx, _, _) in self._native.items():
+                if flags[j] and k not in self._direct_groups:
+                    self._direct_groups.add(k)
+                    self._direct.update(idx)
         key = frozenset(self._direct_groups)
         todo = self._gather_cache.get(key)
         if todo is None:

@@ -148,13 +148,15 @@ def test_every_parameter_gradient_elementwise_vs_oracle(lib):
     assert not bad, bad
 
 
-def test_model_with_the_fused_head_mlps_matches_reference(lib, monkeypatch):
-    """dense.FUSED_MLP2 (off by default — a measured host-time regression, dense.py) routes the seven head MLPs through
-    irx_mlp2_fwd / _bwd with their parameter gradients delivered through the optimizer's sink: same 1e-4 forward bar against the
-    reference's output (tests/golden/model.npz) and the same gradient-norm bar as the default path."""
+@pytest.mark.parametrize("backend", ["cpp", "py", "aten"])
+def test_model_with_the_fused_head_mlps_matches_reference(lib, monkeypatch, backend):
+    """dense.mlp2 routes the seven head MLPs through irx_mlp2_fwd / _bwd — as C++ autograd nodes (csrc/torch_nodes.cpp, the
+    default when built), as the Python autograd.Function, or not at all (the ATen modules): the same 1e-4 forward bar against
+    the reference's output (tests/golden/model.npz) and the same gradient-norm bar on every path."""
     from instancerefer_amd import dense
     from instancerefer_amd.loss_helper import DatasetConfig, get_loss
-    monkeypatch.setattr(dense, "FUSED_MLP2", True)
+    monkeypatch.setattr(dense, "FUSED_MLP2", backend != "aten")
+    monkeypatch.setattr(dense, "MLP2_BACKEND", backend)
     gold = np.load(os.path.join(G, "model.npz"))
     model, dd = _build("train")
     dd = get_loss(model(dd), DatasetConfig())
@@ -498,11 +500,15 @@ def test_gradient_sink_equals_autograd_accumulation(lib):
         opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
         if mode == "autograd":
             opt.sink_slots = lambda key, params: None
+            opt.native_sink = lambda key, params: None
         losses = [float(bench.step_fn(model, resident, "full", None, opt, None).detach()) for _ in range(3)]
-        delivered = len(opt._direct)
+        native = int(opt._native_flags.sum())             # the head MLPs' C++ nodes (csrc/torch_nodes.cpp): 6 parameters each
+        delivered = len(opt._direct) - 6 * native
         torch.cuda.synchronize()
-        out[mode] = (losses, opt.flat_p.clone(), delivered)
+        out[mode] = (losses, opt.flat_p.clone(), delivered, native)
+    from instancerefer_amd import _nodes, dense
     assert out["sink"][2] == 78 and out["autograd"][2] == 0          # 2 encoders x 13 layers x (kernel, gamma, beta)
+    assert out["sink"][3] == (7 if _nodes.load() is not None and dense.FUSED_MLP2 is not False else 0) and out["autograd"][3] == 0
     assert out["sink"][0] == out["autograd"][0], (out["sink"][0], out["autograd"][0])
     assert torch.equal(out["sink"][1], out["autograd"][1])
 

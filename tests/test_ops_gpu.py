@@ -406,13 +406,15 @@ def test_lang_module_constructor_variants_vs_reference_fixture(lib, variant):
                                                          (200, 128, 128, 128, "ln", True), (16, 128, 128, 9, "bn", True),
                                                          (33, 256, 128, 128, "bn", False), (2, 256, 256, 256, "bn", True),
                                                          (1, 128, 128, 128, "ln", True), (513, 128, 128, 128, "bn", True)])
-def test_fused_head_mlp_equals_the_sequential_module(lib, monkeypatch, rows, din, dh, dout, norm, train):
+@pytest.mark.parametrize("backend", ["cpp", "py"])
+def test_fused_head_mlp_equals_the_sequential_module(lib, monkeypatch, backend, rows, din, dh, dout, norm, train):
     """The head MLPs nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, Dropout, Linear) (reference
     models/attribute_module.py:26-34, relation_module.py:18-27, scene_module.py:38-42) through the fused operator
     (dense.mlp2 -> irx_mlp2_fwd / _bwd, csrc/irx_mlp.hip) against the SAME module evaluated by PyTorch on the CPU: output
     1e-5, input gradient and all six parameter gradients 1e-4 of each tensor's largest entry (floor 1e-6: the first Linear's
     bias has a mathematically zero gradient in front of a train-mode BatchNorm), BatchNorm running statistics and
-    num_batches_tracked identical (1e-6). Row counts: one tile, ragged tiles, > 8 tiles, 2 rows (BatchNorm's minimum), 1 row."""
+    num_batches_tracked identical (1e-6). Row counts: one tile, ragged tiles, > 8 tiles, 2 rows (BatchNorm's minimum), 1 row.
+    backend: the C++ autograd node of csrc/torch_nodes.cpp (the default when built) and the Python autograd.Function."""
     import copy
     import torch.nn as nn
     from instancerefer_amd import dense
@@ -431,9 +433,14 @@ def test_fused_head_mlp_equals_the_sequential_module(lib, monkeypatch, rows, din
     yr = ref(xr)
     yr.backward(g)
     xd = x.clone().cuda().requires_grad_(True)
-    monkeypatch.setattr(dense, "FUSED_MLP2", True)          # (off by default: dense.py explains the measurement)
+    monkeypatch.setattr(dense, "FUSED_MLP2", True)
+    monkeypatch.setattr(dense, "MLP2_BACKEND", backend)
+    if backend == "cpp":
+        from instancerefer_amd import _nodes
+        assert _nodes.load() is not None, "csrc/_irx_nodes.so has not been built (python -m instancerefer_amd._build)"
     yd = dense.mlp2(mod, xd)
-    assert type(yd.grad_fn).__name__ == "MLP2FnBackward", type(yd.grad_fn).__name__
+    assert type(yd.grad_fn).__name__ == ("MLP2FnBackward" if backend == "py" else "CppFunction"), type(yd.grad_fn).__name__
+    assert ("MLP2Node" in yd.grad_fn.name()) == (backend == "cpp"), yd.grad_fn.name()
     yd.backward(g.cuda())
 
     def close(a, b, tol, what, floor=1e-6):
@@ -447,7 +454,8 @@ def test_fused_head_mlp_equals_the_sequential_module(lib, monkeypatch, rows, din
         assert float((b.detach().cpu().double() - c.double()).abs().max()) <= 1e-6, n
 
 
-def test_fused_head_mlp_dropout_and_fallbacks(lib, monkeypatch):
+@pytest.mark.parametrize("backend", ["cpp", "py"])
+def test_fused_head_mlp_dropout_and_fallbacks(lib, monkeypatch, backend):
     """Dropout inside the fused MLP: about p of the hidden units are dropped and the rest scaled by 1 / (1 - p) (the output's
     kept ones equal the clean activation / (1 - p)), a different call draws a different mask, eval mode is deterministic and
     equals the clean activations. Shapes the operator does not take (one row in train-mode BatchNorm, host tensors) go
@@ -456,6 +464,7 @@ def test_fused_head_mlp_dropout_and_fallbacks(lib, monkeypatch):
     from instancerefer_amd import dense
     torch.manual_seed(5)
     monkeypatch.setattr(dense, "FUSED_MLP2", True)
+    monkeypatch.setattr(dense, "MLP2_BACKEND", backend)
     p = 0.3
     mod = nn.Sequential(nn.Linear(64, 128), nn.LayerNorm(128), nn.ReLU(), nn.Dropout(p), nn.Linear(128, 128)).cuda().train()
     with torch.no_grad():                                 # second Linear = identity: the output shows the hidden activations
@@ -477,7 +486,7 @@ def test_fused_head_mlp_dropout_and_fallbacks(lib, monkeypatch):
     # fallbacks
     bn = nn.Sequential(nn.Linear(8, 16), nn.BatchNorm1d(16), nn.ReLU(), nn.Linear(16, 4)).train()
     out = dense.mlp2(bn, torch.randn(5, 8))               # host tensors: the module itself
-    assert type(out.grad_fn).__name__ != "MLP2FnBackward"
+    assert "MLP2" not in type(out.grad_fn).__name__
     with pytest.raises(ValueError):
         dense.mlp2(bn.cuda(), torch.randn(1, 8, device="cuda"))     # nn.BatchNorm1d's own error for one training row
 
