@@ -97,3 +97,22 @@ def test_ops_fail_loudly_on_cpu_tensors(lib):
     st = SparseTensor(torch.randn(5, 4), torch.zeros(5, 4, dtype=torch.int32))
     with pytest.raises(RuntimeError, match="HIP device"):
         conv(st)
+
+
+def test_cpp_autograd_nodes_module_builds_loads_and_binds_without_a_gpu():
+    """csrc/_irx_nodes.so (csrc/torch_nodes.cpp: C++ autograd nodes over the C-ABI) is built in-tree, imports on a GPU-less host,
+    binds the entry points of the library instance _lib.py loaded, and refuses to bind when one is missing. (The nodes' arithmetic
+    is the C-ABI's: covered by the -m gpu operator tests.)"""
+    from instancerefer_amd import _build, _lib, _nodes
+    path = _build.build_nodes()
+    assert os.path.exists(path)
+    mod = _nodes.load()
+    assert mod is not None and hasattr(mod, "mlp2") and hasattr(mod, "bind")
+    lib = _lib.load()
+    for name in _nodes._ENTRY_POINTS:
+        assert hasattr(lib, name), name
+    import pytest
+    with pytest.raises(Exception):
+        mod.bind({"irx_mlp2_fwd": 1})                 # incomplete table
+    import ctypes
+    mod.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in _nodes._ENTRY_POINTS})   # restore
