@@ -29,12 +29,17 @@ typedef int (*mlp2_fwd_fn)(const float*, int, int, int, int, const float*, const
                            float*, float*, float, float, unsigned long long, const float*, const float*, float*, float*, void*);
 typedef int (*mlp2_bwd_fn)(const float*, const float*, int, int, int, int, const float*, int, const float*, const float*,
                            const float*, float, float*, float*, float*, float*, float*, float*, float*, float*, void*);
+typedef int (*gru_fwd_fn)(const float*, const int32_t*, const float*, const float*, int, int, int, int, float*, float*, void*);
+typedef int (*gru_bwd_fn)(const float*, const float*, const float*, const int32_t*, const float*, int, int, int, int, float*,
+                          float*, void*);
 typedef const char* (*last_error_fn)();
 
 struct Api {
   saved_floats_fn mlp2_saved_floats = nullptr;
   mlp2_fwd_fn mlp2_fwd = nullptr;
   mlp2_bwd_fn mlp2_bwd = nullptr;
+  gru_fwd_fn gru_fwd = nullptr;
+  gru_bwd_fn gru_bwd = nullptr;
   last_error_fn last_error = nullptr;
 } g_api;
 
@@ -123,6 +128,109 @@ Tensor mlp2(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& g
                          std::move(slot_ptrs), flag);
 }
 
+// One GRU layer, both directions (reference models/lang_module.py:24-32,58-60: nn.GRU over packed sequences; dense.gru_packed).
+// The recurrence and its BPTT are irx_gru_forward / irx_gru_backward; the input / hidden projections and their weight gradients
+// are library GEMMs issued from here (ATen called from C++: no interpreter, no autograd recording). params = per direction
+// (w_ih [3H][I], w_hh [3H][H], b_ih [3H], b_hh [3H]) — nn.GRU's own parameter tensors, so no cat / stack nodes sit between the
+// parameters and this node; with slot_ptrs (4 per direction, same order) the weight gradients are written straight into the
+// optimizer's flat buffer.
+struct GRULayerNode : public torch::autograd::Function<GRULayerNode> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& len32, const Tensor& p0, const Tensor& p1,
+                        const Tensor& p2, const Tensor& p3, const c10::optional<Tensor>& p4, const c10::optional<Tensor>& p5,
+                        const c10::optional<Tensor>& p6, const c10::optional<Tensor>& p7, int64_t stream,
+                        std::vector<int64_t> slot_ptrs, int64_t flag) {
+    // (a std::vector<Tensor> argument would be ONE input of the node: the parameters are separate arguments, the second
+    //  direction's are optional)
+    std::vector<Tensor> params = {p0, p1, p2, p3};
+    if (p4.has_value() && p4->defined()) {
+      params.push_back(*p4); params.push_back(*p5); params.push_back(*p6); params.push_back(*p7);
+    }
+    const int ndir = (int)params.size() / 4;
+    const Tensor x = x_in.contiguous().to(torch::kFloat32);
+    const int B = (int)x.size(0), T = (int)x.size(1), I = (int)x.size(2), H = (int)params[1].size(1);
+    const Tensor x2 = x.view({(int64_t)B * T, I});
+    std::vector<Tensor> wi, wh, bi, bh;
+    for (int d = 0; d < ndir; ++d) {
+      wi.push_back(params[4 * d]); wh.push_back(params[4 * d + 1]); bi.push_back(params[4 * d + 2]); bh.push_back(params[4 * d + 3]);
+    }
+    const Tensor w_ih = ndir == 1 ? wi[0] : at::cat(wi, 0);            // (ndir*3H, I)
+    const Tensor b_ih = ndir == 1 ? bi[0] : at::cat(bi, 0);
+    const Tensor w_hh = (ndir == 1 ? wh[0].unsqueeze(0) : at::stack(wh, 0)).contiguous();      // (ndir, 3H, H)
+    const Tensor b_hh = (ndir == 1 ? bh[0].unsqueeze(0) : at::stack(bh, 0)).contiguous();
+    const Tensor gi = at::addmm(b_ih, x2, w_ih.t());                  // (B*T, ndir*3H), contiguous
+    Tensor out = torch::empty({B, T, (int64_t)ndir * H}, x.options());
+    Tensor gates = torch::empty({B, T, ndir, (int64_t)4 * H}, x.options());
+    check(g_api.gru_fwd(fp(gi), len32.data_ptr<int32_t>(), fp(w_hh), fp(b_hh), B, T, ndir, H, fpm(out), fpm(gates), (void*)stream),
+          "irx_gru_forward");
+    ctx->save_for_backward({x2, len32, w_ih, w_hh, out, gates});
+    ctx->saved_data["dims"] = std::vector<int64_t>{B, T, I, ndir, H};
+    ctx->saved_data["stream"] = stream;
+    ctx->saved_data["flag"] = flag;
+    ctx->saved_data["slots"] = slot_ptrs;
+    return out;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    const auto sv = ctx->get_saved_variables();
+    const Tensor &x2 = sv[0], &len32 = sv[1], &w_ih = sv[2], &w_hh = sv[3], &out = sv[4], &gates = sv[5];
+    const auto dims = ctx->saved_data["dims"].toIntVector();
+    const int B = (int)dims[0], T = (int)dims[1], I = (int)dims[2], ndir = (int)dims[3], H = (int)dims[4];
+    void* stream = (void*)ctx->saved_data["stream"].toInt();
+    int32_t* flag = (int32_t*)ctx->saved_data["flag"].toInt();
+    const auto slots = ctx->saved_data["slots"].toIntVector();
+    const Tensor dout = grad_out[0].contiguous().to(torch::kFloat32);
+    const auto opt = x2.options();
+    Tensor dgi = torch::empty({B, T, ndir, (int64_t)3 * H}, opt), dgh = torch::empty({B, T, ndir, (int64_t)3 * H}, opt);
+    check(g_api.gru_bwd(fp(dout), fp(out), fp(gates), len32.data_ptr<int32_t>(), fp(w_hh), B, T, ndir, H, fpm(dgi), fpm(dgh),
+                        stream),
+          "irx_gru_backward");
+    const int64_t BT = (int64_t)B * T, G = 3 * (int64_t)H;
+    const Tensor dgi2 = dgi.view({BT, ndir * G}), dgh2 = dgh.view({BT, ndir * G});
+    variable_list res(2 + 8 + 3);
+    // layout of the returned list = forward's arguments: x, len32, 8 parameters, stream, slot_ptrs, flag
+    if (ctx->needs_input_grad(0)) res[0] = dgi2.mm(w_ih).view({B, T, I});
+    // h_{t-1} in each direction's own order: forward = out shifted right, reverse = out shifted left
+    const Tensor o = out.view({B, T, ndir, H});
+    Tensor hprev = torch::zeros({B, T, ndir, H}, opt);
+    if (T > 1) {
+      hprev.slice(1, 1, T).select(2, 0).copy_(o.slice(1, 0, T - 1).select(2, 0));
+      if (ndir == 2) hprev.slice(1, 0, T - 1).select(2, 1).copy_(o.slice(1, 1, T).select(2, 1));
+    }
+    const Tensor hp2 = hprev.view({BT, (int64_t)ndir * H});
+    const bool deliver = (int)slots.size() == 4 * ndir && flag != nullptr && *flag == 0;
+    for (int d = 0; d < ndir; ++d) {
+      const Tensor gi_d = dgi2.narrow(1, d * G, G), gh_d = dgh2.narrow(1, d * G, G);      // (BT, 3H) views
+      const Tensor hp_d = hp2.narrow(1, (int64_t)d * H, H);                               // (BT, H)
+      if (deliver) {
+        Tensor s_wi = torch::from_blob((void*)slots[4 * d], {G, I}, opt), s_wh = torch::from_blob((void*)slots[4 * d + 1], {G, H}, opt);
+        Tensor s_bi = torch::from_blob((void*)slots[4 * d + 2], {G}, opt), s_bh = torch::from_blob((void*)slots[4 * d + 3], {G}, opt);
+        at::mm_out(s_wi, gi_d.t(), x2);
+        at::mm_out(s_wh, gh_d.t(), hp_d);
+        at::sum_out(s_bi, gi_d, {0});
+        at::sum_out(s_bh, gh_d, {0});
+      } else {
+        res[2 + 4 * d] = gi_d.t().mm(x2);
+        res[2 + 4 * d + 1] = gh_d.t().mm(hp_d);
+        res[2 + 4 * d + 2] = gi_d.sum({0});
+        res[2 + 4 * d + 3] = gh_d.sum({0});
+      }
+    }
+    if (deliver) *flag = 1;
+    return res;
+  }
+};
+
+Tensor gru_layer(const Tensor& x, const Tensor& len32, std::vector<Tensor> params, int64_t stream, std::vector<int64_t> slot_ptrs,
+                 int64_t flag) {
+  TORCH_CHECK(g_api.gru_fwd && g_api.gru_bwd, "irx nodes: bind() has not been called");
+  TORCH_CHECK(params.size() == 4 || params.size() == 8, "gru_layer: 4 parameters per direction, 1 or 2 directions");
+  c10::optional<Tensor> q[4];
+  if (params.size() == 8)
+    for (int i = 0; i < 4; ++i) q[i] = params[4 + i];
+  return GRULayerNode::apply(x, len32, params[0], params[1], params[2], params[3], q[0], q[1], q[2], q[3], stream,
+                             std::move(slot_ptrs), flag);
+}
+
 // addresses of the C-ABI entry points, taken from the library instance _lib.py loaded
 void bind(const std::unordered_map<std::string, uint64_t>& addr) {
   auto get = [&](const char* name) -> uint64_t {
@@ -133,6 +241,8 @@ void bind(const std::unordered_map<std::string, uint64_t>& addr) {
   g_api.mlp2_saved_floats = (saved_floats_fn)get("irx_mlp2_saved_floats");
   g_api.mlp2_fwd = (mlp2_fwd_fn)get("irx_mlp2_fwd");
   g_api.mlp2_bwd = (mlp2_bwd_fn)get("irx_mlp2_bwd");
+  g_api.gru_fwd = (gru_fwd_fn)get("irx_gru_forward");
+  g_api.gru_bwd = (gru_bwd_fn)get("irx_gru_backward");
   g_api.last_error = (last_error_fn)get("irx_last_error");
 }
 
@@ -142,4 +252,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd nodes over libirx's C-ABI (dense heads)";
   m.def("bind", &bind);
   m.def("mlp2", &mlp2);
+  m.def("gru_layer", &gru_layer);
 }

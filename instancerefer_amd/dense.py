@@ -57,14 +57,34 @@ class GRULayerFn(torch.autograd.Function):
         return dx, None, dw_ih, db_ih, dw_hh, db_hh
 
 
+GRU_BACKEND = os.environ.get("IRX_GRU_BACKEND", "auto")     # "py": the Python autograd.Function below even when the C++ node exists
+
+
 def gru_packed(gru: torch.nn.GRU, x, lengths, t_max):
     """x (B, >=t_max, I) on a HIP device; lengths (B,) int tensor on the same device. -> (B, t_max, ndir*H)."""
     assert gru.batch_first and gru.bias and gru.dropout == 0.0
     ndir = 2 if gru.bidirectional else 1
     len32 = lengths.to(torch.int32)
     h = x[:, :t_max].contiguous().float()
+    nodes = None
+    if h.is_cuda and GRU_BACKEND != "py":
+        from . import _nodes
+        nodes = _nodes.load()
     for layer in range(gru.num_layers):
         sfx = ["", "_reverse"][:ndir]
+        if nodes is not None:
+            # C++ autograd node (csrc/torch_nodes.cpp): nn.GRU's own parameter tensors go in (no cat / stack nodes), the weight
+            # gradients come back through the optimizer's gradient sink when there is one
+            params = [getattr(gru, "%s_l%d%s" % (n, layer, s_)) for s_ in sfx for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+            slots, flag = (), 0
+            if torch.is_grad_enabled():
+                sink = getattr(params[0], "_irx_sink", None)
+                if sink is not None:
+                    ent = sink[0].native_sink(("gru", id(params[0])), params)
+                    if ent is not None:
+                        slots, flag = ent
+            h = nodes.gru_layer(h, len32, params, _lib.stream_ptr(), slots, flag)
+            continue
         w_ih = torch.cat([getattr(gru, "weight_ih_l%d%s" % (layer, s)) for s in sfx], 0)
         b_ih = torch.cat([getattr(gru, "bias_ih_l%d%s" % (layer, s)) for s in sfx], 0)
         w_hh = torch.stack([getattr(gru, "weight_hh_l%d%s" % (layer, s)) for s in sfx], 0)

@@ -180,6 +180,11 @@ class FlatAdam:
             self._native[key] = ent
         return ent[2], ent[3]
 
+    def native_delivered(self):
+        """-> (producers, parameters) whose C++ nodes have delivered since the last zero_grad()"""
+        done = [ent for ent in self._native.values() if self._native_flags[ent[0]]]
+        return len(done), sum(len(ent[1]) for ent in done)
+
     def sink_delivered_inline(self, key, params):
         """sink_delivered for a producer that enqueued its kernels on the CURRENT stream and whose stream is the one
         gather_grads() / the optimizer will run on (the heads' fused MLP nodes: autograd replays them on the main stream): the

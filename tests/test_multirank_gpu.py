@@ -70,8 +70,8 @@ def _worker(rank, world, port, out_dir):
         losses.append(loss)
         if it == 0:
             res["g_first"] = g.cpu()
-            res["native"] = int(opt._native_flags.sum())         # C++ head nodes that delivered (6 parameters each)
-            res["delivered"] = len(opt._direct) - 6 * res["native"]
+            res["native"], n_native = opt.native_delivered()      # C++ head nodes (MLPs, GRU layers) that delivered
+            res["delivered"] = len(opt._direct) - n_native
     torch.cuda.synchronize()
     res["losses"] = losses
     res["p_final"] = opt.flat_p.clone().cpu()
@@ -185,8 +185,8 @@ def _many_worker(rank, world, port, out_dir):
         losses.append(loss)
         if it == 0:
             res["g_first"] = g.cpu()
-            res["native"] = int(opt._native_flags.sum())         # C++ head nodes that delivered (6 parameters each)
-            res["delivered"] = len(opt._direct) - 6 * res["native"]
+            res["native"], n_native = opt.native_delivered()      # C++ head nodes (MLPs, GRU layers) that delivered
+            res["delivered"] = len(opt._direct) - n_native
     torch.cuda.synchronize()
     res.update(losses=losses, p_final=opt.flat_p.clone().cpu(), steps=list(opt.steps), empty=empty)
     index = {id(p): n for n, p in model.named_parameters()}

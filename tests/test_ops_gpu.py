@@ -301,12 +301,19 @@ def test_knn_and_segment_mean(lib):
     assert np.abs(m - pts.astype(np.float32).astype(np.float64).mean(1)).max() <= 1e-6
 
 
-def test_gru_recurrence_matches_torch_and_reference_golden(lib):
+@pytest.mark.parametrize("backend", ["cpp", "py"])
+def test_gru_recurrence_matches_torch_and_reference_golden(lib, monkeypatch, backend):
     """irx GRU (persistent recurrence kernel + GEMM projections) vs torch.nn.GRU on a packed sequence (CPU), fwd+bwd,
-    ragged lengths incl. 1 and T; and the whole LangModule on the GPU vs the reference's lang.npz fixture."""
+    ragged lengths incl. 1 and T; and the whole LangModule on the GPU vs the reference's lang.npz fixture. backend: the layer as
+    a C++ autograd node (csrc/torch_nodes.cpp, the default when built) or as the Python autograd.Function."""
     import os
     from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    from instancerefer_amd import dense
     from instancerefer_amd.dense import gru_packed
+    monkeypatch.setattr(dense, "GRU_BACKEND", backend)
+    if backend == "cpp":
+        from instancerefer_amd import _nodes
+        assert _nodes.load() is not None, "csrc/_irx_nodes.so has not been built (python -m instancerefer_amd._build)"
     torch.manual_seed(3)
     gru = torch.nn.GRU(256, 128, num_layers=2, batch_first=True, bidirectional=True)
     lens = torch.tensor([30, 7, 41, 1, 18])
@@ -320,6 +327,7 @@ def test_gru_recurrence_matches_torch_and_reference_golden(lib):
     gd = gru.cuda()
     xd = x.clone().cuda().requires_grad_(True)
     yd = gru_packed(gd, xd, lens.cuda(), 41)
+    assert ("GRULayerNode" in yd.grad_fn.name()) == (backend == "cpp"), yd.grad_fn.name()
     assert (yd.detach().cpu() - yr.detach()).abs().max().item() <= 2e-6
     yd.backward(g.cuda())
     assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-5
