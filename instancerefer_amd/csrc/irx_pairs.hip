@@ -104,6 +104,30 @@ __device__ __forceinline__ int pairs_shares(const int32_t* __restrict__ counts, 
   return sp;
 }
 
+// The work unit of a weight-gradient workgroup: (share s of offset k, of nsplit). xcd = 0: blockIdx = (s, k); xcd != 0: the
+// XCD-segment mapping of a 1-D grid (pairs_shares above; k_wgrad3 explains it). false: this workgroup has nothing to do.
+__device__ __forceinline__ bool pairs_unit(const int32_t* __restrict__ counts, int K, int G, int smax, int xcd, int& s, int& k,
+                                           int& nsplit) {
+  if (!xcd) {
+    s = blockIdx.x; k = blockIdx.y;
+    nsplit = pairs_shares(counts, K, k, G, smax);
+    return s < nsplit;
+  }
+  const int xseg = blockIdx.x & 7, r = blockIdx.x >> 3;
+  int T = 0;
+  for (int j = 0; j < K; ++j) T += (counts[j] + 63) >> 6;
+  int tgt = (T + G - 1) / G;
+  if (tgt < 1) tgt = 1;
+  int cum = 0;
+  k = -1; s = 0; nsplit = 8;
+  for (int j = 0; j < K; ++j) {
+    const int m = pairs_xcd_m((counts[j] + 63) >> 6, tgt, smax);
+    if (k < 0 && r < cum + m) { k = j; s = xseg * m + (r - cum); nsplit = 8 * m; }
+    cum += m;
+  }
+  return k >= 0;
+}
+
 // part[s][k][c][n] = sum over share s of list k:  x[in][c] * dy[out][n]   (s < pairs_shares(k); grid = (smax, K))
 // ST (bf16 storage, with BF only): x and dy rows are bf16 in HBM; a staging thread loads 8 bytes (its 4 channels) and
 // widens them to fp32 when it writes the LDS tiles (the fragment reads below are unchanged).
@@ -127,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
                                                         const int32_t* __restrict__ in_list,
                                                         const int32_t* __restrict__ out_list, int ldp,
                                                         const int32_t* __restrict__ counts, int K, int G, int smax,
-                                                        float* __restrict__ part, int ldx = CIN) {
+                                                        float* __restrict__ part, int ldx = CIN, int xcd = 0) {
   constexpr int TC = CIN / 16, TN = COUT / 16;
   constexpr int CW = (TC >= 4) ? TC / 4 : 1;             // c-tiles per wave
   constexpr int NW = (TC >= 4) ? TN : TN / (4 / TC);     // n-tiles per wave
@@ -141,12 +165,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs(const float* __restrict_
   __shared__ int sOutRow[2][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g4 = lane >> 4;
-  const int s = blockIdx.x, k = blockIdx.y;
+  int s, k, nsplit;
+  if (!pairs_unit(counts, K, G, smax, xcd, s, k, nsplit)) return;      // block-uniform
   const int ct0 = (TC >= 4) ? wave * CW : (wave % TC);
   const int nt0 = (TC >= 4) ? 0 : (wave / TC) * NW;
   const int cnt = counts[k];
-  const int nsplit = pairs_shares(counts, K, k, G, smax);
-  if (s >= nsplit) return;                               // block-uniform
   // equal shares of this offset's stages
   const int nst = (cnt + 63) / 64;
   const int st0 = (int)(((long long)nst * s) / nsplit), st1 = (int)(((long long)nst * (s + 1)) / nsplit);
@@ -362,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs2(const float* __restrict
                                                          const int32_t* __restrict__ in_list,
                                                          const int32_t* __restrict__ out_list, int ldp,
                                                          const int32_t* __restrict__ counts, int K, int G, int smax,
-                                                         float* __restrict__ part, int ldx = CIN) {
+                                                         float* __restrict__ part, int ldx = CIN, int xcd = 0) {
   constexpr int SP = 32;                                  // pairs per stage
   constexpr int TC = CIN / 16, TN = COUT / 16;
   constexpr int CW = (TC >= 4) ? TC / 4 : 1;             // c-tiles per wave
@@ -377,12 +400,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_pairs2(const float* __restrict
   __shared__ int sIdx[4][64];                             // ring of stages: [0, 32) input rows, [32, 64) output rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g4 = lane >> 4;
-  const int s = blockIdx.x, k = blockIdx.y;
+  int s, k, nsplit;
+  if (!pairs_unit(counts, K, G, smax, xcd, s, k, nsplit)) return;      // block-uniform
   const int ct0 = (TC >= 4) ? wave * CW : (wave % TC);
   const int nt0 = (TC >= 4) ? 0 : (wave / TC) * NW;
   const int cnt = counts[k];
-  const int nsplit = pairs_shares(counts, K, k, G, smax);
-  if (s >= nsplit) return;                               // block-uniform
   // the share of this workgroup in 64-pair units (k_pairs_reduce and the v1 kernel count the same way), walked in 32-pair stages
   const int nst = (cnt + 63) / 64;
   const int st0 = (int)(((long long)nst * s) / nsplit), st1 = (int)(((long long)nst * (s + 1)) / nsplit);
@@ -775,30 +797,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(const unsigned short* __restr
   __shared__ __attribute__((aligned(16))) unsigned sIdx[8][4][64];   // byte offsets of stage u's rows in slot u & 7: [0] x, [1] dy
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // xcd: 1-D grid, workgroup b belongs to XCD b % 8 (the dispatcher deals consecutive workgroups round-robin over the XCDs) and
+  // takes the (b / 8)-th unit of that XCD's list — offset by offset, the m_k shares of list k's segment b % 8 (pairs_unit).
+  // The units of one XCD therefore walk the same eighth of the level's rows, all at the same time (the grid fits the chip at
+  // once): a row fetched for one offset is an L2 hit for the other 26 instead of 27 trips to the fabric.
   int s, k, nsplit;
-  if (xcd) {
-    // 1-D grid: workgroup b belongs to XCD b % 8 (the dispatcher deals consecutive workgroups round-robin over the XCDs) and
-    // takes the (b / 8)-th unit of that XCD's list — offset by offset, the m_k shares of list k's segment b % 8.  The units
-    // of one XCD therefore walk the same eighth of the level's rows, all at the same time (the grid fits the chip at once):
-    // a row fetched for one offset is an L2 hit for the other 26 instead of 27 trips to the fabric.
-    const int xseg = blockIdx.x & 7, r = blockIdx.x >> 3;
-    int T = 0;
-    for (int j = 0; j < K; ++j) T += (counts[j] + 63) >> 6;
-    int tgt = (T + G - 1) / G;
-    if (tgt < 1) tgt = 1;
-    int cum = 0;
-    k = -1; s = 0; nsplit = 8;
-    for (int j = 0; j < K; ++j) {
-      const int m = pairs_xcd_m((counts[j] + 63) >> 6, tgt, smax);
-      if (k < 0 && r < cum + m) { k = j; s = xseg * m + (r - cum); nsplit = 8 * m; }
-      cum += m;
-    }
-    if (k < 0) return;                                   // block-uniform
-  } else {
-    s = blockIdx.x; k = blockIdx.y;
-    nsplit = pairs_shares(counts, K, k, G, smax);
-    if (s >= nsplit) return;                             // block-uniform
-  }
+  if (!pairs_unit(counts, K, G, smax, xcd, s, k, nsplit)) return;      // block-uniform
   const int cnt = counts[k];
   const int nst = (cnt + 63) / 64;
   const int st0 = (int)(((long long)nst * s) / nsplit), st1 = (int)(((long long)nst * (s + 1)) / nsplit);
@@ -1011,13 +1015,15 @@ static void launch_wp(int cout, dim3 grid, hipStream_t st, const float* x, const
     else if (cout == 64) k_wgrad_pairs<CIN, 64, true, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
     else k_wgrad_pairs<CIN, 32, true, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
   } else if (!gen2 || wp_v1()) {
-    if (cout == 128) k_wgrad_pairs<CIN, 128, false, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-    else if (cout == 64) k_wgrad_pairs<CIN, 64, false, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-    else k_wgrad_pairs<CIN, 32, false, false><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    const dim3 g1 = xcd ? dim3(8 * (G / 8 + K + 1)) : grid;
+    if (cout == 128) k_wgrad_pairs<CIN, 128, false, false><<<g1, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part, CIN, xcd);
+    else if (cout == 64) k_wgrad_pairs<CIN, 64, false, false><<<g1, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part, CIN, xcd);
+    else k_wgrad_pairs<CIN, 32, false, false><<<g1, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part, CIN, xcd);
   } else {
-    if (cout == 128) k_wgrad_pairs2<CIN, 128><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-    else if (cout == 64) k_wgrad_pairs2<CIN, 64><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
-    else k_wgrad_pairs2<CIN, 32><<<grid, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part);
+    const dim3 g2 = xcd ? dim3(8 * (G / 8 + K + 1)) : grid;
+    if (cout == 128) k_wgrad_pairs2<CIN, 128><<<g2, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part, CIN, xcd);
+    else if (cout == 64) k_wgrad_pairs2<CIN, 64><<<g2, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part, CIN, xcd);
+    else k_wgrad_pairs2<CIN, 32><<<g2, 256, 0, st>>>(x, dy, il, ol, ldp, counts, K, G, smax, part, CIN, xcd);
   }
   irx_bracket_end(st);
 }
@@ -1111,6 +1117,10 @@ int irx_spconv_wgrad_pairs_impl(const float* x, const float* dy, const int32_t* 
       (long)n_out * K >= irx_knob(IRX_KNOB_WGRAD3_XCD_MIN)) {
     const long units = irx_knob(IRX_KNOB_WGRAD3_UNITS);
     if (units >= 8) { xcd = 1; G = (int)units; }
+  } else if (!irx_conv_bf16() && smax >= 8 && irx_knob(IRX_KNOB_WGRAD_XCD_F32) >= 8 &&
+             (long)n_out * K >= irx_knob(IRX_KNOB_WGRAD3_XCD_MIN)) {
+    xcd = 1;                               // the fp32 kernels on the same work-unit mapping (dev knob: units, 0 = off)
+    G = (int)irx_knob(IRX_KNOB_WGRAD_XCD_F32);
   }
   if (cin == 128) launch_wp<128>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2, xcd);
   else if (cin == 64) launch_wp<64>(cout, grid, S(stream), x, dy, in_list, out_list, ldp, counts, K, G, smax, part, bf_rows != 0, gen2, xcd);

@@ -297,6 +297,7 @@ const KnobDef kKnobs[IRX_KNOB_COUNT] = {
     {"wgrad3", "IRX_WGRAD3", 1},                 // bf16-row pair-list weight-gradient on k_wgrad3 (transposing LDS reads)
     {"wgrad3_units", "IRX_WGRAD3_UNITS", 448},   // ... work units (workgroups) of its XCD-segment mapping
     {"wgrad3_xcd_min", "IRX_WGRAD3_XCD_MIN", 200000},   // ... used from this many table entries (n_out * K) on
+    {"wgrad_xcd_f32", "IRX_WGRAD_XCD_F32", 0},   // fp32 pair-list weight-gradient on XCD-segment work units: their number, 0 = off
 };
 std::atomic<long> g_knob_val[IRX_KNOB_COUNT];
 std::atomic<int> g_knob_set[IRX_KNOB_COUNT];
