@@ -1,7 +1,7 @@
 // torch_nodes.cpp — C++ autograd nodes over the C-ABI of libirx (include/irx.h) for the dense heads.
 //
-// The training step of the bf16 headline configuration is HOST-bound: the GPU finishes a step in ~4.3 ms
-// while the interpreter needs ~5.8 ms to issue it. A torch.autograd.Function written in Python costs 30 us (forward) to 100 us
+// The training step of the bf16 headline configuration is HOST-bound (every main-stream event of the
+// pipelined loop completes as it is issued). A torch.autograd.Function written in Python costs 30 us (forward) to 100 us
 // (backward, entered from the C++ engine through the GIL) of interpreter time per node — more than the handful of ATen
 // dispatches a fused head operator replaces (the round-4 negative result of dense.MLP2Fn). The same operators behind
 // torch::autograd::Function cost a few microseconds: tensors are allocated with ATen, the kernels are the C-ABI entry points
