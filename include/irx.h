@@ -449,6 +449,14 @@ int irx_gru_backward(const float* dout, const float* out, const float* gates, co
                      const float* w_hh, int B, int T, int ndir, int H, float* dgi, float* dgh,
                      void* stream);
 
+/* The four weight gradients of a GRU layer from irx_gru_backward's dgi / dgh in one launch (per direction d: dW_ih[d] [3H][I] =
+ * dgi_d^T x, dW_hh[d] [3H][H] = dgh_d^T h_prev_d, db_ih[d] = column sums of dgi_d, db_hh[d] of dgh_d; x [B*T][I] the layer's input,
+ * out [B][T][ndir*H] its output — h_prev is read from it with the direction's shift). The *1 pointers are the reverse direction's
+ * (NULL when ndir = 1). fp32 FMA tiles, deterministic. */
+int irx_gru_wgrad(const float* dgi, const float* dgh, const float* x, const float* out, int B, int T, int I, int ndir, int H,
+                  float* dw_ih0, float* dw_ih1, float* dw_hh0, float* dw_hh1, float* db_ih0, float* db_ih1, float* db_hh0,
+                  float* db_hh1, void* stream);
+
 /* DynamicEdgeConv of the relation module (models/basic_blocks.py:98-133: MessagePassing(aggr='max') with
  * message = mlp([x_i, weight([pos_j - pos_i, cls_i, cls_j]), x_j])) as one launch per direction over a fixed
  * (n_query, k) neighbour grid (irx_knn_batched's output, -1 = no neighbour). feats [S][fin], pos [S][3]: support rows;

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "irx_instance_split": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
     "irx_gru_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "irx_gru_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "irx_gru_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "irx_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P]),
     "irx_cosine_rows_fwd": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),
     "irx_cosine_rows_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),

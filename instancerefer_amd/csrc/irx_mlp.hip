@@ -448,3 +448,73 @@ extern "C" int irx_mlp2_bwd(const float* x, const float* dy, int rows, int din, 
   IRX_CHECK_LAUNCH("irx_mlp2_bwd(3)");
   return IRX_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------- GRU weight gradients ---
+// The four weight gradients of one GRU layer (reference models/lang_module.py:24-32: nn.GRU) from the BPTT outputs of
+// irx_gru_backward, in ONE launch: per direction d
+//   dW_ih[d][g][i] = sum_r dgi[r][d][g] x[r][i]          dW_hh[d][g][h] = sum_r dgh[r][d][g] hprev_d[r][h]
+//   db_ih[d][g]    = sum_r dgi[r][d][g]                   db_hh[d][g]    = sum_r dgh[r][d][g]
+// r = (b, t) over all B*T rows (padded steps carry zero gradients); hprev is read from the layer's OUTPUT with the
+// direction's own shift (forward: out[b][t-1], reverse: out[b][t+1], zero outside [0, T)) — no shifted copy is materialised.
+// Through ATen this was 8 GEMM / reduction launches + 3 to build hprev per layer; same 64 x 32 fp32 FMA tiles as the head MLPs.
+// blocks: [0, nI) input-weight tiles, [nI, nI + nH) hidden-weight tiles; tile = 64 gate rows x 32 columns of one direction.
+__global__ __launch_bounds__(256) void k_gru_wgrad(const float* __restrict__ dgi, const float* __restrict__ dgh,
+                                                   const float* __restrict__ x, const float* __restrict__ out, int B, int T,
+                                                   int I, int ndir, int H, float* __restrict__ dwi0, float* __restrict__ dwi1,
+                                                   float* __restrict__ dwh0, float* __restrict__ dwh1,
+                                                   float* __restrict__ dbi0, float* __restrict__ dbi1,
+                                                   float* __restrict__ dbh0, float* __restrict__ dbh1, int nI) {
+  __shared__ __attribute__((aligned(16))) float sA[ML_TR][ML_LD], sB[ML_TC][ML_LD];
+  const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
+  const int G = 3 * H, BT = B * T, ldg = ndir * G;
+  const bool hid = (int)blockIdx.x >= nI;
+  const int b = hid ? (int)blockIdx.x - nI : (int)blockIdx.x;
+  const int ncol = hid ? H : I;                             // columns of this weight
+  const int cblocks = (ncol + ML_TC - 1) / ML_TC, gblocks = (G + ML_TR - 1) / ML_TR;
+  const int d = b / (gblocks * cblocks), rem = b % (gblocks * cblocks);
+  const int g0 = (rem / cblocks) * ML_TR, c0 = (rem % cblocks) * ML_TC;
+  const float* gsrc = hid ? dgh : dgi;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (!hid) {
+    ml_tile([&](int i, int r) { return (g0 + i < G) ? gsrc[(size_t)r * ldg + d * G + g0 + i] : 0.f; },
+            [&](int jj, int r) { return (c0 + jj < I) ? x[(size_t)r * I + c0 + jj] : 0.f; }, BT, acc, sA, sB);
+  } else {
+    const int sh = d == 0 ? -1 : 1;                          // forward: h_{t-1} = out[t-1]; reverse: out[t+1]
+    ml_tile([&](int i, int r) { return (g0 + i < G) ? gsrc[(size_t)r * ldg + d * G + g0 + i] : 0.f; },
+            [&](int jj, int r) {
+              const int tt = r % T + sh;
+              return (c0 + jj < H && tt >= 0 && tt < T) ? out[((size_t)(r + sh) * ndir + d) * H + c0 + jj] : 0.f;
+            }, BT, acc, sA, sB);
+  }
+  float* dw = hid ? (d == 0 ? dwh0 : dwh1) : (d == 0 ? dwi0 : dwi1);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int g = g0 + i0 + 8 * m;
+    if (g < G && c0 + j < ncol) dw[(size_t)g * ncol + c0 + j] = acc[m];
+  }
+  if (c0 == 0) {                                            // the bias gradient of this tile's 64 gate rows: 4 threads per row
+    float* db = hid ? (d == 0 ? dbh0 : dbh1) : (d == 0 ? dbi0 : dbi1);
+    const int g = g0 + (t >> 2), q = t & 3;
+    float sdb = 0.f;
+    if (g < G)
+      for (int r = q; r < BT; r += 4) sdb += gsrc[(size_t)r * ldg + d * G + g];
+    sdb += __shfl_xor(sdb, 1);
+    sdb += __shfl_xor(sdb, 2);
+    if (q == 0 && g < G) db[g] = sdb;
+  }
+}
+
+extern "C" int irx_gru_wgrad(const float* dgi, const float* dgh, const float* x, const float* out, int B, int T, int I, int ndir,
+                             int H, float* dw_ih0, float* dw_ih1, float* dw_hh0, float* dw_hh1, float* db_ih0, float* db_ih1,
+                             float* db_hh0, float* db_hh1, void* stream) {
+  IRX_REQUIRE(B >= 0 && T >= 0 && I >= 1 && H >= 1 && (ndir == 1 || ndir == 2), "irx_gru_wgrad: bad sizes");
+  IRX_REQUIRE(dgi && dgh && x && out && dw_ih0 && dw_hh0 && db_ih0 && db_hh0, "irx_gru_wgrad: null pointer");
+  IRX_REQUIRE(ndir == 1 || (dw_ih1 && dw_hh1 && db_ih1 && db_hh1), "irx_gru_wgrad: the second direction's outputs are missing");
+  const int G = 3 * H, gblocks = irx_cdiv(G, ML_TR);
+  const int nI = ndir * gblocks * irx_cdiv(I, ML_TC), nH = ndir * gblocks * irx_cdiv(H, ML_TC);
+  k_gru_wgrad<<<nI + nH, 256, 0, S(stream)>>>(dgi, dgh, x, out, B, T, I, ndir, H, dw_ih0, dw_ih1, dw_hh0, dw_hh1, db_ih0, db_ih1,
+                                              db_hh0, db_hh1, nI);
+  IRX_CHECK_LAUNCH("irx_gru_wgrad");
+  return IRX_OK;
+}

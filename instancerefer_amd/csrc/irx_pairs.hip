@@ -741,7 +741,7 @@ extern "C" int irx_pairs_build_multi(int n_tables, const int32_t* const* nbr, co
 // k_wgrad_pairs in bf16 storage mode is the fp32 design fed narrower rows: it widens them to fp32 when it writes the LDS
 // tiles, reads every fragment element with its own ds_read_b32, packs pairs of them back to bf16 and runs the half-rate
 // 16x16x16 MFMA — 40 LDS reads and 20 packs per 16 MFMAs, two barriers and a full vector-memory drain per 64-pair stage
-// (161 us for the 0.79 M pairs of the largest 128-channel level: 6 % of the matrix-core peak).  Both operands of the weight
+// (150 us in the kernel for the 0.79 M pairs of the largest 128-channel level: 7 % of the matrix-core peak).  Both operands of the weight
 // gradient have the PAIRS as their reduction dimension, i.e. a lane's 8 reduction elements come from 8 different rows — the
 // one access pattern gfx950 has an instruction for:
 //   * rows are gathered with raw buffer loads (16 B per lane, a missing pair is an out-of-range offset = zeros) and written
@@ -749,10 +749,16 @@ extern "C" int irx_pairs_build_multi(int n_tables, const int32_t* const* nbr, co
 //   * ds_read_b64_tr_b16 hands a lane 4 consecutive pairs of ITS channel (a 16-lane group reads a [4 pairs][16 channels]
 //     block); two of them are one operand of v_mfma_f32_32x32x16_bf16 — 1 LDS read per MFMA at 128 x 128 (wave tile 64 x 64),
 //     no packs, no conversion; the swizzle makes the four pair rows of a read land in four different 16-bank windows;
-//   * the row buffers are double-buffered: ONE barrier per stage; stage t+2's rows are requested from inside stage t's MFMA
-//     chain into one register set and written behind the next barrier; the index lists run four stages ahead through a
-//     three-slot LDS ring, so no load ever waits for another load inside the loop;
-//   * fp32 accumulators in registers for the whole share, same (share, offset) partials and reduce as k_wgrad_pairs.
+//   * the row buffers are double-buffered: ONE barrier per stage; TWO register sets of rows in flight — stage t+3's rows are
+//     requested from inside stage t's MFMA chain into the set stage t+1's rows have just left (written to LDS behind the MFMAs
+//     of the stage's first step); the index lists are fetched four stages per load, one chunk ahead, into an 8-slot LDS ring:
+//     every load has at least two whole iterations to land and none sits behind a branch (exact wait counts);
+//   * fp32 accumulators in registers for the whole work unit, deterministic per-unit partials + k_pairs_reduce as
+//     k_wgrad_pairs; on levels with enough work the units are XCD segments (pairs_unit): the 27 offsets of an eighth of the
+//     level's rows run on ONE XCD at the same time, so a gathered row is an L2 hit for 26 of them (the (share, offset) grid
+//     missed L2 on 82 % of its requests: 445 MB from the fabric for 41 MB of rows).
+// Measured (rocprofv3 kernel trace, B = 16 scene pyramid): 150.5 -> 46.8 us at 128 x 128 on 81 k rows, 161.6 -> 49.8 us at
+// 64 x 64 on 259 k rows; ablations and counters in profiles/r04_wgrad3_*.txt, DESIGN.md section 4.
 typedef __bf16 w3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short w3_s16x4 __attribute__((ext_vector_type(4)));
 typedef short w3_s16x8 __attribute__((ext_vector_type(8)));

@@ -32,6 +32,8 @@ typedef int (*mlp2_bwd_fn)(const float*, const float*, int, int, int, int, const
 typedef int (*gru_fwd_fn)(const float*, const int32_t*, const float*, const float*, int, int, int, int, float*, float*, void*);
 typedef int (*gru_bwd_fn)(const float*, const float*, const float*, const int32_t*, const float*, int, int, int, int, float*,
                           float*, void*);
+typedef int (*gru_wgrad_fn)(const float*, const float*, const float*, const float*, int, int, int, int, int, float*, float*, float*,
+                            float*, float*, float*, float*, float*, void*);
 typedef const char* (*last_error_fn)();
 
 struct Api {
@@ -40,6 +42,7 @@ struct Api {
   mlp2_bwd_fn mlp2_bwd = nullptr;
   gru_fwd_fn gru_fwd = nullptr;
   gru_bwd_fn gru_bwd = nullptr;
+  gru_wgrad_fn gru_wgrad = nullptr;
   last_error_fn last_error = nullptr;
 } g_api;
 
@@ -130,7 +133,8 @@ Tensor mlp2(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& g
 
 // One GRU layer, both directions (reference models/lang_module.py:24-32,58-60: nn.GRU over packed sequences; dense.gru_packed).
 // The recurrence and its BPTT are irx_gru_forward / irx_gru_backward; the input / hidden projections and their weight gradients
-// are library GEMMs issued from here (ATen called from C++: no interpreter, no autograd recording). params = per direction
+// are library GEMMs issued from here (ATen called from C++: no interpreter, no autograd recording), the four weight gradients
+// one launch of irx_gru_wgrad. params = per direction
 // (w_ih [3H][I], w_hh [3H][H], b_ih [3H], b_hh [3H]) — nn.GRU's own parameter tensors, so no cat / stack nodes sit between the
 // parameters and this node; with slot_ptrs (4 per direction, same order) the weight gradients are written straight into the
 // optimizer's flat buffer.
@@ -185,36 +189,28 @@ struct GRULayerNode : public torch::autograd::Function<GRULayerNode> {
                         stream),
           "irx_gru_backward");
     const int64_t BT = (int64_t)B * T, G = 3 * (int64_t)H;
-    const Tensor dgi2 = dgi.view({BT, ndir * G}), dgh2 = dgh.view({BT, ndir * G});
+    const Tensor dgi2 = dgi.view({BT, ndir * G});
     variable_list res(2 + 8 + 3);
     // layout of the returned list = forward's arguments: x, len32, 8 parameters, stream, slot_ptrs, flag
     if (ctx->needs_input_grad(0)) res[0] = dgi2.mm(w_ih).view({B, T, I});
-    // h_{t-1} in each direction's own order: forward = out shifted right, reverse = out shifted left
-    const Tensor o = out.view({B, T, ndir, H});
-    Tensor hprev = torch::zeros({B, T, ndir, H}, opt);
-    if (T > 1) {
-      hprev.slice(1, 1, T).select(2, 0).copy_(o.slice(1, 0, T - 1).select(2, 0));
-      if (ndir == 2) hprev.slice(1, 0, T - 1).select(2, 1).copy_(o.slice(1, 1, T).select(2, 1));
-    }
-    const Tensor hp2 = hprev.view({BT, (int64_t)ndir * H});
+    // the four weight gradients of both directions in one launch (irx_gru_wgrad reads h_{t-1} from `out` with the direction's
+    // shift): straight into the optimizer's slots, or into fresh tensors handed to autograd
     const bool deliver = (int)slots.size() == 4 * ndir && flag != nullptr && *flag == 0;
+    float* gp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per direction: w_ih, w_hh, b_ih, b_hh
     for (int d = 0; d < ndir; ++d) {
-      const Tensor gi_d = dgi2.narrow(1, d * G, G), gh_d = dgh2.narrow(1, d * G, G);      // (BT, 3H) views
-      const Tensor hp_d = hp2.narrow(1, (int64_t)d * H, H);                               // (BT, H)
       if (deliver) {
-        Tensor s_wi = torch::from_blob((void*)slots[4 * d], {G, I}, opt), s_wh = torch::from_blob((void*)slots[4 * d + 1], {G, H}, opt);
-        Tensor s_bi = torch::from_blob((void*)slots[4 * d + 2], {G}, opt), s_bh = torch::from_blob((void*)slots[4 * d + 3], {G}, opt);
-        at::mm_out(s_wi, gi_d.t(), x2);
-        at::mm_out(s_wh, gh_d.t(), hp_d);
-        at::sum_out(s_bi, gi_d, {0});
-        at::sum_out(s_bh, gh_d, {0});
+        for (int q = 0; q < 4; ++q) gp[4 * d + q] = (float*)slots[4 * d + q];
       } else {
-        res[2 + 4 * d] = gi_d.t().mm(x2);
-        res[2 + 4 * d + 1] = gh_d.t().mm(hp_d);
-        res[2 + 4 * d + 2] = gi_d.sum({0});
-        res[2 + 4 * d + 3] = gh_d.sum({0});
+        Tensor g_wi = torch::empty({G, I}, opt), g_wh = torch::empty({G, H}, opt), g_bi = torch::empty({G}, opt),
+               g_bh = torch::empty({G}, opt);
+        gp[4 * d] = g_wi.data_ptr<float>(); gp[4 * d + 1] = g_wh.data_ptr<float>();
+        gp[4 * d + 2] = g_bi.data_ptr<float>(); gp[4 * d + 3] = g_bh.data_ptr<float>();
+        res[2 + 4 * d] = g_wi; res[2 + 4 * d + 1] = g_wh; res[2 + 4 * d + 2] = g_bi; res[2 + 4 * d + 3] = g_bh;
       }
     }
+    check(g_api.gru_wgrad(fp(dgi), fp(dgh), fp(x2), fp(out), B, T, I, ndir, H, gp[0], gp[4], gp[1], gp[5], gp[2], gp[6], gp[3], gp[7],
+                          stream),
+          "irx_gru_wgrad");
     if (deliver) *flag = 1;
     return res;
   }
@@ -243,6 +239,7 @@ void bind(const std::unordered_map<std::string, uint64_t>& addr) {
   g_api.mlp2_bwd = (mlp2_bwd_fn)get("irx_mlp2_bwd");
   g_api.gru_fwd = (gru_fwd_fn)get("irx_gru_forward");
   g_api.gru_bwd = (gru_bwd_fn)get("irx_gru_backward");
+  g_api.gru_wgrad = (gru_wgrad_fn)get("irx_gru_wgrad");
   g_api.last_error = (last_error_fn)get("irx_last_error");
 }
 
