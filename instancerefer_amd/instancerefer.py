@@ -14,6 +14,7 @@ import os as _os
 # 0.5 % (9.27-9.30 vs 9.31-9.35 ms/step), the end-to-end loop (tools/e2e_train_bench.py, whose preparation stream also carries
 # the next batches' input pipeline) LOSES 5-15 % (1425-1560 vs 1665-1693 scenes/s). IRX_PREP_TABLES=1 enables it.
 _PREP_TABLES = _os.environ.get('IRX_PREP_TABLES', '0') == '1'
+_PREP_PLANS = _os.environ.get('IRX_PREP_PLANS', '0') == '1'
 _ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
 
 
@@ -87,6 +88,14 @@ class InstanceRefer(nn.Module):
         prep = data_dict.get('_attr_prepared')
         if self.training and _PREP_TABLES and prep is not None and prep[0] is not None:
             prep[0].level().build_tables()
+        if self.training and _PREP_PLANS and torch.is_grad_enabled():
+            # dev (IRX_PREP_PLANS=1): the encoders' plans and level-only descriptors here instead of in the forward (this also
+            # builds the kernel maps on the preparation stream, like IRX_PREP_TABLES)
+            from .sparse import encoder_fn
+            if self.args.scene_module and 'lidar' in data_dict and hasattr(self.scene, 'net'):
+                encoder_fn.prebuild(self.scene.net, data_dict['lidar'].level())
+            if prep is not None and prep[0] is not None and hasattr(self.attribute, 'net'):
+                encoder_fn.prebuild(self.attribute.net, prep[0].level())
         data_dict['_prepared'] = True
         return data_dict
 

@@ -50,9 +50,22 @@ def _skeleton(encoder):
     return sk
 
 
+class Plan(list):
+    """The layers of one encoder pass + what only depends on the coordinate levels (`pre`: descriptor columns, arena layout,
+    workspace size per storage mode). Cached on the pass's finest level, so the preparation stage can build it ahead of the
+    forward (prebuild) — the forward half of the bf16 step is host-paced, DESIGN.md section 5."""
+    __slots__ = ("pre",)
+
+
 def build_plan(encoder, level0):
     """Bind the coordinate levels / tables of this batch to the layer skeleton (the pyramid is already built)."""
-    layers = []
+    cache = level0.__dict__.setdefault("_irx_plans", {})
+    plan = cache.get(id(encoder))
+    if plan is not None:
+        return plan
+    layers = Plan()
+    layers.pre = {}
+    cache[id(encoder)] = layers
     lv = level0
     for conv, bn, down, res in _skeleton(encoder):
         L = _Layer()
@@ -228,6 +241,59 @@ def trace_tensors(tr):
     return out
 
 
+def _level_desc(encoder, layers, params, store):
+    """Everything of the forward descriptor that depends on the coordinate levels, the parameters' addresses and the compute
+    mode only — not on this pass's activations: the table with sizes / table pointers / launch orders filled in and the arena
+    offsets in the C / Y columns, the arena layout and the workspace size. Cached on the plan per (storage, mode)."""
+    lib = _lib.load()
+    mode = int(lib.irx_get_compute_dtype())
+    tmpl, fdesc, counters, cout, poffs, ptotal = _static_template(encoder, layers, params)
+    key = (bool(store), mode, id(tmpl))
+    hit = layers.pre.get(key) if isinstance(layers, Plan) else None
+    if hit is not None:
+        return hit
+    nl = len(layers)
+    n_out = np.fromiter((L.n_out for L in layers), dtype=np.int64, count=nl)
+    desc = tmpl.copy()
+    desc[:, _E["N_IN"]] = np.fromiter((L.n_in for L in layers), dtype=np.int64, count=nl)
+    desc[:, _E["N_OUT"]] = n_out
+    desc[:, _E["TBL"]] = np.fromiter((L.tbl.data_ptr() for L in layers), dtype=np.int64, count=nl)
+    desc[:, _E["LD"]] = np.fromiter((L.ld for L in layers), dtype=np.int64, count=nl)
+    # activation arena (bytes): conv output c_i and layer output y_i of every layer; with bf16 storage every tensor
+    # but the last layer's output is 2 bytes per element
+    esz = np.full(nl, 2 if store else 4, dtype=np.int64)
+    ysz = esz.copy()
+    ysz[-1] = 4
+    cb, yb = _up256(n_out * cout * esz), _up256(n_out * cout * ysz)
+    start = np.concatenate([[0], np.cumsum(cb + yb)[:-1]])
+    total = int((cb + yb).sum())
+    desc[:, _E["STORE"]] = int(store)
+    desc[:, _E["MODE"]] = mode                   # pinned for this pass and its backward (include/irx.h)
+    if TILE_ORDER:                               # heaviest output tiles first on the levels with more than one round of tiles
+        desc[:, _E["ORDER"]] = np.fromiter((L.lv_in.order27().data_ptr() if (not L.down and L.n_out >= TILE_ORDER_MIN_ROWS and
+                                                                             L.cin in _PAIR and L.cout in _PAIR) else 0
+                                            for L in layers), dtype=np.int64, count=nl)      # (k_spconv2 layers only)
+    desc[:, _E["C"]] = start
+    desc[:, _E["Y"]] = start + cb
+    nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 0)
+    out = (desc, fdesc, counters, cout, poffs, ptotal, n_out, cb, start, total, nbytes)
+    if isinstance(layers, Plan):
+        layers.pre[key] = out
+    return out
+
+
+def prebuild(encoder, level0):
+    """Preparation stage (any thread): the plan of `encoder` on this batch's levels and its level-only descriptor, so that the
+    forward only allocates, adds addresses and submits."""
+    if not can_fuse(encoder):
+        return
+    layers = build_plan(encoder, level0)
+    params = []
+    for L in layers:
+        params += [L.conv.kernel, L.bn.weight, L.bn.bias]
+    _level_desc(encoder, layers, params, storage_bf16(False))
+
+
 class EncoderFn(torch.autograd.Function):
     """forward / backward = one irx_encoder_forward / irx_encoder_backward call over a descriptor table; activations,
     gradients-in-flight and parameter gradients live in three arenas allocated once per call. The table is a cached
@@ -239,41 +305,21 @@ class EncoderFn(torch.autograd.Function):
         dev = feats.device
         x0 = feats.contiguous().float()
         nl = len(layers)
-        tmpl, fdesc, counters, cout, poffs, ptotal = _static_template(encoder, layers, params)
-        n_out = np.fromiter((L.n_out for L in layers), dtype=np.int64, count=nl)
-        desc = tmpl.copy()
-        desc[:, _E["N_IN"]] = np.fromiter((L.n_in for L in layers), dtype=np.int64, count=nl)
-        desc[:, _E["N_OUT"]] = n_out
-        desc[:, _E["TBL"]] = np.fromiter((L.tbl.data_ptr() for L in layers), dtype=np.int64, count=nl)
-        desc[:, _E["LD"]] = np.fromiter((L.ld for L in layers), dtype=np.int64, count=nl)
-        # activation arena (bytes): conv output c_i and layer output y_i of every layer; with bf16 storage every tensor
-        # but the last layer's output is 2 bytes per element
         store = storage_bf16(ctx.needs_input_grad[0])
-        esz = np.full(nl, 2 if store else 4, dtype=np.int64)
-        ysz = esz.copy()
-        ysz[-1] = 4
-        cb, yb = _up256(n_out * cout * esz), _up256(n_out * cout * ysz)
-        start = np.concatenate([[0], np.cumsum(cb + yb)[:-1]])
-        total = int((cb + yb).sum())
+        pre, fdesc, counters, cout, poffs, ptotal, n_out, cb, start, total, nbytes = _level_desc(encoder, layers, params, store)
         arena = torch.empty(total, dtype=torch.uint8, device=dev)
         stats = torch.empty((nl, 2, 128), dtype=_f32, device=dev)       # mean / invstd rows (cout <= 128)
         base, sbase = arena.data_ptr(), stats.data_ptr()
-        desc[:, _E["STORE"]] = int(store)
-        desc[:, _E["MODE"]] = int(lib.irx_get_compute_dtype())      # pinned for this pass and its backward (include/irx.h)
-        if TILE_ORDER:                           # heaviest output tiles first on the levels with more than one round of tiles
-            desc[:, _E["ORDER"]] = np.fromiter((L.lv_in.order27().data_ptr() if (not L.down and L.n_out >= TILE_ORDER_MIN_ROWS and
-                                                                                 L.cin in _PAIR and L.cout in _PAIR) else 0
-                                                for L in layers), dtype=np.int64, count=nl)      # (k_spconv2 layers only)
+        desc = pre.copy()                        # (C / Y / MEAN / INVSTD hold offsets: add this pass's arena and stats addresses)
         prof = _profile_slots(layers, store) if F_.PROFILE is not None else None
         if prof is not None:
             desc[:, _E["PROF"]] = prof[1]
-        desc[:, _E["C"]] = base + start
-        desc[:, _E["Y"]] = base + start + cb
+        desc[:, _E["C"]] += base
+        desc[:, _E["Y"]] += base
         desc[0, _E["X"]] = x0.data_ptr()
         desc[1:, _E["X"]] = desc[:-1, _E["Y"]]
         desc[:, _E["MEAN"]] += sbase
         desc[:, _E["INVSTD"]] += sbase
-        nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 0)
         ws = _ws(nbytes, dev)
         lane = lane_of(encoder)
         group = _sync_group_for(layers)
