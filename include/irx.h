@@ -299,7 +299,8 @@ int irx_profile_next_kernel(void* ev_start, void* ev_stop);
  * on the third-generation kernel), "updgrad" (IRX_UPDGRAD, 1) / "updgrad_min" (IRX_UPDGRAD_MIN, 40000: k_updgrad and its
  * size threshold), "wgrad_v1" (IRX_WGRAD_V1, 0: fp32 pair-list weight-gradient on the first-generation kernel), "wgrad3"
  * (IRX_WGRAD3, 1: bf16-row pair-list weight-gradient on k_wgrad3), "wgrad3_units" (IRX_WGRAD3_UNITS, 448: workgroups of its
- * XCD-segment mapping), "wgrad3_xcd_min" (IRX_WGRAD3_XCD_MIN, 200000: table entries n_out * K from which that mapping is used).
+ * XCD-segment mapping), "wgrad3_xcd_min" (IRX_WGRAD3_XCD_MIN, 200000: table entries n_out * K from which that mapping is used),
+ * "wgrad_xcd_f32" (IRX_WGRAD_XCD_F32, 0: number of XCD-segment units for the fp32 pair-list kernels, 0 = their (share, offset) grid).
  * irx_debug_get_knob returns the value in force (-1: unknown name). Not part of the reference-facing surface. */
 int irx_debug_set_knob(const char* name, long value);
 long irx_debug_get_knob(const char* name);

@@ -72,6 +72,10 @@ __host__ __device__ static inline int next_pow2(int v) {
 #ifndef BN_PT
 #define BN_PT 512
 #endif
+// rows whose loads a thread has in flight per trip (-DBN_U=... for A/B builds)
+#ifndef BN_U
+#define BN_U 4
+#endif
 template <int MODE, int V, bool TY, bool RM = false, bool RL = true>
 __global__ __launch_bounds__(BN_PT) void k_bn_partial(const float* __restrict__ x,
                                                     const float* __restrict__ y,
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(BN_PT) void k_bn_partial(const float* __restrict__ 
     }
     // U rows per trip: all their loads are issued before the first add (memory-level parallelism; a load per add left
     // the kernel latency-bound), the adds keep the row order (bit-identical to the one-row loop)
-    constexpr int U = 4;
+    constexpr int U = BN_U;
     auto load_row = [&](int r, float (&xv)[V], float (&yv)[V], float (&dv)[V]) __attribute__((always_inline)) {
       const size_t off = (size_t)r * c + (size_t)qd * V;
       if constexpr (V == 8) {
