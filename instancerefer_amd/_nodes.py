@@ -24,10 +24,16 @@ def load():
     _tried = True
     if not ENABLED or not os.path.exists(_build.NODES_PATH):
         return None
-    spec = importlib.util.spec_from_file_location("_irx_nodes", _build.NODES_PATH)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    lib = _lib.load()
-    mod.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in _ENTRY_POINTS})
+    try:
+        spec = importlib.util.spec_from_file_location("_irx_nodes", _build.NODES_PATH)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        lib = _lib.load()
+        mod.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in _ENTRY_POINTS})
+    except Exception as e:                 # a module built against another torch: say so, run the heads through their Python nodes
+        import warnings
+        warnings.warn("instancerefer_amd: csrc/_irx_nodes.so could not be loaded (%s: %s) — the dense heads run through their "
+                      "Python / ATen path; rebuild with `python -m instancerefer_amd._build`" % (type(e).__name__, e), RuntimeWarning)
+        return None
     _mod = mod
     return mod
