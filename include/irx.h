@@ -543,7 +543,9 @@ int irx_knn_batched(const float* sup_xyz, const int32_t* sup_offsets, const floa
  * scene_module.py:38-42: nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, [Dropout], Linear)) as one operator each way.
  * x [rows][din], w1 [dh][din], w2 [dout][dh] (nn.Linear layouts); norm: 1 = BatchNorm1d with batch statistics (running_mean /
  * running_var, when given, are updated with `momentum` and the unbiased variance), 2 = BatchNorm1d with the running statistics,
- * 3 = LayerNorm over dh; drop_p > 0: dropout of the hidden activations, decided by a counter-based hash of (seed, element).
+ * 3 = LayerNorm over dh, 4 = none (gamma / beta may be NULL: the word projection of models/lang_module.py:22-23, Linear -> ReLU ->
+ * Dropout -> Linear -> ReLU), + 8: ReLU on the output y (the backward then expects dy already masked by y > 0);
+ * drop_p > 0: dropout of the hidden activations, decided by a counter-based hash of (seed, element).
  * saved: irx_mlp2_saved_floats(rows, dh) floats the backward reads back (h, a, statistics). Backward: dhid = scratch
  * [rows][dh]; dx may be NULL; drop_scale = 1 / (1 - drop_p). fp32 FMA tiles, deterministic, any row count. */
 size_t irx_mlp2_saved_floats(int rows, int dh);

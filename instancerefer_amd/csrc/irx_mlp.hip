@@ -85,7 +85,7 @@ __device__ __forceinline__ float ml_colsum(float part, float (*red)[ML_TC]) {
   return s;
 }
 
-enum { ML_BN_TRAIN = 1, ML_BN_EVAL = 2, ML_LN = 3 };
+enum { ML_BN_TRAIN = 1, ML_BN_EVAL = 2, ML_LN = 3, ML_NONE = 4, ML_OUT_RELU = 8 };   // (ML_OUT_RELU: flag, y = relu(...))
 
 // Dropout without a mask tensor: element o of call `seed` is kept iff a counter-based hash of (seed, o) falls above p — the
 // same decision wherever it is evaluated (forward 1 / forward 2 recompute it), scaled by 1 / (1 - p) like F.dropout. The
@@ -164,6 +164,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd1(const float* __restrict__ x, i
       rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
     }
+  } else if (norm == ML_NONE) {                         // Linear -> ReLU -> Dropout -> Linear: the identity "normalisation"
+    mean = 0.f;
+    invstd = 1.f;
   } else {
     mean = cv ? rmean[c] : 0.f;
     invstd = cv ? rsqrtf(rvar[c] + eps) : 0.f;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd1(const float* __restrict__ x, i
     stat[dh + c] = invstd;
   }
   if (!cv) return;
-  const float g = gamma[c] * invstd, bsh = beta[c] - mean * g;
+  const float g = norm == ML_NONE ? 1.f : gamma[c] * invstd, bsh = norm == ML_NONE ? 0.f : beta[c] - mean * g;
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   if (one_tile) {
 #pragma unroll
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, i
                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                   float drop_p, unsigned long long seed, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ stat,
-                                                  float* __restrict__ a, float* __restrict__ y) {
+                                                  float* __restrict__ a, float* __restrict__ y, int out_relu) {
   __shared__ __attribute__((aligned(16))) float sA[ML_TR][ML_LD], sB[ML_TC][ML_LD];
   __shared__ float sMean[ML_TR], sInv[ML_TR];
   const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
@@ -253,7 +256,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, i
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int r = r0 + i0 + 8 * m;
-      if (r < rows && c < dout) y[(size_t)r * dout + c] = acc[m] + b2[c];
+      if (r < rows && c < dout) {
+        const float v = acc[m] + b2[c];
+        y[(size_t)r * dout + c] = out_relu ? fmaxf(v, 0.f) : v;
+      }
     }
   }
 }
@@ -318,11 +324,11 @@ __global__ __launch_bounds__(256) void k_mlp_bwd1(const float* __restrict__ dy, 
     sg += ml_colsum(pg, red);
     sb += ml_colsum(pb, red);
   }
-  if (cv && i0 == 0) {
+  if (cv && i0 == 0 && norm != ML_NONE) {
     dgamma[c] = sg;
     dbeta[c] = sb;
   }
-  if (norm != ML_LN && cv) {                          // (rows i0 + 8 m: this thread's own dhid entries)
+  if (norm != ML_LN && norm != ML_NONE && cv) {       // (rows i0 + 8 m: this thread's own dhid entries; no norm: dhid = dz)
     const float gi = gamma[c] * inv_c;
     const float kb = (norm == ML_BN_TRAIN) ? sb / rows : 0.f, kg = (norm == ML_BN_TRAIN) ? sg / rows : 0.f;
     for (int r = i0; r < rows; r += 8) {
@@ -407,9 +413,12 @@ extern "C" int irx_mlp2_fwd(const float* x, int rows, int din, int dh, int dout,
                             float momentum, float drop_p, unsigned long long seed, const float* w2, const float* b2,
                             float* saved, float* y, void* stream) {
   IRX_REQUIRE(rows >= 0 && din >= 1 && dh >= 1 && dout >= 1, "irx_mlp2_fwd: bad sizes");
-  IRX_REQUIRE(norm >= ML_BN_TRAIN && norm <= ML_LN, "irx_mlp2_fwd: norm %d is not 1 (BatchNorm train), 2 (eval) or 3 (LayerNorm)", norm);
+  const int out_relu = (norm & ML_OUT_RELU) ? 1 : 0;
+  norm &= ~ML_OUT_RELU;
+  IRX_REQUIRE(norm >= ML_BN_TRAIN && norm <= ML_NONE,
+              "irx_mlp2_fwd: norm %d is not 1 (BatchNorm train), 2 (eval), 3 (LayerNorm) or 4 (none) [+ 8: ReLU on the output]", norm);
   if (rows == 0) return IRX_OK;
-  IRX_REQUIRE(x && w1 && b1 && gamma && beta && w2 && b2 && saved && y, "irx_mlp2_fwd: null pointer");
+  IRX_REQUIRE(x && w1 && b1 && w2 && b2 && saved && y && (norm == ML_NONE || (gamma && beta)), "irx_mlp2_fwd: null pointer");
   IRX_REQUIRE(norm != ML_BN_EVAL || (running_mean && running_var), "irx_mlp2_fwd: BatchNorm eval needs the running statistics");
   IRX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "irx_mlp2_fwd: dropout probability %f outside [0, 1)", (double)drop_p);
   IRX_REQUIRE(norm != ML_BN_TRAIN || rows > 1, "irx_mlp2_fwd: train-mode BatchNorm1d needs more than one row");
@@ -419,7 +428,7 @@ extern "C" int irx_mlp2_fwd(const float* x, int rows, int din, int dh, int dout,
   k_mlp_fwd1<<<irx_cdiv(dh, ML_TC), 256, 0, S(stream)>>>(x, rows, din, dh, w1, b1, norm, gamma, beta, eps, running_mean,
                                                           running_var, momentum, drop_p, seed, h, stat, a);
   IRX_CHECK_LAUNCH("irx_mlp2_fwd(1)");
-  k_mlp_fwd2<<<irx_cdiv(dout, ML_TC), 256, 0, S(stream)>>>(h, rows, dh, dout, norm, gamma, beta, eps, drop_p, seed, w2, b2, stat, a, y);
+  k_mlp_fwd2<<<irx_cdiv(dout, ML_TC), 256, 0, S(stream)>>>(h, rows, dh, dout, norm, gamma, beta, eps, drop_p, seed, w2, b2, stat, a, y, out_relu);
   IRX_CHECK_LAUNCH("irx_mlp2_fwd(2)");
   return IRX_OK;
 }
@@ -429,8 +438,9 @@ extern "C" int irx_mlp2_bwd(const float* x, const float* dy, int rows, int din, 
                             const float* gamma, const float* w2, const float* saved, float drop_scale, float* dhid, float* dx,
                             float* dw1, float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, void* stream) {
   IRX_REQUIRE(rows >= 1 && din >= 1 && dh >= 1 && dout >= 1, "irx_mlp2_bwd: bad sizes");
-  IRX_REQUIRE(norm >= ML_BN_TRAIN && norm <= ML_LN, "irx_mlp2_bwd: bad norm %d", norm);
-  IRX_REQUIRE(x && dy && w1 && gamma && w2 && saved && dhid && dw1 && db1 && dgamma && dbeta && dw2 && db2,
+  norm &= ~ML_OUT_RELU;                 // (an output ReLU is the caller's: dy arrives masked by y > 0)
+  IRX_REQUIRE(norm >= ML_BN_TRAIN && norm <= ML_NONE, "irx_mlp2_bwd: bad norm %d", norm);
+  IRX_REQUIRE(x && dy && w1 && w2 && saved && dhid && dw1 && db1 && dw2 && db2 && (norm == ML_NONE || (gamma && dgamma && dbeta)),
               "irx_mlp2_bwd: null pointer");
   const float* h = saved;
   const float* a = saved + (size_t)rows * dh;

@@ -60,11 +60,13 @@ inline float* fpm(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : 
 // delivered there (the optimizer reads it at gather time); a second backward before the flags are cleared, or a backward
 // without slots, returns ordinary gradient tensors.
 struct MLP2Node : public torch::autograd::Function<MLP2Node> {
-  static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w1, const Tensor& b1, const Tensor& gamma,
-                        const Tensor& beta, const Tensor& w2, const Tensor& b2, int64_t norm, double eps,
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w1, const Tensor& b1,
+                        const c10::optional<Tensor>& gamma_o, const c10::optional<Tensor>& beta_o, const Tensor& w2,
+                        const Tensor& b2, int64_t norm, double eps,
                         const c10::optional<Tensor>& rmean, const c10::optional<Tensor>& rvar, double momentum, double drop_p,
                         int64_t seed, int64_t stream, std::vector<int64_t> slot_ptrs, int64_t flag) {
     const Tensor x = x_in.contiguous().to(torch::kFloat32);
+    const Tensor gamma = gamma_o.has_value() ? *gamma_o : Tensor(), beta = beta_o.has_value() ? *beta_o : Tensor();
     const int rows = (int)x.size(0), din = (int)x.size(1), dh = (int)w1.size(0), dout = (int)w2.size(0);
     Tensor y = torch::empty({rows, dout}, x.options());
     Tensor saved = torch::empty({(int64_t)g_api.mlp2_saved_floats(rows, dh)}, x.options());
@@ -72,7 +74,7 @@ struct MLP2Node : public torch::autograd::Function<MLP2Node> {
                          rmean.has_value() ? fpm(*rmean) : nullptr, rvar.has_value() ? fpm(*rvar) : nullptr, (float)momentum,
                          (float)drop_p, (unsigned long long)seed, fp(w2), fp(b2), fpm(saved), fpm(y), (void*)stream),
           "irx_mlp2_fwd");
-    ctx->save_for_backward({x, w1, gamma, w2, saved});
+    ctx->save_for_backward({x, w1, gamma, w2, saved, (norm & 8) ? y : Tensor()});    // (+ 8: ReLU on y — the backward masks dy with it)
     ctx->saved_data["norm"] = norm;
     ctx->saved_data["drop_p"] = drop_p;
     ctx->saved_data["stream"] = stream;          // (the engine replays the node on its forward stream)
@@ -90,23 +92,29 @@ struct MLP2Node : public torch::autograd::Function<MLP2Node> {
     void* stream = (void*)ctx->saved_data["stream"].toInt();
     int32_t* flag = (int32_t*)ctx->saved_data["flag"].toInt();
     const auto slots = ctx->saved_data["slots"].toIntVector();
-    const Tensor dy = grad_out[0].contiguous().to(torch::kFloat32);
+    Tensor dy = grad_out[0].contiguous().to(torch::kFloat32);
+    if (norm & 8) dy = at::threshold_backward(dy, sv[5], 0);          // the output ReLU
+    const bool has_norm = (norm & 7) != 4;                            // 4: no normalisation layer, no gamma / beta
     const bool want_dx = ctx->needs_input_grad(0);
     Tensor scratch = torch::empty({(int64_t)rows * (dh + (want_dx ? din : 0))}, x.options());
     float* base = scratch.data_ptr<float>();
     float* dx_ptr = want_dx ? base + (size_t)rows * dh : nullptr;
-    const bool deliver = slots.size() == 6 && flag != nullptr && *flag == 0;
-    float* gp[6];
+    // slots: (w1, b1, gamma, beta, w2, b2), or (w1, b1, w2, b2) without a normalisation layer
+    const bool deliver = slots.size() == (has_norm ? 6u : 4u) && flag != nullptr && *flag == 0;
+    float* gp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     variable_list out(17);
     if (deliver) {
-      for (int i = 0; i < 6; ++i) gp[i] = (float*)slots[i];
+      int q = 0;
+      for (int i = 0; i < 6; ++i)
+        if (has_norm || (i != 2 && i != 3)) gp[i] = (float*)slots[q++];
     } else {
-      const int64_t sizes[6] = {(int64_t)dh * din, dh, dh, dh, (int64_t)dout * dh, dout};
+      const int64_t sizes[6] = {(int64_t)dh * din, dh, has_norm ? dh : 0, has_norm ? dh : 0, (int64_t)dout * dh, dout};
       int64_t total = 0;
       for (int i = 0; i < 6; ++i) total += sizes[i];
       Tensor buf = torch::empty({total}, x.options());
       int64_t off = 0;
       for (int i = 0; i < 6; ++i) {
+        if (sizes[i] == 0) continue;
         gp[i] = buf.data_ptr<float>() + off;
         Tensor v = buf.narrow(0, off, sizes[i]);
         out[1 + i] = (i == 0) ? v.view({dh, din}) : (i == 4 ? v.view({dout, dh}) : v);
@@ -127,7 +135,8 @@ Tensor mlp2(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& g
             const Tensor& b2, int64_t norm, double eps, const c10::optional<Tensor>& rmean, const c10::optional<Tensor>& rvar,
             double momentum, double drop_p, int64_t seed, int64_t stream, std::vector<int64_t> slot_ptrs, int64_t flag) {
   TORCH_CHECK(g_api.mlp2_fwd && g_api.mlp2_bwd && g_api.mlp2_saved_floats, "irx nodes: bind() has not been called");
-  return MLP2Node::apply(x, w1, b1, gamma, beta, w2, b2, norm, eps, rmean, rvar, momentum, drop_p, seed, stream,
+  return MLP2Node::apply(x, w1, b1, c10::optional<Tensor>(gamma), c10::optional<Tensor>(beta), w2, b2, norm, eps, rmean, rvar, momentum,
+                         drop_p, seed, stream,
                          std::move(slot_ptrs), flag);
 }
 
@@ -227,6 +236,15 @@ Tensor gru_layer(const Tensor& x, const Tensor& len32, std::vector<Tensor> param
                              std::move(slot_ptrs), flag);
 }
 
+// nn.Sequential(Linear, ReLU, Dropout, Linear, ReLU) (reference models/lang_module.py:33-37, the word projection) on the same
+// operator: norm 4 (none) + 8 (ReLU on the output); slot_ptrs: (w1, b1, w2, b2).
+Tensor mlp_relu2(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, double drop_p, int64_t seed,
+                 int64_t stream, std::vector<int64_t> slot_ptrs, int64_t flag) {
+  TORCH_CHECK(g_api.mlp2_fwd && g_api.mlp2_bwd && g_api.mlp2_saved_floats, "irx nodes: bind() has not been called");
+  return MLP2Node::apply(x, w1, b1, c10::optional<Tensor>(), c10::optional<Tensor>(), w2, b2, (int64_t)(4 | 8), 0.0, c10::optional<Tensor>(),
+                         c10::optional<Tensor>(), 0.0, drop_p, seed, stream, std::move(slot_ptrs), flag);
+}
+
 // addresses of the C-ABI entry points, taken from the library instance _lib.py loaded
 void bind(const std::unordered_map<std::string, uint64_t>& addr) {
   auto get = [&](const char* name) -> uint64_t {
@@ -250,4 +268,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("bind", &bind);
   m.def("mlp2", &mlp2);
   m.def("gru_layer", &gru_layer);
+  m.def("mlp_relu2", &mlp_relu2);
 }

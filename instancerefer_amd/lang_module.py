@@ -40,6 +40,9 @@ class LangModule(nn.Module):
             # Only the first max(len) token positions reach the GRU and the attention pooling (the reference projects
             # all 126 padded rows, lang_module.py:100-102, and drops the rest when it packs the sequence): projecting
             # just those is the same function with the same gradients and a quarter of the MLP's GEMM work at 30 tokens.
+            # (dense.mlp_relu2 runs this Sequential as one fused C++ node; at 16 x 30 tokens = 480 rows its 64-row FMA tiles are
+            #  slower on the GPU than rocBLAS and the main stream's chain paces the forward: 5.98 vs 5.64 ms per step, three
+            #  alternating pairs — so the module itself stays)
             embed = self.word_projection(embed[:, :t_max])
             feats = gru_packed(self.gru, embed, length, t_max)     # (B, T_max, o_dim), zeros at t >= len
         else:

@@ -462,6 +462,45 @@ def test_fused_head_mlp_equals_the_sequential_module(lib, monkeypatch, backend, 
         assert float((b.detach().cpu().double() - c.double()).abs().max()) <= 1e-6, n
 
 
+@pytest.mark.parametrize("shape,din,dh,dout", [((16, 30, 300), 300, 256, 256), ((5, 41, 300), 300, 256, 256), ((70, 64), 64, 128, 32),
+                                                ((1, 1, 300), 300, 256, 256)])
+def test_fused_word_projection_equals_the_sequential_module(lib, shape, din, dh, dout):
+    """nn.Sequential(Linear, ReLU, Dropout, Linear, ReLU) — the language module's word projection (reference
+    models/lang_module.py:33-37,52) — through dense.mlp_relu2 (irx_mlp2_fwd / _bwd with norm = 4 | 8: no normalisation layer,
+    ReLU on the output; one C++ autograd node) against the SAME module evaluated by PyTorch on the CPU: output 1e-5, input
+    gradient and the four parameter gradients 1e-4 of each tensor's largest entry; 3-D inputs, ragged row tiles, one row."""
+    import copy
+    import torch.nn as nn
+    from instancerefer_amd import _nodes, dense
+    assert _nodes.load() is not None, "csrc/_irx_nodes.so has not been built (python -m instancerefer_amd._build)"
+    torch.manual_seed(din + dh + shape[0])
+    ref = nn.Sequential(nn.Linear(din, dh), nn.ReLU(), nn.Dropout(0.0), nn.Linear(dh, dout), nn.ReLU()).train()
+    mod = copy.deepcopy(ref).cuda()
+    x = torch.randn(*shape)
+    g = torch.randn(*shape[:-1], dout)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g)
+    xd = x.clone().cuda().requires_grad_(True)
+    yd = dense.mlp_relu2(mod, xd)
+    assert "MLP2Node" in yd.grad_fn.name() or "View" in yd.grad_fn.name(), yd.grad_fn.name()
+    yd.backward(g.cuda())
+
+    def close(a, b, tol, what, floor=1e-6):
+        a, b = a.detach().cpu(), b.detach()
+        assert a.shape == b.shape, what
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), floor), (what, float((a - b).abs().max()), float(b.abs().max()))
+    close(yd, yr, 1e-5, "output", 1.0)
+    close(xd.grad, xr.grad, 1e-4, "dx")
+    for (n, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad, 1e-4, n)
+    # eval mode / dropout off in eval, and host tensors go through the module
+    mod.eval()
+    with torch.no_grad():
+        close(dense.mlp_relu2(mod, xd.detach()), ref.eval()(x), 1e-5, "eval output", 1.0)
+    assert dense.mlp_relu2(ref, x).grad_fn is None or "MLP2" not in dense.mlp_relu2(ref, x).grad_fn.name()
+
+
 @pytest.mark.parametrize("backend", ["cpp", "py"])
 def test_fused_head_mlp_dropout_and_fallbacks(lib, monkeypatch, backend):
     """Dropout inside the fused MLP: about p of the hidden units are dropped and the rest scaled by 1 / (1 - p) (the output's
