@@ -21,6 +21,7 @@ _PREP_PLANS = _os.environ.get('IRX_PREP_PLANS', '0') == '1'
 # 5.83-5.88 -> 5.48-5.61 ms per step on one box, 5.57-5.64 -> 5.51-5.54 on a faster one; neutral in fp32 and at B = 32
 # (GPU-paced). Training mode on a HIP device only; IRX_LANG_THREAD=0 issues it inline.
 _LANG_THREAD = _os.environ.get('IRX_LANG_THREAD', '1') == '1'
+_REL_THREAD = _os.environ.get('IRX_REL_THREAD', '0') == '1'      # dev: the relation head on that thread too (behind the language module)
 _ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
 
 
@@ -141,24 +142,32 @@ class InstanceRefer(nn.Module):
                     job = q_in.get()
                     if job is None:
                         return
-                    dev, stream, grad, dd = job
+                    dev, stream, grad, rel, dd = job
                     try:
                         torch.cuda.set_device(dev)
                         with torch.cuda.stream(stream), torch.set_grad_enabled(grad):     # (both are thread-local state)
-                            q_out.put(self.lang(dd))
+                            dd = self.lang(dd)
+                            if rel:                      # the relation head needs the language features and prepared inputs only
+                                dd = self.relation(dd)
+                            q_out.put(dd)
                     except BaseException as e:          # surfaced by the training thread at join time
                         q_out.put(e)
             th = threading.Thread(target=run, name="irx-lang", daemon=True)
             th.start()
             w = self.__dict__['_lang_worker'] = (q_in, q_out)
-        sub = {k: data_dict[k] for k in ('lang_feat', 'lang_len', 'lang_len_max') if k in data_dict}
-        w[0].put((torch.cuda.current_device(), torch.cuda.current_stream(), torch.is_grad_enabled(), sub))
+        rel = bool(_REL_THREAD and self.args.relation_module and '_rel_prepared' in data_dict)
+        orig = dict(data_dict)                          # what was there when the job was posted
+        sub = dict(orig)                                # the worker adds / replaces keys in its own shallow copy
+        w[0].put((torch.cuda.current_device(), torch.cuda.current_stream(), torch.is_grad_enabled(), rel, sub))
 
         def join():
             out = w[1].get()
             if isinstance(out, BaseException):
                 raise out
-            return out
+            new = {k: v for k, v in out.items() if k not in orig or orig[k] is not v}   # what the worker produced
+            if rel:
+                data_dict.pop('_rel_prepared', None)    # consumed by the worker's copy
+            return new, rel
         return join
 
     def forward(self, data_dict):
@@ -186,13 +195,15 @@ class InstanceRefer(nn.Module):
             # candidates already chosen (prepare()): their encoder does not need the language features either, and its
             # launches are issued by a library thread while this one goes on with the language module (see _attr_early)
             data_dict = self.attribute.encode(data_dict)
+        rel_done = False
         if lang_join is not None:
-            data_dict.update(lang_join())
+            new, rel_done = lang_join()
+            data_dict.update(new)
         else:
             data_dict = self.lang(data_dict)
         if self.args.attribute_module:
             data_dict = self.attribute(data_dict)
-        if self.args.relation_module:
+        if self.args.relation_module and not rel_done:
             data_dict = self.relation(data_dict)
         if side is not None:
             from .sparse.encoder_fn import lane_of, lane_wait
