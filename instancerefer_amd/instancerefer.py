@@ -176,25 +176,15 @@ class InstanceRefer(nn.Module):
         lang_join = None
         if _LANG_THREAD and self.training and data_dict['lang_feat'].is_cuda:
             lang_join = self._lang_async(data_dict)
-        if self.args.scene_module and 'lidar' in data_dict and hasattr(self.scene, 'encode'):
-            # The whole-scene BEVEncoder depends on `lidar` only. It is issued FIRST and, on a HIP device, on its own
-            # stream, so that it runs concurrently with the language / attribute / relation work of the main stream:
-            # the deep levels of both sparse encoders are far too small to fill 256 CUs on their own, and autograd
-            # replays each node's backward on its forward stream, so the two backward passes overlap as well.
-            lidar = data_dict['lidar']
-            if lidar.F.is_cuda and getattr(self.args, 'overlap_streams', True):
-                main = torch.cuda.current_stream()
-                side = self._encoder_stream(lidar.F.device)
-                side.wait_stream(main)                       # inputs and the optimizer's parameter update are complete
-                lidar.record_stream(side)
-                with torch.cuda.stream(side):
-                    data_dict = self.scene.encode(data_dict)
-            else:
-                data_dict = self.scene.encode(data_dict)
-        if self.args.attribute_module and hasattr(self.attribute, 'encode') and self._attr_early():
-            # candidates already chosen (prepare()): their encoder does not need the language features either, and its
-            # launches are issued by a library thread while this one goes on with the language module (see _attr_early)
-            data_dict = self.attribute.encode(data_dict)
+        try:
+            data_dict, side = self._issue_encoders(data_dict)
+        except BaseException:
+            if lang_join is not None:                        # never leave a result behind for the next forward to pick up
+                try:
+                    lang_join()
+                except BaseException:
+                    pass
+            raise
         rel_done = False
         if lang_join is not None:
             new, rel_done = lang_join()
@@ -214,6 +204,30 @@ class InstanceRefer(nn.Module):
         if self.args.scene_module:
             data_dict = self.scene(data_dict)
         return data_dict
+
+    def _issue_encoders(self, data_dict):
+        """The two sparse encoders, which depend on the prepared inputs only -> (data_dict, the scene encoder's stream or None)."""
+        side = None
+        if self.args.scene_module and 'lidar' in data_dict and hasattr(self.scene, 'encode'):
+            # The whole-scene BEVEncoder depends on `lidar` only. It is issued FIRST and, on a HIP device, on its own
+            # stream, so that it runs concurrently with the language / attribute / relation work of the main stream:
+            # the deep levels of both sparse encoders are far too small to fill 256 CUs on their own, and autograd
+            # replays each node's backward on its forward stream, so the two backward passes overlap as well.
+            lidar = data_dict['lidar']
+            if lidar.F.is_cuda and getattr(self.args, 'overlap_streams', True):
+                main = torch.cuda.current_stream()
+                side = self._encoder_stream(lidar.F.device)
+                side.wait_stream(main)                       # inputs and the optimizer's parameter update are complete
+                lidar.record_stream(side)
+                with torch.cuda.stream(side):
+                    data_dict = self.scene.encode(data_dict)
+            else:
+                data_dict = self.scene.encode(data_dict)
+        if self.args.attribute_module and hasattr(self.attribute, 'encode') and self._attr_early():
+            # candidates already chosen (prepare()): their encoder does not need the language features either, and its
+            # launches are issued by a library thread while this one goes on with the language module (see _attr_early)
+            data_dict = self.attribute.encode(data_dict)
+        return data_dict, side
 
     @staticmethod
     def _attr_early():
