@@ -488,6 +488,24 @@ def build_batch_device(scans, object_ids, tables, device, num_points=40000, augm
                               (back_dev, rows32, order32, seg32, gslot, sem, choices_all))
 
 
+MAX_DES_LEN = 126                                   # lib/config.py CONF.TRAIN.MAX_DES_LEN
+
+
+def embed_tokens(tokens, glove, max_len=MAX_DES_LEN, dim=300):
+    """Token list -> (`lang_feat` (max_len, dim) float32, `lang_len`): the language half of the reference's __getitem__
+    (lib/dataset.py:70-92,275-277; the same loop again in `_tranform_des` :403-413). Row t holds glove[token_t], glove["unk"] for
+    an out-of-vocabulary token, zeros for a whitespace token (its row is skipped, not removed) and beyond the utterance;
+    `lang_len` counts the non-whitespace tokens of the WHOLE utterance, capped at max_len. Host code: a dictionary lookup per
+    token, done once per sample when the sample list of ResidentLoader is built."""
+    feat = np.zeros((max_len, dim), np.float64)
+    for t, tok in enumerate(tokens[:max_len]):
+        if tok.isspace():
+            continue
+        feat[t] = glove[tok] if tok in glove else glove["unk"]
+    n = sum(1 for tok in tokens if not tok.isspace())
+    return feat.astype(np.float32), np.int64(min(n, max_len))
+
+
 class ResidentLoader:
     """Iterable of training batches built on the device from resident scans (build_batch_device), in the role of the
     reference's DataLoader(ScannetReferenceDataset, collate_fn) for lib/solver.py-style loops (instancerefer_amd.solver.

@@ -5,21 +5,21 @@ import numpy as np
 
 from . import build_c
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        l = ctypes.CDLL(build_c.build())
+def lib(fast=False):
+    """The strict-IEEE build (parity tests) or, fast=True, the -ffast-math build (bench.py's timed cpu_baseline only)."""
+    if fast not in _libs:
+        l = ctypes.CDLL(build_c.build(fast=fast))
         l.irx_oracle_encoder_fwd_bwd.restype = ctypes.c_double
         l.irx_oracle_encoder_fwd_bwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         l.irx_oracle_set_wgrad_double.argtypes = [ctypes.c_int]
         l.irx_oracle_encoder_param_count.restype = ctypes.c_long
         l.irx_oracle_encoder_param_count.argtypes = [ctypes.c_int]
-        _lib = l
-    return _lib
+        _libs[fast] = l
+    return _libs[fast]
 
 
 def pack_encoder_params(state_dict, prefix):
@@ -36,18 +36,19 @@ def pack_encoder_params(state_dict, prefix):
     return np.ascontiguousarray(np.concatenate(parts).astype(np.float32)), order
 
 
-def encoder_fwd_bwd(coords, feats, nbatch, params, gpool, threads=0, wgrad_double=False):
+def encoder_fwd_bwd(coords, feats, nbatch, params, gpool, threads=0, wgrad_double=False, fast=False):
     """coords (n,4) int32 (x,y,z,b), feats (n,c0) f32 -> (loss, pooled (nbatch,128), grads (like params)).
     wgrad_double: accumulate the weight gradients in float64 (the parity checker at full size; the timed baseline keeps
     float, torchsparse's CPU arithmetic)."""
-    lib().irx_oracle_set_wgrad_double(int(bool(wgrad_double)))
+    L = lib(fast)
+    L.irx_oracle_set_wgrad_double(int(bool(wgrad_double)))
     coords = np.ascontiguousarray(coords, dtype=np.int32)
     feats = np.ascontiguousarray(feats, dtype=np.float32)
     gpool = np.ascontiguousarray(gpool, dtype=np.float32)
     n, c0 = feats.shape
-    assert params.size == lib().irx_oracle_encoder_param_count(c0)
+    assert params.size == L.irx_oracle_encoder_param_count(c0)
     pooled = np.zeros((nbatch, 128), np.float32)
     grads = np.zeros_like(params)
-    loss = lib().irx_oracle_encoder_fwd_bwd(coords.ctypes.data, feats.ctypes.data, n, c0, nbatch, params.ctypes.data,
+    loss = L.irx_oracle_encoder_fwd_bwd(coords.ctypes.data, feats.ctypes.data, n, c0, nbatch, params.ctypes.data,
                                             gpool.ctypes.data, pooled.ctypes.data, grads.ctypes.data, int(threads))
     return loss, pooled, grads

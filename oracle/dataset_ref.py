@@ -147,3 +147,17 @@ def get_item(raw, object_id, object_cat, nyu40ids, nyu40id2class, mean_size_arr,
                 ref_size_residual_label=ref_size_res.astype(np.float32),
                 ref_heading_class_label=np.array(0).astype(np.int64),
                 ref_heading_residual_label=np.array(0).astype(np.int64))
+
+
+def lang_features(tokens, glove, max_len=126):
+    """lib/dataset.py:70-92: (embeddings (max_len, 300) float64, lang_len). Written as the reference's loop."""
+    emb = np.zeros((max_len, 300))
+    for token_id in range(max_len):
+        if token_id >= len(tokens):
+            break
+        token = tokens[token_id]
+        if token.isspace():
+            continue
+        emb[token_id] = glove[token] if token in glove else glove["unk"]
+    n = len([t for t in tokens if not t.isspace()])
+    return emb, (n if n <= max_len else max_len)

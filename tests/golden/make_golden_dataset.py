@@ -72,9 +72,11 @@ def main():
     CONF.PATH.SCANNET_DATA = os.path.join(tmp, "pointgroup_data")
     CONF.PATH.DATA = tmp
     os.makedirs(CONF.PATH.SCANNET_DATA)
-    tokens = ["the", "chair", "is", "next", "to", "the", "brown", "table", "."]
+    tokens = ["the", "chair", "is", "next", " ", "to", "the", "brown", "table", "."]
     rng = np.random.default_rng(1)
-    glove = {t: rng.standard_normal(300) for t in set(tokens[:-2]) | {"unk"}}
+    # SORTED vocabulary: iterating a Python set of strings depends on PYTHONHASHSEED, which made `lang_feat_rows` differ on
+    # every regeneration. "table" and "." are out of vocabulary (-> glove["unk"]), " " exercises isspace().
+    glove = {t: rng.standard_normal(300) for t in sorted(set(tokens[:-2]) - {" "}) + ["unk"]}
     with open(os.path.join(tmp, "glove.p"), "wb") as f:
         pickle.dump(glove, f)
     import lib.dataset as D                                  # the reference's dataset module
@@ -104,6 +106,9 @@ def main():
                   "size_residual_label", "size_class_label", "num_bbox"):
             o[k] = np.asarray(dd[k])
         o["lang_feat_rows"] = np.asarray(dd["lang_feat"][:len(tokens) + 1])
+        o["glove_vocab"] = np.asarray(sorted(glove))
+        o["glove_vectors"] = np.stack([glove[t] for t in sorted(glove)], 0)
+        o["tokens"] = np.asarray(tokens)
         o["instance_points"] = np.stack(dd["instance_points"], 0)
         o["instance_obbs"] = np.stack(dd["instance_obbs"], 0)
         o["instance_class"] = np.asarray(dd["instance_class"])

@@ -153,6 +153,37 @@ def test_oracle_input_pipeline_matches_reference_getitem(case):
     assert np.array_equal(c, g[case + "/pts_batch0_C"]) and np.array_equal(f, g[case + "/pts_batch0_F"])
 
 
+def _glove_case(g, case):
+    glove = {str(t): v for t, v in zip(g[case + "/glove_vocab"], g[case + "/glove_vectors"])}
+    return [str(t) for t in g[case + "/tokens"]], glove
+
+
+@pytest.mark.parametrize("case", ["plain", "augmented"])
+def test_lang_features_match_reference_getitem(case):
+    """GloVe lookup half of __getitem__ (lib/dataset.py:70-92): oracle restatement AND the product's scene_input.embed_tokens
+    against `lang_feat` / `lang_len` as the reference's own dataset produced them (out-of-vocabulary tokens -> "unk", a
+    whitespace token leaves a zero row and does not count). The fixture's vocabulary is drawn in sorted order, so the rows are
+    reproducible (they were not, and nothing read them)."""
+    from oracle import dataset_ref as DR
+    from instancerefer_amd import scene_input as SI
+    g = _dataset_golden()
+    tokens, glove = _glove_case(g, case)
+    rows = g[case + "/lang_feat_rows"]
+    assert rows.dtype == np.float32 and np.abs(rows).max() > 0
+    emb, n = DR.lang_features(tokens, glove)
+    assert n == int(g[case + "/lang_len"])
+    assert np.array_equal(emb.astype(np.float32)[:len(rows)], rows) and not emb[len(rows):].any()
+    feat, m = SI.embed_tokens(tokens, glove)
+    assert feat.dtype == np.float32 and feat.shape == (126, 300) and int(m) == n and m.dtype == np.int64
+    assert np.array_equal(feat[:len(rows)], rows) and not feat[len(rows):].any()
+    assert not feat[tokens.index(" ")].any()                                  # skipped, not compacted
+    assert np.array_equal(feat[tokens.index("table")], glove["unk"].astype(np.float32))
+    long = tokens * 20                                                          # 200 tokens: truncated at 126, length capped
+    feat, m = SI.embed_tokens(long, glove)
+    emb, n = DR.lang_features(long, glove)
+    assert int(m) == n == 126 and np.array_equal(feat, emb.astype(np.float32))
+
+
 def _projection_inputs():
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden_projection", os.path.join(
