@@ -255,13 +255,18 @@ def timeline(model, resident, args, reducer, opt, state, F_, n=12):
     encoder_fn.EVENT_POOL.extend(encoder_fn._new_event() for _ in range(n * 2 * 6 * 13))
     torch.cuda.synchronize()
     _MARKS, F_.PROFILE, encoder_fn.PROFILE_NO_COUNT = [], [], True
+    F_.PROFILE_NO_COUNT = True
+    from instancerefer_amd import instancerefer as _ir
+    _ir.MARK = _mark
     t0 = time.perf_counter()
     for _ in range(n):
         step_fn(model, resident, args.workload, reducer, opt, state)
     torch.cuda.synchronize()
     log("timeline steps: %.2f ms/step" % ((time.perf_counter() - t0) * 1e3 / n))
     marks, recs = _MARKS, F_.PROFILE
+    _ir.MARK = None
     _MARKS, F_.PROFILE, encoder_fn.PROFILE_NO_COUNT = None, None, False
+    F_.PROFILE_NO_COUNT = False
     per = len(marks) // n
     rper = len(recs) // n
     rows = {}

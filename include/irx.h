@@ -260,12 +260,35 @@ int irx_bn_apply(const float* x, int n, int c, const float* mean, const float* i
                  const float* gamma, const float* beta, const float* residual, int relu,
                  float* y, void* stream);
 
+/* irx_bn_stats followed by irx_bn_apply as ONE call (the form spnn.BatchNorm + spnn.ReLU (+ the shortcut add) take in training,
+ * models/basic_blocks.py:20-21,37-38,52-55): mean / invstd are written for the backward, the running statistics updated, y =
+ * act((x - mean) * invstd * gamma + beta (+ residual)). With relu != 0 a tensor small enough to stay on-die (IRX_BN_SLICE_BYTES,
+ * default 6 MB) is ONE launch — a workgroup per 16-byte channel column walks all rows twice — instead of three dependent ones;
+ * irx_bn_backward takes the same single-launch form for such a tensor. workspace: irx_bn_workspace_bytes(n, c). */
+int irx_bn_forward(const float* x, int n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                   const float* residual, int relu, float* mean, float* invstd, float* running_mean,
+                   float* running_var, float* y, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of irx_bn_apply∘irx_bn_stats (train mode). g = dy * (y > 0) when relu.
  * Outputs: dx [n][c]; dgamma, dbeta [c]; dresidual [n][c] (= g) when dresidual != NULL. */
 int irx_bn_backward(const float* x, const float* y, const float* dy, int n, int c,
                     const float* mean, const float* invstd, const float* gamma, int relu,
                     float* dx, float* dgamma, float* dbeta, float* dresidual, void* workspace,
                     size_t workspace_bytes, void* stream);
+
+/* irx_bn_forward / irx_bn_backward on tensors whose element type is chosen per tensor: 0 = float32, 1 = bf16 (round-to-nearest-
+ * even on store, exact widening on load; statistics, arithmetic and parameter gradients stay float32 / float64) — the form the
+ * encoder executor's bf16 storage mode runs (irx_set_compute_dtype(2)). bf16 tensors need c % 4 == 0 and 16-byte aligned
+ * pointers. irx_bn_backward_ex, beta != NULL with relu and no dresidual: the layer had no shortcut, so y = relu(fma(x, invstd *
+ * gamma, fma(-mean, invstd * gamma, beta))) — the ReLU mask is recomputed from x and y is not read. */
+int irx_bn_forward_ex(const void* x, int n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                      const void* residual, int relu, float* mean, float* invstd, float* running_mean,
+                      float* running_var, void* y, void* workspace, size_t workspace_bytes, void* stream, int x_bf,
+                      int res_bf, int y_bf);
+int irx_bn_backward_ex(const void* x, const void* y, const void* dy, int n, int c, const float* mean,
+                       const float* invstd, const float* gamma, const float* beta, int relu, void* dx, float* dgamma,
+                       float* dbeta, void* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf,
+                       int y_bf, int dy_bf, int dx_bf, int dres_bf);
 
 /* Sync BatchNorm (optional; the reference has no multi-GPU path — torch.nn.SyncBatchNorm is the contract):
  * statistics over the rows of ALL ranks. The library computes this rank's sums, the caller folds them over the ranks

@@ -56,6 +56,9 @@ _SIGNATURES = {
     "irx_bn_workspace_bytes": (_Z, [_I, _I]),
     "irx_bn_stats": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "irx_bn_apply": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "irx_bn_forward": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "irx_bn_forward_ex": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _I, _I]),
+    "irx_bn_backward_ex": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _I, _I, _I, _I, _I]),
     "irx_bn_backward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "irx_bn_sums": (_I, [_P, _I, _I, _P, _P, _Z, _P]),
     "irx_bn_stats_from_sums": (_I, [_P, _D, _I, _F, _F, _P, _P, _P, _P, _P]),

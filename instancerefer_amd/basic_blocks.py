@@ -68,11 +68,13 @@ class SparseConvEncoder(nn.Module):
         self.stage3 = nn.Sequential(BasicConvolutionBlock(128, 128, ks=2, stride=2), ResidualBlock(128, 128, 3))
         self.stage4 = nn.Sequential(BasicConvolutionBlock(128, 128, ks=2, stride=2), ResidualBlock(128, 128, 3))
 
-    def forward(self, x):
+    def forward(self, x, defer=False):
+        """defer=True (training executor only): issue the pass now and return an encoder_fn.Deferred whose .attach() creates the
+        autograd node later — the backward then reaches this encoder in the order of the attach, not of the issue."""
         x = x.canonical()
         x.level().build_pyramid(4)       # all level-size syncs up front, while the GPU queue is still empty
         if encoder_fn.can_fuse(self):
-            return encoder_fn.run_encoder(self, x)     # training: the whole encoder as one autograd node
+            return encoder_fn.run_encoder(self, x, defer=defer)     # training: the whole encoder as one autograd node
         x = self.stem(x)
         x = self.stage1(x)
         x = self.stage2(x)

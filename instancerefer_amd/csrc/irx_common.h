@@ -226,6 +226,9 @@ int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, floa
 int irx_bn_apply_t(const float* x, int n, int c, const float* mean, const float* invstd, const float* gamma,
                    const float* beta, const float* residual, int relu, float* y, void* stream, int x_bf, int res_bf,
                    int y_bf);
+int irx_bn_forward_t(const float* x, int n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                     const float* residual, int relu, float* mean, float* invstd, float* running_mean, float* running_var,
+                     float* y, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int res_bf, int y_bf);
 int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, int c, const float* mean,
                       const float* invstd, const float* gamma, int relu, float* dx, float* dgamma, float* dbeta,
                       float* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int y_bf,

@@ -187,14 +187,15 @@ int encoder_forward_impl(const int64_t* desc, const double* fdesc, int n_layers,
       rc = sync.cb(sync.user, sl, 2 * L.cout + 1, 1, stream);
       IRX_REQUIRE(rc == 0, "irx_encoder_forward_sync: the all-reduce callback failed (%d) at layer %d", rc, i);
       rc = irx_bn_stats_from_sums(sl, 0.0, L.cout, L.eps, L.momentum, L.mean, L.invstd, L.running_mean, L.running_var, stream);
-    } else {
-      rc = irx_bn_stats_t(L.c, L.n_out, L.cout, L.eps, L.momentum, L.mean, L.invstd, L.running_mean, L.running_var, ws_b,
-                          r.bn, stream, st);
     }
     if (rc) return rc;
     const float* res = nullptr;
     if (L.res >= 0) res = (const float*)desc[(size_t)L.res * IRX_ENC_NFIELDS + IRX_ENC_Y];
-    rc = irx_bn_apply_t(L.c, L.n_out, L.cout, L.mean, L.invstd, L.gamma, L.beta, res, 1, L.y, stream, st, st, y_bf);
+    if (sync.cb)
+      rc = irx_bn_apply_t(L.c, L.n_out, L.cout, L.mean, L.invstd, L.gamma, L.beta, res, 1, L.y, stream, st, st, y_bf);
+    else      // statistics + apply: one launch for the levels that stay on-die (irx_norm.hip, k_bn_slice_fwd), two + one otherwise
+      rc = irx_bn_forward_t(L.c, L.n_out, L.cout, L.eps, L.momentum, L.gamma, L.beta, res, 1, L.mean, L.invstd, L.running_mean,
+                            L.running_var, L.y, ws_b, r.bn, stream, st, st, y_bf);
     if (rc) return rc;
   }
   return IRX_OK;

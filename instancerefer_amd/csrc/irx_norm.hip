@@ -20,6 +20,7 @@ static inline int bn_rows(int n, int c) {
 }
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+#include <atomic>
 
 // Element types of the tensors of one BatchNorm call (0 = float32, 1 = bf16; bf16 needs the 4-wide path): the encoder
 // executor's bf16 storage mode keeps conv outputs, layer outputs and the gradients in flight as bf16 while the
@@ -56,6 +57,17 @@ __device__ __forceinline__ void bn_st8(float* p, size_t off, const float (&v)[8]
       make_uint4(irx_pk_bf16(v[0], v[1]), irx_pk_bf16(v[2], v[3]), irx_pk_bf16(v[4], v[5]), irx_pk_bf16(v[6], v[7]));
 }
 
+// finalize-in-the-last-workgroup arguments of k_bn_partial (counter == NULL: the separate k_bn_finalize launch does it)
+struct BnFin {
+  unsigned* counter = nullptr;
+  float eps = 0.f, momentum = 0.f;
+  float *out0 = nullptr, *out1 = nullptr, *running_mean = nullptr, *running_var = nullptr;
+};
+// ticket counters of the launches in flight: zero at module load, left at zero by every kernel that used one; handed out round
+// robin (two launches share one only if more than BN_NCOUNTERS statistics kernels are in flight at once)
+#define BN_NCOUNTERS 4096
+__device__ unsigned g_bn_counters[BN_NCOUNTERS];
+
 __host__ __device__ static inline int next_pow2(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -83,13 +95,14 @@ __global__ __launch_bounds__(BN_PT) void k_bn_partial(const float* __restrict__ 
                                                     const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, int relu_arg,
                                                     int qpad, int rows_per_block, float* __restrict__ part, BnTy ty,
-                                                    const float* __restrict__ mk_gamma, const float* __restrict__ mk_beta) {
+                                                    const float* __restrict__ mk_gamma, const float* __restrict__ mk_beta,
+                                                    BnFin fin = BnFin()) {
   // RM (compile time: a run-time flag in front of the loads keeps the compiler from batching a row group's loads, measured
   // again in round 3: 15.8 -> 21.8 us) with mk_gamma / mk_beta (MODE 1, relu, a layer WITHOUT a shortcut): the ReLU mask is recomputed from x —
   // y > 0  <=>  fma(x, invstd * gamma, fma(-mean, invstd * gamma, beta)) > 0, the very expression k_bn_apply evaluated — so y
   // is never read (a third of this pass's bytes)
-  __shared__ float s0[BN_PT * V];
-  __shared__ float s1[BN_PT * V];
+  __shared__ __align__(16) float s0[BN_PT * V];
+  __shared__ __align__(16) float s1[BN_PT * V];
   const int cq = c / V;
   const int qd = threadIdx.x % qpad;
   const int rg = threadIdx.x / qpad;
@@ -190,6 +203,69 @@ __global__ __launch_bounds__(BN_PT) void k_bn_partial(const float* __restrict__ 
       part[((size_t)blockIdx.x * 2 + 0) * c + qd * V + j] = t0;
       part[((size_t)blockIdx.x * 2 + 1) * c + qd * V + j] = t1;
     }
+  }
+  if constexpr (V >= 4 && MODE <= 1) {
+    // Finalize folded into the LAST workgroup to finish (round 5; fin.counter != NULL): every workgroup publishes its partials
+    // (agent-scope release fence), takes a ticket, and the holder of the last ticket folds all partials in float64 — what
+    // k_bn_finalize did in a launch of its own (26 layers x 2 directions x ~5 us of dependent launch latency per step). Nobody
+    // waits for anybody: no spinning, no co-residency requirement. The counter is left at 0 for its next user.
+    if (fin.counter == nullptr) return;
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(fin.counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int nblk = gridDim.x;
+    const int cq4 = c / 4, nsl = BN_PT / cq4;            // float4 columns x slices of the partial blocks
+    const int col = threadIdx.x % cq4, sl = threadIdx.x / cq4;
+    double t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = 0.0;
+    if (sl < nsl) {
+      for (int b = sl; b < nblk; b += nsl) {
+        const float4 p0 = *reinterpret_cast<const float4*>(part + ((size_t)b * 2 + 0) * c + col * 4);
+        const float4 p1 = *reinterpret_cast<const float4*>(part + ((size_t)b * 2 + 1) * c + col * 4);
+        t[0] += (double)p0.x; t[1] += (double)p0.y; t[2] += (double)p0.z; t[3] += (double)p0.w;
+        t[4] += (double)p1.x; t[5] += (double)p1.y; t[6] += (double)p1.z; t[7] += (double)p1.w;
+      }
+    }
+    double* sd = reinterpret_cast<double*>(s0);           // BN_PT doubles fit: V >= 4
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __syncthreads();
+      sd[threadIdx.x] = t[j];
+      __syncthreads();
+      if (sl == 0) {
+        double acc = t[j];
+        for (int q = 1; q < nsl; ++q) acc += sd[q * cq4 + col];
+        t[j] = acc;
+      }
+    }
+    if (sl == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch = col * 4 + j;
+        const double t0 = t[j], t1 = t[4 + j];
+        if (MODE == 0) {
+          const double mu = t0 / (double)n;
+          double var = t1 / (double)n - mu * mu;
+          if (var < 0.0) var = 0.0;
+          fin.out0[ch] = (float)mu;
+          fin.out1[ch] = (float)(1.0 / sqrt(var + (double)fin.eps));
+          if (fin.running_mean) {
+            const double unbiased = (n > 1) ? var * (double)n / (double)(n - 1) : var;
+            fin.running_mean[ch] = (float)((1.0 - fin.momentum) * (double)fin.running_mean[ch] + fin.momentum * mu);
+            fin.running_var[ch] = (float)((1.0 - fin.momentum) * (double)fin.running_var[ch] + fin.momentum * unbiased);
+          }
+        } else {
+          fin.out0[ch] = (float)t0;
+          fin.out1[ch] = (float)t1;
+        }
+      }
+    }
+    if (threadIdx.x == 0) *fin.counter = 0u;
   }
 }
 
@@ -392,6 +468,330 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-launch BatchNorm for tensors that stay on-die ("slice" kernels, round 5).
+// The three-launch form above (partials -> float64 fold -> apply) costs a small level three dependent launches of 4-8 us each
+// for a tensor of a few hundred KB: at B = 16 that was 168 launches and 1.5 ms per step, as much as the convolutions. Here one
+// workgroup owns V consecutive channels (one 16-byte column of every row) and walks ALL rows twice: statistics, then apply
+// (forward) / the two gradient sums, then dx (backward). Nothing crosses workgroups: no partials, no finalize launch, no fence,
+// no counter. The second pass re-reads the rows from L2 / Infinity Cache (the host only takes this path below
+// bn_slice_max_bytes()). C / V workgroups of 1024 threads: 16 at 128 bf16 channels, 32 at 128 fp32 channels.
+// Arithmetic: per-thread fp32 sums over its <= n / 1024 rows, fp32 butterfly inside the wave, float64 across the 16 waves and for
+// mean / variance; scale / shift and the backward expressions are the ones k_bn_apply / k_bn_bwd_apply evaluate, so the ReLU mask
+// recomputed from x (RM) stays exact.
+#define BN_SL_PT 1024
+template <int V, int BF>
+__device__ __forceinline__ void sl_ld(const float* __restrict__ p, size_t off, float (&v)[V]) {
+  if constexpr (BF) {
+    if constexpr (V == 8) {
+      bn_ld8(p, off, v);
+    } else {
+      const float4 t = irx_bf4_to_f4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + off));
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(p + off + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  }
+}
+template <int V, int BF>
+__device__ __forceinline__ void sl_st(float* __restrict__ p, size_t off, const float (&v)[V]) {
+  if constexpr (BF) {
+    if constexpr (V == 8) {
+      bn_st8(p, off, v);
+    } else {
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + off) = irx_f4_to_bf4(make_float4(v[0], v[1], v[2], v[3]));
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q)
+      *reinterpret_cast<float4*>(p + off + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  }
+}
+
+// fold the per-thread sums a0 / a1 over the workgroup -> tot[0..V) / tot[V..2V) as float64 in LDS (valid after the call's barrier)
+template <int V>
+__device__ __forceinline__ void sl_fold(float (&a0)[V], float (&a1)[V], float* s_w, double* tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      a0[j] += __shfl_xor(a0[j], m, 64);
+      a1[j] += __shfl_xor(a1[j], m, 64);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      s_w[wave * 2 * V + j] = a0[j];
+      s_w[wave * 2 * V + V + j] = a1[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * V) {
+    double t = 0.0;
+    for (int w = 0; w < BN_SL_PT / 64; ++w) t += (double)s_w[w * 2 * V + threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+template <int V, int XB, int YB, int RB, bool RES>
+__global__ __launch_bounds__(BN_SL_PT) void k_bn_slice_fwd(const float* __restrict__ x, int n, int c, float eps, float momentum,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ res, float* __restrict__ y,
+                                                           float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var) {
+  __shared__ float s_w[(BN_SL_PT / 64) * 2 * V];
+  __shared__ double tot[2 * V];
+  __shared__ float s_sc[V], s_sh[V];
+  const size_t ch0 = (size_t)blockIdx.x * V;
+  float a0[V], a1[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) a0[j] = a1[j] = 0.f;
+  constexpr int U = 4;
+  int r = threadIdx.x;
+  for (; r + (U - 1) * BN_SL_PT < n; r += U * BN_SL_PT) {
+    float xv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sl_ld<V, XB>(x, (size_t)(r + u * BN_SL_PT) * c + ch0, xv[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        a0[j] += xv[u][j];
+        a1[j] += xv[u][j] * xv[u][j];
+      }
+  }
+  for (; r < n; r += BN_SL_PT) {
+    float xv[V];
+    sl_ld<V, XB>(x, (size_t)r * c + ch0, xv);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      a0[j] += xv[j];
+      a1[j] += xv[j] * xv[j];
+    }
+  }
+  sl_fold<V>(a0, a1, s_w, tot);
+  if (threadIdx.x < V) {
+    const int ch = (int)ch0 + threadIdx.x;
+    const double mu = tot[threadIdx.x] / (double)n;
+    double var = tot[V + threadIdx.x] / (double)n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out[ch] = mf;
+    invstd_out[ch] = isf;
+    if (running_mean) {
+      const double unbiased = (n > 1) ? var * (double)n / (double)(n - 1) : var;
+      running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mu);
+      running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
+    }
+    const float sc = isf * gamma[ch];                    // (k_bn_apply's own expressions, on the stored float statistics)
+    s_sc[threadIdx.x] = sc;
+    s_sh[threadIdx.x] = fmaf(-mf, sc, beta[ch]);
+  }
+  __syncthreads();
+  float sc[V], sh[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    sc[j] = s_sc[j];
+    sh[j] = s_sh[j];
+  }
+  r = threadIdx.x;
+  for (; r + (U - 1) * BN_SL_PT < n; r += U * BN_SL_PT) {
+    float xv[U][V], rv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t off = (size_t)(r + u * BN_SL_PT) * c + ch0;
+      sl_ld<V, XB>(x, off, xv[u]);
+      if constexpr (RES) sl_ld<V, RB>(res, off, rv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float ov[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float o = fmaf(xv[u][j], sc[j], sh[j]);
+        if constexpr (RES) o += rv[u][j];
+        ov[j] = o > 0.f ? o : 0.f;
+      }
+      sl_st<V, YB>(y, (size_t)(r + u * BN_SL_PT) * c + ch0, ov);
+    }
+  }
+  for (; r < n; r += BN_SL_PT) {
+    const size_t off = (size_t)r * c + ch0;
+    float xv[V], rv[V], ov[V];
+    sl_ld<V, XB>(x, off, xv);
+    if constexpr (RES) sl_ld<V, RB>(res, off, rv);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float o = fmaf(xv[j], sc[j], sh[j]);
+      if constexpr (RES) o += rv[j];
+      ov[j] = o > 0.f ? o : 0.f;
+    }
+    sl_st<V, YB>(y, off, ov);
+  }
+}
+
+// backward (ReLU layers): RM = mask recomputed from x (a layer without a shortcut; y is not read), DR = the shortcut's gradient
+// dres = g is written too. XB: x, dx, dres;  YB: y and dy (the executor's last layer keeps both fp32 while x / dx / dres are bf16)
+template <int V, int XB, int YB, bool RM, bool DR>
+__global__ __launch_bounds__(BN_SL_PT) void k_bn_slice_bwd(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, int n, int c,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mk_beta,
+                                                           float* __restrict__ dx, float* __restrict__ dres,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float s_w[(BN_SL_PT / 64) * 2 * V];
+  __shared__ double tot[2 * V];
+  const size_t ch0 = (size_t)blockIdx.x * V;
+  float mu[V], is[V], gi[V], msc[V], msh[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    mu[j] = mean[ch0 + j];
+    is[j] = invstd[ch0 + j];
+    const float g = gamma ? gamma[ch0 + j] : 0.f;
+    gi[j] = g * is[j];
+    msc[j] = msh[j] = 0.f;
+    if constexpr (RM) {
+      msc[j] = is[j] * g;
+      msh[j] = fmaf(-mu[j], msc[j], mk_beta[ch0 + j]);
+    }
+  }
+  float a0[V], a1[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) a0[j] = a1[j] = 0.f;
+  constexpr int U = 2;
+  auto grad = [&](const float (&xv)[V], const float (&yv)[V], const float (&dv)[V], float (&g)[V]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float yy = RM ? fmaf(xv[j], msc[j], msh[j]) : yv[j];
+      g[j] = (yy > 0.f) ? dv[j] : 0.f;
+    }
+  };
+  int r = threadIdx.x;
+  for (; r + (U - 1) * BN_SL_PT < n; r += U * BN_SL_PT) {
+    float xv[U][V], yv[U][V], dv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t off = (size_t)(r + u * BN_SL_PT) * c + ch0;
+      sl_ld<V, XB>(x, off, xv[u]);
+      sl_ld<V, YB>(dy, off, dv[u]);
+      if constexpr (!RM) sl_ld<V, YB>(y, off, yv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float g[V];
+      grad(xv[u], yv[u], dv[u], g);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        a0[j] += g[j];
+        a1[j] += g[j] * ((xv[u][j] - mu[j]) * is[j]);
+      }
+    }
+  }
+  for (; r < n; r += BN_SL_PT) {
+    const size_t off = (size_t)r * c + ch0;
+    float xv[V], yv[V], dv[V], g[V];
+    sl_ld<V, XB>(x, off, xv);
+    sl_ld<V, YB>(dy, off, dv);
+    if constexpr (!RM) sl_ld<V, YB>(y, off, yv);
+    grad(xv, yv, dv, g);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      a0[j] += g[j];
+      a1[j] += g[j] * ((xv[j] - mu[j]) * is[j]);
+    }
+  }
+  sl_fold<V>(a0, a1, s_w, tot);
+  const float inv_n = 1.f / (float)n;
+  float sg[V], sgx[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const float t0 = (float)tot[j], t1 = (float)tot[V + j];     // what k_bn_finalize<1> stores and k_bn_bwd_apply reads back
+    sg[j] = t0 * inv_n;
+    sgx[j] = t1 * inv_n;
+  }
+  if (threadIdx.x < V) {
+    dbeta[ch0 + threadIdx.x] = (float)tot[threadIdx.x];
+    dgamma[ch0 + threadIdx.x] = (float)tot[V + threadIdx.x];
+  }
+  if (dx == nullptr) return;
+  r = threadIdx.x;
+  for (; r + (U - 1) * BN_SL_PT < n; r += U * BN_SL_PT) {
+    float xv[U][V], yv[U][V], dv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t off = (size_t)(r + u * BN_SL_PT) * c + ch0;
+      sl_ld<V, XB>(x, off, xv[u]);
+      sl_ld<V, YB>(dy, off, dv[u]);
+      if constexpr (!RM) sl_ld<V, YB>(y, off, yv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t off = (size_t)(r + u * BN_SL_PT) * c + ch0;
+      float g[V], ox[V];
+      grad(xv[u], yv[u], dv[u], g);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float xh = (xv[u][j] - mu[j]) * is[j];
+        ox[j] = gi[j] * (g[j] - sg[j] - xh * sgx[j]);
+      }
+      sl_st<V, XB>(dx, off, ox);
+      if constexpr (DR) sl_st<V, XB>(dres, off, g);
+    }
+  }
+  for (; r < n; r += BN_SL_PT) {
+    const size_t off = (size_t)r * c + ch0;
+    float xv[V], yv[V], dv[V], g[V], ox[V];
+    sl_ld<V, XB>(x, off, xv);
+    sl_ld<V, YB>(dy, off, dv);
+    if constexpr (!RM) sl_ld<V, YB>(y, off, yv);
+    grad(xv, yv, dv, g);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float xh = (xv[j] - mu[j]) * is[j];
+      ox[j] = gi[j] * (g[j] - sg[j] - xh * sgx[j]);
+    }
+    sl_st<V, XB>(dx, off, ox);
+    if constexpr (DR) sl_st<V, XB>(dres, off, g);
+  }
+}
+
+// a zeroed ticket counter for one k_bn_partial launch that folds its own partials (see the kernel's tail), or NULL when that
+// is switched off (IRX_BN_LASTBLOCK=0: the separate k_bn_finalize launch) or the channel count does not fit its fold
+static unsigned* bn_counter(int c) {
+  static const bool on = !(getenv("IRX_BN_LASTBLOCK") && atoi(getenv("IRX_BN_LASTBLOCK")) == 0);
+  if (!on || c % 4 != 0 || c / 4 > BN_PT) return nullptr;
+  static std::atomic<unsigned*> base[16];
+  static std::atomic<unsigned> next{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  unsigned* b = base[dev].load(std::memory_order_acquire);
+  if (!b) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_bn_counters)) != hipSuccess || !p) return nullptr;
+    b = (unsigned*)p;
+    base[dev].store(b, std::memory_order_release);
+  }
+  return b + (next.fetch_add(1, std::memory_order_relaxed) % BN_NCOUNTERS);
+}
+
+// tensors up to this many bytes (n * c * element size of x) take the slice kernels: IRX_BN_SLICE_BYTES (dev knob; 0 switches
+// them off). Default 6 MB: the 20-29 k-row 128-channel levels of both encoders at B = 16 and everything below.
+static size_t bn_slice_max_bytes() {
+  static const long v = getenv("IRX_BN_SLICE_BYTES") ? atol(getenv("IRX_BN_SLICE_BYTES")) : (6L << 20);
+  return v > 0 ? (size_t)v : 0;
+}
+static bool bn_slice_ok(int n, int c, int x_bf) {
+  const int v = x_bf ? 8 : 4;
+  return n > 0 && c % v == 0 && (size_t)n * c * (x_bf ? 2 : 4) <= bn_slice_max_bytes();
+}
+
 // ------------------------------------------------------------------------------ C entry ------
 extern "C" size_t irx_bn_workspace_bytes(int n, int c) {
   if (n <= 0 || c <= 0) return 0;
@@ -450,22 +850,28 @@ int irx_bn_stats_t(const float* x, int n, int c, float eps, float momentum, floa
   const BnTy ty = {x_bf, 0, 0, 0, 0};
   rc = bn_bf_ok("irx_bn_stats", x_bf != 0, v4);
   if (rc) return rc;
+  BnFin fin;
+  if (v4 && (fin.counter = bn_counter(c)) != nullptr) {
+    fin.eps = eps; fin.momentum = momentum; fin.out0 = mean; fin.out1 = invstd;
+    fin.running_mean = running_mean; fin.running_var = running_var;
+  }
   if (bn_abl() & 1) {
   } else if (v4 && x_bf && c % 8 == 0)
     k_bn_partial<0, 8, false><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                   next_pow2(c / 8), bn_rows(n, c), part, ty, nullptr, nullptr);
+                                                   next_pow2(c / 8), bn_rows(n, c), part, ty, nullptr, nullptr, fin);
   else if (v4 && x_bf)
     k_bn_partial<0, 4, true><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                         next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr);
+                                                         next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr, fin);
   else if (v4)
     k_bn_partial<0, 4, false><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
-                                                          next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr);
+                                                          next_pow2(c / 4), bn_rows(n, c), part, ty, nullptr, nullptr, fin);
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_stats: c=%d needs c %% 4 == 0 or c <= 256", c);
     k_bn_partial<0, 1, false><<<nblk, BN_PT, 0, S(stream)>>>(x, nullptr, nullptr, n, c, nullptr, nullptr, 0,
                                                    next_pow2(c), bn_rows(n, c), part, ty, nullptr, nullptr);
   }
   IRX_CHECK_LAUNCH("irx_bn_stats(partial)");
+  if (fin.counter && !(bn_abl() & 1)) return IRX_OK;       // folded by the last workgroup of the launch above
   k_bn_finalize<0><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, eps, momentum, mean,
                                                           invstd, running_mean, running_var);
   IRX_CHECK_LAUNCH("irx_bn_stats(finalize)");
@@ -619,6 +1025,43 @@ int irx_bn_apply_t(const float* x, int n, int c, const float* mean, const float*
   return IRX_OK;
 }
 
+// Train-mode BatchNorm (+ shortcut) + ReLU in one call: statistics (mean / invstd written for the backward, running statistics
+// updated) and the apply pass. Small tensors take ONE launch (k_bn_slice_fwd), the others irx_bn_stats_t + irx_bn_apply_t.
+int irx_bn_forward_t(const float* x, int n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                     const float* residual, int relu, float* mean, float* invstd, float* running_mean, float* running_var,
+                     float* y, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int res_bf, int y_bf) {
+  const bool types_ok = (!x_bf && !y_bf && (!residual || !res_bf)) || (x_bf && (!residual || res_bf));
+  const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
+  if (relu && types_ok && aligned && bn_slice_ok(n, c, x_bf) && !(bn_abl() & 3)) {
+    IRX_REQUIRE(x && y && gamma && beta && mean && invstd, "irx_bn_forward: null pointer");
+    const hipStream_t st = S(stream);
+#define BN_SL_FWD(V_, XB_, YB_, RB_)                                                                                          \
+  do {                                                                                                                        \
+    if (residual) k_bn_slice_fwd<V_, XB_, YB_, RB_, true><<<c / V_, BN_SL_PT, 0, st>>>(x, n, c, eps, momentum, gamma, beta,  \
+                                                            residual, y, mean, invstd, running_mean, running_var);          \
+    else k_bn_slice_fwd<V_, XB_, YB_, RB_, false><<<c / V_, BN_SL_PT, 0, st>>>(x, n, c, eps, momentum, gamma, beta, nullptr, \
+                                                            y, mean, invstd, running_mean, running_var);                    \
+  } while (0)
+    if (!x_bf) BN_SL_FWD(4, 0, 0, 0);
+    else if (y_bf) BN_SL_FWD(8, 1, 1, 1);
+    else BN_SL_FWD(8, 1, 0, 1);
+#undef BN_SL_FWD
+    IRX_CHECK_LAUNCH("irx_bn_forward(slice)");
+    return IRX_OK;
+  }
+  int rc = irx_bn_stats_t(x, n, c, eps, momentum, mean, invstd, running_mean, running_var, workspace, workspace_bytes, stream,
+                          x_bf);
+  if (rc) return rc;
+  return irx_bn_apply_t(x, n, c, mean, invstd, gamma, beta, residual, relu, y, stream, x_bf, res_bf, y_bf);
+}
+
+extern "C" int irx_bn_forward(const float* x, int n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                              const float* residual, int relu, float* mean, float* invstd, float* running_mean,
+                              float* running_var, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+  return irx_bn_forward_t(x, n, c, eps, momentum, gamma, beta, residual, relu, mean, invstd, running_mean, running_var, y,
+                          workspace, workspace_bytes, stream, 0, 0, 0);
+}
+
 extern "C" int irx_bn_backward(const float* x, const float* y, const float* dy, int n, int c,
                                const float* mean, const float* invstd, const float* gamma, int relu,
                                float* dx, float* dgamma, float* dbeta, float* dresidual,
@@ -664,6 +1107,29 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   const float* mk_gamma = mk_beta ? gamma : nullptr;
   rc = bn_bf_ok("irx_bn_backward", (x_bf | y_bf | dy_bf | dx_bf | dres_bf) != 0, v4);
   if (rc) return rc;
+  {
+    // one launch for a tensor that stays on-die (k_bn_slice_bwd): both passes of the local-statistics case
+    const bool all_f32 = !(x_bf | y_bf | dy_bf | dx_bf | dres_bf);
+    const bool sl_types = all_f32 || (x_bf && dx_bf && (!dresidual || dres_bf) && (dy_bf == y_bf || mk_beta));
+    if (phases == 3 && relu && dx && gamma && sl_types && v4 && bn_slice_ok(n, c, x_bf) && !(bn_abl() & 12)) {
+      const hipStream_t st = S(stream);
+#define BN_SL_BWD(V_, XB_, YB_)                                                                                               \
+  do {                                                                                                                        \
+    if (mk_beta) k_bn_slice_bwd<V_, XB_, YB_, true, false><<<c / V_, BN_SL_PT, 0, st>>>(x, y, dy, n, c, mean, invstd, gamma, \
+                                                                                        mk_beta, dx, nullptr, dgamma, dbeta); \
+    else if (dresidual) k_bn_slice_bwd<V_, XB_, YB_, false, true><<<c / V_, BN_SL_PT, 0, st>>>(x, y, dy, n, c, mean, invstd,  \
+                                                                                 gamma, nullptr, dx, dresidual, dgamma, dbeta); \
+    else k_bn_slice_bwd<V_, XB_, YB_, false, false><<<c / V_, BN_SL_PT, 0, st>>>(x, y, dy, n, c, mean, invstd, gamma, nullptr, \
+                                                                                 dx, nullptr, dgamma, dbeta);                \
+  } while (0)
+      if (all_f32) BN_SL_BWD(4, 0, 0);
+      else if (dy_bf) BN_SL_BWD(8, 1, 1);
+      else BN_SL_BWD(8, 1, 0);
+#undef BN_SL_BWD
+      IRX_CHECK_LAUNCH("irx_bn_backward(slice)");
+      return IRX_OK;
+    }
+  }
   const bool any_bf = (x_bf | y_bf | dy_bf | dx_bf | dres_bf) != 0;
   const bool v8 = v4 && x_bf && (y_bf || !relu) && dy_bf && dx_bf && (!dresidual || dres_bf) && c % 8 == 0;
   const bool rm = mk_beta != nullptr;            // mask recomputed from x: separate instantiations (see k_bn_partial)
@@ -672,14 +1138,18 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   // group's loads, not by their bytes, and the recomputation lengthens the dependent chain behind them) — so only the apply
   // pass recomputes the mask; the statistics pass keeps reading y.
   static const bool rm_stats = getenv("IRX_BN_REMASK_STATS") && atoi(getenv("IRX_BN_REMASK_STATS")) != 0;   // dev A/B knob
+  BnFin fin;
+  if ((phases & 1) && v4 && (fin.counter = bn_counter(c)) != nullptr) {
+    fin.out0 = dbeta; fin.out1 = dgamma;
+  }
 #define BN_PARTIAL1(V_, TY_, QP_)                                                                                          \
   do {                                                                                                                     \
     if (rm && rm_stats) k_bn_partial<1, V_, TY_, true, true><<<nblk, BN_PT, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_,     \
-                                                                        bn_rows(n, c), part, ty, mk_gamma, mk_beta);       \
+                                                                        bn_rows(n, c), part, ty, mk_gamma, mk_beta, fin);  \
     else if (relu) k_bn_partial<1, V_, TY_, false, true><<<nblk, BN_PT, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_, \
-                                                                      bn_rows(n, c), part, ty, nullptr, nullptr);          \
+                                                                      bn_rows(n, c), part, ty, nullptr, nullptr, fin);     \
     else k_bn_partial<1, V_, TY_, false, false><<<nblk, BN_PT, 0, S(stream)>>>(x, y, dy, n, c, mean, invstd, relu, QP_,      \
-                                                                      bn_rows(n, c), part, ty, nullptr, nullptr);          \
+                                                                      bn_rows(n, c), part, ty, nullptr, nullptr, fin);     \
   } while (0)
   if (!(phases & 1) || (bn_abl() & 4)) {
   } else if (v8)
@@ -690,11 +1160,12 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
     BN_PARTIAL1(4, false, next_pow2(c / 4));
   else {
     IRX_REQUIRE(c <= 256, "irx_bn_backward: c=%d needs c %% 4 == 0 or c <= 256", c);
+    fin = BnFin();
     BN_PARTIAL1(1, false, next_pow2(c));
   }
 #undef BN_PARTIAL1
-  if (phases & 1) {
-    IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
+  if (phases & 1) IRX_CHECK_LAUNCH("irx_bn_backward(partial)");
+  if ((phases & 1) && !(fin.counter && !(bn_abl() & 4))) {      // (otherwise: folded by the last workgroup of the launch above)
     k_bn_finalize<1><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S(stream)>>>(part, nblk, n, c, 0.f, 0.f, dbeta, dgamma,
                                                             nullptr, nullptr);
     IRX_CHECK_LAUNCH("irx_bn_backward(finalize)");
@@ -724,4 +1195,24 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
 #undef BN_BWD_APPLY
   IRX_CHECK_LAUNCH("irx_bn_backward(apply)");
   return IRX_OK;
+}
+
+// ---- typed entry points: the same operators on tensors whose element type is float32 (0) or bf16 (1) per tensor — what the
+// encoder executor's bf16 storage mode calls internally, exported for callers that keep activations in bf16 themselves (and for
+// tools/bn_microbench.py). bf16 tensors need c % 4 == 0 (c % 8 == 0 for the fast paths) and 16-byte aligned pointers. beta
+// (irx_bn_backward_ex, relu, no dresidual): the layer had no shortcut — the ReLU mask is recomputed from x and y is not read.
+extern "C" int irx_bn_forward_ex(const void* x, int n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                                 const void* residual, int relu, float* mean, float* invstd, float* running_mean,
+                                 float* running_var, void* y, void* workspace, size_t workspace_bytes, void* stream, int x_bf,
+                                 int res_bf, int y_bf) {
+  return irx_bn_forward_t((const float*)x, n, c, eps, momentum, gamma, beta, (const float*)residual, relu, mean, invstd,
+                          running_mean, running_var, (float*)y, workspace, workspace_bytes, stream, x_bf, res_bf, y_bf);
+}
+extern "C" int irx_bn_backward_ex(const void* x, const void* y, const void* dy, int n, int c, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, int relu, void* dx, float* dgamma,
+                                  float* dbeta, void* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf,
+                                  int y_bf, int dy_bf, int dx_bf, int dres_bf) {
+  return irx_bn_backward_t((const float*)x, (const float*)y, (const float*)dy, n, c, mean, invstd, gamma, relu, (float*)dx, dgamma,
+                           dbeta, (float*)dresidual, workspace, workspace_bytes, stream, x_bf, y_bf, dy_bf, dx_bf, dres_bf, 3,
+                           nullptr, nullptr, 0.0, nullptr, beta);
 }

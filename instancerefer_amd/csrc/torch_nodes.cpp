@@ -52,19 +52,53 @@ void check(int rc, const char* what) {
   throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + (msg ? msg : ""));
 }
 
+// Gradient-sink handle (optim.FlatAdam.native_sink): slot addresses followed by [record address, generation, address of the
+// process-wide generation counter]. deliver() is true when the node may write the optimizer's slots NOW: the expected number of
+// slots came along, the optimizer that handed them out is still the current one (generation unchanged since the forward) and the
+// producer has not delivered since the last zero_grad() (record[0] == 0). The tensors the addresses point into travel with the
+// node (`keep` in saved_data), so a retired optimizer's buffers stay valid until the graph is gone.
+struct Sink {
+  std::vector<int64_t> slots;
+  int64_t* rec = nullptr;
+  int64_t gen = 0;
+  const int64_t* gen_now = nullptr;
+  explicit Sink(const std::vector<int64_t>& v) {
+    if (v.size() > 3) {
+      slots.assign(v.begin(), v.end() - 3);
+      rec = (int64_t*)v[v.size() - 3];
+      gen = v[v.size() - 2];
+      gen_now = (const int64_t*)v[v.size() - 1];
+    }
+  }
+  bool deliver(size_t expected) const {
+    return slots.size() == expected && rec != nullptr && gen_now != nullptr && *gen_now == gen && rec[0] == 0;
+  }
+  void delivered(void* stream) const { rec[1] = (int64_t)stream; rec[0] = 1; }
+};
+
+// the sink's keep-alive tensors (flat gradient buffer, record tensor) ride in the node's saved_data
+inline void keep_alive(AutogradContext* ctx, const c10::optional<Tensor>& a, const c10::optional<Tensor>& b) {
+  if (a.has_value() && a->defined()) ctx->saved_data["keep_a"] = *a;
+  if (b.has_value() && b->defined()) ctx->saved_data["keep_b"] = *b;
+}
+inline c10::optional<Tensor> opt_at(const std::vector<Tensor>& v, size_t i) {
+  return i < v.size() ? c10::optional<Tensor>(v[i]) : c10::optional<Tensor>();
+}
+
 inline const float* fp(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 inline float* fpm(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 
 // y = W2 . D(relu(N(W1 x + b1))) + b2, irx_mlp2_fwd / irx_mlp2_bwd.  slot_ptrs: addresses of the six gradient slots
-// (w1, b1, gamma, beta, w2, b2) in the optimizer's flat buffer, or empty; flag: host int32 the backward sets to 1 when it
-// delivered there (the optimizer reads it at gather time); a second backward before the flags are cleared, or a backward
+// (w1, b1, gamma, beta, w2, b2) in the optimizer's flat buffer + the Sink trailer, or empty (see Sink above); a second backward
+// before the records are cleared, a backward after the optimizer was replaced, or a backward
 // without slots, returns ordinary gradient tensors.
 struct MLP2Node : public torch::autograd::Function<MLP2Node> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w1, const Tensor& b1,
                         const c10::optional<Tensor>& gamma_o, const c10::optional<Tensor>& beta_o, const Tensor& w2,
                         const Tensor& b2, int64_t norm, double eps,
                         const c10::optional<Tensor>& rmean, const c10::optional<Tensor>& rvar, double momentum, double drop_p,
-                        int64_t seed, int64_t stream, std::vector<int64_t> slot_ptrs, int64_t flag) {
+                        int64_t seed, int64_t stream, std::vector<int64_t> slot_ptrs, const c10::optional<Tensor>& keep_a,
+                        const c10::optional<Tensor>& keep_b) {
     const Tensor x = x_in.contiguous().to(torch::kFloat32);
     const Tensor gamma = gamma_o.has_value() ? *gamma_o : Tensor(), beta = beta_o.has_value() ? *beta_o : Tensor();
     const int rows = (int)x.size(0), din = (int)x.size(1), dh = (int)w1.size(0), dout = (int)w2.size(0);
@@ -78,7 +112,7 @@ struct MLP2Node : public torch::autograd::Function<MLP2Node> {
     ctx->saved_data["norm"] = norm;
     ctx->saved_data["drop_p"] = drop_p;
     ctx->saved_data["stream"] = stream;          // (the engine replays the node on its forward stream)
-    ctx->saved_data["flag"] = flag;
+    keep_alive(ctx, keep_a, keep_b);
     ctx->saved_data["slots"] = slot_ptrs;
     return y;
   }
@@ -90,8 +124,8 @@ struct MLP2Node : public torch::autograd::Function<MLP2Node> {
     const int64_t norm = ctx->saved_data["norm"].toInt();
     const double drop_p = ctx->saved_data["drop_p"].toDouble();
     void* stream = (void*)ctx->saved_data["stream"].toInt();
-    int32_t* flag = (int32_t*)ctx->saved_data["flag"].toInt();
-    const auto slots = ctx->saved_data["slots"].toIntVector();
+    const Sink sink(ctx->saved_data["slots"].toIntVector());
+    const auto& slots = sink.slots;
     Tensor dy = grad_out[0].contiguous().to(torch::kFloat32);
     if (norm & 8) dy = at::threshold_backward(dy, sv[5], 0);          // the output ReLU
     const bool has_norm = (norm & 7) != 4;                            // 4: no normalisation layer, no gamma / beta
@@ -100,9 +134,9 @@ struct MLP2Node : public torch::autograd::Function<MLP2Node> {
     float* base = scratch.data_ptr<float>();
     float* dx_ptr = want_dx ? base + (size_t)rows * dh : nullptr;
     // slots: (w1, b1, gamma, beta, w2, b2), or (w1, b1, w2, b2) without a normalisation layer
-    const bool deliver = slots.size() == (has_norm ? 6u : 4u) && flag != nullptr && *flag == 0;
+    const bool deliver = sink.deliver(has_norm ? 6u : 4u);
     float* gp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    variable_list out(17);
+    variable_list out(18);
     if (deliver) {
       int q = 0;
       for (int i = 0; i < 6; ++i)
@@ -125,7 +159,7 @@ struct MLP2Node : public torch::autograd::Function<MLP2Node> {
                          drop_p > 0 ? (float)(1.0 / (1.0 - drop_p)) : 1.f, base, dx_ptr, gp[0], gp[1], gp[2], gp[3], gp[4], gp[5],
                          stream),
           "irx_mlp2_bwd");
-    if (deliver) *flag = 1;
+    if (deliver) sink.delivered(stream);
     if (want_dx) out[0] = scratch.narrow(0, (int64_t)rows * dh, (int64_t)rows * din).view({rows, din});
     return out;
   }
@@ -133,11 +167,11 @@ struct MLP2Node : public torch::autograd::Function<MLP2Node> {
 
 Tensor mlp2(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& gamma, const Tensor& beta, const Tensor& w2,
             const Tensor& b2, int64_t norm, double eps, const c10::optional<Tensor>& rmean, const c10::optional<Tensor>& rvar,
-            double momentum, double drop_p, int64_t seed, int64_t stream, std::vector<int64_t> slot_ptrs, int64_t flag) {
+            double momentum, double drop_p, int64_t seed, int64_t stream, std::vector<int64_t> slot_ptrs, std::vector<Tensor> keep) {
   TORCH_CHECK(g_api.mlp2_fwd && g_api.mlp2_bwd && g_api.mlp2_saved_floats, "irx nodes: bind() has not been called");
   return MLP2Node::apply(x, w1, b1, c10::optional<Tensor>(gamma), c10::optional<Tensor>(beta), w2, b2, norm, eps, rmean, rvar, momentum,
                          drop_p, seed, stream,
-                         std::move(slot_ptrs), flag);
+                         std::move(slot_ptrs), opt_at(keep, 0), opt_at(keep, 1));
 }
 
 // One GRU layer, both directions (reference models/lang_module.py:24-32,58-60: nn.GRU over packed sequences; dense.gru_packed).
@@ -151,7 +185,7 @@ struct GRULayerNode : public torch::autograd::Function<GRULayerNode> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& len32, const Tensor& p0, const Tensor& p1,
                         const Tensor& p2, const Tensor& p3, const c10::optional<Tensor>& p4, const c10::optional<Tensor>& p5,
                         const c10::optional<Tensor>& p6, const c10::optional<Tensor>& p7, int64_t stream,
-                        std::vector<int64_t> slot_ptrs, int64_t flag) {
+                        std::vector<int64_t> slot_ptrs, const c10::optional<Tensor>& keep_a, const c10::optional<Tensor>& keep_b) {
     // (a std::vector<Tensor> argument would be ONE input of the node: the parameters are separate arguments, the second
     //  direction's are optional)
     std::vector<Tensor> params = {p0, p1, p2, p3};
@@ -178,7 +212,7 @@ struct GRULayerNode : public torch::autograd::Function<GRULayerNode> {
     ctx->save_for_backward({x2, len32, w_ih, w_hh, out, gates});
     ctx->saved_data["dims"] = std::vector<int64_t>{B, T, I, ndir, H};
     ctx->saved_data["stream"] = stream;
-    ctx->saved_data["flag"] = flag;
+    keep_alive(ctx, keep_a, keep_b);
     ctx->saved_data["slots"] = slot_ptrs;
     return out;
   }
@@ -189,8 +223,8 @@ struct GRULayerNode : public torch::autograd::Function<GRULayerNode> {
     const auto dims = ctx->saved_data["dims"].toIntVector();
     const int B = (int)dims[0], T = (int)dims[1], I = (int)dims[2], ndir = (int)dims[3], H = (int)dims[4];
     void* stream = (void*)ctx->saved_data["stream"].toInt();
-    int32_t* flag = (int32_t*)ctx->saved_data["flag"].toInt();
-    const auto slots = ctx->saved_data["slots"].toIntVector();
+    const Sink sink(ctx->saved_data["slots"].toIntVector());
+    const auto& slots = sink.slots;
     const Tensor dout = grad_out[0].contiguous().to(torch::kFloat32);
     const auto opt = x2.options();
     Tensor dgi = torch::empty({B, T, ndir, (int64_t)3 * H}, opt), dgh = torch::empty({B, T, ndir, (int64_t)3 * H}, opt);
@@ -199,12 +233,12 @@ struct GRULayerNode : public torch::autograd::Function<GRULayerNode> {
           "irx_gru_backward");
     const int64_t BT = (int64_t)B * T, G = 3 * (int64_t)H;
     const Tensor dgi2 = dgi.view({BT, ndir * G});
-    variable_list res(2 + 8 + 3);
-    // layout of the returned list = forward's arguments: x, len32, 8 parameters, stream, slot_ptrs, flag
+    variable_list res(2 + 8 + 4);      // (stream, slot_ptrs, keep_a, keep_b: no gradients)
+    // layout of the returned list = forward's arguments: x, len32, 8 parameters, stream, slot_ptrs, keep_a, keep_b
     if (ctx->needs_input_grad(0)) res[0] = dgi2.mm(w_ih).view({B, T, I});
     // the four weight gradients of both directions in one launch (irx_gru_wgrad reads h_{t-1} from `out` with the direction's
     // shift): straight into the optimizer's slots, or into fresh tensors handed to autograd
-    const bool deliver = (int)slots.size() == 4 * ndir && flag != nullptr && *flag == 0;
+    const bool deliver = sink.deliver((size_t)4 * ndir);
     float* gp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per direction: w_ih, w_hh, b_ih, b_hh
     for (int d = 0; d < ndir; ++d) {
       if (deliver) {
@@ -220,29 +254,29 @@ struct GRULayerNode : public torch::autograd::Function<GRULayerNode> {
     check(g_api.gru_wgrad(fp(dgi), fp(dgh), fp(x2), fp(out), B, T, I, ndir, H, gp[0], gp[4], gp[1], gp[5], gp[2], gp[6], gp[3], gp[7],
                           stream),
           "irx_gru_wgrad");
-    if (deliver) *flag = 1;
+    if (deliver) sink.delivered(stream);
     return res;
   }
 };
 
 Tensor gru_layer(const Tensor& x, const Tensor& len32, std::vector<Tensor> params, int64_t stream, std::vector<int64_t> slot_ptrs,
-                 int64_t flag) {
+                 std::vector<Tensor> keep) {
   TORCH_CHECK(g_api.gru_fwd && g_api.gru_bwd, "irx nodes: bind() has not been called");
   TORCH_CHECK(params.size() == 4 || params.size() == 8, "gru_layer: 4 parameters per direction, 1 or 2 directions");
   c10::optional<Tensor> q[4];
   if (params.size() == 8)
     for (int i = 0; i < 4; ++i) q[i] = params[4 + i];
   return GRULayerNode::apply(x, len32, params[0], params[1], params[2], params[3], q[0], q[1], q[2], q[3], stream,
-                             std::move(slot_ptrs), flag);
+                             std::move(slot_ptrs), opt_at(keep, 0), opt_at(keep, 1));
 }
 
 // nn.Sequential(Linear, ReLU, Dropout, Linear, ReLU) (reference models/lang_module.py:33-37, the word projection) on the same
 // operator: norm 4 (none) + 8 (ReLU on the output); slot_ptrs: (w1, b1, w2, b2).
 Tensor mlp_relu2(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, double drop_p, int64_t seed,
-                 int64_t stream, std::vector<int64_t> slot_ptrs, int64_t flag) {
+                 int64_t stream, std::vector<int64_t> slot_ptrs, std::vector<Tensor> keep) {
   TORCH_CHECK(g_api.mlp2_fwd && g_api.mlp2_bwd && g_api.mlp2_saved_floats, "irx nodes: bind() has not been called");
   return MLP2Node::apply(x, w1, b1, c10::optional<Tensor>(), c10::optional<Tensor>(), w2, b2, (int64_t)(4 | 8), 0.0, c10::optional<Tensor>(),
-                         c10::optional<Tensor>(), 0.0, drop_p, seed, stream, std::move(slot_ptrs), flag);
+                         c10::optional<Tensor>(), 0.0, drop_p, seed, stream, std::move(slot_ptrs), opt_at(keep, 0), opt_at(keep, 1));
 }
 
 // addresses of the C-ABI entry points, taken from the library instance _lib.py loaded

@@ -76,14 +76,14 @@ def gru_packed(gru: torch.nn.GRU, x, lengths, t_max):
             # C++ autograd node (csrc/torch_nodes.cpp): nn.GRU's own parameter tensors go in (no cat / stack nodes), the weight
             # gradients come back through the optimizer's gradient sink when there is one
             params = [getattr(gru, "%s_l%d%s" % (n, layer, s_)) for s_ in sfx for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
-            slots, flag = (), 0
+            slots, keep = (), ()
             if torch.is_grad_enabled():
                 sink = getattr(params[0], "_irx_sink", None)
                 if sink is not None:
                     ent = sink[0].native_sink(("gru", id(params[0])), params)
                     if ent is not None:
-                        slots, flag = ent
-            h = nodes.gru_layer(h, len32, params, _lib.stream_ptr(), slots, flag)
+                        slots, keep = ent
+            h = nodes.gru_layer(h, len32, params, _lib.stream_ptr(), slots, keep)
             continue
         w_ih = torch.cat([getattr(gru, "weight_ih_l%d%s" % (layer, s)) for s in sfx], 0)
         b_ih = torch.cat([getattr(gru, "bias_ih_l%d%s" % (layer, s)) for s in sfx], 0)
@@ -271,15 +271,15 @@ def mlp_relu2(seq, x):
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     seed = _dropout_seed(x.device) if drop_p > 0 else 0
-    slots, flag = (), 0
+    slots, keep = (), ()
     if torch.is_grad_enabled():
         sink = getattr(lin1.weight, "_irx_sink", None)
         if sink is not None:
             ent = sink[0].native_sink(("mlp_relu2", id(lin1.weight)), (lin1.weight, lin1.bias, lin2.weight, lin2.bias))
             if ent is not None:
-                slots, flag = ent
+                slots, keep = ent
     y = backend.mlp_relu2(x2, lin1.weight, lin1.bias, lin2.weight, lin2.bias, drop_p, seed if seed < (1 << 63) else seed - (1 << 64),
-                          _lib.stream_ptr(), slots, flag)
+                          _lib.stream_ptr(), slots, keep)
     return y.view(*lead, lin2.out_features)
 
 
@@ -326,15 +326,15 @@ def mlp2(seq, x):
     seed = _dropout_seed(x.device) if drop_p > 0 else 0
     if backend != "py":
         # C++ node: the optimizer's slot addresses (gradient sink) are looked up once per MLP and travel as integers
-        slots, flag = (), 0
+        slots, keep = (), ()
         if torch.is_grad_enabled():
             sink = getattr(lin1.weight, "_irx_sink", None)
             if sink is not None:
                 ent = sink[0].native_sink(("mlp2", id(lin1.weight)),
                                           (lin1.weight, lin1.bias, nrm.weight, nrm.bias, lin2.weight, lin2.bias))
                 if ent is not None:
-                    slots, flag = ent
+                    slots, keep = ent
         return backend.mlp2(x, lin1.weight, lin1.bias, nrm.weight, nrm.bias, lin2.weight, lin2.bias, norm, nrm.eps, rmean, rvar,
-                            momentum, drop_p, seed if seed < (1 << 63) else seed - (1 << 64), _lib.stream_ptr(), slots, flag)
+                            momentum, drop_p, seed if seed < (1 << 63) else seed - (1 << 64), _lib.stream_ptr(), slots, keep)
     return MLP2Fn.apply(x, lin1.weight, lin1.bias, nrm.weight, nrm.bias, lin2.weight, lin2.bias, norm, nrm.eps, rmean, rvar,
                         momentum, drop_p, seed)

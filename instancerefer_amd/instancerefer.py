@@ -21,7 +21,9 @@ _PREP_PLANS = _os.environ.get('IRX_PREP_PLANS', '0') == '1'
 # 5.83-5.88 -> 5.48-5.61 ms per step on one box, 5.57-5.64 -> 5.51-5.54 on a faster one; neutral in fp32 and at B = 32
 # (GPU-paced). Training mode on a HIP device only; IRX_LANG_THREAD=0 issues it inline.
 _LANG_THREAD = _os.environ.get('IRX_LANG_THREAD', '1') == '1'
+_STREAMS = _os.environ.get('IRX_STREAMS', '1') == '1'            # three-stream training forward (_forward_streams); 0: round-4 layout
 _REL_THREAD = _os.environ.get('IRX_REL_THREAD', '0') == '1'      # dev: the relation head on that thread too (behind the language module)
+MARK = None        # dev: bench.py's timeline mode installs a callable(name) here (phase marks inside forward)
 _ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
 
 
@@ -31,6 +33,52 @@ def _import(name):
         return importlib.import_module(_PKG + '.' + name)
     except ModuleNotFoundError:
         return importlib.import_module(name)
+
+
+class _LangWorker:
+    """One daemon thread running (modules, data_dict) jobs posted by InstanceRefer._lang_async; see there."""
+
+    def __init__(self):
+        import queue
+        import threading
+        self.q_in, self.q_out, self.seq = queue.SimpleQueue(), queue.SimpleQueue(), 0
+        self.thread = threading.Thread(target=_LangWorker._run, args=(self.q_in, self.q_out), name="irx-lang", daemon=True)
+        self.thread.start()
+
+    @staticmethod
+    def _run(q_in, q_out):
+        while True:
+            job = q_in.get()
+            if job is None:
+                return
+            seq, dev, stream, grad, mods, dd = job
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(stream), torch.set_grad_enabled(grad):     # (both are thread-local state)
+                    for i, m in enumerate(mods):
+                        if m is not None:
+                            dd = m(dd)
+                        if i == 0 and dd.get('_lang_event') is not None:
+                            dd['_lang_event'].record(stream)             # the language features are complete on `stream`
+                q_out.put((seq, dd))
+            except BaseException as e:              # surfaced by the training thread at join time
+                q_out.put((seq, e))
+            del job, mods, dd                       # nothing of the model stays referenced between jobs
+
+    def post(self, mods, dd, stream=None):
+        self.seq += 1
+        self.q_in.put((self.seq, torch.cuda.current_device(), stream if stream is not None else torch.cuda.current_stream(),
+                       torch.is_grad_enabled(), mods, dd))
+        return self.seq
+
+    def take(self, seq):
+        while True:
+            got, out = self.q_out.get()
+            if got == seq:
+                return out                          # (older results: a join that was interrupted — dropped)
+
+    def stop(self):
+        self.q_in.put(None)
 
 
 class InstanceRefer(nn.Module):
@@ -128,40 +176,26 @@ class InstanceRefer(nn.Module):
             for t in (lab['buf'], lab['fbuf']):
                 t.record_stream(stream)
 
-    def _lang_async(self, data_dict):
+    def _lang_async(self, data_dict, stream=None, rel=None):
         """The language module on a helper thread, same stream (see _LANG_THREAD above) -> join() returning its data_dict keys.
-        Grad mode and the current stream are thread-local: both are handed over with the job."""
-        import queue
-        import threading
+        Grad mode and the current stream are thread-local: both are handed over with the job. The worker holds no reference to
+        this model (jobs carry the modules they run; a finalizer stops the thread when the model is collected), every job and
+        result carries a sequence number (a result left behind by an interrupted join is discarded, never consumed by the next
+        forward), and the worker's queues are not part of the module's pickled / deep-copied state (__getstate__)."""
         w = self.__dict__.get('_lang_worker')
         if w is None:
-            q_in, q_out = queue.SimpleQueue(), queue.SimpleQueue()
-
-            def run():
-                while True:
-                    job = q_in.get()
-                    if job is None:
-                        return
-                    dev, stream, grad, rel, dd = job
-                    try:
-                        torch.cuda.set_device(dev)
-                        with torch.cuda.stream(stream), torch.set_grad_enabled(grad):     # (both are thread-local state)
-                            dd = self.lang(dd)
-                            if rel:                      # the relation head needs the language features and prepared inputs only
-                                dd = self.relation(dd)
-                            q_out.put(dd)
-                    except BaseException as e:          # surfaced by the training thread at join time
-                        q_out.put(e)
-            th = threading.Thread(target=run, name="irx-lang", daemon=True)
-            th.start()
-            w = self.__dict__['_lang_worker'] = (q_in, q_out)
-        rel = bool(_REL_THREAD and self.args.relation_module and '_rel_prepared' in data_dict)
+            w = self.__dict__['_lang_worker'] = _LangWorker()
+            import weakref
+            weakref.finalize(self, w.stop)
+        if rel is None:
+            rel = _REL_THREAD
+        rel = bool(rel and self.args.relation_module and '_rel_prepared' in data_dict)
         orig = dict(data_dict)                          # what was there when the job was posted
         sub = dict(orig)                                # the worker adds / replaces keys in its own shallow copy
-        w[0].put((torch.cuda.current_device(), torch.cuda.current_stream(), torch.is_grad_enabled(), rel, sub))
+        seq = w.post((self.lang, self.relation if rel else None), sub, stream)
 
         def join():
-            out = w[1].get()
+            out = w.take(seq)
             if isinstance(out, BaseException):
                 raise out
             new = {k: v for k, v in out.items() if k not in orig or orig[k] is not v}   # what the worker produced
@@ -170,8 +204,104 @@ class InstanceRefer(nn.Module):
             return new, rel
         return join
 
+    def __getstate__(self):
+        """Module state without the per-process runtime objects (helper-thread queues, HIP streams): copy.deepcopy(model) and
+        torch.save(model) work after a training forward; the copy creates its own lazily."""
+        state = dict(self.__dict__)
+        state.pop('_lang_worker', None)
+        state.pop('_enc_streams', None)
+        return state
+
+    def _streams_ok(self, data_dict):
+        """The three-stream forward needs the training configuration the bench / Solver run: every module present, candidates
+        prepared from the GT classes (the encoders do not wait for the language module), a HIP device."""
+        a = self.args
+        return (_STREAMS and self.training and torch.is_grad_enabled() and a.attribute_module and a.relation_module
+                and a.scene_module and data_dict['lang_feat'].is_cuda and 'lidar' in data_dict
+                and getattr(a, 'overlap_streams', True) and hasattr(self.scene, 'head')
+                and data_dict.get('_attr_prepared') is not None and data_dict['_attr_prepared'][0] is not None
+                and data_dict.get('_rel_prepared') is not None and data_dict['_rel_prepared'][0] is not None)
+
+    def _forward_streams(self, data_dict):
+        """Training forward on three HIP streams (round 5). The step at B = 16 is a handful of long kernels (the two encoders)
+        and ~400 short ones in dependent chains (heads, language module, loss): on one stream the chains add up — 0.7 ms of
+        heads behind the encoders forward, 0.6 ms before the encoders' backward can start, 0.3 ms of GRU backward behind it
+        (profiles/r05_timeline_*.txt). Here:
+          side  : scene encoder -> scene head up to the scene vector / area classifier (SceneModule.head)
+          lang  : language module -> relation head (neither needs an encoder), issued by the helper thread
+          main  : candidate encoder -> attribute head -> scene scores (needs obj_feats + the scene vector) -> [loss]
+        Autograd replays every node on its forward stream and orders gradients that cross streams, so the backward overlaps the
+        same way: the scene encoder's backward starts behind the short scene head instead of behind every head, the GRU backward
+        runs beside the encoders'. Same kernels, same arithmetic: bit-identical to the one-stream forward (tested)."""
+        from .sparse.encoder_fn import lane_of, lane_wait
+        main = torch.cuda.current_stream()
+        dev = data_dict['lang_feat'].device
+        side = self._encoder_stream(dev)
+        lstream = self._aux_stream(dev)
+        side.wait_stream(main)                               # inputs and the optimizer's parameter update are complete
+        lstream.wait_stream(main)
+        self.hand_over(data_dict, lstream)                   # prepared tensors (relation node features, index lists) used on `lang`
+        data_dict['_lang_event'] = torch.cuda.Event()
+        if MARK: MARK("fwd: start")
+        lang_join = self._lang_async(data_dict, stream=lstream, rel=True) if _LANG_THREAD else None
+        try:
+            lidar = data_dict['lidar']
+            lidar.record_stream(side)
+            with torch.cuda.stream(side):
+                data_dict = self.scene.encode(data_dict)
+            if MARK: MARK("fwd: scene encoder issued")
+            data_dict = self.attribute.encode(data_dict)
+        except BaseException:
+            if lang_join is not None:                        # never leave a result behind for the next forward to pick up
+                try:
+                    lang_join()
+                except BaseException:
+                    pass
+            raise
+        if MARK: MARK("fwd: encoders issued")
+        if lang_join is not None:
+            new, _ = lang_join()
+            data_dict.update(new)
+        else:
+            with torch.cuda.stream(lstream):
+                data_dict = self.lang(data_dict)
+                data_dict['_lang_event'].record(lstream)
+                data_dict = self.relation(data_dict)
+        ev = data_dict.pop('_lang_event')
+        if MARK: MARK("fwd: lang joined")
+        pooled = data_dict['lang_attr_feats']                # the four language vectors are views of one tensor
+        pooled.record_stream(main)
+        pooled.record_stream(side)
+        # scene head on the encoder's stream (its launches were issued by a library thread: wait for that first)
+        lane_wait(lane_of(self.scene.net))
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            data_dict = self.scene.head(data_dict)
+        if MARK: MARK("fwd: scene head issued")
+        main.wait_event(ev)
+        data_dict = self.attribute(data_dict)
+        if MARK: MARK("fwd: attribute head issued")
+        main.wait_stream(side)
+        for k in ('_scene_feats', 'seg_scores', 'vis_atten'):
+            data_dict[k].record_stream(main)
+        data_dict = self.scene(data_dict)                    # scene scores: needs obj_feats and the scene vector
+        main.wait_stream(lstream)
+        for k in ('relation_scores', 'lang_scores', 'lang_feat', 'atten_attr'):
+            if isinstance(data_dict.get(k), torch.Tensor):
+                data_dict[k].record_stream(main)
+        return data_dict
+
+    def _aux_stream(self, device):
+        cache = self.__dict__.setdefault('_enc_streams', {})
+        st = cache.get((str(device), 'lang'))
+        if st is None:
+            st = cache[(str(device), 'lang')] = torch.cuda.Stream(device=device)
+        return st
+
     def forward(self, data_dict):
         data_dict = self.prepare(data_dict)
+        if self._streams_ok(data_dict):
+            return self._forward_streams(data_dict)
         side = None
         lang_join = None
         if _LANG_THREAD and self.training and data_dict['lang_feat'].is_cuda:
@@ -186,18 +316,24 @@ class InstanceRefer(nn.Module):
                     pass
             raise
         rel_done = False
+        if MARK: MARK("fwd: encoders issued")
         if lang_join is not None:
             new, rel_done = lang_join()
             data_dict.update(new)
         else:
             data_dict = self.lang(data_dict)
+        if MARK: MARK("fwd: lang joined")
         if self.args.attribute_module:
             data_dict = self.attribute(data_dict)
+        if MARK: MARK("fwd: attribute head issued")
         if self.args.relation_module and not rel_done:
             data_dict = self.relation(data_dict)
+        if MARK: MARK("fwd: relation head issued")
         if side is not None:
             from .sparse.encoder_fn import lane_of, lane_wait
+            if MARK: MARK("fwd: before scene lane wait")
             lane_wait(lane_of(self.scene.net))               # every launch of the scene encoder is on `side` now
+            if MARK: MARK("fwd: scene lane idle")
             main = torch.cuda.current_stream()
             main.wait_stream(side)
             data_dict['_scene_encoded'].record_stream(main)
@@ -214,6 +350,7 @@ class InstanceRefer(nn.Module):
             # the deep levels of both sparse encoders are far too small to fill 256 CUs on their own, and autograd
             # replays each node's backward on its forward stream, so the two backward passes overlap as well.
             lidar = data_dict['lidar']
+            if MARK: MARK("fwd: start")
             if lidar.F.is_cuda and getattr(self.args, 'overlap_streams', True):
                 main = torch.cuda.current_stream()
                 side = self._encoder_stream(lidar.F.device)
@@ -223,6 +360,7 @@ class InstanceRefer(nn.Module):
                     data_dict = self.scene.encode(data_dict)
             else:
                 data_dict = self.scene.encode(data_dict)
+        if MARK: MARK("fwd: scene encoder issued")
         if self.args.attribute_module and hasattr(self.attribute, 'encode') and self._attr_early():
             # candidates already chosen (prepare()): their encoder does not need the language features either, and its
             # launches are issued by a library thread while this one goes on with the language module (see _attr_early)

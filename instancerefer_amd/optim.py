@@ -52,6 +52,14 @@ def broadcast_buffers(module, src=0):
                 off += b.numel()
 
 
+# Generation of the native gradient sink: one process-wide counter that lives as long as the module (C++ nodes hold its
+# ADDRESS). Every FlatAdam construction bumps it; a node captures (generation, address) at forward time and delivers into the
+# optimizer's slots at backward time only if the counter still has that value — a node whose optimizer was replaced between its
+# forward and its backward returns ordinary gradient tensors instead of writing into a retired buffer.
+_SINK_GEN = np.zeros(1, dtype=np.int64)
+_SINK_LOCK = __import__("threading").Lock()
+
+
 class FlatAdam:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=None, module=None,
                  broadcast=True, overlap=True):
@@ -93,8 +101,14 @@ class FlatAdam:
             p._irx_sink = (self, slot)
         # ... and the C++ autograd nodes (csrc/torch_nodes.cpp): they get the slot ADDRESSES at forward time and raise one host
         # flag per producer when their backward wrote them (no interpreter on that path); gather_grads() folds the flags in
-        self._native_flags = np.zeros(256, dtype=np.int32)
-        self._native = {}               # producer key -> (flag index, parameter indices, slot addresses, flag address)
+        # one record per producer: [delivered flag, HIP stream the backward ran on]; a torch tensor so that the nodes can keep it
+        # (and flat_g) alive for as long as their graph exists
+        self._native_rec_t = torch.zeros((256, 2), dtype=torch.int64)
+        self._native_rec = self._native_rec_t.numpy()
+        with _SINK_LOCK:
+            _SINK_GEN[0] += 1
+            self._gen = int(_SINK_GEN[0])
+        self._native = {}               # producer key -> (record index, parameter indices, (slot addresses + record), keep-alive)
         self._direct = set()            # parameter indices whose slot already holds this step's gradient
         self._direct_groups = set()     # producer keys that delivered since the last zero_grad()
         self._gather_cache = {}
@@ -149,7 +163,7 @@ class FlatAdam:
         self._direct_groups.clear()
         self._reduced.clear()
         if self._native:
-            self._native_flags[:len(self._native)] = 0
+            self._native_rec[:len(self._native)] = 0
 
     # ---- gradient-sink protocol (see __init__) ----
     def sink_slots(self, key, params):
@@ -163,26 +177,35 @@ class FlatAdam:
             return None
 
     def native_sink(self, key, params):
-        """-> (slot addresses, address of the producer's delivered flag) for a C++ node that computes all gradients of
-        `params` on the stream gather_grads() runs on, or None when a parameter is not ours. The node writes the slots and
-        sets the flag in its backward if the flag is still 0 (a second backward before zero_grad() returns ordinary
-        gradients, which gather_grads() adds)."""
+        """-> (sink vector, keep-alive tensors) for a C++ node (csrc/torch_nodes.cpp) that computes all gradients of `params`,
+        or None when a parameter is not ours. Sink vector = the slot addresses followed by [record address, generation, address
+        of the generation counter]; the node writes the slots in its backward, sets record[0] = 1 and record[1] = the stream it
+        ran on — if the generation still matches (this optimizer has not been replaced since the forward) and the record is
+        still 0 (a second backward before zero_grad() returns ordinary gradients, which gather_grads() adds). The keep-alive
+        list (flat_g, the record tensor) travels with the node, so its addresses stay valid whatever happens to this object.
+        gather_grads() makes its stream wait for a delivering stream that is not its own. Thread-safe (the language module's
+        helper thread calls it)."""
         ent = self._native.get(key)
         if ent is None:
-            try:
-                idx = [self._index[id(p)] for p in params]
-            except KeyError:
-                return None
-            j = len(self._native)
-            if j >= self._native_flags.shape[0]:
-                return None
-            ent = (j, idx, [self._slots[i].data_ptr() for i in idx], self._native_flags.ctypes.data + 4 * j)
-            self._native[key] = ent
+            with _SINK_LOCK:
+                ent = self._native.get(key)
+                if ent is None:
+                    try:
+                        idx = [self._index[id(p)] for p in params]
+                    except KeyError:
+                        return None
+                    j = len(self._native)
+                    if j >= self._native_rec.shape[0]:
+                        return None
+                    vec = [self._slots[i].data_ptr() for i in idx] + [self._native_rec.ctypes.data + 16 * j, self._gen,
+                                                                      _SINK_GEN.ctypes.data]
+                    ent = (j, idx, vec, [self.flat_g, self._native_rec_t])
+                    self._native[key] = ent
         return ent[2], ent[3]
 
     def native_delivered(self):
         """-> (producers, parameters) whose C++ nodes have delivered since the last zero_grad()"""
-        done = [ent for ent in self._native.values() if self._native_flags[ent[0]]]
+        done = [ent for ent in self._native.values() if self._native_rec[ent[0], 0]]
         return len(done), sum(len(ent[1]) for ent in done)
 
     def sink_delivered_inline(self, key, params):
@@ -255,11 +278,21 @@ class FlatAdam:
                     cur.wait_stream(stream)
             self._pending.clear()
         if self._native:
-            flags = self._native_flags
+            rec = self._native_rec
+            cur_ptr = None
             for k, (j, idx, _, _) in self._native.items():
-                if flags[j] and k not in self._direct_groups:
+                if rec[j, 0] and k not in self._direct_groups:
                     self._direct_groups.add(k)
                     self._direct.update(idx)
+                    if self.device.type == "cuda":
+                        # the node ran on the stream autograd replayed it on; backward() has returned, so every launch is enqueued
+                        # there: if that is not the stream the gather / optimizer run on, order them behind it
+                        if cur_ptr is None:
+                            cur = torch.cuda.current_stream(self.device)
+                            cur_ptr = int(cur.cuda_stream)
+                        sp = int(rec[j, 1])
+                        if sp != cur_ptr:
+                            cur.wait_stream(torch.cuda.ExternalStream(sp, device=self.device))
         key = frozenset(self._direct_groups)
         todo = self._gather_cache.get(key)
         if todo is None:

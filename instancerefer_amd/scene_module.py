@@ -16,6 +16,10 @@ from .sparse.encoder_fn import lane_of, lane_wait
 from .sparse import nn as spnn
 
 
+import os as _os
+_DEFER = _os.environ.get('IRX_SCENE_DEFER', '1') != '0'     # dev A/B switch (bit-identical results)
+
+
 class SceneModule(nn.Module):
     def __init__(self, input_feature_dim, args, v_dim=128, h_dim=128, l_dim=256, dropout_rate=0.15):
         super().__init__()
@@ -48,18 +52,23 @@ class SceneModule(nn.Module):
         feats = data_dict['lidar']
         if feats._batch_size is None:
             feats._batch_size = data_dict['point_min'].shape[0]
-        data_dict['_scene_encoded'] = self.net(feats)
+        # deferred node: issued now, attached at the head of forward() so that the backward replays it right behind this module's
+        # head instead of last (sparse/encoder_fn.py: Launched)
+        data_dict['_scene_encoded'] = self.net(feats, defer=_DEFER)
         return data_dict
 
-    def forward(self, data_dict):
+    def head(self, data_dict):
+        """Everything of forward() that does not need the candidates' features: encoder output -> BEV -> BatchNorm / ReLU ->
+        2 x Conv2d -> language attention -> scene vector + area classifier (reference scene_module.py:61-96). InstanceRefer's
+        multi-stream forward issues it on the scene encoder's own stream, right behind the encoder and beside the candidate
+        encoder; forward() runs it when nobody has."""
         feats = data_dict['lidar']
         batch_size = data_dict['point_min'].shape[0]
-        pred_obb_batch = data_dict['pred_obb_batch']
-        obj_feats_flatten = data_dict['obj_feats']
         lang_feats = data_dict['lang_scene_feats']
-
         if '_scene_encoded' in data_dict:
             feats = data_dict.pop('_scene_encoded')
+            if hasattr(feats, 'attach'):
+                feats = feats.attach()
         else:
             if feats._batch_size is None:
                 feats._batch_size = batch_size   # known from the collate; avoids the reference's .item() sync
@@ -83,7 +92,16 @@ class SceneModule(nn.Module):
 
         scene_feats = torch.sum(feats * atten.unsqueeze(2), dim=1)
         data_dict['seg_scores'] = mlp2(self.cls, scene_feats)
+        data_dict['_scene_feats'] = scene_feats
+        return data_dict
 
+    def forward(self, data_dict):
+        if '_scene_feats' not in data_dict:
+            data_dict = self.head(data_dict)
+        scene_feats = data_dict.pop('_scene_feats')
+        batch_size = data_dict['point_min'].shape[0]
+        pred_obb_batch = data_dict['pred_obb_batch']
+        obj_feats_flatten = data_dict['obj_feats']
         cand_scene = [i for i in range(batch_size) for _ in range(len(pred_obb_batch[i]))
                       if len(pred_obb_batch[i]) >= 2]
         if len(cand_scene) == 0:

@@ -294,72 +294,98 @@ def prebuild(encoder, level0):
     _level_desc(encoder, layers, params, storage_bf16(False))
 
 
+class Launched:
+    """An encoder forward pass that has been ISSUED (kernels enqueued or handed to a lane) but whose autograd node does not exist
+    yet: launch() -> Launched, EncoderFn.apply(feats, encoder, launched, *params) creates the node later without launching
+    anything. Why: the autograd engine runs ready nodes in the reverse order of their CREATION. The scene encoder must be issued
+    first in the forward (it is the long pole) — as an ordinary node it would then be the LAST one the backward reaches, after
+    every head and the candidate encoder (measured, round 5: its backward started 1.0 ms after the candidate encoder's, the side
+    stream idle meanwhile). Created at the head of SceneModule.forward instead, it is replayed right behind the scene head."""
+    __slots__ = ("layers", "desc", "fdesc", "extra", "store", "prof", "lane", "sync", "sink", "saved", "out", "need_dx0")
+
+
+def launch(feats, encoder, layers, params, need_dx0=False):
+    """Issue the forward pass (one irx_encoder_forward call / lane submission over a descriptor table) -> Launched."""
+    lib = _lib.load()
+    dev = feats.device
+    x0 = feats.detach().contiguous().float()
+    nl = len(layers)
+    store = storage_bf16(need_dx0)
+    pre, fdesc, counters, cout, poffs, ptotal, n_out, cb, start, total, nbytes = _level_desc(encoder, layers, params, store)
+    arena = torch.empty(total, dtype=torch.uint8, device=dev)
+    stats = torch.empty((nl, 2, 128), dtype=_f32, device=dev)       # mean / invstd rows (cout <= 128)
+    base, sbase = arena.data_ptr(), stats.data_ptr()
+    desc = pre.copy()                        # (C / Y / MEAN / INVSTD hold offsets: add this pass's arena and stats addresses)
+    prof = _profile_slots(layers, store) if F_.PROFILE is not None else None
+    if prof is not None:
+        desc[:, _E["PROF"]] = prof[1]
+    desc[:, _E["C"]] += base
+    desc[:, _E["Y"]] += base
+    desc[0, _E["X"]] = x0.data_ptr()
+    desc[1:, _E["X"]] = desc[:-1, _E["Y"]]
+    desc[:, _E["MEAN"]] += sbase
+    desc[:, _E["INVSTD"]] += sbase
+    ws = _ws(nbytes, dev)
+    lane = lane_of(encoder)
+    group = _sync_group_for(layers)
+    st = Launched()
+    st.sync = None
+    if group is not None:
+        lane = None
+        sums = torch.zeros(nl * SYNC_STRIDE, dtype=torch.float64, device=dev)
+        key = id(sums)
+        _SYNC_CTX[key] = (sums, None, group)
+        try:
+            rc = lib.irx_encoder_forward_sync(desc.ctypes.data, fdesc.ctypes.data, nl, ws.data_ptr(), nbytes,
+                                              _lib.stream_ptr(), sums.data_ptr(), _ALLREDUCE_C, key)
+        finally:
+            del _SYNC_CTX[key]
+        if rc and _SYNC_ERR:
+            raise RuntimeError("sync BatchNorm all-reduce inside the encoder executor failed: %s" % _SYNC_ERR.pop())
+        st.sync = (sums, group)
+        SYNC_CALLS[0] += 1
+    elif lane is not None:
+        rc = lib.irx_encoder_submit(lane, 0, desc.ctypes.data, fdesc.ctypes.data, nl, None, None, ws.data_ptr(),
+                                    nbytes, _lib.stream_ptr())
+        _HELD.setdefault(lane, []).append((ws, x0, arena, stats, prof))
+    else:
+        rc = lib.irx_encoder_forward(desc.ctypes.data, fdesc.ctypes.data, nl, ws.data_ptr(), nbytes, _lib.stream_ptr())
+    if rc:
+        _lib.check(rc, "irx_encoder_forward")
+    st.lane = lane
+    if counters:
+        with torch.no_grad():
+            torch._foreach_add_(counters, 1)
+    st.layers, st.desc, st.fdesc, st.extra = layers, desc, fdesc, (n_out, cout, poffs, ptotal)
+    st.store, st.prof, st.need_dx0 = store, prof, bool(need_dx0)
+    if TRACE is not None:
+        TRACE["fwd"] = dict(layers=layers, arena=arena, stats=stats, x0=x0, start=start, cb=cb, n_out=n_out, cout=cout,
+                            store=store)
+    # gradient sink (optim.FlatAdam): parameter gradients can go straight into the optimizer's flat buffer
+    sink = getattr(params[0], "_irx_sink", None)
+    st.sink = (sink[0], id(encoder), params) if sink is not None else None
+    st.saved = (x0, arena, stats)
+    o0 = int(start[-1] + cb[-1])
+    st.out = arena[o0:o0 + 4 * layers[-1].n_out * layers[-1].cout].view(_f32).view(layers[-1].n_out, layers[-1].cout)
+    return st
+
+
 class EncoderFn(torch.autograd.Function):
     """forward / backward = one irx_encoder_forward / irx_encoder_backward call over a descriptor table; activations,
     gradients-in-flight and parameter gradients live in three arenas allocated once per call. The table is a cached
-    static template plus a handful of vectorised numpy fills (level sizes, table pointers, arena offsets)."""
+    static template plus a handful of vectorised numpy fills (level sizes, table pointers, arena offsets).
+    apply(feats, encoder, layers | Launched, *params): with a Launched pass (launch() above) the forward only binds it."""
 
     @staticmethod
     def forward(ctx, feats, encoder, layers, *params):
-        lib = _lib.load()
-        dev = feats.device
-        x0 = feats.contiguous().float()
-        nl = len(layers)
-        store = storage_bf16(ctx.needs_input_grad[0])
-        pre, fdesc, counters, cout, poffs, ptotal, n_out, cb, start, total, nbytes = _level_desc(encoder, layers, params, store)
-        arena = torch.empty(total, dtype=torch.uint8, device=dev)
-        stats = torch.empty((nl, 2, 128), dtype=_f32, device=dev)       # mean / invstd rows (cout <= 128)
-        base, sbase = arena.data_ptr(), stats.data_ptr()
-        desc = pre.copy()                        # (C / Y / MEAN / INVSTD hold offsets: add this pass's arena and stats addresses)
-        prof = _profile_slots(layers, store) if F_.PROFILE is not None else None
-        if prof is not None:
-            desc[:, _E["PROF"]] = prof[1]
-        desc[:, _E["C"]] += base
-        desc[:, _E["Y"]] += base
-        desc[0, _E["X"]] = x0.data_ptr()
-        desc[1:, _E["X"]] = desc[:-1, _E["Y"]]
-        desc[:, _E["MEAN"]] += sbase
-        desc[:, _E["INVSTD"]] += sbase
-        ws = _ws(nbytes, dev)
-        lane = lane_of(encoder)
-        group = _sync_group_for(layers)
-        ctx.sync = None
-        if group is not None:
-            lane = None
-            sums = torch.zeros(nl * SYNC_STRIDE, dtype=torch.float64, device=dev)
-            key = id(sums)
-            _SYNC_CTX[key] = (sums, None, group)
-            try:
-                rc = lib.irx_encoder_forward_sync(desc.ctypes.data, fdesc.ctypes.data, nl, ws.data_ptr(), nbytes,
-                                                  _lib.stream_ptr(), sums.data_ptr(), _ALLREDUCE_C, key)
-            finally:
-                del _SYNC_CTX[key]
-            if rc and _SYNC_ERR:
-                raise RuntimeError("sync BatchNorm all-reduce inside the encoder executor failed: %s" % _SYNC_ERR.pop())
-            ctx.sync = (sums, group)
-            SYNC_CALLS[0] += 1
-        elif lane is not None:
-            rc = lib.irx_encoder_submit(lane, 0, desc.ctypes.data, fdesc.ctypes.data, nl, None, None, ws.data_ptr(),
-                                        nbytes, _lib.stream_ptr())
-            _HELD.setdefault(lane, []).append((ws, x0, arena, stats, prof))
-        else:
-            rc = lib.irx_encoder_forward(desc.ctypes.data, fdesc.ctypes.data, nl, ws.data_ptr(), nbytes, _lib.stream_ptr())
-        if rc:
-            _lib.check(rc, "irx_encoder_forward")
-        ctx.lane = lane
-        if counters:
-            torch._foreach_add_(counters, 1)
-        ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = layers, desc, fdesc, (n_out, cout, poffs, ptotal)
-        ctx.store, ctx.prof = store, prof
-        if TRACE is not None:
-            TRACE["fwd"] = dict(layers=layers, arena=arena, stats=stats, x0=x0, start=start, cb=cb, n_out=n_out, cout=cout,
-                                store=store)
-        # gradient sink (optim.FlatAdam): parameter gradients can go straight into the optimizer's flat buffer
-        sink = getattr(params[0], "_irx_sink", None)
-        ctx.sink = (sink[0], id(encoder), params) if sink is not None else None
-        ctx.save_for_backward(x0, arena, stats, *params)
-        o0 = int(start[-1] + cb[-1])
-        return arena[o0:o0 + 4 * layers[-1].n_out * layers[-1].cout].view(_f32).view(layers[-1].n_out, layers[-1].cout)
+        st = layers if isinstance(layers, Launched) else launch(feats, encoder, layers, params, ctx.needs_input_grad[0])
+        if ctx.needs_input_grad[0] and not st.need_dx0:
+            raise RuntimeError("encoder pass was launched without an input gradient (bf16 storage) but its features require one")
+        ctx.lane, ctx.sync = st.lane, st.sync
+        ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = st.layers, st.desc, st.fdesc, st.extra
+        ctx.store, ctx.prof, ctx.sink = st.store, st.prof, st.sink
+        ctx.save_for_backward(*st.saved, *params)
+        return st.out.view_as(st.out) if isinstance(layers, Launched) else st.out
 
     @staticmethod
     def backward(ctx, dout):
@@ -519,16 +545,43 @@ def _profile_slots(layers, store):
     return (evs, handles), ptrs
 
 
-def run_encoder(encoder, st):
-    """Fused training forward of a SparseConvEncoder on a canonical SparseTensor -> SparseTensor at stride 16."""
+def run_encoder(encoder, st, defer=False):
+    """Fused training forward of a SparseConvEncoder on a canonical SparseTensor -> SparseTensor at stride 16.
+    defer=True: issue the pass now, create its autograd node later -> Deferred (see Launched); .attach() -> SparseTensor."""
     from .tensor import SparseTensor
     layers = build_plan(encoder, st.level())
     params = []
     for L in layers:
         params += [L.conv.kernel, L.bn.weight, L.bn.bias]
-    y = EncoderFn.apply(st.F, encoder, layers, *params)
     out = layers[-1].lv_out
+    if defer and not st.F.requires_grad:
+        return Deferred(st.F, encoder, launch(st.F, encoder, layers, params, False), params, out)
+    y = EncoderFn.apply(st.F, encoder, layers, *params)
     return SparseTensor(y, out.coords, out.stride, out.batch_size, out)
+
+
+class Deferred:
+    """An issued encoder pass waiting for its autograd node (run_encoder(defer=True))."""
+    __slots__ = ("feats", "encoder", "launched", "params", "level", "stream")
+
+    def __init__(self, feats, encoder, launched, params, level):
+        self.feats, self.encoder, self.launched, self.params, self.level = feats, encoder, launched, params, level
+        # autograd replays a node on the stream that was current when the node was CREATED: attach() restores the issue stream
+        self.stream = torch.cuda.current_stream(feats.device) if feats.is_cuda else None
+
+    def record_stream(self, stream):
+        for t in self.launched.saved:
+            t.record_stream(stream)
+
+    def attach(self):
+        from .tensor import SparseTensor
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                y = EncoderFn.apply(self.feats, self.encoder, self.launched, *self.params)
+        else:
+            y = EncoderFn.apply(self.feats, self.encoder, self.launched, *self.params)
+        out = self.level
+        return SparseTensor(y, out.coords, out.stride, out.batch_size, out)
 
 
 def can_fuse(encoder):

@@ -11,6 +11,7 @@ from .. import _lib
 # bench.py sets PROFILE to a list to collect (kind, n_out, K, cin, cout, M, start_event, end_event) per sparse-conv
 # launch, with events recorded on the launch stream. None (default) = no instrumentation at all.
 PROFILE = None
+PROFILE_NO_COUNT = False     # bench.py's timeline mode: no pair counting (it syncs)
 _PAIR_COUNT = {}
 
 _i32 = torch.int32
@@ -276,6 +277,8 @@ def _pairs(tbl, K, n_out):
     """Number of valid (input, output) pairs M of a table (profiling only; cached per table storage). Only the first
     n_out columns are meaningful: tables may be wider (ld > n_out, e.g. the shared pyramid buffers) and the rest is
     uninitialised."""
+    if PROFILE_NO_COUNT:
+        return 0                   # timeline mode: only the events matter, a count would be a host sync inside the loop
     key = (tbl.data_ptr(), tuple(tbl.shape), K, n_out)
     if key not in _PAIR_COUNT:
         if len(_PAIR_COUNT) > 4096:
@@ -288,12 +291,12 @@ def spconv_gather_gemm(x, w, tbl, ld, n_out, K, cin, cout, flip_k, trans_w):
     y = torch.empty((n_out, cout), dtype=_f32, device=x.device)
     wsb = int(_lib.load().irx_spconv_fwd_workspace_bytes(n_out, K, cin, cout, int(trans_w)))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
-    if PROFILE is not None:
+    if PROFILE is not None and not PROFILE_NO_COUNT:
         m = _pairs(tbl, K, n_out)
         e0, e1 = _bracket()
     _lib.call("irx_spconv_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(tbl), ld, n_out, K, cin, cout,
               int(flip_k), int(trans_w), _lib.ptr(y), _lib.ptr(ws), wsb, _stream())
-    if PROFILE is not None:
+    if PROFILE is not None and not PROFILE_NO_COUNT:
         PROFILE.append(("dgrad" if trans_w else "fwd", n_out, K, cin, cout, m, e0, e1))
     return y
 
@@ -307,12 +310,12 @@ def spconv_gather_gemm_t(x, w, tbl, ld, n_out, K, cin, cout, flip_k, trans_w, y_
     y_bf = y.dtype == torch.bfloat16
     wsb = int(_lib.load().irx_spconv_fwd_workspace_bytes(n_out, K, cin, cout, int(trans_w)))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
-    if PROFILE is not None:
+    if PROFILE is not None and not PROFILE_NO_COUNT:
         m = _pairs(tbl, K, n_out)
         e0, e1 = _bracket()
     _lib.call("irx_spconv_fwd_t", _lib.ptr(x), _lib.ptr(w), _lib.ptr(tbl), ld, x.shape[0], n_out, K, cin, cout, int(flip_k),
               int(trans_w), _lib.ptr(y), int(accumulate_into is not None), int(x_bf), int(y_bf), _lib.ptr(ws), wsb, _stream())
-    if PROFILE is not None:
+    if PROFILE is not None and not PROFILE_NO_COUNT:
         PROFILE.append(("dgrad" if trans_w else "fwd", n_out, K, cin, cout, m, e0, e1))
     return y
 
@@ -321,12 +324,12 @@ def spconv_wgrad(x, dy, tbl, ld, n_out, K, cin, cout):
     dw = torch.empty((K, cin, cout), dtype=_f32, device=x.device)
     wsb = int(_lib.load().irx_spconv_wgrad_workspace_bytes(n_out, K, cin, cout))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
-    if PROFILE is not None:
+    if PROFILE is not None and not PROFILE_NO_COUNT:
         m = _pairs(tbl, K, n_out)
         e0, e1 = _bracket()
     _lib.call("irx_spconv_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(tbl), ld, n_out, K, cin, cout,
               _lib.ptr(dw), _lib.ptr(ws), wsb, _stream())
-    if PROFILE is not None:
+    if PROFILE is not None and not PROFILE_NO_COUNT:
         PROFILE.append(("wgrad", n_out, K, cin, cout, m, e0, e1))
     return dw
 
@@ -386,7 +389,7 @@ def spconv_wgrad_pairs(x, dy, pairs, n_out, K, cin, cout, m_for_profile=None):
     dw = torch.empty((K, cin, cout), dtype=_f32, device=x.device)
     wsb = int(_lib.load().irx_spconv_wgrad_pairs_workspace_bytes(n_out, K, cin, cout))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
-    if PROFILE is not None:
+    if PROFILE is not None and not PROFILE_NO_COUNT:
         m = int(counts.sum().item())
         e0, e1 = _bracket()
     bf = x.dtype == torch.bfloat16
@@ -394,7 +397,7 @@ def spconv_wgrad_pairs(x, dy, pairs, n_out, K, cin, cout, m_for_profile=None):
         raise ValueError("spconv_wgrad_pairs: x and dy must have the same element type")
     _lib.call("irx_spconv_wgrad_pairs_t", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_list), _lib.ptr(out_list), ldp,
               _lib.ptr(counts), int(x.shape[0]), n_out, K, cin, cout, _lib.ptr(dw), int(bf), _lib.ptr(ws), wsb, _stream())
-    if PROFILE is not None:
+    if PROFILE is not None and not PROFILE_NO_COUNT:
         PROFILE.append(("wgrad", n_out, K, cin, cout, m, e0, e1))
     return dw
 
@@ -476,15 +479,17 @@ class BatchNormActFn(torch.autograd.Function):
             _lib.call("irx_bn_stats_from_sums", _lib.ptr(sums), 0.0, c, float(eps), float(momentum), _lib.ptr(mean),
                       _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), _stream())
             ctx.count = sums[2 * c:]                     # folded row count, on the device
-        else:
-            _lib.call("irx_bn_stats", _lib.ptr(x), n, c, float(eps), float(momentum), _lib.ptr(mean),
-                      _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ws), wsb,
-                      _stream())
         y = torch.empty_like(x)
         g = _f32c(gamma)
         b = _f32c(beta)
-        _lib.call("irx_bn_apply", _lib.ptr(x), n, c, _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(g),
-                  _lib.ptr(b), _lib.ptr(res), int(relu), _lib.ptr(y), _stream())
+        if sync is None:
+            # statistics + apply as one call: ONE launch for a tensor that stays on-die (csrc/irx_norm.hip, k_bn_slice_fwd)
+            _lib.call("irx_bn_forward", _lib.ptr(x), n, c, float(eps), float(momentum), _lib.ptr(g), _lib.ptr(b), _lib.ptr(res),
+                      int(relu), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(y),
+                      _lib.ptr(ws), wsb, _stream())
+        else:
+            _lib.call("irx_bn_apply", _lib.ptr(x), n, c, _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(g),
+                      _lib.ptr(b), _lib.ptr(res), int(relu), _lib.ptr(y), _stream())
         ctx.save_for_backward(x, y, mean, invstd, g)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None

@@ -700,3 +700,115 @@ def test_training_trajectory_tracks_the_oracle(lib, tmp_path):
     #  8e-4 at steps 0..2 with the heads through ATen, 2e-7, 5e-5, 2e-3 with the fused head MLPs' own summation order)
     assert max(free_dev[:2]) <= 1e-3 and max(free_dev) <= 1e-2, free_dev
     assert np.mean(losses[-10:]) < np.mean(losses[:10]), losses
+
+
+def _three_steps(dev, dtype="fp32", no_dropout=False):
+    import argparse
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from instancerefer_amd import synthetic as S
+    from instancerefer_amd.loss_helper import DatasetConfig
+    from instancerefer_amd.optim import FlatAdam
+    bench.step_fn.cfg = DatasetConfig()
+    torch.manual_seed(11)
+    model = bench.build_model(argparse.Namespace(), "full", dev)
+    if no_dropout:                       # (the order in which the modules draw their dropout seeds follows the issue order)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    resident = S.to_device(S.make_batch(4, seed=33, num_points=6000, num_instances=6, num_candidates=3,
+                                        points_per_instance=256), dev)
+    lidar = resident.pop("lidar")
+    resident["lidar_F"], resident["lidar_C"], resident["B"] = lidar.F, lidar.C, 4
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=1)
+    losses = [float(bench.step_fn(model, resident, "full", None, opt, None).detach()) for _ in range(3)]
+    torch.cuda.synchronize()
+    return model, resident, opt, losses
+
+
+@pytest.mark.parametrize("knob", ["lang_thread", "scene_defer", "streams", "streams_inline_lang"])
+def test_helper_thread_and_deferred_scene_node_change_nothing(lib, monkeypatch, knob):
+    """(1) The language module issued by the helper thread vs inline (IRX_LANG_THREAD=0): same kernels on the same stream.
+    (2) The scene encoder's autograd node created at the head of SceneModule.forward (its pass issued earlier:
+    encoder_fn.Launched) vs created at issue time: only the ORDER in which the backward reaches the encoders changes.
+    (3) The three-stream forward (InstanceRefer._forward_streams: scene encoder + scene head | language + relation | candidate
+    encoder + attribute head + scores) vs the one-stream layout, with the language module on the helper thread or inline.
+    Bit-identical losses and parameters after 3 training steps either way."""
+    from instancerefer_amd import instancerefer as IR, scene_module as SM
+    dev = torch.device("cuda")
+    out = {}
+    for on in (True, False):
+        if knob == "lang_thread":
+            monkeypatch.setattr(IR, "_LANG_THREAD", on)
+        elif knob == "scene_defer":
+            monkeypatch.setattr(SM, "_DEFER", on)
+        else:
+            monkeypatch.setattr(IR, "_STREAMS", on)
+            monkeypatch.setattr(IR, "_LANG_THREAD", knob == "streams")
+        _, _, opt, losses = _three_steps(dev, no_dropout=knob.startswith("streams"))
+        out[on] = (losses, opt.flat_p.clone())
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
+
+
+def test_helper_thread_lifecycle(lib, monkeypatch):
+    """(a) an exception inside the language module (on the helper thread) and one inside the encoders' issue (main
+    thread, helper job in flight) both surface in forward() and the NEXT forward is unaffected — no stale result is consumed;
+    (b) copy.deepcopy(model) and pickling work after a training forward; (c) the worker thread holds no reference to the model:
+    dropping the model stops it."""
+    import copy
+    import gc
+    import io
+    import weakref
+    from instancerefer_amd import instancerefer as IR
+    dev = torch.device("cuda")
+    monkeypatch.setattr(IR, "_LANG_THREAD", True)
+    model, resident, opt, losses = _three_steps(dev)
+    import bench
+    worker = model.__dict__["_lang_worker"]
+    assert worker.thread.is_alive()
+    ref = float(bench.step_fn(model, resident, "full", None, opt, None).detach())
+    state = opt.flat_p.clone()
+
+    class Boom(RuntimeError):
+        pass
+    # (a1) inside the language module
+    orig_lang = type(model.lang).forward
+
+    def bad_lang(self, dd):
+        raise Boom("lang")
+    monkeypatch.setattr(type(model.lang), "forward", bad_lang)
+    with pytest.raises(Boom):
+        model(bench.fresh_batch(resident))
+    monkeypatch.setattr(type(model.lang), "forward", orig_lang)
+    # (a2) inside the encoders' issue, while the helper job is in flight
+    orig_encode = type(model.scene).encode
+
+    def bad_encode(self, dd):
+        raise Boom("encoders")
+    monkeypatch.setattr(type(model.scene), "encode", bad_encode)
+    with pytest.raises(Boom):
+        model(bench.fresh_batch(resident))
+    monkeypatch.setattr(type(model.scene), "encode", orig_encode)
+    # (a3) an interrupted join: the result of that job stays in the queue; the next forward must not consume it
+    stale = worker.post((model.lang, None), dict(bench.fresh_batch(resident), lang_feat=resident["lang_feat"] * 0))
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flat_p, state)
+    nxt = float(bench.step_fn(model, resident, "full", None, opt, None).detach())
+    assert np.isfinite(nxt) and abs(nxt - ref) < 0.5 * abs(ref) + 1.0 and stale < worker.seq
+    # (b) copies
+    twin = copy.deepcopy(model)
+    assert "_lang_worker" not in twin.__dict__ and "_enc_streams" not in twin.__dict__
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    assert buf.tell() > 1 << 20
+    # (c) the thread ends with the model
+    th = worker.thread
+    wr = weakref.ref(model)
+    del model, opt, twin, worker
+    gc.collect()
+    assert wr() is None
+    th.join(timeout=5.0)
+    assert not th.is_alive()
