@@ -681,6 +681,16 @@ def main():
              "at_backward": not args.no_prep_at_backward and not args.prep_thread}
     if os.environ.get("IRX_BENCH_PREP_MAIN") == "1":   # dev A/B: the preparation on the main stream
         state["side"] = torch.cuda.current_stream()
+    if os.environ.get("IRX_BENCH_SERIAL") == "1":
+        # dev (profiling): EVERYTHING on one stream, issued by one thread — under rocprofv3 every kernel's duration is then its
+        # time alone on the GPU and the sum over a step is the step's serial GPU time (the budget overlap can only re-arrange)
+        from instancerefer_amd import instancerefer as _ir
+        from instancerefer_amd.sparse import encoder_fn as _ef
+        _ir._STREAMS = _ir._LANG_THREAD = False
+        _ef.ASYNC = False
+        model.args.overlap_streams = False
+        state["side"] = torch.cuda.current_stream()
+        state["at_backward"] = False
     from instancerefer_amd.loss_helper import prepare_labels
     state["labels"] = lambda dd: prepare_labels(dd, step_fn.cfg, device) if "_attr_prepared" in dd else None
     for i in range(args.warmup):

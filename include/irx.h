@@ -600,6 +600,18 @@ int irx_contrastive_bwd(const float* s1, const float* s2, const float* s3, const
                         const float* act, const float* lse, const float* dout, int nseg, float gamma, float* ds,
                         void* stream);
 
+/* The whole training loss of get_loss (lib/loss_helper.py:196-269) in one launch, gradients included: lang_loss = cross-entropy of
+ * lang_scores [B][n_lang] (:110-118), seg_loss / seg_acc = cross-entropy / accuracy of seg_scores [B][n_seg] (:121-150), ref_loss =
+ * the batched ContrastiveLoss above / batch_size (:248-260), loss = ref_weight * ref_loss + lang_loss + seg_loss (:263).
+ * out[5] = loss, ref_loss, lang_loss, seg_loss, seg_acc;  d_lang [B][n_lang], d_seg [B][n_seg], d_s [seg_off[nscored]] =
+ * d loss / d input (d_s is the gradient of EACH of s1, s2, s3) for an upstream gradient of 1. nscored == 0: no scored scene
+ * (ref_loss = 0, the score pointers may be NULL). */
+int irx_total_loss(const float* lang_scores, const int64_t* lang_label, int B, int n_lang, const float* seg_scores,
+                   const int64_t* seg_label, int n_seg, const float* s1, const float* s2, const float* s3,
+                   const float* lab, const int64_t* seg_off, const float* keep, int nscored, float gamma,
+                   float margin, float ref_weight, int batch_size, float* out, float* d_lang, float* d_seg, float* d_s,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

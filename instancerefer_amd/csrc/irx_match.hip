@@ -196,3 +196,101 @@ extern "C" int irx_contrastive_bwd(const float* s1, const float* s2, const float
   return IRX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole training loss of get_loss (reference lib/loss_helper.py:196-269) as ONE launch, gradients included (round 5):
+//   lang_loss = CE(lang_scores [B][n_lang], lang_label)  (:110-118, mean over B)
+//   seg_loss  = CE(seg_scores [B][n_seg], seg_label), seg_acc = mean(argmax == label)  (:121-150)
+//   ref_loss  = sum_s keep_s * max(logsumexp(x (1 - lab)) - sum(x lab) + margin, 0) / B, x = gamma (s1 + s2 + s3)  (:93-107,248-260)
+//   loss      = ref_weight * ref_loss + lang_loss + seg_loss  (:263)
+// The loss sits between the last head's forward and the first head's backward, on the step's critical path, and was ~18 forward
+// + ~12 backward launches of 2-5 us each. One workgroup: a thread per utterance for the two cross-entropies, a thread per
+// scored scene for the contrastive term, fixed-order sums. d_lang / d_seg / d_s hold d loss / d input for an upstream gradient
+// of 1 (the backward scales them). out[5] = loss, ref_loss, lang_loss, seg_loss, seg_acc.
+#define TL_PT 256
+__device__ __forceinline__ float tl_ce_row(const float* __restrict__ x, int n, int label, float inv_b, float* __restrict__ d, int* hit) {
+  float mx = -INFINITY;
+  int am = 0;
+  for (int j = 0; j < n; ++j)
+    if (x[j] > mx) { mx = x[j]; am = j; }                // first maximum, like torch.argmax
+  float se = 0.f;
+  for (int j = 0; j < n; ++j) se += expf(x[j] - mx);
+  const float lse = mx + logf(se);
+  for (int j = 0; j < n; ++j) d[j] = (expf(x[j] - lse) - (j == label ? 1.f : 0.f)) * inv_b;
+  if (hit) *hit = (am == label) ? 1 : 0;
+  return lse - x[label];
+}
+
+__global__ __launch_bounds__(TL_PT) void k_total_loss(const float* __restrict__ lang_scores, const int64_t* __restrict__ lang_label,
+                                                      int B, int n_lang, const float* __restrict__ seg_scores,
+                                                      const int64_t* __restrict__ seg_label, int n_seg,
+                                                      const float* __restrict__ s1, const float* __restrict__ s2,
+                                                      const float* __restrict__ s3, const float* __restrict__ lab,
+                                                      const int64_t* __restrict__ seg_off, const float* __restrict__ keep,
+                                                      int nscored, float gamma, float margin, float ref_weight, float inv_batch,
+                                                      float* __restrict__ out, float* __restrict__ d_lang,
+                                                      float* __restrict__ d_seg, float* __restrict__ d_s) {
+  __shared__ float sh[3][TL_PT];
+  __shared__ int shi[TL_PT];
+  const int tid = threadIdx.x;
+  const float inv_b = 1.f / (float)B;
+  float l_lang = 0.f, l_seg = 0.f;
+  int hits = 0;
+  for (int b = tid; b < B; b += TL_PT) {
+    l_lang += tl_ce_row(lang_scores + (size_t)b * n_lang, n_lang, (int)lang_label[b], inv_b, d_lang + (size_t)b * n_lang, nullptr);
+    int h = 0;
+    l_seg += tl_ce_row(seg_scores + (size_t)b * n_seg, n_seg, (int)seg_label[b], inv_b, d_seg + (size_t)b * n_seg, &h);
+    hits += h;
+  }
+  float l_ref = 0.f;
+  for (int s = tid; s < nscored; s += TL_PT) {
+    const int lo = (int)seg_off[s], hi = (int)seg_off[s + 1];
+    float mx = -INFINITY, sim = 0.f;
+    for (int i = lo; i < hi; ++i) {
+      const float x = gamma * (s1[i] + s2[i] + s3[i]);
+      const float l = lab[i];
+      sim += x * l;
+      mx = fmaxf(mx, x * (1.f - l));
+    }
+    float se = 0.f;
+    for (int i = lo; i < hi; ++i) se += expf(gamma * (s1[i] + s2[i] + s3[i]) * (1.f - lab[i]) - mx);
+    const float lse = (hi > lo) ? mx + logf(se) : -INFINITY;
+    const float v = lse - sim + margin;
+    const float act = (v > 0.f) ? keep[s] : 0.f;
+    l_ref += (v > 0.f) ? keep[s] * v : 0.f;
+    const float k = ref_weight * inv_batch * act * gamma;
+    for (int i = lo; i < hi; ++i) {
+      const float lb = lab[i];
+      const float p = expf(gamma * (s1[i] + s2[i] + s3[i]) * (1.f - lb) - lse);
+      d_s[i] = k * (p * (1.f - lb) - lb);
+    }
+  }
+  sh[0][tid] = l_lang; sh[1][tid] = l_seg; sh[2][tid] = l_ref; shi[tid] = hits;
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, b = 0.f, c = 0.f;
+    int h = 0;
+    for (int t = 0; t < TL_PT; ++t) { a += sh[0][t]; b += sh[1][t]; c += sh[2][t]; h += shi[t]; }     // fixed order
+    const float lang = a * inv_b, seg = b * inv_b, ref = c * inv_batch;
+    out[0] = ref_weight * ref + lang + seg;
+    out[1] = ref;
+    out[2] = lang;
+    out[3] = seg;
+    out[4] = (float)h * inv_b;
+  }
+}
+
+extern "C" int irx_total_loss(const float* lang_scores, const int64_t* lang_label, int B, int n_lang, const float* seg_scores,
+                              const int64_t* seg_label, int n_seg, const float* s1, const float* s2, const float* s3,
+                              const float* lab, const int64_t* seg_off, const float* keep, int nscored, float gamma,
+                              float margin, float ref_weight, int batch_size, float* out, float* d_lang, float* d_seg, float* d_s,
+                              void* stream) {
+  IRX_REQUIRE(B >= 1 && n_lang >= 1 && n_seg >= 1 && nscored >= 0 && batch_size >= 1, "irx_total_loss: bad sizes");
+  IRX_REQUIRE(lang_scores && lang_label && seg_scores && seg_label && out && d_lang && d_seg, "irx_total_loss: null pointer");
+  IRX_REQUIRE(nscored == 0 || (s1 && s2 && s3 && lab && seg_off && keep && d_s), "irx_total_loss: null pointer (scores)");
+  k_total_loss<<<1, TL_PT, 0, S(stream)>>>(lang_scores, lang_label, B, n_lang, seg_scores, seg_label, n_seg, s1, s2, s3, lab,
+                                          seg_off, keep, nscored, gamma, margin, ref_weight, 1.f / (float)batch_size, out, d_lang,
+                                          d_seg, d_s);
+  IRX_CHECK_LAUNCH("irx_total_loss");
+  return IRX_OK;
+}

@@ -85,6 +85,23 @@ __device__ __forceinline__ float ml_colsum(float part, float (*red)[ML_TC]) {
   return s;
 }
 
+// sum of p[0], p[stride], ... (n terms) with the loads of 8 terms in flight at a time: these kernels are a handful of workgroups, so a
+// loop of dependent "load, add" steps costs a full memory round trip per term (64 terms = 25-50 us)
+template <typename F>
+__device__ __forceinline__ float ml_sum8(int n, F term) {
+  float s = 0.f;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = term(i + u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < n; ++i) s += term(i);
+  return s;
+}
+
 enum { ML_BN_TRAIN = 1, ML_BN_EVAL = 2, ML_LN = 3, ML_NONE = 4, ML_OUT_RELU = 8 };   // (ML_OUT_RELU: flag, y = relu(...))
 
 // Dropout without a mask tensor: element o of call `seed` is kept iff a counter-based hash of (seed, o) falls above p — the
@@ -216,13 +233,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, i
         // mean^2 / var of the variance, enough to show in the gradient's direction (training-trajectory test: cosine 2e-6)
         const int i = t >> 2, q = t & 3, r = r0 + i;
         float p1 = 0.f, p2 = 0.f;
-        if (r < rows)
-          for (int k = q; k < dh; k += 4) p1 += h[(size_t)r * dh + k];
+        const float* hr = h + (size_t)(r < rows ? r : 0) * dh;
+        const int nq = (r < rows) ? (dh - q + 3) / 4 : 0;            // this thread's terms: k = q, q + 4, ...
+        p1 = ml_sum8(nq, [&](int u) { return hr[q + 4 * u]; });
         p1 += __shfl_xor(p1, 1);
         p1 += __shfl_xor(p1, 2);
         const float m = p1 / dh;
-        if (r < rows)
-          for (int k = q; k < dh; k += 4) { const float d = h[(size_t)r * dh + k] - m; p2 = fmaf(d, d, p2); }
+        p2 = ml_sum8(nq, [&](int u) { const float d = hr[q + 4 * u] - m; return d * d; });
         p2 += __shfl_xor(p2, 1);
         p2 += __shfl_xor(p2, 2);
         if (q == 0) {
@@ -234,11 +251,20 @@ __global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, i
       }
       __syncthreads();
       if (blockIdx.x == 0) {                          // a (needed by the backward) is written once
-        for (int e = t; e < ML_TR * dh; e += 256) {
-          const int i = e / dh, k = e % dh, r = r0 + i;
-          if (r < rows) {
-            const size_t o = (size_t)r * dh + k;
-            a[o] = ml_drop(fmaxf(fmaf((h[o] - sMean[i]) * sInv[i], gamma[k], beta[k]), 0.f), drop_p, dscale, seed, o);
+        for (int e0 = t; e0 < ML_TR * dh; e0 += 256 * 8) {         // 8 elements' loads in flight per thread
+          float hv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, i = e / dh, r = r0 + i;
+            hv[u] = (e < ML_TR * dh && r < rows) ? h[(size_t)r * dh + e % dh] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, i = e / dh, k = e % dh, r = r0 + i;
+            if (e < ML_TR * dh && r < rows) {
+              const size_t o = (size_t)r * dh + k;
+              a[o] = ml_drop(fmaxf(fmaf((hv[u] - sMean[i]) * sInv[i], gamma[k], beta[k]), 0.f), drop_p, dscale, seed, o);
+            }
           }
         }
       }
@@ -292,9 +318,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd1(const float* __restrict__ dy, 
     if (blockIdx.x == 0)                                // db2 of this tile's outputs: 4 threads per output, fixed order
       for (int e = t; e < 4 * ML_TR; e += 256) {
         const int o = o0 + (e >> 2), q = e & 3;
-        float sdb = 0.f;
-        if (o < dout)
-          for (int r = q; r < rows; r += 4) sdb += dy[(size_t)r * dout + o];
+        float sdb = (o < dout) ? ml_sum8((rows - q + 3) / 4, [&](int u) { return dy[(size_t)(q + 4 * u) * dout + o]; }) : 0.f;
         sdb += __shfl_xor(sdb, 1);
         sdb += __shfl_xor(sdb, 2);
         if (q == 0 && o < dout) db2[o] = sdb;
@@ -303,22 +327,40 @@ __global__ __launch_bounds__(256) void k_mlp_bwd1(const float* __restrict__ dy, 
   }
   const float mean_c = (norm != ML_LN && cv) ? stat[c] : 0.f, inv_c = (norm != ML_LN && cv) ? stat[dh + c] : 0.f;
   float sg = 0.f, sb = 0.f;
+  // one row tile (every head of the model: 16 or 64 rows) with a column normalisation: dz and xhat stay in registers and dhid is
+  // written ONCE below — the write-then-read-modify-write over dhid was 8 dependent round trips per thread
+  const bool one_tile = rows <= ML_TR && norm != ML_LN && norm != ML_NONE;
+  float dzv[8], xhv[8];
   for (int r0 = 0; r0 < rows; r0 += ML_TR) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     ml_tile([&](int i, int k) { return (r0 + i < rows) ? dy[(size_t)(r0 + i) * dout + k] : 0.f; },
             [&](int jj, int k) { const int cc = blockIdx.x * ML_TC + jj; return cc < dh ? w2[(size_t)k * dh + cc] : 0.f; },
             dout, acc, sA, sB);
     float pg = 0.f, pb = 0.f;
+    float av[8], hv[8], m0[8], m1[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {                      // all loads of the tile's epilogue first
+      const int r = r0 + i0 + 8 * m;
+      const bool ok = r < rows && cv;
+      const size_t o = ok ? (size_t)r * dh + c : 0;
+      av[m] = ok ? a[o] : 0.f;
+      hv[m] = ok ? h[o] : 0.f;
+      m0[m] = (ok && norm == ML_LN) ? stat[2 * r] : mean_c;
+      m1[m] = (ok && norm == ML_LN) ? stat[2 * r + 1] : inv_c;
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int r = r0 + i0 + 8 * m;
+      dzv[m] = xhv[m] = 0.f;
       if (r < rows && cv) {
         const size_t o = (size_t)r * dh + c;
-        const float dz = a[o] > 0.f ? acc[m] * drop_scale : 0.f;
-        const float xh = (norm == ML_LN) ? (h[o] - stat[2 * r]) * stat[2 * r + 1] : (h[o] - mean_c) * inv_c;
+        const float dz = av[m] > 0.f ? acc[m] * drop_scale : 0.f;
+        const float xh = (hv[m] - m0[m]) * m1[m];
         pg = fmaf(dz, xh, pg);
         pb += dz;
-        dhid[o] = (norm == ML_LN) ? dz * gamma[c] : dz;      // (BatchNorm: finished below)
+        dzv[m] = dz;
+        xhv[m] = xh;
+        if (!one_tile) dhid[o] = (norm == ML_LN) ? dz * gamma[c] : dz;      // (BatchNorm: finished below)
       }
     }
     sg += ml_colsum(pg, red);
@@ -331,6 +373,14 @@ __global__ __launch_bounds__(256) void k_mlp_bwd1(const float* __restrict__ dy, 
   if (norm != ML_LN && norm != ML_NONE && cv) {       // (rows i0 + 8 m: this thread's own dhid entries; no norm: dhid = dz)
     const float gi = gamma[c] * inv_c;
     const float kb = (norm == ML_BN_TRAIN) ? sb / rows : 0.f, kg = (norm == ML_BN_TRAIN) ? sg / rows : 0.f;
+    if (one_tile) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int r = i0 + 8 * m;
+        if (r < rows) dhid[(size_t)r * dh + c] = gi * (dzv[m] - kb - xhv[m] * kg);
+      }
+      return;
+    }
     for (int r = i0; r < rows; r += 8) {
       const size_t o = (size_t)r * dh + c;
       const float xh = (h[o] - mean_c) * inv_c;
@@ -384,9 +434,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd3(const float* __restrict__ x, i
     }
     if (k0 == 0)
       for (int c = c0 + t; c < c0 + ML_TR && c < dh; c += 256) {
-        float s = 0.f;
-        for (int r = 0; r < rows; ++r) s += dhid[(size_t)r * dh + c];
-        db1[c] = s;
+        db1[c] = ml_sum8(rows, [&](int r) { return dhid[(size_t)r * dh + c]; });
       }
   } else if (dx) {
     const int b = (int)blockIdx.x - nW;
@@ -506,9 +554,7 @@ __global__ __launch_bounds__(256) void k_gru_wgrad(const float* __restrict__ dgi
   if (c0 == 0) {                                            // the bias gradient of this tile's 64 gate rows: 4 threads per row
     float* db = hid ? (d == 0 ? dbh0 : dbh1) : (d == 0 ? dbi0 : dbi1);
     const int g = g0 + (t >> 2), q = t & 3;
-    float sdb = 0.f;
-    if (g < G)
-      for (int r = q; r < BT; r += 4) sdb += gsrc[(size_t)r * ldg + d * G + g];
+    float sdb = (g < G) ? ml_sum8((BT - q + 3) / 4, [&](int u) { return gsrc[(size_t)(q + 4 * u) * ldg + d * G + g]; }) : 0.f;
     sdb += __shfl_xor(sdb, 1);
     sdb += __shfl_xor(sdb, 2);
     if (q == 0 && g < G) db[g] = sdb;

@@ -200,8 +200,15 @@ __global__ __launch_bounds__(BN_PT) void k_bn_partial(const float* __restrict__ 
         t0 += s0[(g2 * qpad + qd) * V + j];
         t1 += s1[(g2 * qpad + qd) * V + j];
       }
-      part[((size_t)blockIdx.x * 2 + 0) * c + qd * V + j] = t0;
-      part[((size_t)blockIdx.x * 2 + 1) * c + qd * V + j] = t1;
+      if (V >= 4 && MODE <= 1 && fin.counter != nullptr) {
+        // published for the last workgroup (below): agent-scope relaxed atomic stores go THROUGH the L2 to memory (sc1), so that
+        // no cache write-back is needed to make them visible to a workgroup on another XCD
+        __hip_atomic_store(&part[((size_t)blockIdx.x * 2 + 0) * c + qd * V + j], t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part[((size_t)blockIdx.x * 2 + 1) * c + qd * V + j], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        part[((size_t)blockIdx.x * 2 + 0) * c + qd * V + j] = t0;
+        part[((size_t)blockIdx.x * 2 + 1) * c + qd * V + j] = t1;
+      }
     }
   }
   if constexpr (V >= 4 && MODE <= 1) {
@@ -211,12 +218,18 @@ __global__ __launch_bounds__(BN_PT) void k_bn_partial(const float* __restrict__ 
     // waits for anybody: no spinning, no co-residency requirement. The counter is left at 0 for its next user.
     if (fin.counter == nullptr) return;
     __shared__ int s_last;
-    __threadfence();
+    // Round 5, second attempt. The first (and round 2's) used __threadfence() on both sides: an agent-scope release / acquire is
+    // a write-back / invalidate of the XCD's whole L2 on gfx950 and cost more than the launch it replaced (39.9 -> 57.8 us at
+    // 489 k x 32). Here nothing is flushed: the partials are written and read with agent-scope RELAXED atomics (memory-side, sc1),
+    // and the only ordering needed — "my partial stores are acknowledged before my ticket" — is a wait for this wave's stores
+    // (workgroup-scope release = s_waitcnt, no cache operation) followed by the workgroup barrier.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(fin.counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    if (threadIdx.x == 0)
+      s_last = (__hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     const int nblk = gridDim.x;
     const int cq4 = c / 4, nsl = BN_PT / cq4;            // float4 columns x slices of the partial blocks
     const int col = threadIdx.x % cq4, sl = threadIdx.x / cq4;
@@ -225,10 +238,14 @@ __global__ __launch_bounds__(BN_PT) void k_bn_partial(const float* __restrict__ 
     for (int j = 0; j < 8; ++j) t[j] = 0.0;
     if (sl < nsl) {
       for (int b = sl; b < nblk; b += nsl) {
-        const float4 p0 = *reinterpret_cast<const float4*>(part + ((size_t)b * 2 + 0) * c + col * 4);
-        const float4 p1 = *reinterpret_cast<const float4*>(part + ((size_t)b * 2 + 1) * c + col * 4);
-        t[0] += (double)p0.x; t[1] += (double)p0.y; t[2] += (double)p0.z; t[3] += (double)p0.w;
-        t[4] += (double)p1.x; t[5] += (double)p1.y; t[6] += (double)p1.z; t[7] += (double)p1.w;
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pv[j] = __hip_atomic_load(part + ((size_t)b * 2 + 0) * c + col * 4 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pv[4 + j] = __hip_atomic_load(part + ((size_t)b * 2 + 1) * c + col * 4 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] += (double)pv[j];
       }
     }
     double* sd = reinterpret_cast<double*>(s0);           // BN_PT doubles fit: V >= 4
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(BN_PT) void k_bn_partial(const float* __restrict__ 
         }
       }
     }
-    if (threadIdx.x == 0) *fin.counter = 0u;
+    if (threadIdx.x == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -765,7 +782,10 @@ __global__ __launch_bounds__(BN_SL_PT) void k_bn_slice_bwd(const float* __restri
 // a zeroed ticket counter for one k_bn_partial launch that folds its own partials (see the kernel's tail), or NULL when that
 // is switched off (IRX_BN_LASTBLOCK=0: the separate k_bn_finalize launch) or the channel count does not fit its fold
 static unsigned* bn_counter(int c) {
-  static const bool on = !(getenv("IRX_BN_LASTBLOCK") && atoi(getenv("IRX_BN_LASTBLOCK")) == 0);
+  // OFF by default — a measured negative result (tools/bn_microbench.py, MI355X): the two agent-scope fences cost more than the
+  // launch they replace (gfx950 writes back / invalidates a whole L2 per fence): bf16 fwd 488 800 x 32: 39.9 -> 57.8 us,
+  // 81 261 x 128: 22.2 -> 43.8 us, 2 244 x 128: 12.2 -> 17.3 us. IRX_BN_LASTBLOCK=1 enables it.
+  static const bool on = getenv("IRX_BN_LASTBLOCK") && atoi(getenv("IRX_BN_LASTBLOCK")) != 0;
   if (!on || c % 4 != 0 || c / 4 > BN_PT) return nullptr;
   static std::atomic<unsigned*> base[16];
   static std::atomic<unsigned> next{0};
@@ -782,9 +802,13 @@ static unsigned* bn_counter(int c) {
 }
 
 // tensors up to this many bytes (n * c * element size of x) take the slice kernels: IRX_BN_SLICE_BYTES (dev knob; 0 switches
-// them off). Default 6 MB: the 20-29 k-row 128-channel levels of both encoders at B = 16 and everything below.
+// them off). Default 640 KB — measured (tools/bn_microbench.py, MI355X, bf16, us per call, three launches | slice kernel):
+//   2 244 x 128: fwd 12.2 | 10.4, bwd 14.2 | 12.0      4 636 x 128: 12.9 | 14.0, 15.0 | 18.3      8 990 x 128: 13.1 | 25.0, 15.6 | 59.4
+//   20 267 x 128: 14.7 | 77.5      81 261 x 128: 22.2 | 298
+// i.e. a workgroup walking one 16-byte column streams ~12 GB/s (every lane of a load touches its own cache line and uses 16 of its
+// 128 bytes), so the single launch only pays below ~3 k rows, where three dependent launches (~4 us each) are all there is.
 static size_t bn_slice_max_bytes() {
-  static const long v = getenv("IRX_BN_SLICE_BYTES") ? atol(getenv("IRX_BN_SLICE_BYTES")) : (6L << 20);
+  static const long v = getenv("IRX_BN_SLICE_BYTES") ? atol(getenv("IRX_BN_SLICE_BYTES")) : (640L << 10);
   return v > 0 ? (size_t)v : 0;
 }
 static bool bn_slice_ok(int n, int c, int x_bf) {
@@ -1111,7 +1135,8 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
     // one launch for a tensor that stays on-die (k_bn_slice_bwd): both passes of the local-statistics case
     const bool all_f32 = !(x_bf | y_bf | dy_bf | dx_bf | dres_bf);
     const bool sl_types = all_f32 || (x_bf && dx_bf && (!dresidual || dres_bf) && (dy_bf == y_bf || mk_beta));
-    if (phases == 3 && relu && dx && gamma && sl_types && v4 && bn_slice_ok(n, c, x_bf) && !(bn_abl() & 12)) {
+    if (phases == 3 && relu && dx && gamma && sl_types && v4 && !dresidual && bn_slice_ok(n, c, x_bf) && !(bn_abl() & 12)) {
+      // (with a shortcut gradient to write the slice kernel measured slower even at 2 244 rows: 16.1 vs 14.5 us)
       const hipStream_t st = S(stream);
 #define BN_SL_BWD(V_, XB_, YB_)                                                                                               \
   do {                                                                                                                        \

@@ -164,6 +164,45 @@ class ContrastiveFn(torch.autograd.Function):
 
 
 
+class TotalLossFn(torch.autograd.Function):
+    """get_loss's arithmetic in ONE launch, gradients included (irx_total_loss, csrc/irx_match.hip): language cross-entropy,
+    area cross-entropy + accuracy, batched ContrastiveLoss / batch_size and their weighted sum (reference lib/loss_helper.py:
+    93-118,121-150,248-263). -> (loss (1,), ref_loss (1,), lang_loss (), seg_loss (), seg_acc ()); only `loss` is differentiable.
+    The backward is one multiply of the stored gradients by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, lang_scores, seg_scores, s1, s2, s3, lang_label, seg_label, lab, seg_off, keep, gamma, margin, ref_weight,
+                batch_size):
+        lang_scores, seg_scores = lang_scores.contiguous().float(), seg_scores.contiguous().float()
+        s1, s2, s3 = s1.contiguous().float(), s2.contiguous().float(), s3.contiguous().float()
+        B, n_lang = lang_scores.shape
+        n_seg = seg_scores.shape[1]
+        nscored, ns = int(keep.shape[0]), int(s1.shape[0])
+        dev = lang_scores.device
+        out = torch.empty(5, dtype=_f32, device=dev)
+        grads = torch.zeros(B * n_lang + B * n_seg + ns, dtype=_f32, device=dev) if nscored == 0 else \
+            torch.empty(B * n_lang + B * n_seg + ns, dtype=_f32, device=dev)
+        o1, o2 = B * n_lang, B * n_lang + B * n_seg
+        _lib.call("irx_total_loss", _lib.ptr(lang_scores), _lib.ptr(lang_label), B, n_lang, _lib.ptr(seg_scores), _lib.ptr(seg_label),
+                  n_seg, _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(s3), _lib.ptr(lab), _lib.ptr(seg_off), _lib.ptr(keep), nscored,
+                  float(gamma), float(margin), float(ref_weight), int(batch_size), _lib.ptr(out), grads.data_ptr(),
+                  grads.data_ptr() + 4 * o1, grads.data_ptr() + 4 * o2, _lib.stream_ptr())
+        ctx.save_for_backward(grads)
+        ctx.dims = (B, n_lang, n_seg, ns)
+        loss, ref, lang, seg, acc = out[0:1], out[1:2], out[2], out[3], out[4]
+        ctx.mark_non_differentiable(ref, lang, seg, acc)
+        return loss, ref, lang, seg, acc
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        (grads,) = ctx.saved_tensors
+        B, n_lang, n_seg, ns = ctx.dims
+        scaled = grads * g.reshape(1).to(grads.dtype)
+        o1, o2 = B * n_lang, B * n_lang + B * n_seg
+        ds = scaled[o2:o2 + ns]
+        return (scaled[:o1].view(B, n_lang), scaled[o1:o2].view(B, n_seg), ds, ds, ds) + (None,) * 9
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The head MLPs nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, [Dropout], Linear) as ONE autograd node (csrc/irx_mlp.hip)
 class MLP2Fn(torch.autograd.Function):

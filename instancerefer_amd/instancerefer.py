@@ -22,6 +22,7 @@ _PREP_PLANS = _os.environ.get('IRX_PREP_PLANS', '0') == '1'
 # (GPU-paced). Training mode on a HIP device only; IRX_LANG_THREAD=0 issues it inline.
 _LANG_THREAD = _os.environ.get('IRX_LANG_THREAD', '1') == '1'
 _STREAMS = _os.environ.get('IRX_STREAMS', '1') == '1'            # three-stream training forward (_forward_streams); 0: round-4 layout
+_PREBUILD_BWD = _os.environ.get('IRX_PREBUILD_BWD', '0') == '1'   # backward-only tables built behind the scene head: measured neutral (3004-3013 vs 2920-2998 scenes/s), off
 _REL_THREAD = _os.environ.get('IRX_REL_THREAD', '0') == '1'      # dev: the relation head on that thread too (behind the language module)
 MARK = None        # dev: bench.py's timeline mode installs a callable(name) here (phase marks inside forward)
 _ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
@@ -277,6 +278,15 @@ class InstanceRefer(nn.Module):
         with torch.cuda.stream(side):
             side.wait_event(ev)
             data_dict = self.scene.head(data_dict)
+            # ... and, behind it, the tables only the encoders' backward passes need (pair lists, transposed maps): this stream
+            # idles until the loss comes back, and they would otherwise head the backward chains
+            if _PREBUILD_BWD:
+                from .sparse.encoder_fn import prebuild_backward
+                prebuild_backward(self.scene.net, data_dict['lidar'].level())
+                prep = data_dict.get('_attr_prepared')
+                if prep is not None and prep[0] is not None:
+                    side.wait_stream(main)                   # the candidate levels' kernel maps were built on the main stream
+                    prebuild_backward(self.attribute.net, prep[0].level(), use_stream=main)
         if MARK: MARK("fwd: scene head issued")
         main.wait_event(ev)
         data_dict = self.attribute(data_dict)

@@ -274,17 +274,35 @@ def prepare_labels(data_dict, config, device=None):
     return out
 
 
+import os as _os
+FUSED_LOSS = _os.environ.get('IRX_FUSED_LOSS', '1') != '0'     # dev / test switch: 0 = the operator-by-operator formulation
+
+
 def get_loss(data_dict, config):
     """Same outputs as the reference (loss, ref_loss, lang_loss, seg_loss, seg_acc, cluster_label), but batched:
     IoU labelling = one vectorised numpy pass over all candidates (prepare_labels), ONE H2D copy of the labels, and the
     per-sample ContrastiveLoss evaluated for all scenes at once on a (scenes x max_candidates) padded matrix (-inf
     padding for the log-sum-exp) — ~10 launches instead of ~10 per sample."""
-    lang_loss = compute_lang_classification_loss(data_dict)
-    data_dict["lang_loss"] = lang_loss
-    dev = lang_loss.device
+    dev = data_dict["lang_scores"].device
     lp = data_dict.pop('_loss_prepared', None)
     if lp is None:
         lp = prepare_labels(data_dict, config, dev)
+    if (FUSED_LOSS and dev.type == 'cuda' and lp.get('area_label') is not None and lp['total'] > 0 and lp['srow'] > 0
+            and data_dict['lang_scores'].dim() == 2 and data_dict['seg_scores'].dim() == 2):
+        # the whole loss in one launch each way (csrc/irx_match.hip, k_total_loss): it sits on the step's critical path between
+        # the last head's forward and the first head's backward
+        from .dense import TotalLossFn
+        loss, ref_loss, lang_loss, seg_loss, seg_acc = TotalLossFn.apply(
+            data_dict['lang_scores'], data_dict['seg_scores'], data_dict['attribute_scores'], data_dict['relation_scores'],
+            data_dict['scene_scores'], data_dict['object_cat'].to(dev), lp['area_label'], lp['lab'], lp['seg_off'], lp['keep_dev'],
+            5.0, 0.2, 10.0, lp['batch_size'])
+        starts, label_dev, counts = lp['starts'], lp['label_dev'], lp['counts']
+        data_dict.update(lang_loss=lang_loss, ref_loss=ref_loss, loss=loss, seg_loss=seg_loss, seg_acc=seg_acc,
+                         cluster_label=[label_dev[starts[i]:starts[i + 1]] if counts[i] else [] for i in range(lp['batch_size'])])
+        data_dict['_labels'] = lp
+        return data_dict
+    lang_loss = compute_lang_classification_loss(data_dict)
+    data_dict["lang_loss"] = lang_loss
     if lp.get('area_label') is not None:             # label computed with the other labels on the host
         pred, label = data_dict['seg_scores'], lp['area_label']
         seg_loss = nn.functional.cross_entropy(pred, label)

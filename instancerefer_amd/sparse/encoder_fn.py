@@ -294,6 +294,53 @@ def prebuild(encoder, level0):
     _level_desc(encoder, layers, params, storage_bf16(False))
 
 
+def _backward_tables(layers):
+    """The tables only the backward pass needs: pair lists of every layer whose weight gradient runs over them (all missing ones
+    in ONE library call) and the transposed child maps of the strided layers. Lazily built and cached on the levels."""
+    missing, seen = [], set()
+    for L in layers:
+        if _uses_pairs(L):
+            if L.down:
+                dm = L.lv_in.down()
+                if dm._pairs is None and id(dm) not in seen:
+                    seen.add(id(dm))
+                    missing.append((dm, (dm.child, dm.ld, dm.out_level.n, 8)))
+            elif L.lv_in._pairs27 is None and id(L.lv_in) not in seen:
+                seen.add(id(L.lv_in))
+                tbl27, ld27 = L.lv_in.nbr27()
+                missing.append((L.lv_in, (tbl27, ld27, L.lv_in.n, 27)))
+    if missing:
+        for (holder, _), built in zip(missing, F_.pairs_build_multi([m[1] for m in missing])):
+            if hasattr(holder, "_pairs27"):
+                holder._pairs27 = built
+            else:
+                holder._pairs = built
+    for L in layers:
+        if L.down:
+            L.lv_in.down().child_t()
+
+
+def prebuild_backward(encoder, level0, use_stream=None):
+    """Build the backward-only tables of `encoder`'s pass over this pyramid NOW, on the current stream (~70 us of kernels for the
+    scene encoder at B = 16 that otherwise sit at the head of its backward, on the step's critical path): InstanceRefer's
+    multi-stream forward calls it behind the scene head, when that stream has nothing else to do until the loss comes back.
+    use_stream: the stream the backward will run on when it is not the current one (an event orders it behind the build)."""
+    if not can_fuse(encoder):
+        return
+    layers = build_plan(encoder, level0)
+    _backward_tables(layers)
+    if use_stream is not None and use_stream != torch.cuda.current_stream():
+        ev = torch.cuda.Event()
+        ev.record()
+        layers.pre["bwd_event"] = ev
+        for L in layers:
+            if _uses_pairs(L):
+                for t in (L.lv_in.down().pairs() if L.down else L.lv_in.pairs27())[:3]:
+                    t.record_stream(use_stream)
+            if L.down:
+                L.lv_in.down().child_t()[0].record_stream(use_stream)
+
+
 class Launched:
     """An encoder forward pass that has been ISSUED (kernels enqueued or handed to a lane) but whose autograd node does not exist
     yet: launch() -> Launched, EncoderFn.apply(feats, encoder, launched, *params) creates the node later without launching
@@ -415,25 +462,10 @@ class EncoderFn(torch.autograd.Function):
             TRACE["bwd"] = dict(garena=garena, goffs=goffs, dout=dout, store=store)
         desc = ctx.desc.copy()
         need_dx0 = ctx.needs_input_grad[0]
-        # pair lists still missing for this pyramid: all of them in one library call
-        missing, seen = [], set()
-        for L in layers:
-            if _uses_pairs(L):
-                if L.down:
-                    dm = L.lv_in.down()
-                    if dm._pairs is None and id(dm) not in seen:
-                        seen.add(id(dm))
-                        missing.append((dm, (dm.child, dm.ld, dm.out_level.n, 8)))
-                elif L.lv_in._pairs27 is None and id(L.lv_in) not in seen:
-                    seen.add(id(L.lv_in))
-                    tbl27, ld27 = L.lv_in.nbr27()
-                    missing.append((L.lv_in, (tbl27, ld27, L.lv_in.n, 27)))
-        if missing:
-            for (holder, _), built in zip(missing, F_.pairs_build_multi([m[1] for m in missing])):
-                if hasattr(holder, "_pairs27"):
-                    holder._pairs27 = built
-                else:
-                    holder._pairs = built
+        ev = layers.pre.pop("bwd_event", None) if isinstance(layers, Plan) else None
+        if ev is not None:                                  # tables prebuilt on another stream (prebuild_backward)
+            torch.cuda.current_stream().wait_event(ev)
+        _backward_tables(layers)                            # pair lists / transposed maps still missing: built here
         tb, pr = [], []
         for L in layers:
             if L.down:
