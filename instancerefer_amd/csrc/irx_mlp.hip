@@ -6,9 +6,10 @@
 // KB — with the bf16 step host-bound that is ~1 ms per step of pure dispatch.  Here: 2 launches forward, 2 (BatchNorm) or 3
 // (LayerNorm) backward, issued by one C-ABI call each; deterministic (no atomics); any row count.
 //
-// The GEMMs are 16..512 rows x 128..256: far too small for the matrix core to matter (8 MFLOP), so they run as LDS-tiled
-// fp32 FMA loops; a workgroup owns a block of 32 hidden (or output) columns for ALL rows, which makes every per-column
-// reduction over the rows (BatchNorm statistics, d gamma, d beta, d bias) local to one workgroup.
+// The GEMMs are 16..512 rows x 128..256 (8 MFLOP): LDS-staged 64 x 32 tiles multiplied with v_mfma_f32_16x16x4_f32 (round 5; the
+// fp32 FMA loop they replaced was most of a kernel's time once its dependent global round trips had been batched); a workgroup
+// owns a block of 32 hidden (or output) columns for ALL rows, which makes every per-column reduction over the rows (BatchNorm
+// statistics, d gamma, d beta, d bias) local to one workgroup.
 #include "irx_common.h"
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
@@ -28,6 +29,9 @@ static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 template <typename FA, typename FB>
 __device__ __forceinline__ void ml_tile(FA A, FB B, int K, float (&acc)[8], float (*sA)[ML_LD], float (*sB)[ML_LD]) {
   const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
+  const int wv = t >> 6, mm = t & 15, g4 = (t & 63) >> 4;
+  typedef float ml_f32x4 __attribute__((ext_vector_type(4)));
+  ml_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
   constexpr int NA = ML_TR * ML_TK / 256, NB = ML_TC * ML_TK / 256;
   float ra[NA], rb[NB];
   auto fetch = [&](int k0) __attribute__((always_inline)) {
@@ -57,19 +61,28 @@ __device__ __forceinline__ void ml_tile(FA A, FB B, int K, float (&acc)[8], floa
     }
     __syncthreads();
     if (k0 + ML_TK < K) fetch(k0 + ML_TK);            // the next chunk travels while this one is multiplied
-    const int kn = (K - k0 < ML_TK) ? K - k0 : ML_TK;  // (columns kn .. of the chunk hold zeros: whole float4 steps are safe)
+    const int kn = (K - k0 < ML_TK) ? K - k0 : ML_TK;  // (columns kn .. of the chunk hold zeros: whole 4-steps are safe)
+    // round 5: the products on the matrix core — v_mfma_f32_16x16x4_f32, wave w owns rows 16 w .. 16 w + 15 x both 16-column
+    // halves: 3 conflict-free ds_read_b32 + 2 MFMAs per 4 reduction steps instead of 9 ds_read_b128 + 32 v_fma per thread
+    // (the FMA loop was ~2.7 us per 128-wide chunk with one wave per SIMD and nothing to overlap its LDS waits with)
+#pragma unroll 8
     for (int k = 0; k < kn; k += 4) {
-      const float4 b = *reinterpret_cast<const float4*>(&sB[j][k]);
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const float4 a4 = *reinterpret_cast<const float4*>(&sA[i0 + 8 * m][k]);
-        acc[m] = fmaf(a4.x, b.x, acc[m]);
-        acc[m] = fmaf(a4.y, b.y, acc[m]);
-        acc[m] = fmaf(a4.z, b.z, acc[m]);
-        acc[m] = fmaf(a4.w, b.w, acc[m]);
-      }
+      const float av = sA[16 * wv + mm][k + g4];
+      const float b0 = sB[mm][k + g4], b1 = sB[16 + mm][k + g4];
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, d1, 0, 0, 0);
     }
   }
+  // accumulator layout of the MFMA (rows 16 w + 4 g4 + r, column mm | 16 + mm) -> the callers' (row i0 + 8 m, column j)
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    sA[16 * wv + 4 * g4 + r][mm] = d0[r];
+    sA[16 * wv + 4 * g4 + r][16 + mm] = d1[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] += sA[i0 + 8 * m][j];
 }
 
 // block-wide column sums: v[m] of thread (j, i0) for rows i0 + 8 m -> total over the 64 rows of the tile, valid in threads
@@ -127,13 +140,18 @@ __global__ __launch_bounds__(256) void k_mlp_fwd1(const float* __restrict__ x, i
   const bool cv = c < dh;
   double s1 = 0.0, s2 = 0.0;
   float hv[8];
+  // the column's parameters travel with the first tile's operands (loaded behind the tile they were one more dependent round
+  // trip each: bias, then gamma / beta, then the running statistics)
+  const bool has_nrm = norm != ML_NONE && norm != ML_LN;
+  const float bias = cv ? b1[c] : 0.f;
+  const float gam_c = (cv && has_nrm) ? gamma[c] : 1.f, bet_c = (cv && has_nrm) ? beta[c] : 0.f;
+  const float rm_c = (cv && has_nrm && rmean) ? rmean[c] : 0.f, rv_c = (cv && has_nrm && rvar) ? rvar[c] : 1.f;
   for (int r0 = 0; r0 < rows; r0 += ML_TR) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     ml_tile([&](int i, int k) { return (r0 + i < rows) ? x[(size_t)(r0 + i) * din + k] : 0.f; },
             [&](int jj, int k) { const int cc = blockIdx.x * ML_TC + jj; return cc < dh ? w1[(size_t)cc * din + k] : 0.f; },
             din, acc, sA, sB);
     float p1 = 0.f, p2 = 0.f;
-    const float bias = cv ? b1[c] : 0.f;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int r = r0 + i0 + 8 * m;
@@ -178,22 +196,22 @@ __global__ __launch_bounds__(256) void k_mlp_fwd1(const float* __restrict__ x, i
     invstd = (float)(1.0 / sqrt(var + (double)eps));
     if (cv && i0 == 0 && rmean) {                     // nn.BatchNorm1d: running statistics with the unbiased variance
       const double unb = rows > 1 ? var * rows / (rows - 1) : var;
-      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+      rmean[c] = (1.f - momentum) * rm_c + momentum * mean;
+      rvar[c] = (1.f - momentum) * rv_c + momentum * (float)unb;
     }
   } else if (norm == ML_NONE) {                         // Linear -> ReLU -> Dropout -> Linear: the identity "normalisation"
     mean = 0.f;
     invstd = 1.f;
   } else {
-    mean = cv ? rmean[c] : 0.f;
-    invstd = cv ? rsqrtf(rvar[c] + eps) : 0.f;
+    mean = cv ? rm_c : 0.f;
+    invstd = cv ? rsqrtf(rv_c + eps) : 0.f;
   }
   if (cv && i0 == 0) {
     stat[c] = mean;
     stat[dh + c] = invstd;
   }
   if (!cv) return;
-  const float g = norm == ML_NONE ? 1.f : gamma[c] * invstd, bsh = norm == ML_NONE ? 0.f : beta[c] - mean * g;
+  const float g = norm == ML_NONE ? 1.f : gam_c * invstd, bsh = norm == ML_NONE ? 0.f : bet_c - mean * g;
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   if (one_tile) {
 #pragma unroll
@@ -223,6 +241,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, i
   const int t = threadIdx.x, j = t & 31, i0 = t >> 5;
   const int c = blockIdx.x * ML_TC + j;
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const float bias2 = c < dout ? b2[c] : 0.f;           // (travels with the first loads instead of behind the tile)
   for (int r0 = 0; r0 < rows; r0 += ML_TR) {
     if (norm == ML_LN) {                              // every block recomputes the tile's row statistics (dh <= 512 floats a row)
       __syncthreads();
@@ -234,12 +253,34 @@ __global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, i
         const int i = t >> 2, q = t & 3, r = r0 + i;
         float p1 = 0.f, p2 = 0.f;
         const float* hr = h + (size_t)(r < rows ? r : 0) * dh;
-        const int nq = (r < rows) ? (dh - q + 3) / 4 : 0;            // this thread's terms: k = q, q + 4, ...
-        p1 = ml_sum8(nq, [&](int u) { return hr[q + 4 * u]; });
-        p1 += __shfl_xor(p1, 1);
-        p1 += __shfl_xor(p1, 2);
-        const float m = p1 / dh;
-        p2 = ml_sum8(nq, [&](int u) { const float d = hr[q + 4 * u] - m; return d * d; });
+        float m;
+        if (dh <= 256 && (dh & 15) == 0) {
+          // the thread's quarter of the row in ONE round trip (<= 16 float4 loads, all in flight) and kept for the second pass:
+          // this prologue was 16 dependent round trips (two passes of 8 batches) = 10-13 us of a 29 us kernel (round 5)
+          float4 v[16];
+          const int nv = (r < rows) ? dh / 16 : 0;
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            v[u] = (u < nv) ? *reinterpret_cast<const float4*>(hr + 4 * (q + 4 * u)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int u = 0; u < 16; ++u) p1 += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+          p1 += __shfl_xor(p1, 1);
+          p1 += __shfl_xor(p1, 2);
+          m = p1 / dh;
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (u < nv) {
+              const float d0 = v[u].x - m, d1 = v[u].y - m, d2 = v[u].z - m, d3 = v[u].w - m;
+              p2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        } else {
+          const int nq = (r < rows) ? (dh - q + 3) / 4 : 0;            // this thread's terms: k = q, q + 4, ...
+          p1 = ml_sum8(nq, [&](int u) { return hr[q + 4 * u]; });
+          p1 += __shfl_xor(p1, 1);
+          p1 += __shfl_xor(p1, 2);
+          m = p1 / dh;
+          p2 = ml_sum8(nq, [&](int u) { const float d = hr[q + 4 * u] - m; return d * d; });
+        }
         p2 += __shfl_xor(p2, 1);
         p2 += __shfl_xor(p2, 2);
         if (q == 0) {
@@ -250,24 +291,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, i
         }
       }
       __syncthreads();
-      if (blockIdx.x == 0) {                          // a (needed by the backward) is written once
-        for (int e0 = t; e0 < ML_TR * dh; e0 += 256 * 8) {         // 8 elements' loads in flight per thread
-          float hv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int e = e0 + 256 * u, i = e / dh, r = r0 + i;
-            hv[u] = (e < ML_TR * dh && r < rows) ? h[(size_t)r * dh + e % dh] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int e = e0 + 256 * u, i = e / dh, k = e % dh, r = r0 + i;
-            if (e < ML_TR * dh && r < rows) {
-              const size_t o = (size_t)r * dh + k;
-              a[o] = ml_drop(fmaxf(fmaf((hv[u] - sMean[i]) * sInv[i], gamma[k], beta[k]), 0.f), drop_p, dscale, seed, o);
-            }
-          }
-        }
-      }
+      // a (needed by the backward) is written once: every block's tile fetch below evaluates all of the tile's activations
+      // anyway, so block b stores the rows r = b (mod blocks) as it goes — the separate loop in block 0 was 8 more dependent
+      // round trips on the slowest workgroup
     }
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     ml_tile([&](int i, int k) {
@@ -275,7 +301,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, i
               if (r >= rows) return 0.f;
               const size_t o = (size_t)r * dh + k;
               if (norm != ML_LN) return a[o];
-              return ml_drop(fmaxf(fmaf((h[o] - sMean[i]) * sInv[i], gamma[k], beta[k]), 0.f), drop_p, dscale, seed, o);
+              const float v = ml_drop(fmaxf(fmaf((h[o] - sMean[i]) * sInv[i], gamma[k], beta[k]), 0.f), drop_p, dscale, seed, o);
+              if (r % (int)gridDim.x == (int)blockIdx.x) a[o] = v;
+              return v;
             },
             [&](int jj, int k) { const int cc = blockIdx.x * ML_TC + jj; return cc < dout ? w2[(size_t)cc * dh + k] : 0.f; },
             dh, acc, sA, sB);
@@ -283,7 +311,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd2(const float* __restrict__ h, i
     for (int m = 0; m < 8; ++m) {
       const int r = r0 + i0 + 8 * m;
       if (r < rows && c < dout) {
-        const float v = acc[m] + b2[c];
+        const float v = acc[m] + bias2;
         y[(size_t)r * dout + c] = out_relu ? fmaxf(v, 0.f) : v;
       }
     }
