@@ -21,7 +21,8 @@ _PREP_PLANS = _os.environ.get('IRX_PREP_PLANS', '0') == '1'
 # 5.83-5.88 -> 5.48-5.61 ms per step on one box, 5.57-5.64 -> 5.51-5.54 on a faster one; neutral in fp32 and at B = 32
 # (GPU-paced). Training mode on a HIP device only; IRX_LANG_THREAD=0 issues it inline.
 _LANG_THREAD = _os.environ.get('IRX_LANG_THREAD', '1') == '1'
-_STREAMS = _os.environ.get('IRX_STREAMS', '1') == '1'            # three-stream training forward (_forward_streams); 0: round-4 layout
+_STREAMS_ENV = _os.environ.get('IRX_STREAMS')                     # dev A/B switch: '0' / '1' overrides the policy in _streams_ok
+_STREAMS = _STREAMS_ENV != '0'                                   # three-stream training forward (_forward_streams); 0: round-4 layout
 _PREBUILD_BWD = _os.environ.get('IRX_PREBUILD_BWD', '0') == '1'   # backward-only tables built behind the scene head: measured neutral (3004-3013 vs 2920-2998 scenes/s), off
 _REL_THREAD = _os.environ.get('IRX_REL_THREAD', '0') == '1'      # dev: the relation head on that thread too (behind the language module)
 MARK = None        # dev: bench.py's timeline mode installs a callable(name) here (phase marks inside forward)
@@ -217,6 +218,13 @@ class InstanceRefer(nn.Module):
         """The three-stream forward needs the training configuration the bench / Solver run: every module present, candidates
         prepared from the GT classes (the encoders do not wait for the language module), a HIP device."""
         a = self.args
+        if _STREAMS_ENV is None:
+            # policy follows the compute dtype (measured on MI355X, B = 16, alternating runs): with bf16 operands the step is a
+            # set of latency-bound chains and the three-stream layout is +0.5-2 %; in fp32 it is bound by the fp32-MFMA
+            # convolutions, and the extra concurrency takes CUs from the scene encoder: 1816 -> 1664-1676 scenes/s (-8 %)
+            from . import get_compute_dtype
+            if get_compute_dtype() == 'fp32':
+                return False
         return (_STREAMS and self.training and torch.is_grad_enabled() and a.attribute_module and a.relation_module
                 and a.scene_module and data_dict['lang_feat'].is_cuda and 'lidar' in data_dict
                 and getattr(a, 'overlap_streams', True) and hasattr(self.scene, 'head')
@@ -389,19 +397,22 @@ class InstanceRefer(nn.Module):
         return get_compute_dtype() != 'fp32'
 
     def _encoder_stream(self, device):
-        """The scene encoder's stream. Priority follows the compute dtype (measured on MI355X, B = 16, alternating runs in
-        one session): in fp32 the step is GPU-bound and a NORMAL-priority scene stream is +1.5 % (1652 vs 1627 scenes/s:
-        the latency-bound chains of the main stream get their CUs sooner and everything is filled anyway); with bf16
-        operands the scene encoder is the long pole of a host-paced step and HIGH priority is +5 % (2056 vs 1960).
-        IRX_ENC_PRIO overrides."""
-        env = _os.environ.get('IRX_ENC_PRIO')
-        if env is not None:
-            prio = int(env)
-        else:
-            from . import get_compute_dtype
-            prio = -1 if get_compute_dtype() != 'fp32' else 0
+        """The scene encoder's stream: ONE per model and device, created on first use. Its priority follows the compute dtype in
+        force at that moment (measured on MI355X, B = 16, alternating runs in one session): in fp32 the step is GPU-bound and a
+        NORMAL-priority scene stream is +1.5 % (1652 vs 1627 scenes/s); with bf16 operands the scene encoder is the long pole
+        and HIGH priority is +5 % (2056 vs 1960). IRX_ENC_PRIO overrides.
+        Never a second stream after a dtype switch (round 5): the HIP runtime maps streams onto 4 hardware queues, this model
+        already uses four (main, scene, language, the loop's preparation stream), and a fifth shares a queue with one of them —
+        bench.py's second-dtype leg ran at HALF speed (fp32 992-1061 scenes/s in-process against 1816 in a process of its own)
+        until the scene stream was reused."""
         cache = self.__dict__.setdefault('_enc_streams', {})     # not module attributes: never pickled with the state
-        st = cache.get((str(device), prio))
+        st = cache.get((str(device), 'scene'))
         if st is None:
-            st = cache[(str(device), prio)] = torch.cuda.Stream(device=device, priority=prio)
+            env = _os.environ.get('IRX_ENC_PRIO')
+            if env is not None:
+                prio = int(env)
+            else:
+                from . import get_compute_dtype
+                prio = -1 if get_compute_dtype() != 'fp32' else 0
+            st = cache[(str(device), 'scene')] = torch.cuda.Stream(device=device, priority=prio)
         return st

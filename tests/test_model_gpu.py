@@ -746,6 +746,7 @@ def test_helper_thread_and_deferred_scene_node_change_nothing(lib, monkeypatch, 
             monkeypatch.setattr(SM, "_DEFER", on)
         else:
             monkeypatch.setattr(IR, "_STREAMS", on)
+            monkeypatch.setattr(IR, "_STREAMS_ENV", "1" if on else "0")     # (the policy alone keeps fp32 on one stream pair)
             monkeypatch.setattr(IR, "_LANG_THREAD", knob == "streams")
         _, _, opt, losses = _three_steps(dev, no_dropout=knob.startswith("streams"))
         out[on] = (losses, opt.flat_p.clone())
