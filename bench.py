@@ -111,7 +111,26 @@ _SPIN_US = float(os.environ.get("IRX_BENCH_SPIN_US", "0"))
 _MARKS = None          # dev (IRX_BENCH_TIMELINE=1): list receiving (name, event on the main stream, host clock) per step
 
 
+_HOSTCLK = [0.0, 0.0, 0.0, 0] if os.environ.get("IRX_BENCH_HOSTCLOCK") == "1" else None   # issue | backward() | in step_fn, steps
+
+
 def _mark(name):
+    if _HOSTCLK is not None:
+        # dev (IRX_BENCH_HOSTCLOCK=1; multi-rank rehearsal on one box): the training thread's own clock from "step start" to
+        # "optimizer issued" — what a rank's host needs to ISSUE a step, whatever the (shared) GPU is doing behind it
+        now = time.perf_counter()
+        if name == "step start":
+            _HOSTCLK.append(now)
+        elif name == "loss issued" and len(_HOSTCLK) > 4:
+            _HOSTCLK.append(now)
+            _HOSTCLK[0] += now - _HOSTCLK[4]          # forward + loss issued
+        elif name == "backward returned" and len(_HOSTCLK) > 5:
+            _HOSTCLK[1] += now - _HOSTCLK[5]          # inside backward()
+            _HOSTCLK.append(now)
+        elif name == "optimizer issued" and len(_HOSTCLK) > 6:
+            _HOSTCLK[2] += now - _HOSTCLK[6]          # gather + all-reduce (gloo here: a blocking host copy) + Adam launch
+            _HOSTCLK[3] += 1
+            del _HOSTCLK[4:]
     if _MARKS is not None:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
@@ -743,11 +762,23 @@ def main():
         gc.disable()
     barrier()
     log("warmup done")
+    if _HOSTCLK is not None:
+        _HOSTCLK[0] = _HOSTCLK[1] = 0.0
+        _HOSTCLK[3] = 0
+        del _HOSTCLK[4:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step_fn(model, resident, args.workload, reducer, opt, state)
     barrier()
     dt = time.perf_counter() - t0
+    if _HOSTCLK is not None and _HOSTCLK[3]:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "hostclock_rank%d_of_%d.txt" % (rank, world)), "w") as f:
+            f.write("rank %d of %d: training thread's clock per step: forward + loss issued %.3f ms | inside backward() %.3f ms | gather + "
+                    "all-reduce + Adam launch %.3f ms (gloo on a shared GPU: a blocking host copy of the 32 MB gradient buffer); wall "
+                    "%.3f ms/step over %d steps; B = %d; cores %s\n"
+                    % (rank, world, 1e3 * _HOSTCLK[0] / _HOSTCLK[3], 1e3 * _HOSTCLK[1] / _HOSTCLK[3], 1e3 * _HOSTCLK[2] / _HOSTCLK[3],
+                       1e3 * dt / args.steps, _HOSTCLK[3], B, binding))
     if world > 1 or force_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

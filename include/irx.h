@@ -612,6 +612,15 @@ int irx_total_loss(const float* lang_scores, const int64_t* lang_label, int B, i
                    float margin, float ref_weight, int batch_size, float* out, float* d_lang, float* d_seg, float* d_s,
                    void* stream);
 
+/* Language-guided attention pooling of the scene head (models/scene_module.py:84-93): logit[b][i] = <feats[b][i], lang[b]> * scale
+ * (scale = 1 / sqrt(d)), atten[b] = softmax over the n cells, out[b] = sum_i atten[b][i] feats[b][i]. feats [B][n][d], lang [B][d],
+ * atten [B][n], out [B][d]. Backward: dfeats [B][n][d], dlang [B][d] from dout [B][d] and (optional, may be NULL) datten [B][n].
+ * One workgroup per scene, deterministic. */
+int irx_attn_pool_fwd(const float* feats, const float* lang, int B, int n, int d, float scale, float* atten, float* out,
+                      void* stream);
+int irx_attn_pool_bwd(const float* feats, const float* lang, const float* atten, const float* dout, const float* datten,
+                      int B, int n, int d, float scale, float* dfeats, float* dlang, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

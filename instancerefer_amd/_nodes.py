@@ -13,16 +13,32 @@ ENABLED = os.environ.get("IRX_CPP_NODES", "1") != "0"
 _ENTRY_POINTS = ("irx_mlp2_saved_floats", "irx_mlp2_fwd", "irx_mlp2_bwd", "irx_gru_forward", "irx_gru_backward", "irx_gru_wgrad", "irx_last_error")
 _mod = None
 _tried = False
+_lock = __import__("threading").Lock()
 
 
 def load():
     """The extension module, bound to libirx — or None when it is switched off or has not been built (the callers then use
-    their Python autograd.Function: same kernels, more interpreter time; nothing here is a CPU fallback)."""
+    their Python autograd.Function: same kernels, more interpreter time; nothing here is a CPU fallback). Thread-safe (the language
+    module's helper thread reaches it too); a module OLDER than csrc/torch_nodes.cpp is refused with a warning — it would call the
+    C-ABI through the function types of another revision."""
     global _mod, _tried
     if _tried:
         return _mod
-    _tried = True
+    with _lock:
+        if _tried:
+            return _mod
+        mod = _load_locked()
+        _mod, _tried = mod, True
+        return mod
+
+
+def _load_locked():
     if not ENABLED or not os.path.exists(_build.NODES_PATH):
+        return None
+    if os.path.exists(_build.NODES_SRC) and os.path.getmtime(_build.NODES_PATH) < os.path.getmtime(_build.NODES_SRC):
+        import warnings
+        warnings.warn("instancerefer_amd: csrc/_irx_nodes.so is older than csrc/torch_nodes.cpp — the dense heads run through their "
+                      "Python / ATen path; rebuild with `python -m instancerefer_amd._build`", RuntimeWarning)
         return None
     try:
         spec = importlib.util.spec_from_file_location("_irx_nodes", _build.NODES_PATH)
@@ -35,5 +51,4 @@ def load():
         warnings.warn("instancerefer_amd: csrc/_irx_nodes.so could not be loaded (%s: %s) — the dense heads run through their "
                       "Python / ATen path; rebuild with `python -m instancerefer_amd._build`" % (type(e).__name__, e), RuntimeWarning)
         return None
-    _mod = mod
     return mod

@@ -294,3 +294,132 @@ extern "C" int irx_total_loss(const float* lang_scores, const int64_t* lang_labe
   IRX_CHECK_LAUNCH("irx_total_loss");
   return IRX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Language-guided attention pooling of the scene head (reference models/scene_module.py:84-93):
+//   logit[b][i] = <feats[b][i][:], lang[b][:]> / sqrt(D);  atten[b][:] = softmax_i(logit[b][:]);  out[b][:] = sum_i atten[b][i] feats[b][i][:]
+// Through ATen: bmm, div, softmax, mul, sum forward and ~10 launches backward on a (B, 231, 128) tensor — all on the step's
+// critical path (between the scene encoder's forward and its backward). Here one workgroup per scene each way, deterministic.
+#define AP_PT 256
+__global__ __launch_bounds__(AP_PT) void k_attn_pool_fwd(const float* __restrict__ feats, const float* __restrict__ lang, int n, int d,
+                                                         float scale, float* __restrict__ atten, float* __restrict__ out) {
+  extern __shared__ float ap_sm[];                 // [n] logits / weights, then [AP_PT] scratch
+  float* w = ap_sm;
+  float* red = ap_sm + n;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* f = feats + (size_t)b * n * d;
+  const float* l = lang + (size_t)b * d;
+  for (int i = wave; i < n; i += AP_PT / 64) {     // one wave per cell row
+    float p = 0.f;
+    for (int c = lane; c < d; c += 64) p = fmaf(f[(size_t)i * d + c], l[c], p);
+    p = wave_sum(p);
+    if (lane == 0) w[i] = p * scale;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int i = tid; i < n; i += AP_PT) mx = fmaxf(mx, w[i]);
+  red[tid] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    float m = -INFINITY;
+    for (int t = 0; t < AP_PT; ++t) m = fmaxf(m, red[t]);
+    red[0] = m;
+  }
+  __syncthreads();
+  mx = red[0];
+  __syncthreads();
+  float se = 0.f;
+  for (int i = tid; i < n; i += AP_PT) {
+    const float e = expf(w[i] - mx);
+    w[i] = e;
+    se += e;
+  }
+  red[tid] = se;
+  __syncthreads();
+  if (tid == 0) {
+    float t2 = 0.f;
+    for (int t = 0; t < AP_PT; ++t) t2 += red[t];      // fixed order
+    red[0] = t2;
+  }
+  __syncthreads();
+  const float inv = 1.f / red[0];
+  for (int i = tid; i < n; i += AP_PT) {
+    const float a = w[i] * inv;
+    w[i] = a;
+    atten[(size_t)b * n + i] = a;
+  }
+  __syncthreads();
+  for (int c = tid; c < d; c += AP_PT) {           // thread per channel, rows in order
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc = fmaf(w[i], f[(size_t)i * d + c], acc);
+    out[(size_t)b * d + c] = acc;
+  }
+}
+
+// d feats[i][:] = atten_i d out + dlogit_i scale lang;  dlogit_i = atten_i (g_i - sum_j atten_j g_j), g_i = <d out, feats_i> + d atten_i;
+// d lang = scale sum_i dlogit_i feats_i
+__global__ __launch_bounds__(AP_PT) void k_attn_pool_bwd(const float* __restrict__ feats, const float* __restrict__ lang,
+                                                         const float* __restrict__ atten, const float* __restrict__ dout,
+                                                         const float* __restrict__ datten, int n, int d, float scale,
+                                                         float* __restrict__ dfeats, float* __restrict__ dlang) {
+  extern __shared__ float ap_sm[];                 // [n] g / dlogit, then [AP_PT] scratch
+  float* g = ap_sm;
+  float* red = ap_sm + n;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* f = feats + (size_t)b * n * d;
+  const float* l = lang + (size_t)b * d;
+  const float* a = atten + (size_t)b * n;
+  const float* go = dout + (size_t)b * d;
+  for (int i = wave; i < n; i += AP_PT / 64) {
+    float p = 0.f;
+    for (int c = lane; c < d; c += 64) p = fmaf(go[c], f[(size_t)i * d + c], p);
+    p = wave_sum(p);
+    if (lane == 0) g[i] = p + (datten ? datten[(size_t)b * n + i] : 0.f);
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int i = tid; i < n; i += AP_PT) s += a[i] * g[i];
+  red[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float t2 = 0.f;
+    for (int t = 0; t < AP_PT; ++t) t2 += red[t];
+    red[0] = t2;
+  }
+  __syncthreads();
+  const float dot = red[0];
+  __syncthreads();
+  for (int i = tid; i < n; i += AP_PT) g[i] = a[i] * (g[i] - dot);       // dlogit
+  __syncthreads();
+  for (int c = tid; c < d; c += AP_PT) {
+    const float lc = l[c] * scale, gc = go[c];
+    float dl = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const size_t o = (size_t)i * d + c;
+      dfeats[(size_t)b * n * d + o] = fmaf(a[i], gc, g[i] * lc);
+      dl = fmaf(g[i], f[o], dl);
+    }
+    dlang[(size_t)b * d + c] = dl * scale;
+  }
+}
+
+extern "C" int irx_attn_pool_fwd(const float* feats, const float* lang, int B, int n, int d, float scale, float* atten, float* out,
+                                 void* stream) {
+  IRX_REQUIRE(B >= 0 && n >= 1 && d >= 1 && n <= 8192, "irx_attn_pool_fwd: bad sizes");
+  if (B == 0) return IRX_OK;
+  IRX_REQUIRE(feats && lang && atten && out, "irx_attn_pool_fwd: null pointer");
+  k_attn_pool_fwd<<<B, AP_PT, (size_t)(n + AP_PT) * sizeof(float), S(stream)>>>(feats, lang, n, d, scale, atten, out);
+  IRX_CHECK_LAUNCH("irx_attn_pool_fwd");
+  return IRX_OK;
+}
+
+extern "C" int irx_attn_pool_bwd(const float* feats, const float* lang, const float* atten, const float* dout, const float* datten,
+                                 int B, int n, int d, float scale, float* dfeats, float* dlang, void* stream) {
+  IRX_REQUIRE(B >= 0 && n >= 1 && d >= 1 && n <= 8192, "irx_attn_pool_bwd: bad sizes");
+  if (B == 0) return IRX_OK;
+  IRX_REQUIRE(feats && lang && atten && dout && dfeats && dlang, "irx_attn_pool_bwd: null pointer");
+  k_attn_pool_bwd<<<B, AP_PT, (size_t)(n + AP_PT) * sizeof(float), S(stream)>>>(feats, lang, atten, dout, datten, n, d, scale, dfeats,
+                                                                              dlang);
+  IRX_CHECK_LAUNCH("irx_attn_pool_bwd");
+  return IRX_OK;
+}

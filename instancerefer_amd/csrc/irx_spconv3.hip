@@ -420,7 +420,10 @@ int irx_spconv3_launch(const float* x, const float* wimg, const int32_t* nbr, in
   IRX_REQUIRE(irx_spconv3_supported(cin, cout), "irx_spconv3: channels (%d, %d) unsupported", cin, cout);
   IRX_REQUIRE(K <= 27, "irx_spconv3: K = %d > 27", K);
   IRX_REQUIRE(splits == 1 || (!accumulate && !y_bf), "irx_spconv3: offset-split slabs are plain fp32");
-  const dim3 grid(irx_cdiv(n_out, irx_spconv3_tile()), splits);
+  // rows per workgroup of the instantiation launched below: 32 rows per wave; Cin = 32 always runs 4 waves (IRX_S3_NW=8 only has
+  // 64- / 128-channel instantiations — the grid must follow the launch, not the knob: ADVICE r4)
+  const int tile = (s3_nw() == 8 && cin != 32) ? 256 : 128;
+  const dim3 grid(irx_cdiv(n_out, tile), splits);
   const int kps = irx_cdiv(K, splits);
   const unsigned short* xb = reinterpret_cast<const unsigned short*>(x);
   const uint4* wi = reinterpret_cast<const uint4*>(wimg);

@@ -5,6 +5,7 @@
 `gru_packed(gru, x, lengths)` reproduces `pad_packed_sequence(gru(pack_padded_sequence(x, lengths)))` of an
 `nn.GRU(batch_first=True)` (reference models/lang_module.py:53-57) using that module's own parameters
 (state-dict keys unchanged)."""
+import math
 import os
 
 import torch
@@ -162,6 +163,36 @@ class ContrastiveFn(torch.autograd.Function):
                   _lib.stream_ptr())
         return ds, ds, ds, None, None, None, None, None
 
+
+
+class AttentionPoolFn(torch.autograd.Function):
+    """(feats (B, n, D), lang (B, D)) -> (atten (B, n) = softmax_i(<feats_i, lang> / sqrt(D)), pooled (B, D) = sum_i atten_i feats_i):
+    the scene head's language-guided attention (reference models/scene_module.py:84-93) in one launch each way
+    (irx_attn_pool_fwd / _bwd, csrc/irx_match.hip) instead of bmm, div, softmax, mul, sum and their ~10 backward launches."""
+
+    @staticmethod
+    def forward(ctx, feats, lang):
+        feats, lang = feats.contiguous().float(), lang.contiguous().float()
+        B, n, d = feats.shape
+        atten = torch.empty((B, n), dtype=_f32, device=feats.device)
+        out = torch.empty((B, d), dtype=_f32, device=feats.device)
+        ctx.scale = 1.0 / math.sqrt(d)
+        _lib.call("irx_attn_pool_fwd", _lib.ptr(feats), _lib.ptr(lang), B, n, d, ctx.scale, _lib.ptr(atten), _lib.ptr(out),
+                  _lib.stream_ptr())
+        ctx.save_for_backward(feats, lang, atten)
+        return atten, out
+
+    @staticmethod
+    def backward(ctx, datten, dout):
+        feats, lang, atten = ctx.saved_tensors
+        B, n, d = feats.shape
+        dfeats = torch.empty_like(feats)
+        dlang = torch.empty_like(lang)
+        dout = dout.contiguous().float() if dout is not None else torch.zeros((B, d), dtype=_f32, device=feats.device)
+        datten = datten.contiguous().float() if datten is not None else None
+        _lib.call("irx_attn_pool_bwd", _lib.ptr(feats), _lib.ptr(lang), _lib.ptr(atten), _lib.ptr(dout), _lib.ptr(datten), B, n, d,
+                  ctx.scale, _lib.ptr(dfeats), _lib.ptr(dlang), _lib.stream_ptr())
+        return dfeats, dlang
 
 
 class TotalLossFn(torch.autograd.Function):

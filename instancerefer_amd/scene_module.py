@@ -11,13 +11,14 @@ import torch.nn as nn
 
 from .basic_blocks import BEVEncoder, SparseCrop, ToDenseBEVConvolution, batchnorm_rows, conv2d_rows
 from .data import idx_tensor
-from .dense import cosine_rows, mlp2
+from .dense import AttentionPoolFn, cosine_rows, mlp2
 from .sparse.encoder_fn import lane_of, lane_wait
 from .sparse import nn as spnn
 
 
 import os as _os
 _DEFER = _os.environ.get('IRX_SCENE_DEFER', '1') != '0'     # dev A/B switch (bit-identical results)
+_FUSED_ATTN = _os.environ.get('IRX_FUSED_ATTN', '0') == '1'  # AttentionPoolFn instead of bmm / softmax / sum through ATen: measured -1 % (3011-3023 vs 3032-3061 scenes/s: one workgroup per scene walks 231 rows serially), off
 
 
 class SceneModule(nn.Module):
@@ -85,12 +86,15 @@ class SceneModule(nn.Module):
         rows = conv2d_rows(self.vis_emb_fc[4], rows, batch_size, nx - 2, ny - 2)  # -> (B*11*21, D)
         h, w = nx - 4, ny - 4
         feats = rows.view(batch_size, h * w, self.h_dim)                        # (B, n_vis, D)
-        lang_feats = mlp2(self.lang_emb_fc, lang_feats).unsqueeze(2)
-        atten = torch.bmm(feats, lang_feats) / math.sqrt(feats.shape[2])
-        atten = torch.softmax(atten.squeeze(2), dim=1)
+        lang_feats = mlp2(self.lang_emb_fc, lang_feats)
+        if feats.is_cuda and _FUSED_ATTN:
+            atten, scene_feats = AttentionPoolFn.apply(feats, lang_feats)     # one launch each way (csrc/irx_match.hip)
+        else:
+            atten = torch.bmm(feats, lang_feats.unsqueeze(2)) / math.sqrt(feats.shape[2])
+            atten = torch.softmax(atten.squeeze(2), dim=1)
+            scene_feats = torch.sum(feats * atten.unsqueeze(2), dim=1)
         data_dict['vis_atten'] = atten.reshape(batch_size, h, w)
 
-        scene_feats = torch.sum(feats * atten.unsqueeze(2), dim=1)
         data_dict['seg_scores'] = mlp2(self.cls, scene_feats)
         data_dict['_scene_feats'] = scene_feats
         return data_dict

@@ -152,7 +152,9 @@ class Solver:
         args = getattr(self.model, "args", None)
         if args is not None and not getattr(args, "use_gt_lang", True):
             return True                            # arg-max of lang_scores: not known on the host before the forward
-        cats = [int(c) for c in torch.as_tensor(data_dict["object_cat"]).reshape(-1).tolist()]
+        host = data_dict.get("_host") or {}
+        src = host["object_cat"] if "object_cat" in host else data_dict["object_cat"]      # (the host copy: no D2H sync)
+        cats = [int(c) for c in torch.as_tensor(src).reshape(-1).tolist()]
         return any(sum(int(c) == cat for c in cls) >= 2 for cls, cat in zip(data_dict["instance_class"], cats))
 
     def sync_bn_guard(self, data_dict):
@@ -162,6 +164,12 @@ class Solver:
         runs only if EVERY rank can run every layer, otherwise all ranks drop this batch (counted in sync_bn_skipped)."""
         if not (self.sync_bn and self.world > 1):
             return True
+        args = getattr(self.model, "args", None)
+        if args is not None and not getattr(args, "use_gt_lang", True):
+            # the candidate set then depends on arg-max(lang_scores), unknown before the forward: the guard cannot promise that every
+            # rank runs every layer, and a rank without candidates would leave the others hanging in a collective
+            raise RuntimeError("sync BatchNorm with use_gt_lang=False is not supported: whether a rank runs the candidate encoder "
+                               "is only known inside the forward; train with the per-rank BatchNorm or with use_gt_lang=True")
         flag = torch.tensor([1 if self.has_scored_candidates(data_dict) else 0], dtype=torch.int32,
                             device=self.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -60,12 +60,12 @@ class Plan(list):
 def build_plan(encoder, level0):
     """Bind the coordinate levels / tables of this batch to the layer skeleton (the pyramid is already built)."""
     cache = level0.__dict__.setdefault("_irx_plans", {})
-    plan = cache.get(id(encoder))
+    token = encoder.__dict__.setdefault("_irx_token", _Token())     # (id() of a collected encoder can be handed out again)
+    plan = cache.get(token)
     if plan is not None:
         return plan
     layers = Plan()
     layers.pre = {}
-    cache[id(encoder)] = layers
     lv = level0
     for conv, bn, down, res in _skeleton(encoder):
         L = _Layer()
@@ -80,7 +80,13 @@ def build_plan(encoder, level0):
         L.n_in, L.n_out = lv.n, L.lv_out.n
         layers.append(L)
         lv = L.lv_out
+    cache[token] = layers               # only a COMPLETE plan is ever cached (an exception above leaves nothing behind)
     return layers
+
+
+class _Token:
+    """Identity of an encoder instance in the per-level plan cache."""
+    __slots__ = ("__weakref__",)
 
 
 def _ws(nbytes, dev):
@@ -248,7 +254,8 @@ def _level_desc(encoder, layers, params, store):
     lib = _lib.load()
     mode = int(lib.irx_get_compute_dtype())
     tmpl, fdesc, counters, cout, poffs, ptotal = _static_template(encoder, layers, params)
-    key = (bool(store), mode, id(tmpl))
+    # (the spconv3 / wgrad3 knobs change the workspace size and the split counts: part of the key)
+    key = (bool(store), mode, id(tmpl), int(lib.irx_debug_get_knob(b"spconv3")), int(lib.irx_debug_get_knob(b"wgrad3")))
     hit = layers.pre.get(key) if isinstance(layers, Plan) else None
     if hit is not None:
         return hit

@@ -60,6 +60,11 @@ side = torch.cuda.Stream()
 main = torch.cuda.current_stream()
 
 
+TIMES = [0.0, 0.0, 0]      # stage_launch on the worker, main thread waiting for it, steps
+WORKER = None
+if os.environ.get("IRX_E2E_WORKER", "1") != "0":
+    import bench as _bench
+    WORKER = _bench._Worker(torch.cuda.current_device())
 RESIDENT = None      # second leg: the sampled batch of the last end-to-end step, reused as a resident input
 
 
@@ -96,10 +101,28 @@ def loop(cur, n_warm, n_steps):
         for t in list(cur.values()) + [cur["irx"].xyz64, cur["irx"].pts32, cur["irx"].centres]:   # made on the side stream
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(main)
-        launched = stage_launch(step)
+        if WORKER is None:
+            launched = stage_launch(step)
         opt.zero_grad()
         out = get_loss(model(cur), cfg)
+        if WORKER is not None:
+            # the next batches' host work (box labels, augmentation draws, ~40 small launches) on a helper thread while this
+            # thread sits in the autograd engine's C++ loop (GIL released): in the host-paced bf16 mode that Python was 1.5 ms
+            # of a 6.4 ms step on the training thread (round 5: end to end / resident 0.73)
+            box = {}
+
+            def job():
+                t_ = time.perf_counter()
+                box["dd"] = stage_launch(step)
+                TIMES[0] += time.perf_counter() - t_
+            WORKER.post(job)
         out["loss"].backward()
+        if WORKER is not None:
+            t_ = time.perf_counter()
+            WORKER.wait()
+            TIMES[1] += time.perf_counter() - t_
+            TIMES[2] += 1
+            launched = box["dd"]
         if os.environ.get("IRX_E2E_FINISH_EARLY") == "1":      # dev A/B: collect the level sizes (and enqueue the tables) before the optimizer
             cur = stage_finish(launched)
             opt.backward_step()
@@ -122,6 +145,8 @@ with torch.cuda.stream(side):
     RESIDENT = finish(pend)
 torch.cuda.synchronize()
 dt_res, _, _ = loop(cur, max(5, a.warmup // 3), a.steps)
+if os.environ.get("IRX_E2E_TIMES") and TIMES[2]:
+    sys.stderr.write("worker: stage_launch %.3f ms/step, training thread waited %.3f ms/step\n" % (1e3 * TIMES[0] / TIMES[2], 1e3 * TIMES[1] / TIMES[2]))
 if a.json:
     import json
     print(json.dumps({"value": B * a.steps / dt, "unit": "scenes/s", "ms_per_step": 1e3 * dt / a.steps, "steps": a.steps,
