@@ -134,12 +134,17 @@ struct IrxStore {
   const int32_t* order = nullptr;   // launch order of the 64-row output tiles (irx_tile_order) or NULL = blockIdx order
   long long x_rows = 0;             // rows of x when the caller knows them (the third-generation bf16 kernel addresses rows with
                                     // 32-bit byte offsets and is only taken for a known size below 2 GiB); 0 = unknown
+  // the caller folds the offset-split slabs itself (encoder executor: into the BatchNorm statistics pass, irx_bn_forward_slabs_t):
+  // when both are set and the launch used S > 1 fp32 slabs [S][n_out][cout], *slabs_out / *splits_out receive them, y is NOT
+  // written and the reduce launch is skipped (the slabs live in the conv workspace: consume them before the next conv call)
+  float** slabs_out = nullptr;
+  int* splits_out = nullptr;
 };
 
 // ---- dev / test knobs (irx_debug_set_knob, include/irx.h): each is read from its environment variable ONCE, on first use, and
 // can afterwards only be changed through the setter (an atomic store) — a per-call getenv() from library lane threads raced
 // with tests that mutate os.environ from the Python thread.
-enum IrxKnob { IRX_KNOB_SPCONV3 = 0, IRX_KNOB_UPDGRAD, IRX_KNOB_UPDGRAD_MIN, IRX_KNOB_WGRAD_V1, IRX_KNOB_WGRAD3, IRX_KNOB_WGRAD3_UNITS, IRX_KNOB_WGRAD3_XCD_MIN, IRX_KNOB_WGRAD_XCD_F32, IRX_KNOB_COUNT };
+enum IrxKnob { IRX_KNOB_SPCONV3 = 0, IRX_KNOB_UPDGRAD, IRX_KNOB_UPDGRAD_MIN, IRX_KNOB_WGRAD_V1, IRX_KNOB_WGRAD3, IRX_KNOB_WGRAD3_UNITS, IRX_KNOB_WGRAD3_XCD_MIN, IRX_KNOB_WGRAD_XCD_F32, IRX_KNOB_FOLD_SLABS, IRX_KNOB_COUNT };
 long irx_knob(int id);
 
 // ---- measurement aid (irx_profile_next_kernel, include/irx.h): brackets the next DOMINANT sparse-conv kernel of this
@@ -229,6 +234,10 @@ int irx_bn_apply_t(const float* x, int n, int c, const float* mean, const float*
 int irx_bn_forward_t(const float* x, int n, int c, float eps, float momentum, const float* gamma, const float* beta,
                      const float* residual, int relu, float* mean, float* invstd, float* running_mean, float* running_var,
                      float* y, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int res_bf, int y_bf);
+int irx_bn_forward_slabs_t(const float* slabs, int S, int n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                           const float* residual, int relu, float* mean, float* invstd, float* running_mean, float* running_var,
+                           float* x_out, float* y, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int res_bf,
+                           int y_bf);
 int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, int c, const float* mean,
                       const float* invstd, const float* gamma, int relu, float* dx, float* dgamma, float* dbeta,
                       float* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int y_bf,

@@ -173,6 +173,13 @@ int encoder_forward_impl(const int64_t* desc, const double* fdesc, int n_layers,
     ty.order = L.order;
     ty.x_rows = L.n_in;
     const int y_bf = (st && i < n_layers - 1) ? 1 : 0;   // the encoder's output stays fp32
+    // offset-split layers (the small levels): the slabs are folded by the BatchNorm statistics pass instead of a reduce launch
+    float* slabs = nullptr;
+    int nslabs = 0;
+    if (!sync.cb && irx_knob(IRX_KNOB_FOLD_SLABS) != 0) {         // ("enc_fold_slabs" / IRX_ENC_FOLD_SLABS=0: dev A/B knob)
+      ty.slabs_out = &slabs;
+      ty.splits_out = &nslabs;
+    }
     if (L.prof) irx_profile_next_kernel(L.prof[0], L.prof[1]);
     int rc = irx_spconv_fwd_impl(L.x, L.w, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, 0, 0, L.c, 0, wimg[i], ws_c, r.conv,
                                  stream, ty);
@@ -193,6 +200,9 @@ int encoder_forward_impl(const int64_t* desc, const double* fdesc, int n_layers,
     if (L.res >= 0) res = (const float*)desc[(size_t)L.res * IRX_ENC_NFIELDS + IRX_ENC_Y];
     if (sync.cb)
       rc = irx_bn_apply_t(L.c, L.n_out, L.cout, L.mean, L.invstd, L.gamma, L.beta, res, 1, L.y, stream, st, st, y_bf);
+    else if (slabs)
+      rc = irx_bn_forward_slabs_t(slabs, nslabs, L.n_out, L.cout, L.eps, L.momentum, L.gamma, L.beta, res, 1, L.mean, L.invstd,
+                                  L.running_mean, L.running_var, L.c, L.y, ws_b, r.bn, stream, st, st, y_bf);
     else      // statistics + apply: one launch for the levels that stay on-die (irx_norm.hip, k_bn_slice_fwd), two + one otherwise
       rc = irx_bn_forward_t(L.c, L.n_out, L.cout, L.eps, L.momentum, L.gamma, L.beta, res, 1, L.mean, L.invstd, L.running_mean,
                             L.running_var, L.y, ws_b, r.bn, stream, st, st, y_bf);

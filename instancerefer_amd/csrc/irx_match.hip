@@ -300,33 +300,38 @@ extern "C" int irx_total_loss(const float* lang_scores, const int64_t* lang_labe
 //   logit[b][i] = <feats[b][i][:], lang[b][:]> / sqrt(D);  atten[b][:] = softmax_i(logit[b][:]);  out[b][:] = sum_i atten[b][i] feats[b][i][:]
 // Through ATen: bmm, div, softmax, mul, sum forward and ~10 launches backward on a (B, 231, 128) tensor — all on the step's
 // critical path (between the scene encoder's forward and its backward). Here one workgroup per scene each way, deterministic.
-#define AP_PT 256
+#define AP_PT 1024
+#define AP_NW (AP_PT / 64)
+// row-parallel everywhere: wave w owns rows w, w + 16, ...; lane l owns channels l, l + 64, ... (d <= 256: 4 per lane). A thread
+// per channel walking all n rows (the first version) was n dependent round trips: slower than the five ATen launches it replaced.
 __global__ __launch_bounds__(AP_PT) void k_attn_pool_fwd(const float* __restrict__ feats, const float* __restrict__ lang, int n, int d,
                                                          float scale, float* __restrict__ atten, float* __restrict__ out) {
-  extern __shared__ float ap_sm[];                 // [n] logits / weights, then [AP_PT] scratch
+  extern __shared__ float ap_sm[];                 // [n] logits / weights | [AP_NW][d] per-wave partial pooled rows | [AP_PT] scratch
   float* w = ap_sm;
-  float* red = ap_sm + n;
+  float* part = ap_sm + n;
+  float* red = part + AP_NW * d;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* f = feats + (size_t)b * n * d;
   const float* l = lang + (size_t)b * d;
-  for (int i = wave; i < n; i += AP_PT / 64) {     // one wave per cell row
+  float lv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) lv[q] = (lane + 64 * q < d) ? l[lane + 64 * q] : 0.f;
+  for (int i = wave; i < n; i += AP_NW) {
     float p = 0.f;
-    for (int c = lane; c < d; c += 64) p = fmaf(f[(size_t)i * d + c], l[c], p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (lane + 64 * q < d) p = fmaf(f[(size_t)i * d + lane + 64 * q], lv[q], p);
     p = wave_sum(p);
     if (lane == 0) w[i] = p * scale;
   }
   __syncthreads();
   float mx = -INFINITY;
   for (int i = tid; i < n; i += AP_PT) mx = fmaxf(mx, w[i]);
-  red[tid] = mx;
-  __syncthreads();
-  if (tid == 0) {
-    float m = -INFINITY;
-    for (int t = 0; t < AP_PT; ++t) m = fmaxf(m, red[t]);
-    red[0] = m;
-  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) red[wave] = mx;
   __syncthreads();
   mx = red[0];
+  for (int t = 1; t < AP_NW; ++t) mx = fmaxf(mx, red[t]);
   __syncthreads();
   float se = 0.f;
   for (int i = tid; i < n; i += AP_PT) {
@@ -334,25 +339,34 @@ __global__ __launch_bounds__(AP_PT) void k_attn_pool_fwd(const float* __restrict
     w[i] = e;
     se += e;
   }
-  red[tid] = se;
+  se = wave_sum(se);
+  if (lane == 0) red[wave] = se;
   __syncthreads();
-  if (tid == 0) {
-    float t2 = 0.f;
-    for (int t = 0; t < AP_PT; ++t) t2 += red[t];      // fixed order
-    red[0] = t2;
-  }
+  float tot = 0.f;
+  for (int t = 0; t < AP_NW; ++t) tot += red[t];     // fixed order, the same in every thread
+  const float inv = 1.f / tot;
   __syncthreads();
-  const float inv = 1.f / red[0];
   for (int i = tid; i < n; i += AP_PT) {
     const float a = w[i] * inv;
     w[i] = a;
     atten[(size_t)b * n + i] = a;
   }
   __syncthreads();
-  for (int c = tid; c < d; c += AP_PT) {           // thread per channel, rows in order
-    float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc = fmaf(w[i], f[(size_t)i * d + c], acc);
-    out[(size_t)b * d + c] = acc;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = wave; i < n; i += AP_NW) {
+    const float a = w[i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (lane + 64 * q < d) acc[q] = fmaf(a, f[(size_t)i * d + lane + 64 * q], acc[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (lane + 64 * q < d) part[wave * d + lane + 64 * q] = acc[q];
+  __syncthreads();
+  for (int c = tid; c < d; c += AP_PT) {
+    float t2 = 0.f;
+    for (int t = 0; t < AP_NW; ++t) t2 += part[t * d + c];
+    out[(size_t)b * d + c] = t2;
   }
 }
 
@@ -362,63 +376,77 @@ __global__ __launch_bounds__(AP_PT) void k_attn_pool_bwd(const float* __restrict
                                                          const float* __restrict__ atten, const float* __restrict__ dout,
                                                          const float* __restrict__ datten, int n, int d, float scale,
                                                          float* __restrict__ dfeats, float* __restrict__ dlang) {
-  extern __shared__ float ap_sm[];                 // [n] g / dlogit, then [AP_PT] scratch
+  extern __shared__ float ap_sm[];                 // [n] g / dlogit | [AP_NW][d] per-wave partial d lang | [AP_PT] scratch
   float* g = ap_sm;
-  float* red = ap_sm + n;
+  float* part = ap_sm + n;
+  float* red = part + AP_NW * d;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* f = feats + (size_t)b * n * d;
-  const float* l = lang + (size_t)b * d;
   const float* a = atten + (size_t)b * n;
-  const float* go = dout + (size_t)b * d;
-  for (int i = wave; i < n; i += AP_PT / 64) {
+  float lv[4], gv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool ok = lane + 64 * q < d;
+    lv[q] = ok ? lang[(size_t)b * d + lane + 64 * q] * scale : 0.f;
+    gv[q] = ok ? dout[(size_t)b * d + lane + 64 * q] : 0.f;
+  }
+  for (int i = wave; i < n; i += AP_NW) {
     float p = 0.f;
-    for (int c = lane; c < d; c += 64) p = fmaf(go[c], f[(size_t)i * d + c], p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (lane + 64 * q < d) p = fmaf(gv[q], f[(size_t)i * d + lane + 64 * q], p);
     p = wave_sum(p);
     if (lane == 0) g[i] = p + (datten ? datten[(size_t)b * n + i] : 0.f);
   }
   __syncthreads();
-  float s = 0.f;
-  for (int i = tid; i < n; i += AP_PT) s += a[i] * g[i];
-  red[tid] = s;
+  float sdot = 0.f;
+  for (int i = tid; i < n; i += AP_PT) sdot += a[i] * g[i];
+  sdot = wave_sum(sdot);
+  if (lane == 0) red[wave] = sdot;
   __syncthreads();
-  if (tid == 0) {
-    float t2 = 0.f;
-    for (int t = 0; t < AP_PT; ++t) t2 += red[t];
-    red[0] = t2;
-  }
-  __syncthreads();
-  const float dot = red[0];
+  float dot = 0.f;
+  for (int t = 0; t < AP_NW; ++t) dot += red[t];
   __syncthreads();
   for (int i = tid; i < n; i += AP_PT) g[i] = a[i] * (g[i] - dot);       // dlogit
   __syncthreads();
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = wave; i < n; i += AP_NW) {
+    const float ai = a[i], gi = g[i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (lane + 64 * q < d) {
+        const size_t o = (size_t)i * d + lane + 64 * q;
+        dfeats[(size_t)b * n * d + o] = fmaf(ai, gv[q], gi * lv[q]);
+        acc[q] = fmaf(gi, f[o], acc[q]);
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (lane + 64 * q < d) part[wave * d + lane + 64 * q] = acc[q];
+  __syncthreads();
   for (int c = tid; c < d; c += AP_PT) {
-    const float lc = l[c] * scale, gc = go[c];
-    float dl = 0.f;
-    for (int i = 0; i < n; ++i) {
-      const size_t o = (size_t)i * d + c;
-      dfeats[(size_t)b * n * d + o] = fmaf(a[i], gc, g[i] * lc);
-      dl = fmaf(g[i], f[o], dl);
-    }
-    dlang[(size_t)b * d + c] = dl * scale;
+    float t2 = 0.f;
+    for (int t = 0; t < AP_NW; ++t) t2 += part[t * d + c];
+    dlang[(size_t)b * d + c] = t2 * scale;
   }
 }
 
 extern "C" int irx_attn_pool_fwd(const float* feats, const float* lang, int B, int n, int d, float scale, float* atten, float* out,
                                  void* stream) {
-  IRX_REQUIRE(B >= 0 && n >= 1 && d >= 1 && n <= 8192, "irx_attn_pool_fwd: bad sizes");
+  IRX_REQUIRE(B >= 0 && n >= 1 && d >= 1 && d <= 256 && n <= 8192, "irx_attn_pool_fwd: bad sizes (d <= 256, n <= 8192)");
   if (B == 0) return IRX_OK;
   IRX_REQUIRE(feats && lang && atten && out, "irx_attn_pool_fwd: null pointer");
-  k_attn_pool_fwd<<<B, AP_PT, (size_t)(n + AP_PT) * sizeof(float), S(stream)>>>(feats, lang, n, d, scale, atten, out);
+  k_attn_pool_fwd<<<B, AP_PT, (size_t)(n + AP_NW * d + AP_PT) * sizeof(float), S(stream)>>>(feats, lang, n, d, scale, atten, out);
   IRX_CHECK_LAUNCH("irx_attn_pool_fwd");
   return IRX_OK;
 }
 
 extern "C" int irx_attn_pool_bwd(const float* feats, const float* lang, const float* atten, const float* dout, const float* datten,
                                  int B, int n, int d, float scale, float* dfeats, float* dlang, void* stream) {
-  IRX_REQUIRE(B >= 0 && n >= 1 && d >= 1 && n <= 8192, "irx_attn_pool_bwd: bad sizes");
+  IRX_REQUIRE(B >= 0 && n >= 1 && d >= 1 && d <= 256 && n <= 8192, "irx_attn_pool_bwd: bad sizes (d <= 256, n <= 8192)");
   if (B == 0) return IRX_OK;
   IRX_REQUIRE(feats && lang && atten && dout && dfeats && dlang, "irx_attn_pool_bwd: null pointer");
-  k_attn_pool_bwd<<<B, AP_PT, (size_t)(n + AP_PT) * sizeof(float), S(stream)>>>(feats, lang, atten, dout, datten, n, d, scale, dfeats,
+  k_attn_pool_bwd<<<B, AP_PT, (size_t)(n + AP_NW * d + AP_PT) * sizeof(float), S(stream)>>>(feats, lang, atten, dout, datten, n, d, scale, dfeats,
                                                                               dlang);
   IRX_CHECK_LAUNCH("irx_attn_pool_bwd");
   return IRX_OK;

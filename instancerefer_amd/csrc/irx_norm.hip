@@ -20,6 +20,7 @@ static inline int bn_rows(int n, int c) {
 }
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+static inline hipStream_t S_(void* s) { return (hipStream_t)s; }   // (where a parameter named S shadows the helper)
 #include <atomic>
 
 // Element types of the tensors of one BatchNorm call (0 = float32, 1 = bf16; bf16 needs the 4-wide path): the encoder
@@ -779,6 +780,88 @@ __global__ __launch_bounds__(BN_SL_PT) void k_bn_slice_bwd(const float* __restri
   }
 }
 
+// k_bn_partial<0> with the offset-split reduce of the convolution folded in (round 5): x does not exist yet — the conv left S fp32
+// slabs [S][n][c] — so this pass sums them (slab order, the adds of k_wgrad_reduce), stores x (bf16: XB, else fp32) for the apply
+// pass / the backward, and accumulates the statistics of the STORED value exactly like k_bn_partial<0> (same thread mapping, same
+// row order, same fold): bit-identical to reduce-then-statistics, one dependent launch fewer per split layer (~9 per encoder pass).
+template <int V, int XB>
+__global__ __launch_bounds__(BN_PT) void k_bn_partial_slabs(const float* __restrict__ slabs, int S, size_t elems, int n, int c,
+                                                          int qpad, int rows_per_block, float* __restrict__ x_out,
+                                                          float* __restrict__ part) {
+  __shared__ __align__(16) float s0[BN_PT * V];
+  __shared__ __align__(16) float s1[BN_PT * V];
+  const int cq = c / V;
+  const int qd = threadIdx.x % qpad;
+  const int rg = threadIdx.x / qpad;
+  const int nrg = BN_PT / qpad;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  float a0[V], a1[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) a0[j] = a1[j] = 0.f;
+  if (qd < cq) {
+    for (int r = r0 + rg; r < r1; r += nrg) {
+      const size_t off = (size_t)r * c + (size_t)qd * V;
+      float v[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = 0.f;
+      int sidx = 0;
+      for (; sidx + 4 <= S; sidx += 4) {                // 4 slabs' loads in flight, adds in slab order
+        float4 t[4][V / 4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < V / 4; ++q) t[u][q] = *reinterpret_cast<const float4*>(slabs + (size_t)(sidx + u) * elems + off + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < V / 4; ++q) {
+            v[4 * q] += t[u][q].x; v[4 * q + 1] += t[u][q].y; v[4 * q + 2] += t[u][q].z; v[4 * q + 3] += t[u][q].w;
+          }
+      }
+      for (; sidx < S; ++sidx)
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(slabs + (size_t)sidx * elems + off + 4 * q);
+          v[4 * q] += t.x; v[4 * q + 1] += t.y; v[4 * q + 2] += t.z; v[4 * q + 3] += t.w;
+        }
+      if constexpr (XB) {
+#pragma unroll
+        for (int j = 0; j < V; j += 2) {                  // what the store keeps is what the statistics see
+          const unsigned pk = irx_pk_bf16(v[j], v[j + 1]);
+          v[j] = __uint_as_float(pk << 16);
+          v[j + 1] = __uint_as_float(pk & 0xffff0000u);
+        }
+      }
+      sl_st<V, XB>(x_out, off, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        a0[j] += v[j];
+        a1[j] += v[j] * v[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    s0[threadIdx.x * V + j] = a0[j];
+    s1[threadIdx.x * V + j] = a1[j];
+  }
+  __syncthreads();
+  if (rg == 0 && qd < cq) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int g2 = 0; g2 < nrg; ++g2) {
+        t0 += s0[(g2 * qpad + qd) * V + j];
+        t1 += s1[(g2 * qpad + qd) * V + j];
+      }
+      part[((size_t)blockIdx.x * 2 + 0) * c + qd * V + j] = t0;
+      part[((size_t)blockIdx.x * 2 + 1) * c + qd * V + j] = t1;
+    }
+  }
+}
+
 // a zeroed ticket counter for one k_bn_partial launch that folds its own partials (see the kernel's tail), or NULL when that
 // is switched off (IRX_BN_LASTBLOCK=0: the separate k_bn_finalize launch) or the channel count does not fit its fold
 static unsigned* bn_counter(int c) {
@@ -1084,6 +1167,46 @@ extern "C" int irx_bn_forward(const float* x, int n, int c, float eps, float mom
                               float* running_var, float* y, void* workspace, size_t workspace_bytes, void* stream) {
   return irx_bn_forward_t(x, n, c, eps, momentum, gamma, beta, residual, relu, mean, invstd, running_mean, running_var, y,
                           workspace, workspace_bytes, stream, 0, 0, 0);
+}
+
+// irx_bn_forward_t for a convolution output that still is S offset-split slabs (IrxStore::slabs_out): the statistics pass folds them
+// and writes x_out (the tensor the backward reads); a tensor small enough for the slice kernel is reduced first and takes that path.
+__global__ void k_bn_slab_reduce(const float* __restrict__ part, int S, size_t elems, float* __restrict__ out, int out_bf) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= elems) return;
+  float s = 0.f;
+  for (int j = 0; j < S; ++j) s += part[(size_t)j * elems + i];
+  if (out_bf) reinterpret_cast<unsigned short*>(out)[i] = (unsigned short)(irx_pk_bf16(s, 0.f) & 0xffffu);
+  else out[i] = s;
+}
+int irx_bn_forward_slabs_t(const float* slabs, int S, int n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                           const float* residual, int relu, float* mean, float* invstd, float* running_mean, float* running_var,
+                           float* x_out, float* y, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int res_bf,
+                           int y_bf) {
+  IRX_REQUIRE(slabs && S >= 1 && x_out, "irx_bn_forward_slabs: bad arguments");
+  const size_t elems = (size_t)n * c;
+  const int v = x_bf ? 8 : 4;
+  const bool fold = n > 0 && c % v == 0 && (((uintptr_t)slabs | (uintptr_t)x_out) & 15) == 0 && !(relu && bn_slice_ok(n, c, x_bf)) &&
+                    !(bn_abl() & 1);
+  if (!fold) {
+    if (n > 0) {
+      k_bn_slab_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S_(stream)>>>(slabs, S, elems, x_out, x_bf);
+      IRX_CHECK_LAUNCH("irx_bn_forward_slabs(reduce)");
+    }
+    return irx_bn_forward_t(x_out, n, c, eps, momentum, gamma, beta, residual, relu, mean, invstd, running_mean, running_var, y,
+                            workspace, workspace_bytes, stream, x_bf, res_bf, y_bf);
+  }
+  int rc = bn_check("irx_bn_forward_slabs", n, c, workspace, workspace_bytes);
+  if (rc) return rc;
+  const int nblk = irx_cdiv(n, bn_rows(n, c));
+  float* part = (float*)workspace;
+  if (x_bf) k_bn_partial_slabs<8, 1><<<nblk, BN_PT, 0, S_(stream)>>>(slabs, S, elems, n, c, next_pow2(c / 8), bn_rows(n, c), x_out, part);
+  else k_bn_partial_slabs<4, 0><<<nblk, BN_PT, 0, S_(stream)>>>(slabs, S, elems, n, c, next_pow2(c / 4), bn_rows(n, c), x_out, part);
+  IRX_CHECK_LAUNCH("irx_bn_forward_slabs(partial)");
+  k_bn_finalize<0><<<irx_cdiv(c, 32), 32 * BN_FIN_SLICES, 0, S_(stream)>>>(part, nblk, n, c, eps, momentum, mean, invstd, running_mean,
+                                                                          running_var);
+  IRX_CHECK_LAUNCH("irx_bn_forward_slabs(finalize)");
+  return irx_bn_apply_t(x_out, n, c, mean, invstd, gamma, beta, residual, relu, y, stream, x_bf, res_bf, y_bf);
 }
 
 extern "C" int irx_bn_backward(const float* x, const float* y, const float* dy, int n, int c,

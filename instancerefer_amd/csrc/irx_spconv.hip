@@ -298,6 +298,7 @@ const KnobDef kKnobs[IRX_KNOB_COUNT] = {
     {"wgrad3_units", "IRX_WGRAD3_UNITS", 448},   // ... work units (workgroups) of its XCD-segment mapping
     {"wgrad3_xcd_min", "IRX_WGRAD3_XCD_MIN", 200000},   // ... used from this many table entries (n_out * K) on
     {"wgrad_xcd_f32", "IRX_WGRAD_XCD_F32", 0},   // fp32 pair-list weight-gradient on XCD-segment work units: their number, 0 = off
+    {"enc_fold_slabs", "IRX_ENC_FOLD_SLABS", 1}, // encoder executor: offset-split slabs folded by the BatchNorm statistics pass
 };
 std::atomic<long> g_knob_val[IRX_KNOB_COUNT];
 std::atomic<int> g_knob_set[IRX_KNOB_COUNT];
@@ -474,6 +475,11 @@ int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int 
                               splits > 1 ? slabs : y, splits, accumulate, S(stream), 0, ty);
     if (rc) return rc;
     if (splits > 1) {
+      if (ty.slabs_out && ty.splits_out && !accumulate) {      // the caller folds the slabs (into its BatchNorm statistics pass)
+        *ty.slabs_out = slabs;
+        *ty.splits_out = splits;
+        return IRX_OK;
+      }
       const size_t elems = (size_t)n_out * cout;
       k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(slabs, splits, elems, y, accumulate, ty.y);
       IRX_CHECK_LAUNCH("irx_spconv_fwd(split reduce)");

@@ -18,7 +18,7 @@ from .sparse import nn as spnn
 
 import os as _os
 _DEFER = _os.environ.get('IRX_SCENE_DEFER', '1') != '0'     # dev A/B switch (bit-identical results)
-_FUSED_ATTN = _os.environ.get('IRX_FUSED_ATTN', '0') == '1'  # AttentionPoolFn instead of bmm / softmax / sum through ATen: measured -1 % (3011-3023 vs 3032-3061 scenes/s: one workgroup per scene walks 231 rows serially), off
+_FUSED_ATTN = _os.environ.get('IRX_FUSED_ATTN', '1') != '0'  # dense.AttentionPoolFn (one launch each way) instead of bmm / softmax / mul / sum through ATen
 
 
 class SceneModule(nn.Module):
@@ -87,7 +87,7 @@ class SceneModule(nn.Module):
         h, w = nx - 4, ny - 4
         feats = rows.view(batch_size, h * w, self.h_dim)                        # (B, n_vis, D)
         lang_feats = mlp2(self.lang_emb_fc, lang_feats)
-        if feats.is_cuda and _FUSED_ATTN:
+        if feats.is_cuda and _FUSED_ATTN and feats.shape[2] <= 256:
             atten, scene_feats = AttentionPoolFn.apply(feats, lang_feats)     # one launch each way (csrc/irx_match.hip)
         else:
             atten = torch.bmm(feats, lang_feats.unsqueeze(2)) / math.sqrt(feats.shape[2])
