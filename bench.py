@@ -266,14 +266,14 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
 
 
 def prime(model, resident, args, reducer, opt, state):
-    """model.warm(): bring the PROCESS and the GPU to their steady state before the contract's warm-up steps are counted, then
-    put the training state back. The driver runs 5 warm-up + 20 timed steps = 0.15 s of GPU work in a fresh process on a GPU that
-    idled while torch was imported: the caching allocator's per-stream pools, rocBLAS' kernel choices, the library's lanes and,
-    above all, the GPU's clocks (which ramp over a few hundred milliseconds of load) were still settling inside the timed region —
-    round 4's driver line read 10 % below the same commit's 30 + 100 capture. IRX_BENCH_PRIME steps (default 40, 0 = off) of the
-    real training step on the resident batch; parameters, Adam moments / step counts, BatchNorm running statistics and the RNG
-    state are restored afterwards, so the warm-up and the timed steps start from the same state as without it."""
-    n = int(os.environ.get("IRX_BENCH_PRIME", "40"))
+    """model.warm(): IRX_BENCH_PRIME untimed steps of the real training step BEFORE the contract's warm-up steps are
+    counted, with parameters, Adam moments / step counts, BatchNorm running statistics and the RNG state restored afterwards. OFF by
+    default (0) — measured, round 5, alternating runs on one box, 5 warm-up + 20 timed steps: 0 primed steps 3 036 / 2 940, 40 primed
+    2 996 / 3 020, 150 primed 2 822 / 2 929 scenes/s, 30 + 100 without priming 2 746-3 067 on the same box within minutes: the spread
+    of the pool's boxes (+-5 %, other tenants on the host, and a downward drift under SUSTAINED load: consecutive 30-step blocks of
+    one process read 5.4 -> 7.6 ms/step over ten seconds) is larger than anything the first five steps leave behind, and more
+    untimed load before the timed region makes the reading worse, not better."""
+    n = int(os.environ.get("IRX_BENCH_PRIME", "0"))
     if n <= 0:
         return 0
     bufs = [b for b in model.buffers()]

@@ -10,7 +10,8 @@ import os
 from . import _build, _lib
 
 ENABLED = os.environ.get("IRX_CPP_NODES", "1") != "0"
-_ENTRY_POINTS = ("irx_mlp2_saved_floats", "irx_mlp2_fwd", "irx_mlp2_bwd", "irx_gru_forward", "irx_gru_backward", "irx_gru_wgrad", "irx_last_error")
+_ENTRY_POINTS = ("irx_mlp2_saved_floats", "irx_mlp2_fwd", "irx_mlp2_bwd", "irx_gru_forward", "irx_gru_backward", "irx_gru_wgrad", "irx_last_error",
+                 "irx_hash_capacity", "irx_hash_build", "irx_kmap_build_s1")
 _mod = None
 _tried = False
 _lock = __import__("threading").Lock()

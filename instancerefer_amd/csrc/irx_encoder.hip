@@ -305,8 +305,11 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
                              3, nullptr, nullptr, 0.0, nullptr, mk_beta);
     }
     if (rc) return rc;
+    const long abl = irx_knob(IRX_KNOB_ABL);         // dev, timing only: what the chain costs without a kernel family
     if (L.prof) irx_profile_next_kernel(L.prof[4], L.prof[5]);
-    if (pairs_path(L)) {
+    if (abl & 1) {
+      rc = IRX_OK;
+    } else if (pairs_path(L)) {
       IRX_REQUIRE(!st || i > 0, "irx_encoder_backward: bf16 storage expects a stem (Cin <= 8 or 129..136) as layer 0");
       rc = irx_spconv_wgrad_pairs_impl(L.x, dc_scratch, L.pair_in, L.pair_out, L.ld_pairs, L.pair_counts, L.n_out, L.K,
                                        L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st, L.n_in);
@@ -321,7 +324,7 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
     }
     if (rc) return rc;
     float* dx = (i > 0) ? (float*)desc[(size_t)(i - 1) * IRX_ENC_NFIELDS + IRX_ENC_GY] : dx0;
-    if (dx) {
+    if (dx && !(abl & 2)) {
       const int acc = (i > 0 && is_res_source[i - 1]) ? 1 : 0;
       IrxStore ty;
       ty.x = st;                                  // dc

@@ -299,6 +299,7 @@ const KnobDef kKnobs[IRX_KNOB_COUNT] = {
     {"wgrad3_xcd_min", "IRX_WGRAD3_XCD_MIN", 200000},   // ... used from this many table entries (n_out * K) on
     {"wgrad_xcd_f32", "IRX_WGRAD_XCD_F32", 0},   // fp32 pair-list weight-gradient on XCD-segment work units: their number, 0 = off
     {"enc_fold_slabs", "IRX_ENC_FOLD_SLABS", 1}, // encoder executor: offset-split slabs folded by the BatchNorm statistics pass
+    {"enc_abl", "IRX_ENC_ABL", 0},               // dev, TIMING ONLY (results wrong): encoder backward without bit 0 = weight gradients, bit 1 = data gradients
 };
 std::atomic<long> g_knob_val[IRX_KNOB_COUNT];
 std::atomic<int> g_knob_set[IRX_KNOB_COUNT];

@@ -35,6 +35,9 @@ typedef int (*gru_bwd_fn)(const float*, const float*, const float*, const int32_
 typedef int (*gru_wgrad_fn)(const float*, const float*, const float*, const float*, int, int, int, int, int, float*, float*, float*,
                             float*, float*, float*, float*, float*, void*);
 typedef const char* (*last_error_fn)();
+typedef size_t (*hash_capacity_fn)(int);
+typedef int (*hash_build_fn)(const uint64_t*, int, uint64_t*, int32_t*, size_t, void*);
+typedef int (*kmap_s1_fn)(const int32_t*, int, int, const uint64_t*, const int32_t*, size_t, int32_t*, int, void*);
 
 struct Api {
   saved_floats_fn mlp2_saved_floats = nullptr;
@@ -44,6 +47,9 @@ struct Api {
   gru_bwd_fn gru_bwd = nullptr;
   gru_wgrad_fn gru_wgrad = nullptr;
   last_error_fn last_error = nullptr;
+  hash_capacity_fn hash_capacity = nullptr;
+  hash_build_fn hash_build = nullptr;
+  kmap_s1_fn kmap_s1 = nullptr;
 } g_api;
 
 void check(int rc, const char* what) {
@@ -279,6 +285,38 @@ Tensor mlp_relu2(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tens
                          c10::optional<Tensor>(), 0.0, drop_p, seed, stream, std::move(slot_ptrs), opt_at(keep, 0), opt_at(keep, 1));
 }
 
+// The hash tables and 27-neighbour tables of every level of a coordinate pyramid in ONE call (reference: torchsparse builds a
+// kernel map per (stride, kernel size) lazily inside spnn.Conv3d — models/basic_blocks.py:14,32-39): per level irx_hash_build +
+// irx_kmap_build_s1 on tensors allocated here with ATen. From Python each level was two ctypes calls and three torch.empty —
+// 0.4-0.6 ms of interpreter time per step at the head of the forward (5 levels x 2 encoders; round 5 host profile). Levels whose
+// `have` flag is set, or that hold no rows, are skipped. -> per level (table keys int64 [cap], table values int32 [cap],
+// neighbours int32 [27][max(n, 1)]) or three undefined tensors.
+std::vector<Tensor> kmaps_build(const std::vector<Tensor>& keys, const std::vector<Tensor>& coords, const std::vector<int64_t>& strides,
+                                const std::vector<int64_t>& have, int64_t stream) {
+  TORCH_CHECK(g_api.hash_build && g_api.kmap_s1 && g_api.hash_capacity, "irx nodes: bind() has not been called");
+  TORCH_CHECK(keys.size() == coords.size() && keys.size() == strides.size() && keys.size() == have.size(), "kmaps_build: list sizes");
+  std::vector<Tensor> out;
+  out.reserve(3 * keys.size());
+  for (size_t l = 0; l < keys.size(); ++l) {
+    const int64_t n = coords[l].size(0);
+    if (have[l] || n == 0) {
+      out.emplace_back(); out.emplace_back(); out.emplace_back();
+      continue;
+    }
+    const size_t cap = g_api.hash_capacity((int)n);
+    Tensor tk = torch::empty({(int64_t)cap}, keys[l].options().dtype(torch::kInt64));
+    Tensor tv = torch::empty({(int64_t)cap}, keys[l].options().dtype(torch::kInt32));
+    Tensor nbr = torch::empty({27, n > 0 ? n : 1}, keys[l].options().dtype(torch::kInt32));
+    check(g_api.hash_build((const uint64_t*)keys[l].data_ptr<int64_t>(), (int)n, (uint64_t*)tk.data_ptr<int64_t>(),
+                           tv.data_ptr<int32_t>(), cap, (void*)stream), "irx_hash_build");
+    check(g_api.kmap_s1(coords[l].data_ptr<int32_t>(), (int)n, (int)strides[l], (const uint64_t*)tk.data_ptr<int64_t>(),
+                        tv.data_ptr<int32_t>(), cap, nbr.data_ptr<int32_t>(), (int)(n > 0 ? n : 1), (void*)stream),
+          "irx_kmap_build_s1");
+    out.push_back(tk); out.push_back(tv); out.push_back(nbr);
+  }
+  return out;
+}
+
 // addresses of the C-ABI entry points, taken from the library instance _lib.py loaded
 void bind(const std::unordered_map<std::string, uint64_t>& addr) {
   auto get = [&](const char* name) -> uint64_t {
@@ -293,6 +331,9 @@ void bind(const std::unordered_map<std::string, uint64_t>& addr) {
   g_api.gru_bwd = (gru_bwd_fn)get("irx_gru_backward");
   g_api.gru_wgrad = (gru_wgrad_fn)get("irx_gru_wgrad");
   g_api.last_error = (last_error_fn)get("irx_last_error");
+  g_api.hash_capacity = (hash_capacity_fn)get("irx_hash_capacity");
+  g_api.hash_build = (hash_build_fn)get("irx_hash_build");
+  g_api.kmap_s1 = (kmap_s1_fn)get("irx_kmap_build_s1");
 }
 
 }  // namespace
@@ -303,4 +344,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("mlp2", &mlp2);
   m.def("gru_layer", &gru_layer);
   m.def("mlp_relu2", &mlp_relu2);
+  m.def("kmaps_build", &kmaps_build);
 }

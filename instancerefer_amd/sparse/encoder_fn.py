@@ -66,6 +66,7 @@ def build_plan(encoder, level0):
         return plan
     layers = Plan()
     layers.pre = {}
+    level0.build_kmaps()                # every level's kernel map in one native call (no-op for the ones already built)
     lv = level0
     for conv, bn, down, res in _skeleton(encoder):
         L = _Layer()

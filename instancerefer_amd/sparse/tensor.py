@@ -160,6 +160,30 @@ class Level:
             first = False
             lv = lv._down.out_level if lv._down is not None else None
 
+    def build_kmaps(self):
+        """Hash table + 27-neighbour table of EVERY level of the (already built) pyramid that does not have them yet, in one call
+        of the C++ nodes module (csrc/torch_nodes.cpp kmaps_build: allocation and both launches per level without the interpreter);
+        falls back to the lazy per-level builders when the module is not there. Same kernels, same tables."""
+        from .. import _nodes
+        mod = _nodes.load() if self.coords.is_cuda else None
+        if mod is None or not hasattr(mod, "kmaps_build"):
+            return
+        lvs, lv = [], self
+        while lv is not None:
+            lvs.append(lv)
+            lv = lv._down.out_level if lv._down is not None else None
+        have = [int(lv._nbr27 is not None or lv.n == 0) for lv in lvs]
+        if all(have):
+            return
+        from .. import _lib
+        out = mod.kmaps_build([lv.keys for lv in lvs], [lv.coords for lv in lvs], [lv.stride for lv in lvs], have, _lib.stream_ptr())
+        for i, lv in enumerate(lvs):
+            if not have[i]:
+                tk, tv, nbr = out[3 * i:3 * i + 3]
+                if lv._table is None:
+                    lv._table = (tk, tv, int(tk.shape[0]))
+                lv._nbr27 = nbr
+
     def offsets(self):
         if self._offsets is None:
             self._offsets = F_.batch_offsets(self.coords, self.batch_size)

@@ -35,7 +35,10 @@ state["labels"] = lambda dd: prepare_labels(dd, bench.step_fn.cfg, dev) if "_att
 def setter(sw):
     kind, name = sw.split(":", 1)
     if kind == "knob":
-        return lambda on: _lib.set_knob(name, 1 if on else 0)
+        val = 1
+        if "=" in name:
+            name, val = name.split("=")[0], int(name.split("=")[1])
+        return lambda on: _lib.set_knob(name, val if on else 0)
     mod = importlib.import_module(kind)
     return lambda on: setattr(mod, name, bool(on))
 
