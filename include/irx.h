@@ -624,6 +624,19 @@ int irx_attn_pool_fwd(const float* feats, const float* lang, int B, int n, int d
 int irx_attn_pool_bwd(const float* feats, const float* lang, const float* atten, const float* dout, const float* datten,
                       int B, int n, int d, float scale, float* dfeats, float* dlang, void* stream);
 
+/* The four attention heads of the language module (models/lang_module.py:61-83) in one launch each way: logit[b][t][h] =
+ * <feats[b][t], w[h]> + bias[h][0]; p = softmax over ALL T positions; q = p * [t < len[b]]; att = q / sum_t q; pooled[b][h] =
+ * sum_t att[b][t][h] embed[b][t]. feats [B][T][O], embed [B][T][E], len [B] int64, w / bias: 4 pointers each (the fc_a, fc_cls,
+ * fc_rel, fc_scene parameters in the caller's order). Outputs att [B][T][4], pooled [B][4][E]; prob [B][T][4] and qsum [B][4] are
+ * kept for the backward, which returns dfeats [B][T][O], dembed [B][T][E], dw [4][O], db [4] from dpooled [B][4][E] and (optional)
+ * datt [B][T][4]; part: scratch of B * 4 * (O + 1) floats. Deterministic. */
+int irx_lang_pool_fwd(const float* feats, const float* embed, const int64_t* len, int B, int T, int O, int E,
+                      const float* const* w, const float* const* bias, float* att, float* prob, float* qsum, float* pooled,
+                      void* stream);
+int irx_lang_pool_bwd(const float* feats, const float* embed, const int64_t* len, int B, int T, int O, int E,
+                      const float* const* w, const float* att, const float* prob, const float* qsum, const float* dpooled,
+                      const float* datt, float* dfeats, float* dembed, float* dw, float* db, float* part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,8 @@ _SIGNATURES = {
     "irx_total_loss": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P]),
     "irx_attn_pool_fwd": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "irx_attn_pool_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "irx_lang_pool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "irx_lang_pool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "irx_mlp2_saved_floats": (_Z, [_I, _I]),
     "irx_mlp2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _F, _P, _P, _F, _F, _c.c_uint64, _P, _P, _P, _P, _P]),
     "irx_mlp2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

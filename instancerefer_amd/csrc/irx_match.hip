@@ -451,3 +451,212 @@ extern "C" int irx_attn_pool_bwd(const float* feats, const float* lang, const fl
   IRX_CHECK_LAUNCH("irx_attn_pool_bwd");
   return IRX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The four attention heads of the language module (reference models/lang_module.py:61-83) as one launch each way:
+//   logit[b][t][h] = <feats[b][t][:], w_h> + b_h;  p = softmax over ALL T positions (padded ones included: reference quirk);
+//   q = p * [t < len_b];  att = q / sum_t q;  pooled[b][h][:] = sum_t att[b][t][h] * embed[b][t][:]
+// feats [B][T][O] = GRU output, embed [B][T][E] = projected word embeddings. Through ATen: 2 cat + matmul + add + softmax + mul + sum +
+// div + transpose + bmm forward and ~20 nodes backward, issued by the language helper thread — which the training thread waits
+// for before it can issue the attribute head. One workgroup per utterance, deterministic.
+#define LP_PT 256
+struct LpHeads { const float* w[4]; const float* b[4]; };
+
+__global__ __launch_bounds__(LP_PT) void k_lang_pool_fwd(const float* __restrict__ feats, const float* __restrict__ embed,
+                                                         const int64_t* __restrict__ len, int T, int O, int E, LpHeads hd,
+                                                         float* __restrict__ att, float* __restrict__ prob, float* __restrict__ qsum,
+                                                         float* __restrict__ pooled) {
+  extern __shared__ float lp_sm[];                  // [T][4] logits -> p -> att
+  float* a = lp_sm;
+  __shared__ float s_q[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* f = feats + (size_t)b * T * O;
+  const float* e = embed + (size_t)b * T * E;
+  const int n = (int)len[b];
+  for (int t = wave; t < T; t += LP_PT / 64) {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    for (int o = lane; o < O; o += 64) {
+      const float x = f[(size_t)t * O + o];
+      p0 = fmaf(x, hd.w[0][o], p0); p1 = fmaf(x, hd.w[1][o], p1); p2 = fmaf(x, hd.w[2][o], p2); p3 = fmaf(x, hd.w[3][o], p3);
+    }
+    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2); p3 = wave_sum(p3);
+    if (lane == 0) {
+      a[t * 4 + 0] = p0 + hd.b[0][0]; a[t * 4 + 1] = p1 + hd.b[1][0]; a[t * 4 + 2] = p2 + hd.b[2][0]; a[t * 4 + 3] = p3 + hd.b[3][0];
+    }
+  }
+  __syncthreads();
+  if (tid < 4) {                                    // T <= 126: one thread per head walks the positions (fixed order)
+    const int h = tid;
+    float mx = -INFINITY;
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, a[t * 4 + h]);
+    float se = 0.f;
+    for (int t = 0; t < T; ++t) se += expf(a[t * 4 + h] - mx);
+    float sq = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float p = expf(a[t * 4 + h] - mx) / se;
+      prob[((size_t)b * T + t) * 4 + h] = p;
+      const float q = (t < n) ? p : 0.f;
+      a[t * 4 + h] = q;
+      sq += q;
+    }
+    s_q[h] = sq;
+    qsum[b * 4 + h] = sq;
+    for (int t = 0; t < T; ++t) {
+      const float v = a[t * 4 + h] / sq;
+      a[t * 4 + h] = v;
+      att[((size_t)b * T + t) * 4 + h] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < E; c += LP_PT) {
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    int t = 0;
+    for (; t + 4 <= T; t += 4) {                    // 4 rows' loads in flight
+      float x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = e[(size_t)(t + u) * E + c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        o0 = fmaf(a[(t + u) * 4 + 0], x[u], o0); o1 = fmaf(a[(t + u) * 4 + 1], x[u], o1);
+        o2 = fmaf(a[(t + u) * 4 + 2], x[u], o2); o3 = fmaf(a[(t + u) * 4 + 3], x[u], o3);
+      }
+    }
+    for (; t < T; ++t) {
+      const float x = e[(size_t)t * E + c];
+      o0 = fmaf(a[t * 4 + 0], x, o0); o1 = fmaf(a[t * 4 + 1], x, o1); o2 = fmaf(a[t * 4 + 2], x, o2); o3 = fmaf(a[t * 4 + 3], x, o3);
+    }
+    float* po = pooled + (size_t)b * 4 * E;
+    po[c] = o0; po[E + c] = o1; po[2 * E + c] = o2; po[3 * E + c] = o3;
+  }
+}
+
+// part_w [B][4][O], part_b [B][4]: this utterance's share of the head weights' / biases' gradients (summed by k_lang_pool_wsum)
+__global__ __launch_bounds__(LP_PT) void k_lang_pool_bwd(const float* __restrict__ feats, const float* __restrict__ embed,
+                                                         const int64_t* __restrict__ len, int T, int O, int E, LpHeads hd,
+                                                         const float* __restrict__ att, const float* __restrict__ prob,
+                                                         const float* __restrict__ qsum, const float* __restrict__ dpooled,
+                                                         const float* __restrict__ datt, float* __restrict__ dfeats,
+                                                         float* __restrict__ dembed, float* __restrict__ part_w,
+                                                         float* __restrict__ part_b) {
+  extern __shared__ float lp_sm[];                  // [T][4] g_att -> d logit | [T][4] att
+  float* g = lp_sm;
+  float* a = lp_sm + 4 * T;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* f = feats + (size_t)b * T * O;
+  const float* e = embed + (size_t)b * T * E;
+  const float* dp = dpooled + (size_t)b * 4 * E;
+  const int n = (int)len[b];
+  for (int i = tid; i < 4 * T; i += LP_PT) a[i] = att[(size_t)b * T * 4 + i];
+  for (int t = wave; t < T; t += LP_PT / 64) {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    for (int c = lane; c < E; c += 64) {
+      const float x = e[(size_t)t * E + c];
+      p0 = fmaf(dp[c], x, p0); p1 = fmaf(dp[E + c], x, p1); p2 = fmaf(dp[2 * E + c], x, p2); p3 = fmaf(dp[3 * E + c], x, p3);
+    }
+    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2); p3 = wave_sum(p3);
+    if (lane == 0) {
+      const float* da = datt ? datt + ((size_t)b * T + t) * 4 : nullptr;
+      g[t * 4 + 0] = p0 + (da ? da[0] : 0.f); g[t * 4 + 1] = p1 + (da ? da[1] : 0.f);
+      g[t * 4 + 2] = p2 + (da ? da[2] : 0.f); g[t * 4 + 3] = p3 + (da ? da[3] : 0.f);
+    }
+  }
+  __syncthreads();
+  if (tid < 4) {
+    const int h = tid;
+    const float s = qsum[b * 4 + h];
+    float d1 = 0.f;
+    for (int t = 0; t < T; ++t) d1 += a[t * 4 + h] * g[t * 4 + h];
+    float d2 = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float dpv = (t < n) ? (g[t * 4 + h] - d1) / s : 0.f;       // d p_t = d q_t * mask
+      g[t * 4 + h] = dpv;
+      d2 += prob[((size_t)b * T + t) * 4 + h] * dpv;
+    }
+    float sb = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float dl = prob[((size_t)b * T + t) * 4 + h] * (g[t * 4 + h] - d2);
+      g[t * 4 + h] = dl;
+      sb += dl;
+    }
+    part_b[b * 4 + h] = sb;
+  }
+  __syncthreads();
+  for (int c = tid; c < E; c += LP_PT) {            // d embed[t][c] = sum_h att[t][h] d pooled[h][c]
+    const float q0 = dp[c], q1 = dp[E + c], q2 = dp[2 * E + c], q3 = dp[3 * E + c];
+    for (int t = 0; t < T; ++t)
+      dembed[((size_t)b * T + t) * E + c] = fmaf(a[t * 4 + 0], q0, fmaf(a[t * 4 + 1], q1, fmaf(a[t * 4 + 2], q2, a[t * 4 + 3] * q3)));
+  }
+  for (int o = tid; o < O; o += LP_PT) {            // d feats[t][o] = sum_h d logit[t][h] w_h[o];  d w_h[o] += sum_t d logit[t][h] feats[t][o]
+    const float w0 = hd.w[0][o], w1 = hd.w[1][o], w2 = hd.w[2][o], w3 = hd.w[3][o];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = 0;
+    for (; t + 4 <= T; t += 4) {
+      float x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = f[(size_t)(t + u) * O + o];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* gl = g + (t + u) * 4;
+        dfeats[((size_t)b * T + t + u) * O + o] = fmaf(gl[0], w0, fmaf(gl[1], w1, fmaf(gl[2], w2, gl[3] * w3)));
+        s0 = fmaf(gl[0], x[u], s0); s1 = fmaf(gl[1], x[u], s1); s2 = fmaf(gl[2], x[u], s2); s3 = fmaf(gl[3], x[u], s3);
+      }
+    }
+    for (; t < T; ++t) {
+      const float x = f[(size_t)t * O + o];
+      const float* gl = g + t * 4;
+      dfeats[((size_t)b * T + t) * O + o] = fmaf(gl[0], w0, fmaf(gl[1], w1, fmaf(gl[2], w2, gl[3] * w3)));
+      s0 = fmaf(gl[0], x, s0); s1 = fmaf(gl[1], x, s1); s2 = fmaf(gl[2], x, s2); s3 = fmaf(gl[3], x, s3);
+    }
+    float* pw = part_w + (size_t)b * 4 * O;
+    pw[o] = s0; pw[O + o] = s1; pw[2 * O + o] = s2; pw[3 * O + o] = s3;
+  }
+}
+
+__global__ void k_lang_pool_wsum(const float* __restrict__ part_w, const float* __restrict__ part_b, int B, int O,
+                                 float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 4 * O weights, then 4 biases
+  if (i < 4 * O) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += part_w[(size_t)b * 4 * O + i];
+    dw[i] = s;
+  } else if (i < 4 * O + 4) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += part_b[b * 4 + (i - 4 * O)];
+    db[i - 4 * O] = s;
+  }
+}
+
+extern "C" int irx_lang_pool_fwd(const float* feats, const float* embed, const int64_t* len, int B, int T, int O, int E,
+                                 const float* const* w, const float* const* bias, float* att, float* prob, float* qsum, float* pooled,
+                                 void* stream) {
+  IRX_REQUIRE(B >= 0 && T >= 1 && T <= 1024 && O >= 1 && E >= 1, "irx_lang_pool_fwd: bad sizes");
+  if (B == 0) return IRX_OK;
+  IRX_REQUIRE(feats && embed && len && w && bias && att && prob && qsum && pooled, "irx_lang_pool_fwd: null pointer");
+  LpHeads hd;
+  for (int h = 0; h < 4; ++h) {
+    IRX_REQUIRE(w[h] && bias[h], "irx_lang_pool_fwd: null head parameter");
+    hd.w[h] = w[h]; hd.b[h] = bias[h];
+  }
+  k_lang_pool_fwd<<<B, LP_PT, (size_t)4 * T * sizeof(float), S(stream)>>>(feats, embed, len, T, O, E, hd, att, prob, qsum, pooled);
+  IRX_CHECK_LAUNCH("irx_lang_pool_fwd");
+  return IRX_OK;
+}
+
+// dw [4][O], db [4]; part: scratch of B * 4 * (O + 1) floats
+extern "C" int irx_lang_pool_bwd(const float* feats, const float* embed, const int64_t* len, int B, int T, int O, int E,
+                                 const float* const* w, const float* att, const float* prob, const float* qsum, const float* dpooled,
+                                 const float* datt, float* dfeats, float* dembed, float* dw, float* db, float* part, void* stream) {
+  IRX_REQUIRE(B >= 1 && T >= 1 && T <= 1024 && O >= 1 && E >= 1, "irx_lang_pool_bwd: bad sizes");
+  IRX_REQUIRE(feats && embed && len && w && att && prob && qsum && dpooled && dfeats && dembed && dw && db && part,
+              "irx_lang_pool_bwd: null pointer");
+  LpHeads hd;
+  for (int h = 0; h < 4; ++h) { hd.w[h] = w[h]; hd.b[h] = nullptr; }
+  float* part_w = part;
+  float* part_b = part + (size_t)B * 4 * O;
+  k_lang_pool_bwd<<<B, LP_PT, (size_t)8 * T * sizeof(float), S(stream)>>>(feats, embed, len, T, O, E, hd, att, prob, qsum, dpooled,
+                                                                          datt, dfeats, dembed, part_w, part_b);
+  IRX_CHECK_LAUNCH("irx_lang_pool_bwd");
+  k_lang_pool_wsum<<<irx_cdiv(4 * O + 4, 256), 256, 0, S(stream)>>>(part_w, part_b, B, O, dw, db);
+  IRX_CHECK_LAUNCH("irx_lang_pool_bwd(sum)");
+  return IRX_OK;
+}

@@ -165,6 +165,55 @@ class ContrastiveFn(torch.autograd.Function):
 
 
 
+class LangPoolFn(torch.autograd.Function):
+    """The language module's four attention heads (reference models/lang_module.py:61-83) in one launch each way
+    (irx_lang_pool_fwd / _bwd, csrc/irx_match.hip): (feats (B, T, O), embed (B, T, E), lengths (B,), w0, b0, ..., w3, b3) ->
+    (att (B, T, 4), pooled (B, 4, E)) with softmax over ALL T positions, then mask + renormalise. The heads' own nn.Linear
+    parameters go in one by one (no cat node between them and this one)."""
+
+    @staticmethod
+    def forward(ctx, feats, embed, length, *wb):
+        import ctypes
+        feats, embed = feats.contiguous().float(), embed.contiguous().float()
+        length = length.contiguous().to(torch.int64)
+        B, T, O = feats.shape
+        E = embed.shape[2]
+        dev = feats.device
+        ws = [w.contiguous() for w in wb[0::2]]
+        bs = [b.contiguous() for b in wb[1::2]]
+        att = torch.empty((B, T, 4), dtype=_f32, device=dev)
+        prob = torch.empty((B, T, 4), dtype=_f32, device=dev)
+        qsum = torch.empty((B, 4), dtype=_f32, device=dev)
+        pooled = torch.empty((B, 4, E), dtype=_f32, device=dev)
+        wp = (ctypes.c_void_p * 4)(*[w.data_ptr() for w in ws])
+        bp = (ctypes.c_void_p * 4)(*[b.data_ptr() for b in bs])
+        _lib.call("irx_lang_pool_fwd", _lib.ptr(feats), _lib.ptr(embed), _lib.ptr(length), B, T, O, E, wp, bp, _lib.ptr(att),
+                  _lib.ptr(prob), _lib.ptr(qsum), _lib.ptr(pooled), _lib.stream_ptr())
+        ctx.save_for_backward(feats, embed, length, att, prob, qsum, *ws)
+        return att, pooled
+
+    @staticmethod
+    def backward(ctx, datt, dpooled):
+        import ctypes
+        feats, embed, length, att, prob, qsum, *ws = ctx.saved_tensors
+        B, T, O = feats.shape
+        E = embed.shape[2]
+        dev = feats.device
+        dpooled = dpooled.contiguous().float() if dpooled is not None else torch.zeros((B, 4, E), dtype=_f32, device=dev)
+        datt = datt.contiguous().float() if datt is not None else None
+        dfeats, dembed = torch.empty_like(feats), torch.empty_like(embed)
+        dwb = torch.empty(4 * O + 4, dtype=_f32, device=dev)
+        part = torch.empty(B * 4 * (O + 1), dtype=_f32, device=dev)
+        wp = (ctypes.c_void_p * 4)(*[w.data_ptr() for w in ws])
+        _lib.call("irx_lang_pool_bwd", _lib.ptr(feats), _lib.ptr(embed), _lib.ptr(length), B, T, O, E, wp, _lib.ptr(att), _lib.ptr(prob),
+                  _lib.ptr(qsum), _lib.ptr(dpooled), _lib.ptr(datt), _lib.ptr(dfeats), _lib.ptr(dembed), dwb.data_ptr(),
+                  dwb.data_ptr() + 16 * O, _lib.ptr(part), _lib.stream_ptr())
+        grads = []
+        for h in range(4):
+            grads += [dwb[h * O:(h + 1) * O].view(1, O), dwb[4 * O + h:4 * O + h + 1]]
+        return (dfeats, dembed, None) + tuple(grads)
+
+
 class AttentionPoolFn(torch.autograd.Function):
     """(feats (B, n, D), lang (B, D)) -> (atten (B, n) = softmax_i(<feats_i, lang> / sqrt(D)), pooled (B, D) = sum_i atten_i feats_i):
     the scene head's language-guided attention (reference models/scene_module.py:84-93) in one launch each way

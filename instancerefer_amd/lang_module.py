@@ -10,7 +10,11 @@ import torch
 import torch.nn as nn
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
-from .dense import gru_packed
+import os as _os
+
+from .dense import LangPoolFn, gru_packed
+
+_FUSED_POOL = _os.environ.get('IRX_FUSED_LANG_POOL', '1') != '0'   # dev / test switch: 0 = the heads through ATen (cat, matmul, softmax, bmm)
 
 
 class LangModule(nn.Module):
@@ -54,6 +58,19 @@ class LangModule(nn.Module):
             feats, _ = pad_packed_sequence(feats, batch_first=True)  # (B, T_max, o_dim)
         data_dict['lang_feat'] = feats
         t_max = feats.shape[1]
+        if feats.is_cuda and _FUSED_POOL and embed.shape[1] >= t_max:
+            # the four heads in one launch each way (csrc/irx_match.hip, dense.LangPoolFn): order attr, cls, rel, scene
+            att, pooled = LangPoolFn.apply(feats, embed[:, :t_max], length, self.fc_a.weight, self.fc_a.bias, self.fc_cls.weight,
+                                           self.fc_cls.bias, self.fc_rel.weight, self.fc_rel.bias, self.fc_scene.weight,
+                                           self.fc_scene.bias)
+            data_dict['atten_attr'] = att[:, :, 0]
+            data_dict['atten_rel'] = att[:, :, 2]
+            data_dict['atten_scene'] = att[:, :, 3]
+            data_dict['lang_attr_feats'] = pooled[:, 0]
+            data_dict['lang_cls_feats'] = pooled[:, 1]
+            data_dict['lang_rel_feats'] = pooled[:, 2]
+            data_dict['lang_scene_feats'] = pooled[:, 3]
+            return data_dict
         mask = (torch.arange(t_max, device=feats.device).unsqueeze(0) <
                 length.to(feats.device).unsqueeze(1)).to(feats.dtype)
         # the four heads as one (o_dim x 4) projection; order: attr, cls, rel, scene

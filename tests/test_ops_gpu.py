@@ -1235,3 +1235,41 @@ def test_attention_pool_matches_the_aten_formulation(lib, shape):
         assert (out.detach().cpu().double() - out_r.detach()).abs().max() <= 1e-5
         for got, exp in ((f.grad, f64.grad), (l.grad, l64.grad)):
             assert (got.cpu().double() - exp).abs().max() <= 1e-4 * max(1.0, float(exp.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(16, 30, 256, 256), (3, 126, 128, 256), (5, 7, 64, 32)])
+def test_lang_attention_heads_match_the_aten_formulation(lib, shape):
+    """irx_lang_pool_fwd / _bwd (the four attention heads of LangModule, reference models/lang_module.py:61-83: softmax over ALL
+    positions, then mask + renormalise, pooling the PROJECTED embeddings) against the reference's operator sequence in float64,
+    ragged lengths (one utterance of a single token, one of full length): outputs 1e-5, gradients 1e-4 of their max-norm."""
+    from instancerefer_amd.dense import LangPoolFn
+    B, T, O, E = shape
+    g = torch.Generator().manual_seed(9)
+    feats, embed = torch.randn(B, T, O, generator=g), torch.randn(B, T, E, generator=g)
+    length = torch.randint(1, T + 1, (B,), generator=g)
+    length[0], length[-1] = 1, T
+    ws = [torch.randn(1, O, generator=g) * 0.2 for _ in range(4)]
+    bs = [torch.randn(1, generator=g) for _ in range(4)]
+    w_att, w_pool = torch.randn(B, T, 4, generator=g), torch.randn(B, 4, E, generator=g)
+
+    def ref(f, e, ws_, bs_):
+        w = torch.cat(ws_, 0)
+        b = torch.cat(bs_, 0)
+        mask = (torch.arange(T).unsqueeze(0) < length.unsqueeze(1)).to(f.dtype)
+        att = torch.softmax(f.matmul(w.t()) + b, dim=1) * mask.unsqueeze(2)
+        att = att / att.sum(1, keepdim=True)
+        return att, torch.bmm(att.transpose(1, 2), e)
+    f64, e64 = feats.double().requires_grad_(), embed.double().requires_grad_()
+    w64, b64 = [w.double().requires_grad_() for w in ws], [b.double().requires_grad_() for b in bs]
+    att_r, pool_r = ref(f64, e64, w64, b64)
+    ((att_r * w_att.double()).sum() + (pool_r * w_pool.double()).sum()).backward()
+    dev = torch.device("cuda")
+    f, e = feats.to(dev).requires_grad_(), embed.to(dev).requires_grad_()
+    wd, bd = [w.to(dev).requires_grad_() for w in ws], [b.to(dev).requires_grad_() for b in bs]
+    att, pool = LangPoolFn.apply(f, e, length.to(dev), wd[0], bd[0], wd[1], bd[1], wd[2], bd[2], wd[3], bd[3])
+    ((att * w_att.to(dev)).sum() + (pool * w_pool.to(dev)).sum()).backward()
+    assert (att.detach().cpu().double() - att_r.detach()).abs().max() <= 1e-6
+    assert (pool.detach().cpu().double() - pool_r.detach()).abs().max() <= 1e-5
+    for got, exp in [(f.grad, f64.grad), (e.grad, e64.grad)] + list(zip([w.grad for w in wd], [w.grad for w in w64])) + \
+            list(zip([b.grad for b in bd], [b.grad for b in b64])):
+        assert (got.cpu().double() - exp).abs().max() <= 1e-4 * max(1.0, float(exp.abs().max())), (got.shape,)
