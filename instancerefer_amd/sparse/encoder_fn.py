@@ -433,13 +433,20 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feats, encoder, layers, *params):
+        # compact form (apply_encoder below): only the FIRST parameter is an autograd input, the others ride in a _Hidden — their
+        # gradients go to the optimizer's sink, and 38 AccumulateGrad nodes that would each be evaluated with an undefined gradient
+        # (plus 38 saved variables) per encoder pass are not created
+        ctx.n_inputs = 3 + len(params)
+        if params and isinstance(params[-1], _Hidden):
+            params = params[-1].params
+        ctx.all_params = params
         st = layers if isinstance(layers, Launched) else launch(feats, encoder, layers, params, ctx.needs_input_grad[0])
         if ctx.needs_input_grad[0] and not st.need_dx0:
             raise RuntimeError("encoder pass was launched without an input gradient (bf16 storage) but its features require one")
         ctx.lane, ctx.sync = st.lane, st.sync
         ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = st.layers, st.desc, st.fdesc, st.extra
         ctx.store, ctx.prof, ctx.sink = st.store, st.prof, st.sink
-        ctx.save_for_backward(*st.saved, *params)
+        ctx.save_for_backward(*st.saved)
         return st.out.view_as(st.out) if isinstance(layers, Launched) else st.out
 
     @staticmethod
@@ -513,15 +520,8 @@ class EncoderFn(torch.autograd.Function):
             SYNC_CALLS[1] += 1
             if slots is not None:
                 owner.sink_delivered(ctx.sink[1], sparams)
-                return (dfeats, None, None) + (None,) * (3 * nl)
-            grads = []
-            po = poffs // 4
-            for i, L in enumerate(layers):
-                o = po[i]
-                grads.append(pgrad[o[0]:o[0] + L.K * L.cin * L.cout].view(L.K, L.cin, L.cout))
-                grads.append(pgrad[o[1]:o[1] + L.cout])
-                grads.append(pgrad[o[2]:o[2] + L.cout])
-            return (dfeats, None, None) + tuple(grads)
+                return _returns(ctx, dfeats, None)
+            return _returns(ctx, dfeats, _grad_views(pgrad, poffs, layers))
         if ctx.lane is not None and slots is not None and not need_dx0:
             # nothing autograd will touch depends on this pass: a library thread issues it; the optimizer waits for the
             # lane before it records the delivery event (FlatAdam.gather_grads)
@@ -531,7 +531,7 @@ class EncoderFn(torch.autograd.Function):
                 _lib.check(rc, "irx_encoder_submit")
             _HELD.setdefault(ctx.lane, []).append((ws, garena, dout, slots, ctx.saved_tensors, ctx.prof))
             owner.sink_delivered(key, sparams, lane=ctx.lane)
-            return (None, None, None) + (None,) * (3 * nl)
+            return _returns(ctx, None, None)
         lane_wait(ctx.lane)                                  # same-stream order with the (possibly queued) forward
         rc = lib.irx_encoder_backward(desc.ctypes.data, fdesc.ctypes.data, nl, gbase + dc_off,
                                       dfeats.data_ptr() if need_dx0 else None, ws.data_ptr(), nbytes,
@@ -540,15 +540,53 @@ class EncoderFn(torch.autograd.Function):
             _lib.check(rc, "irx_encoder_backward")
         if slots is not None:
             owner.sink_delivered(key, sparams)
-            return (dfeats, None, None) + (None,) * (3 * nl)
-        grads = []
-        po = poffs // 4
-        for i, L in enumerate(layers):
-            o = po[i]
-            grads.append(pgrad[o[0]:o[0] + L.K * L.cin * L.cout].view(L.K, L.cin, L.cout))
-            grads.append(pgrad[o[1]:o[1] + L.cout])
-            grads.append(pgrad[o[2]:o[2] + L.cout])
+            return _returns(ctx, dfeats, None)
+        return _returns(ctx, dfeats, _grad_views(pgrad, poffs, layers))
+
+
+class _Hidden:
+    """Parameters handed to EncoderFn without being autograd inputs (see EncoderFn.forward)."""
+    __slots__ = ("params",)
+
+    def __init__(self, params):
+        self.params = tuple(params)
+
+
+def apply_encoder(feats, encoder, layers, params):
+    """EncoderFn.apply in its compact form when the parameters' gradients can go to an optimizer's sink (optim.FlatAdam re-homed
+    them), else with every parameter as an input."""
+    if getattr(params[0], "_irx_sink", None) is not None and not feats.requires_grad:
+        return EncoderFn.apply(feats, encoder, layers, params[0], _Hidden(params))
+    return EncoderFn.apply(feats, encoder, layers, *params)
+
+
+def _grad_views(pgrad, poffs, layers):
+    grads = []
+    po = poffs // 4
+    for i, L in enumerate(layers):
+        o = po[i]
+        grads.append(pgrad[o[0]:o[0] + L.K * L.cin * L.cout].view(L.K, L.cin, L.cout))
+        grads.append(pgrad[o[1]:o[1] + L.cout])
+        grads.append(pgrad[o[2]:o[2] + L.cout])
+    return grads
+
+
+def _returns(ctx, dfeats, grads):
+    """backward()'s return tuple. grads None: delivered through the sink. Compact form with ordinary gradients (a second backward
+    before zero_grad(), a sink that refused): the hidden parameters' gradients are accumulated into .grad by hand, exactly what their
+    AccumulateGrad nodes would have done."""
+    n_params = ctx.n_inputs - 3
+    if grads is None:
+        return (dfeats, None, None) + (None,) * n_params
+    if n_params == len(grads):
         return (dfeats, None, None) + tuple(grads)
+    with torch.no_grad():
+        for p, g in zip(ctx.all_params[1:], grads[1:]):
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.add_(g)
+    return (dfeats, None, None, grads[0], None)
 
 
 PROFILE_NO_COUNT = False     # timeline mode: only the events matter; no pair counting (it syncs)
@@ -596,7 +634,7 @@ def run_encoder(encoder, st, defer=False):
     out = layers[-1].lv_out
     if defer and not st.F.requires_grad:
         return Deferred(st.F, encoder, launch(st.F, encoder, layers, params, False), params, out)
-    y = EncoderFn.apply(st.F, encoder, layers, *params)
+    y = apply_encoder(st.F, encoder, layers, params)
     return SparseTensor(y, out.coords, out.stride, out.batch_size, out)
 
 
@@ -617,9 +655,9 @@ class Deferred:
         from .tensor import SparseTensor
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
-                y = EncoderFn.apply(self.feats, self.encoder, self.launched, *self.params)
+                y = apply_encoder(self.feats, self.encoder, self.launched, self.params)
         else:
-            y = EncoderFn.apply(self.feats, self.encoder, self.launched, *self.params)
+            y = apply_encoder(self.feats, self.encoder, self.launched, self.params)
         out = self.level
         return SparseTensor(y, out.coords, out.stride, out.batch_size, out)
 
