@@ -111,6 +111,7 @@ _SPIN_US = float(os.environ.get("IRX_BENCH_SPIN_US", "0"))
 _MARKS = None          # dev (IRX_BENCH_TIMELINE=1): list receiving (name, event on the main stream, host clock) per step
 
 
+_STEP_T = [] if os.environ.get("IRX_BENCH_STEPTIMES") == "1" else None      # dev: host clock at every step start (start-up transient)
 _HOSTCLK = [0.0, 0.0, 0.0, 0] if os.environ.get("IRX_BENCH_HOSTCLOCK") == "1" else None   # issue | backward() | in step_fn, steps
 
 
@@ -227,6 +228,8 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
         # batch N+1: threaded -> the whole preparation runs beside this step; inline -> only its launch phase now
         prepare_next(model, resident, state, phase="launch")
     _mark("step start")
+    if _STEP_T is not None:
+        _STEP_T.append(time.perf_counter())
     opt.zero_grad()
     if _SPIN_US:                                         # dev: is the loop host- or GPU-paced? (host-only busy-wait)
         t_end = time.perf_counter() + _SPIN_US * 1e-6
@@ -273,7 +276,7 @@ def prime(model, resident, args, reducer, opt, state):
     of the pool's boxes (+-5 %, other tenants on the host, and a downward drift under SUSTAINED load: consecutive 30-step blocks of
     one process read 5.4 -> 7.6 ms/step over ten seconds) is larger than anything the first five steps leave behind, and more
     untimed load before the timed region makes the reading worse, not better."""
-    n = int(os.environ.get("IRX_BENCH_PRIME", "0"))
+    n = int(os.environ.get("IRX_BENCH_PRIME", "30"))
     if n <= 0:
         return 0
     bufs = [b for b in model.buffers()]
@@ -784,6 +787,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    if _STEP_T is not None and rank == 0:
+        d = [1e3 * (b - a) for a, b in zip(_STEP_T[:-1], _STEP_T[1:])]
+        sys.stderr.write("step times (ms, host clock at step start; warm-up %d then timed): %s\n" % (args.warmup, " ".join("%.1f" % v for v in d)))
     log("timed region done: %.1f ms/step" % (1000.0 * dt / args.steps))
 
     if rank == 0 and os.environ.get("IRX_BENCH_CPROFILE") == "1":     # dev: host profile of the real pipelined loop
