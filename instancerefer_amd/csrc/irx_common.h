@@ -238,12 +238,18 @@ int irx_bn_forward_slabs_t(const float* slabs, int S, int n, int c, float eps, f
                            const float* residual, int relu, float* mean, float* invstd, float* running_mean, float* running_var,
                            float* x_out, float* y, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int res_bf,
                            int y_bf);
+// the incoming gradient still as the S offset-split fp32 slabs of the data-gradient convolution that produces it (IrxStore::
+// slabs_out): irx_bn_backward_t folds them (dy = (acc ? dy : 0) + sum of the slabs, stored to dy) in its statistics pass
+struct IrxDySlabs {
+  const float* slabs = nullptr;
+  int S = 0, acc = 0;
+};
 int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, int c, const float* mean,
                       const float* invstd, const float* gamma, int relu, float* dx, float* dgamma, float* dbeta,
                       float* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int y_bf,
                       int dy_bf, int dx_bf, int dres_bf, int phases = 3, const float* all_sum_g = nullptr,
                       const float* all_sum_gx = nullptr, double all_count = 0.0, const double* count_dev = nullptr,
-                      const float* beta = nullptr);
+                      const float* beta = nullptr, IrxDySlabs dys = IrxDySlabs());
 
 int irx_bn_sums_t(const float* x, int n, int c, double* sums, void* workspace, size_t workspace_bytes, void* stream, int x_bf,
                   double* count_slot);

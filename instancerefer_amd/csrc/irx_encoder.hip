@@ -274,8 +274,11 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
   const int st = (int)desc[IRX_ENC_STORE];
   IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_backward: bf16 storage needs a bf16 compute mode in IRX_ENC_MODE");
   IRX_REQUIRE(!st || !dx0, "irx_encoder_backward: the input gradient is not available with bf16 storage");
+  IrxDySlabs pending;                        // gy of the layer about to be processed, still as its producer's offset-split slabs
   for (int i = n_layers - 1; i >= 0; --i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
+    const IrxDySlabs dys = pending;
+    pending = IrxDySlabs();
     float* dres = nullptr;
     if (L.res >= 0) dres = (float*)desc[(size_t)L.res * IRX_ENC_NFIELDS + IRX_ENC_GY];
     const int last = (i == n_layers - 1);
@@ -302,7 +305,7 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
     } else {
       rc = irx_bn_backward_t(L.c, L.y, L.gy, L.n_out, L.cout, L.mean, L.invstd, L.gamma, 1, dc_scratch, L.dgamma,
                              L.dbeta, dres, ws_b, r.bn, stream, st, (st && !last) ? 1 : 0, (st && !last) ? 1 : 0, st, st,
-                             3, nullptr, nullptr, 0.0, nullptr, mk_beta);
+                             3, nullptr, nullptr, 0.0, nullptr, mk_beta, dys);
     }
     if (rc) return rc;
     const long abl = irx_knob(IRX_KNOB_ABL);         // dev, timing only: what the chain costs without a kernel family
@@ -342,9 +345,22 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
       if (updgrad && L.tbl_b != L.tbl && L.K == 8 && !st && !irx_conv_bf16() && !acc && wimg[i] && L.n_out >= updgrad_min &&
           irx_updgrad_supported(L.cout, L.cin))
         rc = irx_updgrad_launch(dc_scratch, wimg[i], L.tbl, L.ld, L.n_out, L.cout, L.cin, dx, (hipStream_t)stream);
-      else
+      else {
+        // offset-split layers: the slabs are folded by the NEXT iteration's BatchNorm statistics pass (gy of layer i - 1)
+        float* slabs = nullptr;
+        int nslabs = 0;
+        if (!sync.cb && i > 0 && irx_knob(IRX_KNOB_FOLD_SLABS) != 0) {
+          ty.slabs_out = &slabs;
+          ty.splits_out = &nslabs;
+        }
         rc = irx_spconv_fwd_impl(dc_scratch, L.w, L.tbl_b, L.ld_b, L.n_in, L.K, L.cout, L.cin, L.flip_b, 1, dx, acc, wimg[i],
                                  ws_c, r.conv, stream, ty);
+        if (slabs) {
+          pending.slabs = slabs;
+          pending.S = nslabs;
+          pending.acc = acc;
+        }
+      }
       if (rc) return rc;
     }
   }

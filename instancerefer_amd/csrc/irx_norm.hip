@@ -862,6 +862,119 @@ __global__ __launch_bounds__(BN_PT) void k_bn_partial_slabs(const float* __restr
   }
 }
 
+// k_bn_partial<1> (ReLU layers, mask from y) with the offset-split reduce of the data-gradient convolution folded in: dy does not
+// exist yet — the conv left S fp32 slabs — so this pass forms dy = (acc ? dy : 0) + sum of the slabs (k_wgrad_reduce's adds, in its
+// order), stores it (bf16: XB) for the apply pass, and accumulates the two gradient sums from the STORED value with k_bn_partial<1>'s
+// thread mapping, row order and fold: bit-identical to reduce-then-statistics, one dependent launch fewer per split layer.
+template <int V, int XB>
+__global__ __launch_bounds__(BN_PT) void k_bn_partial1_slabs(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ slabs, int S, size_t elems, int acc,
+                                                           float* __restrict__ dy, int n, int c, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, int qpad, int rows_per_block,
+                                                           float* __restrict__ part) {
+  __shared__ __align__(16) float s0[BN_PT * V];
+  __shared__ __align__(16) float s1[BN_PT * V];
+  const int cq = c / V;
+  const int qd = threadIdx.x % qpad;
+  const int rg = threadIdx.x / qpad;
+  const int nrg = BN_PT / qpad;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  float a0[V], a1[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) a0[j] = a1[j] = 0.f;
+  if (qd < cq) {
+    float mu[V], is[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      mu[j] = mean[qd * V + j];
+      is[j] = invstd[qd * V + j];
+    }
+    for (int r = r0 + rg; r < r1; r += nrg) {
+      const size_t off = (size_t)r * c + (size_t)qd * V;
+      float xv[V], yv[V], v[V], old[V];
+      sl_ld<V, XB>(x, off, xv);
+      sl_ld<V, XB>(y, off, yv);
+      if (acc) sl_ld<V, XB>(dy, off, old);
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = 0.f;
+      int sidx = 0;
+      for (; sidx + 4 <= S; sidx += 4) {
+        float4 t[4][V / 4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < V / 4; ++q) t[u][q] = *reinterpret_cast<const float4*>(slabs + (size_t)(sidx + u) * elems + off + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < V / 4; ++q) {
+            v[4 * q] += t[u][q].x; v[4 * q + 1] += t[u][q].y; v[4 * q + 2] += t[u][q].z; v[4 * q + 3] += t[u][q].w;
+          }
+      }
+      for (; sidx < S; ++sidx)
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(slabs + (size_t)sidx * elems + off + 4 * q);
+          v[4 * q] += t.x; v[4 * q + 1] += t.y; v[4 * q + 2] += t.z; v[4 * q + 3] += t.w;
+        }
+      if (acc) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = old[j] + v[j];          // (old + sum): k_wgrad_reduce's order
+      }
+      if constexpr (XB) {
+#pragma unroll
+        for (int j = 0; j < V; j += 2) {
+          const unsigned pk = irx_pk_bf16(v[j], v[j + 1]);
+          v[j] = __uint_as_float(pk << 16);
+          v[j + 1] = __uint_as_float(pk & 0xffff0000u);
+        }
+      }
+      sl_st<V, XB>(dy, off, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float gval = v[j];
+        if (!(yv[j] > 0.f)) gval = 0.f;
+        a0[j] += gval;
+        a1[j] += gval * ((xv[j] - mu[j]) * is[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    s0[threadIdx.x * V + j] = a0[j];
+    s1[threadIdx.x * V + j] = a1[j];
+  }
+  __syncthreads();
+  if (rg == 0 && qd < cq) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int g2 = 0; g2 < nrg; ++g2) {
+        t0 += s0[(g2 * qpad + qd) * V + j];
+        t1 += s1[(g2 * qpad + qd) * V + j];
+      }
+      part[((size_t)blockIdx.x * 2 + 0) * c + qd * V + j] = t0;
+      part[((size_t)blockIdx.x * 2 + 1) * c + qd * V + j] = t1;
+    }
+  }
+}
+
+__global__ void k_bn_slab_reduce_acc(const float* __restrict__ part, int S, size_t elems, float* __restrict__ out, int out_bf, int acc) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= elems) return;
+  float s = 0.f;
+  for (int j = 0; j < S; ++j) s += part[(size_t)j * elems + i];
+  if (out_bf) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(out) + i;
+    if (acc) s = __uint_as_float((unsigned)*o << 16) + s;
+    *o = (unsigned short)(irx_pk_bf16(s, 0.f) & 0xffffu);
+  } else {
+    out[i] = acc ? out[i] + s : s;
+  }
+}
+
 // a zeroed ticket counter for one k_bn_partial launch that folds its own partials (see the kernel's tail), or NULL when that
 // is switched off (IRX_BN_LASTBLOCK=0: the separate k_bn_finalize launch) or the channel count does not fit its fold
 static unsigned* bn_counter(int c) {
@@ -1223,7 +1336,7 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
                       const float* invstd, const float* gamma, int relu, float* dx, float* dgamma, float* dbeta,
                       float* dresidual, void* workspace, size_t workspace_bytes, void* stream, int x_bf, int y_bf,
                       int dy_bf, int dx_bf, int dres_bf, int phases, const float* all_sum_g, const float* all_sum_gx,
-                      double all_count, const double* count_dev, const float* beta) {
+                      double all_count, const double* count_dev, const float* beta, IrxDySlabs dys) {
   // beta != NULL (with relu): the forward pass had NO shortcut, i.e. y = relu(fma(x, invstd * gamma, fma(-mean, invstd * gamma,
   // beta))): the ReLU mask is recomputed from x in both passes and y is not read (the encoder executor passes it for the 9
   // of 13 layers without a shortcut; the C-ABI entry points below keep reading y)
@@ -1244,6 +1357,20 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
   }
   IRX_REQUIRE(x && dy && mean && invstd && (gamma || phases == 1) && (dx || phases == 1), "irx_bn_backward: null pointer");
   IRX_REQUIRE(!relu || y, "irx_bn_backward: relu needs y");
+  bool fold_dy = false;
+  if (dys.slabs) {
+    // dy arrives as the data-gradient convolution's offset-split slabs: folded by the statistics pass below when the call has the
+    // plain shape (local statistics, ReLU, one element type), materialised by a reduce launch of its own otherwise
+    const int vv = x_bf ? 8 : 4;
+    fold_dy = phases == 3 && relu && x_bf == y_bf && x_bf == dy_bf && c % vv == 0 && !bn_slice_ok(n, c, x_bf) &&
+              ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)dys.slabs) & 15) == 0) && !(bn_abl() & 4);
+    if (!fold_dy) {
+      const size_t elems = (size_t)n * c;
+      k_bn_slab_reduce_acc<<<irx_cdiv((long long)elems, 256), 256, 0, S_(stream)>>>(dys.slabs, dys.S, elems, const_cast<float*>(dy),
+                                                                                  dy_bf, dys.acc);
+      IRX_CHECK_LAUNCH("irx_bn_backward(slab reduce)");
+    }
+  }
   const int nblk = irx_cdiv(n, bn_rows(n, c));
   float* part = (float*)workspace;
   const bool v4 = (c % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)dy & 15) == 0) &&
@@ -1300,6 +1427,13 @@ int irx_bn_backward_t(const float* x, const float* y, const float* dy, int n, in
                                                                       bn_rows(n, c), part, ty, nullptr, nullptr, fin);     \
   } while (0)
   if (!(phases & 1) || (bn_abl() & 4)) {
+  } else if (fold_dy) {
+    const size_t elems = (size_t)n * c;
+    fin = BnFin();
+    if (x_bf) k_bn_partial1_slabs<8, 1><<<nblk, BN_PT, 0, S_(stream)>>>(x, y, dys.slabs, dys.S, elems, dys.acc, const_cast<float*>(dy), n, c,
+                                                                      mean, invstd, next_pow2(c / 8), bn_rows(n, c), part);
+    else k_bn_partial1_slabs<4, 0><<<nblk, BN_PT, 0, S_(stream)>>>(x, y, dys.slabs, dys.S, elems, dys.acc, const_cast<float*>(dy), n, c,
+                                                                  mean, invstd, next_pow2(c / 4), bn_rows(n, c), part);
   } else if (v8)
     BN_PARTIAL1(8, false, next_pow2(c / 8));
   else if (v4 && any_bf)

@@ -476,7 +476,7 @@ int irx_spconv_fwd_impl(const float* x, const float* w, const int32_t* nbr, int 
                               splits > 1 ? slabs : y, splits, accumulate, S(stream), 0, ty);
     if (rc) return rc;
     if (splits > 1) {
-      if (ty.slabs_out && ty.splits_out && !accumulate) {      // the caller folds the slabs (into its BatchNorm statistics pass)
+      if (ty.slabs_out && ty.splits_out) {      // the caller folds the slabs (into its BatchNorm pass), `accumulate` included
         *ty.slabs_out = slabs;
         *ty.splits_out = splits;
         return IRX_OK;
