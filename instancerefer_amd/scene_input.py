@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .data import InstancePack
+from .data import InstancePack, idx_tensor
 
 MEAN_COLOR_RGB = np.array([109.8, 97.2, 83.8])     # lib/dataset.py:22
 MAX_NUM_OBJ = 128                                  # lib/dataset.py:21
@@ -303,7 +303,7 @@ class PendingBatch:
             host[k] = np.stack([d.labels[k] for d in self.draws], 0)
         dd["_host"] = dict(dd.get("_host", {}), **host)
         for k in ("ref_center_label", "ref_size_residual_label"):
-            dd[k] = torch.from_numpy(host[k]).to(self.device, non_blocking=True)
+            dd[k] = idx_tensor(host[k], self.device, dtype=torch.from_numpy(host[k]).dtype)    # (pinned staging, as above)
         for k in ("ref_size_class_label", "ref_heading_class_label", "ref_heading_residual_label"):
             dd[k] = torch.from_numpy(host[k])
         dd["point_clouds"] = self.clouds
@@ -388,7 +388,7 @@ class PendingDeviceBatch:
         obbs = back[2 * S:2 * S + 7 * S].reshape(S, 7)
         ext = back[9 * S:].reshape(B, 6).copy()
         keep = np.flatnonzero((counts > 0) & (cls >= 0))
-        kept_dev = torch.from_numpy(keep).to(self.device, non_blocking=True)
+        kept_dev = idx_tensor(keep, self.device)       # (pinned staging: a pageable H2D copy blocks until the stream drains)
         inst_points = self.inst_points.index_select(0, kept_dev)
         obbs_dev = self.obbs_dev.index_select(0, kept_dev)
         for i, d in enumerate(self.draws):
@@ -466,8 +466,13 @@ def build_batch_device(scans, object_ids, tables, device, num_points=40000, augm
     # semantic id of each instance's FIRST sampled point (lib/dataset.py:213: semantic_labels[ind[0]])
     first = order.index_select(0, seg[:-1].clamp(max=B * n - 1))
     nyu = sem.view(-1).index_select(0, first)
-    lut = torch.from_numpy(np.where(tables._is_object[:len(tables.nyu40id2class)], tables.nyu40id2class, -1)
-                           .astype(np.int64)).to(device, non_blocking=True)
+    lut = tables.__dict__.get("_lut_dev")
+    if lut is None or lut.device != torch.device(device):
+        # once per ClassTables and device: a pageable H2D copy blocks the issuing thread until its stream has drained (4 ms per
+        # batch of the preparation worker's time in the round-5 host profile of tools/e2e_train_bench.py)
+        lut = torch.from_numpy(np.where(tables._is_object[:len(tables.nyu40id2class)], tables.nyu40id2class, -1)
+                               .astype(np.int64)).to(device)
+        tables.__dict__["_lut_dev"] = lut
     cls = torch.where((nyu >= 0) & (nyu < lut.shape[0]), lut[nyu.clamp(0, lut.shape[0] - 1)], torch.full_like(nyu, -1))
     rows32 = torch.empty((S, NUM_INSTANCE_POINTS), dtype=torch.int32, device=device)
     _lib.call("irx_resample_rows", _lib.ptr(order32), _lib.ptr(seg32), S, NUM_INSTANCE_POINTS,
