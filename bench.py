@@ -30,6 +30,12 @@ import os
 import sys
 import time
 
+# The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4). One rank uses four streams (main, scene encoder,
+# language, input preparation); with more than one rank RCCL adds streams of its own, and a stream that shares a queue with another
+# runs behind it — round 5 measured a HALVED step when a fifth stream appeared. 8 queues measured neutral at N = 1 (2 984 vs 2 999
+# scenes/s). Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 

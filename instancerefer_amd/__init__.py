@@ -9,6 +9,11 @@ __version__ = "0.1.0"
 
 import os as _os
 
+# More hardware queues than the runtime's default of 4 (see bench.py): the training forward of the bf16 modes runs on three
+# streams beside the caller's preparation stream, and a collective library adds its own. Only effective when this package is
+# imported before the HIP runtime initialises (first GPU call); harmless otherwise.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # Host-side dispatch cost of the small dense GEMMs of the language / matching heads (M <= a few hundred rows), measured on
 # MI355X with PyTorch 2.10: hipBLASLt 18 us per mm / 21 us per nn.Linear, rocBLAS 7 / 16 us (tools/micro/gemm_host.py).
 # With ~70 such calls per training step and the step host-bound, that is ~0.6 ms of 12.  The kernels themselves are
