@@ -326,7 +326,8 @@ int irx_profile_next_kernel(void* ev_start, void* ev_stop);
  * "wgrad_xcd_f32" (IRX_WGRAD_XCD_F32, 0: number of XCD-segment units for the fp32 pair-list kernels, 0 = their (share, offset) grid),
  * "enc_fold_slabs" (IRX_ENC_FOLD_SLABS, 1: inside irx_encoder_forward the offset-split slabs of a small level's convolution are
  * folded by the BatchNorm statistics pass instead of a reduce launch of their own; bit-identical), "enc_abl" (IRX_ENC_ABL, 0: TIMING
- * ONLY, results wrong — irx_encoder_backward without its weight-gradient (bit 0) / data-gradient (bit 1) launches).
+ * ONLY, results wrong — irx_encoder_backward without its weight-gradient (bit 0) / data-gradient (bit 1) launches), "stem_mfma"
+ * (IRX_STEM_MFMA, 1: the 7-channel stem forward as an im2col tile + fp32 MFMA; 0: the vector-ALU kernel).
  * irx_debug_get_knob returns the value in force (-1: unknown name). Not part of the reference-facing surface. */
 int irx_debug_set_knob(const char* name, long value);
 long irx_debug_get_knob(const char* name);

@@ -300,6 +300,7 @@ const KnobDef kKnobs[IRX_KNOB_COUNT] = {
     {"wgrad_xcd_f32", "IRX_WGRAD_XCD_F32", 0},   // fp32 pair-list weight-gradient on XCD-segment work units: their number, 0 = off
     {"enc_fold_slabs", "IRX_ENC_FOLD_SLABS", 1}, // encoder executor: offset-split slabs folded by the BatchNorm statistics pass
     {"enc_abl", "IRX_ENC_ABL", 0},               // dev, TIMING ONLY (results wrong): encoder backward without bit 0 = weight gradients, bit 1 = data gradients
+    {"stem_mfma", "IRX_STEM_MFMA", 1},           // 7-channel stem forward as im2col + fp32 MFMA (k_stem_fwd_mfma); 0: vector-ALU kernel
 };
 std::atomic<long> g_knob_val[IRX_KNOB_COUNT];
 std::atomic<int> g_knob_set[IRX_KNOB_COUNT];

@@ -5,6 +5,7 @@
 //             neighbour one broadcast read of the input row and Cin LDS float4 reads.
 //   wgrad   : dense im2col tile assembled in LDS per 64-row chunk, MFMA with the rows as the reduction dimension
 //             (see k_stem_wgrad); per-workgroup partial sums are reduced by k_wgrad_reduce (deterministic).
+#include <stdlib.h>
 #include "irx_common.h"
 
 #define ST_COUT 32
@@ -186,11 +187,127 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad(const float* __restrict__
   }
 }
 
+// Forward as a dense im2col tile + fp32 MFMA (round 5). k_stem_fwd above executes 27 x CIN x 32 MASKED multiply-
+// adds per row on the vector ALU whether a neighbour exists or not (19 % useful at 5 neighbours per voxel) and is bound by that: 124 us
+// on the 489 k-voxel level. Here, per 64-row chunk, the im2col tile X[row][k * CIN + c] (zeros where the neighbour is missing) is
+// assembled in LDS exactly as k_stem_wgrad does — one coalesced table read, the valid neighbours' rows as two 16-byte loads — and
+// Y = X W runs on v_mfma_f32_16x16x4_f32: M = 64 rows (wave w owns rows 16 w ..), N = 32, K = 27 CIN padded to 192. The B operand
+// (W, 24 KB) lives in REGISTERS — lane (n = l & 15, g = l >> 4) holds W[4 s + g][16 t + n] for the 48 steps s and both column
+// halves t, 96 VGPRs, loaded once per workgroup — so LDS only holds the X tile (53.5 KB) and a 9 KB output staging tile: two
+// workgroups per CU, whose gather / multiply / store phases overlap each other. The accumulators are transposed through LDS once
+// per chunk for whole-row stores.
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void k_stem_fwd_mfma(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const int32_t* __restrict__ nbr, int ld, int n_out,
+                                                          int rows_per_block, float* __restrict__ y, int ldx, int y_bf) {
+  constexpr int K = 27;
+  constexpr int MREAL = K * CIN;                 // 189 for CIN = 7
+  constexpr int KS = (MREAL + 3) / 4;            // reduction steps of 4 (48)
+  constexpr int LDX = ((MREAL + 15) / 16) * 16 + 17;   // 209: see k_stem_wgrad (conflict-free column writes, <= 2-way fragment reads)
+  constexpr int LDO = ST_COUT + 4;               // output staging [64][36]
+  __shared__ __attribute__((aligned(16))) float sX[64 * LDX];
+  __shared__ __attribute__((aligned(16))) float sO[64 * LDO];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mm = lane & 15, g4 = lane >> 4;
+  float wr[KS][2];
+#pragma unroll
+  for (int s2 = 0; s2 < KS; ++s2) {
+    const int k = 4 * s2 + g4;
+    wr[s2][0] = (k < MREAL) ? w[(size_t)k * ST_COUT + mm] : 0.f;
+    wr[s2][1] = (k < MREAL) ? w[(size_t)k * ST_COUT + 16 + mm] : 0.f;
+  }
+  for (int i = tid; i < 64 * LDX; i += 256) sX[i] = 0.f;     // pad columns stay zero for the whole kernel
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > n_out) r1 = n_out;
+  // software pipeline: chunk q + 1's table entries are requested before chunk q's MFMA loop and its rows from the middle of it, so
+  // the two dependent round trips of the gather travel under the matrix work instead of in front of it
+  constexpr int EPT = (K * 64 + 255) / 256;
+  int idx[EPT];
+  float v[EPT][CIN];
+  auto fetch_idx = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * 256;
+      const int k = i >> 6, r = i & 63;
+      idx[e] = (i < K * 64 && q + r < r1) ? nbr[(size_t)k * ld + q + r] : -1;
+    }
+  };
+  auto fetch_rows = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      // (predicating the load on idx >= 0 — four slots of five are empty — measured 6 % SLOWER: the branch per element costs more
+      //  than the dummy, always-cached load of row 0 it saves)
+      const float* xr = x + (size_t)(idx[e] < 0 ? 0 : idx[e]) * ldx;
+      st_load_row<CIN>(xr, v[e]);
+    }
+  };
+  if (r0 < r1) {
+    fetch_idx(r0);
+    fetch_rows();
+  }
+  for (int q0 = r0; q0 < r1; q0 += 64) {
+    __syncthreads();                                         // previous chunk's fragment reads are done
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * 256;
+      if (i < K * 64) {
+        const int k = i >> 6, r = i & 63;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) sX[r * LDX + k * CIN + c] = idx[e] >= 0 ? v[e][c] : 0.f;
+      }
+    }
+    __syncthreads();
+    const bool more = q0 + 64 < r1;
+    if (more) fetch_idx(q0 + 64);
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    const float* xa = sX + (16 * wave + mm) * LDX + g4;
+#pragma unroll
+    for (int s2 = 0; s2 < KS / 2; ++s2) {
+      const float av = xa[4 * s2];
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[s2][0], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[s2][1], d1, 0, 0, 0);
+    }
+    if (more) fetch_rows();
+#pragma unroll
+    for (int s2 = KS / 2; s2 < KS; ++s2) {
+      const float av = xa[4 * s2];
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[s2][0], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[s2][1], d1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sO[(16 * wave + 4 * g4 + r) * LDO + mm] = d0[r];
+      sO[(16 * wave + 4 * g4 + r) * LDO + 16 + mm] = d1[r];
+    }
+    __syncthreads();
+    for (int f = tid; f < 64 * (ST_COUT / 4); f += 256) {
+      const int r = f >> 3, c4 = (f & 7) * 4;
+      if (q0 + r < r1) irx_st4(y, (size_t)(q0 + r) * ST_COUT + c4, y_bf, *reinterpret_cast<const float4*>(&sO[r * LDO + c4]));
+    }
+  }
+}
+
 bool irx_stem_supported(int K, int cin, int cout) { return K == 27 && cout == ST_COUT && cin >= 1 && cin <= 8; }
 
 int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int ld, int n_out, int K, int cin,
                         float* y, hipStream_t st, int ldx, int y_bf) {
   if (ldx <= 0) ldx = cin;
+  // im2col + MFMA form (k_stem_fwd_mfma) for the usual 7-channel stem; "stem_mfma" / IRX_STEM_MFMA=0 keeps the vector-ALU kernel (dev A/B; the
+  // two differ in summation order only)
+  const bool mfma = irx_knob(IRX_KNOB_STEM_MFMA) != 0;
+  if (mfma && K == 27 && cin == 7 && n_out >= 64) {
+    int blocks = irx_cdiv(n_out, 64 * 4);                    // >= 4 chunks of 64 rows per workgroup
+    if (blocks > 2048) blocks = 2048;
+    int rpb = irx_cdiv(n_out, blocks);
+    rpb = irx_cdiv(rpb, 64) * 64;
+    blocks = irx_cdiv(n_out, rpb);
+    irx_bracket_begin(st);
+    k_stem_fwd_mfma<7><<<blocks, 256, 0, st>>>(x, w, nbr, ld, n_out, rpb, y, ldx, y_bf);
+    irx_bracket_end(st);
+    IRX_CHECK_LAUNCH("irx_spconv_fwd(stem, mfma)");
+    return IRX_OK;
+  }
   const int grid = irx_cdiv(n_out, 32 * ST_R);
   irx_bracket_begin(st);
   switch (cin) {
