@@ -144,7 +144,7 @@ struct IrxStore {
 // ---- dev / test knobs (irx_debug_set_knob, include/irx.h): each is read from its environment variable ONCE, on first use, and
 // can afterwards only be changed through the setter (an atomic store) — a per-call getenv() from library lane threads raced
 // with tests that mutate os.environ from the Python thread.
-enum IrxKnob { IRX_KNOB_SPCONV3 = 0, IRX_KNOB_UPDGRAD, IRX_KNOB_UPDGRAD_MIN, IRX_KNOB_WGRAD_V1, IRX_KNOB_WGRAD3, IRX_KNOB_WGRAD3_UNITS, IRX_KNOB_WGRAD3_XCD_MIN, IRX_KNOB_WGRAD_XCD_F32, IRX_KNOB_FOLD_SLABS, IRX_KNOB_ABL, IRX_KNOB_STEM_MFMA, IRX_KNOB_COUNT };
+enum IrxKnob { IRX_KNOB_SPCONV3 = 0, IRX_KNOB_UPDGRAD, IRX_KNOB_UPDGRAD_MIN, IRX_KNOB_WGRAD_V1, IRX_KNOB_WGRAD3, IRX_KNOB_WGRAD3_UNITS, IRX_KNOB_WGRAD3_XCD_MIN, IRX_KNOB_WGRAD_XCD_F32, IRX_KNOB_FOLD_SLABS, IRX_KNOB_ABL, IRX_KNOB_STEM_MFMA, IRX_KNOB_SPCONV3_XCD_MIN, IRX_KNOB_SPCONV4, IRX_KNOB_COUNT };
 long irx_knob(int id);
 
 // ---- measurement aid (irx_profile_next_kernel, include/irx.h): brackets the next DOMINANT sparse-conv kernel of this

@@ -301,6 +301,8 @@ const KnobDef kKnobs[IRX_KNOB_COUNT] = {
     {"enc_fold_slabs", "IRX_ENC_FOLD_SLABS", 1}, // encoder executor: offset-split slabs folded by the BatchNorm statistics pass
     {"enc_abl", "IRX_ENC_ABL", 0},               // dev, TIMING ONLY (results wrong): encoder backward without bit 0 = weight gradients, bit 1 = data gradients
     {"stem_mfma", "IRX_STEM_MFMA", 1},           // 7-channel stem forward as im2col + fp32 MFMA (k_stem_fwd_mfma); 0: vector-ALU kernel
+    {"spconv3_xcd_min", "IRX_SPCONV3_XCD_MIN", 16},   // k_spconv3: XCD-contiguous tile ranges from this many row tiles on (0 = off)
+    {"spconv4", "IRX_SPCONV4", 1},               // bf16-input convs with 64 / 128 input channels on k_spconv4 (LDS-DMA, row-shaped gathers)
 };
 std::atomic<long> g_knob_val[IRX_KNOB_COUNT];
 std::atomic<int> g_knob_set[IRX_KNOB_COUNT];

@@ -42,6 +42,20 @@ __host__ __device__ constexpr int s3_chan(int s, int h, int j) {
   return IRX_S3_AMAP ? (CIN / 2) * h + 8 * s + j : 16 * s + 8 * h + j;
 }
 
+// dev: per-wave s_memtime stamps (tools/micro/s3_trace.py): 256 slots per wave, buffer set by irx_debug_s3_trace
+#ifndef IRX_S3_TRACE
+#define IRX_S3_TRACE 0
+#endif
+#if IRX_S3_TRACE
+__device__ unsigned long long* g_s3_trace = nullptr;
+extern "C" int irx_debug_s3_trace(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_s3_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define S3_EV(i_) do { if (trc && lane == 0) trc[i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S3_EV(i_) do { } while (0)
+#endif
+
 #define S3_OOB 0x80000000u
 #ifndef IRX_S3_SKIP
 #define IRX_S3_SKIP 1
@@ -60,7 +74,7 @@ template <int CIN, int COUT, int NW, int KH>
 __global__ __launch_bounds__(64 * NW, (NW <= 4 ? (KH > 1 ? 3 : 2) : 1))
 void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ wimg, const int32_t* __restrict__ nbr,
                int ld, int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate, int ldx,
-               int y_bf) {
+               int y_bf, int xcd_tiles, int splits) {
   constexpr int TM = 32 * NW, NTH = 64 * NW;
   constexpr int NS = CIN / 16 / KH, NCB = COUT / 32;    // MFMA steps of one item
   constexpr int WPK = CIN * COUT * 2 / 16;          // 16-byte pieces of one offset's image
@@ -80,23 +94,54 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q0 = blockIdx.x * TM;
-  const int kb = blockIdx.y * k_per_split;
+  // Work unit -> (row tile, offset split).  xcd_tiles = 0: grid (tiles, splits).  xcd_tiles = T > 0: 1-D grid of 8 * T * splits
+  // workgroups; the dispatcher deals consecutive workgroups round-robin over the 8 XCDs (workgroup b runs on XCD b % 8), so
+  // XCD x is given the T CONSECUTIVE tiles x T .. x T + T - 1: rows are in Morton order within a scene, hence the rows an XCD's
+  // tiles gather — their own range plus a halo — are an eighth of the tensor and stay in that XCD's 4 MB L2, instead of every
+  // L2 fetching the whole tensor once (measured fabric traffic of the round-robin form: ~8x the tensor per launch).
+  int tile = blockIdx.x, split = blockIdx.y;
+  if (xcd_tiles) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = xcd * xcd_tiles + j / splits;
+    split = j % splits;
+    if (tile * TM >= n_out) return;                 // (block-uniform: the last XCD's range may be short)
+  }
+#if IRX_S3_TRACE
+  unsigned long long* trc = g_s3_trace ? g_s3_trace + ((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * NW + wave) * 256 : nullptr;
+  int itn = 0;
+  if (trc && lane == 0) { trc[255] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); trc[254] = ((unsigned long long)tile << 32) | (unsigned)split; }
+#endif
+  S3_EV(0);
+  const int q0 = tile * TM;
+  const int kb = split * k_per_split;
   const int ke = (kb + k_per_split < K) ? kb + k_per_split : K;
   const int nk = ke - kb;
-  y += (size_t)blockIdx.y * n_out * COUT;           // offset-split slabs (fp32; y_bf and accumulate are 0 then)
+  y += (size_t)split * n_out * COUT;           // offset-split slabs (fp32; y_bf and accumulate are 0 then)
   const unsigned rowbytes = (unsigned)ldx * 2u;
 
   // ---- setup: the tile's table columns as byte offsets; per-wave and per-tile activity masks ----
-  for (int e = tid; e < nk * TM; e += NTH) {
-    const int kk = e / TM, r = e % TM;
-    const int k = kb + kk;
-    const int kt = flip_k ? (K - 1 - k) : k;
-    const int idx = (q0 + r < n_out) ? nbr[(size_t)kt * ld + q0 + r] : -1;
-    sOff[e] = (idx >= 0 && !(IRX_S3_ABL & 1)) ? (unsigned)idx * rowbytes : S3_OOB;
+  // (all of a thread's table reads are issued before the first one is used: as a plain load-then-store loop they went out one at a
+  // time — 17 k cycles of dependent round trips on the 81 k-row level, s_memtime stamps of tools/micro/s3_trace.py)
+  {
+    constexpr int NLD = (KMAX * TM + NTH - 1) / NTH;
+    int idxv[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int e = tid + j * NTH;
+      const int kk = e / TM, r = e % TM;
+      const int k = kb + kk;
+      const int kt = flip_k ? (K - 1 - k) : k;
+      idxv[j] = (e < nk * TM && q0 + r < n_out) ? nbr[(size_t)kt * ld + q0 + r] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int e = tid + j * NTH;
+      if (e < nk * TM) sOff[e] = (idxv[j] >= 0 && !(IRX_S3_ABL & 1)) ? (unsigned)idxv[j] * rowbytes : S3_OOB;
+    }
   }
   if (tid == 0) sMask = 0;
   __syncthreads();
+  S3_EV(1);
   unsigned wm = 0;                                   // offsets at which this wave's 32 rows have a neighbour
   for (int kk = 0; kk < nk; ++kk) {
     const unsigned o = sOff[kk * TM + wave * 32 + (lane & 31)];
@@ -106,6 +151,7 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
   wm = __builtin_amdgcn_readfirstlane(wm);
   if (lane == 0 && wm) atomicOr(&sMask, wm);
   __syncthreads();
+  S3_EV(2);
   unsigned act = __builtin_amdgcn_readfirstlane(sMask);
 
   s3_f32x16 acc[NCB];
@@ -196,6 +242,7 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
     }
     s3_wait_vmcnt<0>();                               // once per tile: the per-step waits below count from a clean slate
     S3_BARRIER();
+    S3_EV(3);
 
     auto item = [&](auto C_, auto T_, Cur c, Cur cn, Cur cn2) __attribute__((always_inline)) {
       constexpr int C = decltype(C_)::value, T = decltype(T_)::value;
@@ -203,6 +250,7 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
       // that issues them back to back sits in the texture-address queue (~25 cycles per 1 KiB instruction and CU) with its
       // MFMA pipe idle.  IRX_S3_SKIP: a wave whose 32 rows have no neighbour at this offset skips the MFMAs (per step,
       // wave-uniform; the requests stay unconditional so that the counts below are exact).
+      S3_EV(4 + 4 * itn);
       const unsigned offA = S3_OFF_A(cn);
       const bool live = c.kk >= 0 && (!IRX_S3_SKIP || ((wm >> c.kk) & 1u));
       const s3_u32x4* bw = sW + C * WP + lane;
@@ -224,6 +272,7 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
           if (s < WPT) s3_wait_vmcnt<NS + WPT - 2>();
           else s3_wait_vmcnt<NS + WPT - 1>();
         }
+        if (s == 0) S3_EV(5 + 4 * itn);
         if (s < WPT) {
           S3_STORE_W(T, s);
           S3_LOAD_W(cn2, s);
@@ -243,7 +292,12 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      S3_EV(6 + 4 * itn);
       S3_BARRIER();
+      S3_EV(7 + 4 * itn);
+#if IRX_S3_TRACE
+      ++itn;
+#endif
     };
     // Items go in pairs (register-set parity is a compile-time constant) and the loop has ONE exit, at the bottom: an odd number
     // of items ends with an empty one (kk < 0: no MFMAs, all requests out of range).  A mid-loop exit made the compiler
@@ -268,6 +322,10 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
   // ---- epilogue: D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  One 32-column block at a time through
   // the wave's OWN LDS region (no workgroup barrier: the loop's last barrier is behind every read of sW / sOff), then whole
   // 32-column row pieces go out with 16 B (fp32) / 8 B (bf16) per lane ----
+  S3_EV(250);
+#if IRX_S3_TRACE
+  if (trc && lane == 0) trc[253] = (unsigned long long)itn;
+#endif
   float* so = reinterpret_cast<float*>(smem) + wave * 32 * LDO;
   const int col = lane & 31, r4 = 4 * (lane >> 5);
 #pragma unroll
@@ -290,6 +348,491 @@ void k_spconv3(const unsigned short* __restrict__ x, const uint4* __restrict__ w
       }
     }
   }
+  S3_EV(251);
+}
+
+// LDS-DMA issue as inline asm.  With the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc treats every later ds_read as
+// possibly aliasing the pending DMA and puts s_waitcnt vmcnt(0) in front of it — the request is then waited for where it is
+// issued.  As asm the requests are invisible to the compiler's counter model (its own waits can only over-wait: vmcnt retires in
+// order), and the kernel's explicit vmcnt(0) at the item barrier is the only wait they get.  M0 (the LDS destination) is saved and
+// restored around a group.  `pre_lgkm0`: s_waitcnt lgkmcnt(0) first (the fragment reads of the buffer being refilled are back).
+typedef int s4_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s4_i32x4 s4_rsrc(const void* base, unsigned num_records) {
+  const unsigned long long b = (unsigned long long)base;
+  return (s4_i32x4){(int)(unsigned)b, (int)((unsigned)(b >> 32) & 0xffffu), (int)num_records, 0x00020000};
+}
+__device__ __forceinline__ unsigned s4_lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+// The accumulate-in-place form of the MFMA as asm: with the builtin inside k_spconv4's conditional (wave-skip) item body the
+// register allocator gave every accumulator a second home (D != C, 64 more VGPRs -> spills at three workgroups per CU).  The
+// operands come from ds_read (the compiler's lgkmcnt covers asm inputs); dependent MFMAs on one accumulator are interlocked by
+// the hardware; the accumulators are next read behind the tile's last barrier.
+__device__ __forceinline__ void s4_mfma(s3_f32x16& acc, const s3_u32x4& a, const s3_u32x4& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// one instruction: LDS address lds, per-lane byte offset v, scalar offset soff
+__device__ __forceinline__ void s4_dma1(s4_i32x4 rs, unsigned lds, unsigned v, unsigned soff) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds), "v"(v), "s"(rs), "s"(soff)
+      : "memory");
+}
+// the row instructions of one set, as many as it has groups of 8 present rows (np rows: ceil(np / 8) of the four); the count is
+// tested INSIDE the asm: branches around the requests in the C++ made the register allocator split the accumulators' live ranges
+__device__ __forceinline__ void s4_dma_rows_n(s4_i32x4 rs, unsigned lds0, unsigned v0, unsigned v1, unsigned v2, unsigned v3,
+                                              unsigned soff, int np) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_cmp_lt_i32 %8, 1\n\t"
+      "s_cbranch_scc1 s4_rows_done_%=\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %6, %7 offen lds\n\t"
+      "s_cmp_lt_i32 %8, 9\n\t"
+      "s_cbranch_scc1 s4_rows_done_%=\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %3, %6, %7 offen lds\n\t"
+      "s_cmp_lt_i32 %8, 17\n\t"
+      "s_cbranch_scc1 s4_rows_done_%=\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %4, %6, %7 offen lds\n\t"
+      "s_cmp_lt_i32 %8, 25\n\t"
+      "s_cbranch_scc1 s4_rows_done_%=\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %5, %6, %7 offen lds\n"
+      "s4_rows_done_%=:\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds0), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(rs), "s"(soff), "s"(np)
+      : "memory", "scc");
+}
+// four row instructions: LDS lds0 + {0, 1, 2, 3} KB, per-lane byte offsets v0..v3, one scalar offset
+__device__ __forceinline__ void s4_dma_rows(s4_i32x4 rs, unsigned lds0, unsigned v0, unsigned v1, unsigned v2, unsigned v3,
+                                            unsigned soff) {
+  unsigned keep;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %6, %7 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %3, %6, %7 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %4, %6, %7 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %5, %6, %7 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds0), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(rs), "s"(soff)
+      : "memory", "scc");
+}
+// N image instructions: LDS lds0 + i * 4 KB, scalar offsets soff0 + i * 4 KB, per-lane offset v
+template <int N>
+__device__ __forceinline__ void s4_dma_img(s4_i32x4 rs, unsigned lds0, unsigned v, unsigned soff0) {
+  unsigned keep, so;
+  if constexpr (N == 1) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %3, %4, %5 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(so)
+        : "s"(lds0), "v"(v), "s"(rs), "s"(soff0)
+        : "memory", "scc");
+  } else if constexpr (N == 2) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_add_u32 %1, %5, 0x1000\n\t"
+        "buffer_load_dwordx4 %3, %4, %5 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %3, %4, %1 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(so)
+        : "s"(lds0), "v"(v), "s"(rs), "s"(soff0)
+        : "memory", "scc");
+  } else {
+    static_assert(N == 4, "1, 2 or 4 image instructions per wave");
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_add_u32 %1, %5, 0x1000\n\t"
+        "buffer_load_dwordx4 %3, %4, %5 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %3, %4, %1 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_add_u32 %1, %1, 0x1000\n\t"
+        "buffer_load_dwordx4 %3, %4, %1 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_add_u32 %1, %1, 0x1000\n\t"
+        "buffer_load_dwordx4 %3, %4, %1 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(so)
+        : "s"(lds0), "v"(v), "s"(rs), "s"(soff0)
+        : "memory", "scc");
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_spconv4 — the same operator with every global read of the offset loop as an LDS-DMA (buffer_load ... lds) and the gathered
+// rows fetched ROW-shaped.  What the probe tools/micro/ta/ta_rate.hip measured on gfx950 (cycles of the CU's vector-memory path
+// per 64-lane x 16-byte instruction, operands L2-resident): 1 KB contiguous 21; four whole 256-byte rows ~25; the A-FRAGMENT
+// shape k_spconv3 gathers with (32 rows x 32 bytes: 32 cache lines per instruction) 75, 35 with 62 % of the rows missing — and
+// k_spconv3's item time on the 81 k-row level (2 650 cycles per half offset, s_memtime stamps of tools/micro/s3_trace.py) is
+// exactly its 48 row + 48 image instructions per CU at those prices: the kernel is bound by the instruction rate of the texture
+// path, not by bytes.  So here
+//   * an item = (offset, 64 reduction channels): a wave's 32 rows x 128 bytes arrive as FOUR instructions of 8 rows x one
+//     128-byte line each (8 lanes per row), straight into the wave's own 4 KB of LDS (no VGPRs, no ds_write); a missing
+//     neighbour is an out-of-range offset: zeros are written, no memory access;  the 16-byte pieces of a row are permuted on the
+//     SOURCE side (piece p of row r lands at position p ^ ((r >> 1) & 7): the DMA destination is lane-linear), which makes the
+//     A-fragment ds_read_b128 of the MFMA steps conflict-free;
+//   * the item's part of the W image (B-fragment order, as k_spconv3) arrives the same way, NCB instructions per wave, into a
+//     double buffer shared by the workgroup;
+//   * A fragments go LDS -> registers at the top of an item, so the wave's row buffer is free for the next item's DMA during the
+//     MFMA chain: one row buffer per wave, 48 KB of LDS per workgroup at 128 x 128 -> three resident workgroups per CU;
+//   * the tile's table columns stay in REGISTERS (14 per lane: lane l holds row l & 31 of offsets 2 j + (l >> 5)); an offset's
+//     row addresses are a select chain + four ds_bpermute: no table in LDS, no dependent global read in the loop;
+//   * everything an item requests is waited for (vmcnt(0)) at its closing barrier: no counted waits, one barrier per item.
+// NW waves per workgroup, RS sets of 32 rows per wave: a B fragment read from LDS feeds RS MFMAs (at RS = 1 the B-fragment
+// reads alone are half of the CU's LDS bandwidth and, with the rows now going through LDS too, LDS is what bounds the item).
+// dev ablation of k_spconv4 (timing only, results wrong): 1 = no row requests, 2 = no MFMA, 4 = no image requests, 8 = no B-fragment
+// reads, 16 = no item barrier / wait, 32 = no A-fragment reads
+#ifndef IRX_S4_ABL
+#define IRX_S4_ABL 0
+#endif
+template <int CIN, int COUT, int NW, int RS>
+__global__ __launch_bounds__(64 * NW, (RS == 1 ? 3 : (NW == 2 ? 3 : 2)))
+void k_spconv4(const unsigned short* __restrict__ x, const uint4* __restrict__ wimg, const int32_t* __restrict__ nbr,
+               int ld, int n_out, int K, int flip_k, float* __restrict__ y, int k_per_split, int accumulate, int ldx,
+               int y_bf, int xcd_tiles, int splits) {
+  constexpr int WR = 32 * RS, TM = WR * NW;         // rows per wave / per workgroup
+  constexpr int KH = CIN / 64, NS = 4, NCB = COUT / 32;
+  constexpr int WPK = CIN * COUT * 2 / 16;          // 16-byte pieces of one offset's image
+  constexpr int WP = WPK / KH;                      // ... of one item's part
+  constexpr int WI = WP / 64;                       // 1 KB DMA instructions per item image (= NS * NCB)
+  static_assert(CIN % 64 == 0 && WI % NW == 0, "items are 64 reduction channels; image instructions split evenly over the waves");
+  constexpr int WIW = WI / NW;
+  constexpr int NA = 4 * RS;                        // row instructions per wave and item
+  constexpr int LDO = 32 + 4;
+  constexpr int SA = 33 * 128;                      // a row set in LDS: 32 row slots + one row of zeros (absent neighbours read it)
+  constexpr int SM_MAIN = 2 * WP * 16 + NW * RS * SA;
+  constexpr int SM_EPI = NW * 32 * LDO * 4;
+  constexpr int SM = SM_MAIN > SM_EPI ? SM_MAIN : SM_EPI;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SM];
+  __shared__ unsigned sMask;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile = blockIdx.x, split = blockIdx.y;
+  if (xcd_tiles) {                                   // XCD-contiguous tile ranges (k_spconv3's work-unit comment)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = xcd * xcd_tiles + j / splits;
+    split = j % splits;
+    if (tile * TM >= n_out) return;
+  }
+#if IRX_S3_TRACE
+  unsigned long long* trc = g_s3_trace ? g_s3_trace + ((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * NW + wave) * 256 : nullptr;
+  int itn = 0;
+  if (trc && lane == 0) { trc[255] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); trc[254] = ((unsigned long long)tile << 32) | (unsigned)split; }
+#endif
+  S3_EV(0);
+  const int q0 = tile * TM;
+  const int kb = split * k_per_split;
+  const int ke = (kb + k_per_split < K) ? kb + k_per_split : K;
+  const int nk = ke - kb;
+  y += (size_t)split * n_out * COUT;
+  const unsigned rowbytes = (unsigned)ldx * 2u;
+
+  // ---- the wave's rows of every table column of this split: lanes 0-31 hold the even offsets, 32-63 the odd ones ----
+  const int r32 = lane & 31, hsel = lane >> 5;
+  int idxr[RS][14];
+#pragma unroll
+  for (int t = 0; t < RS; ++t) {
+    const int grow = q0 + wave * WR + 32 * t + r32;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      const int kk = 2 * j + hsel;
+      int v = -1;
+      if (kk < nk && grow < n_out) {
+        const int k = kb + kk;
+        v = nbr[(size_t)(flip_k ? (K - 1 - k) : k) * ld + grow];
+      }
+      idxr[t][j] = v;
+    }
+  }
+  if (tid == 0) sMask = 0;
+  __syncthreads();
+  unsigned wm = 0;                                   // offsets at which this wave's rows have a neighbour
+#pragma unroll
+  for (int t = 0; t < RS; ++t)
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      const unsigned long long b = __ballot(idxr[t][j] >= 0);
+      if ((unsigned)b) wm |= 1u << (2 * j);
+      if ((unsigned)(b >> 32)) wm |= 2u << (2 * j);
+    }
+  wm = __builtin_amdgcn_readfirstlane(wm);
+  if (lane == 0 && wm) atomicOr(&sMask, wm);
+  __syncthreads();
+  S3_EV(1);
+  unsigned act = __builtin_amdgcn_readfirstlane(sMask);
+
+  s3_f32x16 acc[RS][NCB];
+#pragma unroll
+  for (int t = 0; t < RS; ++t)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][cb][i] = 0.f;
+
+  if (act) {
+    const s4_i32x4 rs_x = s4_rsrc(x, 0x7FFFFFF0u);
+    const s4_i32x4 rs_w = s4_rsrc(wimg, (unsigned)K * (unsigned)(WPK * 16));
+    unsigned char* sW = smem;                                        // [2][WP * 16]
+    unsigned char* sAw = smem + 2 * WP * 16 + wave * (RS * SA);      // this wave's rows: [RS][33][128 B], pieces permuted
+    // DMA instruction jj of a row set covers rows 8 jj + (lane >> 3); lane & 7 = position of the piece in the LDS row
+    const unsigned pc0 = (unsigned)((lane & 7) ^ ((lane >> 4) & 7)) * 16u;            // jj even: (r >> 1) & 7 = lane >> 4
+    const unsigned pc1 = (unsigned)((lane & 7) ^ (((lane >> 4) + 4) & 7)) * 16u;      // jj odd
+    // The rows of an offset are COMPACTED: the j-th present row of a set goes to row slot j, so that an offset with p present rows
+    // costs ceil(p / 8) row instructions (an instruction whose lanes are all out of range costs ~1 cycle, one with a single
+    // valid lane the full ~21-25).  A fragment of step s, row r32: piece 2 s + hsel of slot rank(r32) (or of the zero row,
+    // slot 32), at position (2 s + hsel) ^ ((slot >> 1) & 7).
+    const unsigned sAwa = s4_lds_addr(sAw);
+    if (lane < 32) {
+#pragma unroll
+      for (int t = 0; t < RS; ++t) *reinterpret_cast<unsigned*>(sAw + t * SA + 4096 + lane * 4) = 0u;
+    }
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(s4_lds_addr(sAw));
+    const unsigned ldsW = __builtin_amdgcn_readfirstlane(s4_lds_addr(sW) + (unsigned)wave * 1024u);
+
+    auto pop = [&]() __attribute__((always_inline)) {
+      int k = -1;
+      if (act) { k = __builtin_ctz(act); act &= act - 1; }
+      return k;
+    };
+    // row byte offsets of offset kk for the row instructions (S3_OOB: nothing) and the fragment read addresses of its rows
+    auto rowoffs = [&](int kk, unsigned (&ro)[NA], unsigned (&fa)[RS][NS], int (&np)[RS]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < RS; ++t) {
+        int v = -1;
+#pragma unroll
+        for (int j = 0; j < 14; ++j) v = ((kk >> 1) == j) ? idxr[t][j] : v;
+        const bool mine = hsel == (kk & 1);
+        const unsigned long long bal = __ballot(mine && v >= 0);
+        const unsigned m32 = (kk & 1) ? (unsigned)(bal >> 32) : (unsigned)bal;      // present rows of the set (wave-uniform)
+        const int npres = __builtin_popcount(m32);
+        np[t] = npres;
+        const int rank = __builtin_popcount(m32 & ((1u << r32) - 1u));
+        const bool pres = (m32 >> r32) & 1u;
+        // row index of the j-th present row -> lane j (lanes that have nothing to send target the upper half: never read)
+        const int comp = __builtin_amdgcn_ds_permute(((mine && pres) ? rank : 32 + r32) * 4, v);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int slot = 8 * jj + (lane >> 3);
+          const int id = __shfl(comp, slot, 64);
+          ro[4 * t + jj] = slot < npres ? (unsigned)id * rowbytes + ((jj & 1) ? pc1 : pc0) : S3_OOB;
+        }
+        const int slot = pres ? rank : 32;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          fa[t][s] = sAwa + (unsigned)(t * SA + slot * 128 + (((2 * s + hsel) ^ ((slot >> 1) & 7)) * 16));
+      }
+    };
+    typedef __attribute__((address_space(3))) const s3_u32x4* lds_frag_ptr;
+
+    int kcur = pop(), knext = pop();
+    unsigned roC[NA], roN[NA], faC[RS][NS], faN[RS][NS];
+    int npC[RS], npN[RS];
+    rowoffs(kcur, roC, faC, npC);
+#pragma unroll
+    for (int t = 0; t < RS; ++t) npN[t] = 0;
+#pragma unroll
+    for (int jj = 0; jj < NA; ++jj) roN[jj] = S3_OOB;
+#pragma unroll
+    for (int t = 0; t < RS; ++t)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) faN[t][s] = faC[t][s];
+    if (knext >= 0) rowoffs(knext, roN, faN, npN);
+    // row instruction jj of set t is issued only if the set has more than 8 jj present rows: an LDS-DMA whose lanes are all out
+    // of range still moves 1 KB of zeros over the CU's 64 B/clk return path
+    auto issue_rows = [&](const unsigned (&ro)[NA], const int (&np)[RS], unsigned soff) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < RS; ++t)
+        if (!(IRX_S4_ABL & 1)) s4_dma_rows_n(rs_x, ldsA + (unsigned)(t * SA), ro[4 * t], ro[4 * t + 1], ro[4 * t + 2], ro[4 * t + 3], soff,
+                      __builtin_amdgcn_readfirstlane(np[t]));
+    };
+    {
+      const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(kb + kcur) * (unsigned)(KH * WP * 16) + (unsigned)wave * 1024u);
+#pragma unroll
+      for (int i = 0; i < WIW; ++i) s4_dma1(rs_w, ldsW + (unsigned)i * (NW * 1024u), wlane, wbase + (unsigned)i * (NW * 1024u));
+      issue_rows(roC, npC, 0u);
+    }
+    s3_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    S3_EV(3);
+    int par = 0;
+    // One loop iteration = one offset = KH items.  Whether this wave has rows at the offset is decided ONCE per iteration and the
+    // two forms of the item body are straight-line code (a request that is not wanted gets an out-of-range offset: ~1 cycle).
+    while (kcur >= 0) {
+      // (an empty asm that "modifies" the accumulators at the head of every iteration: without it the allocator keeps them in one
+      // register set at loop level and in another inside the branch below — 64 copies per item, and spills)
+#pragma unroll
+      for (int t = 0; t < RS; ++t)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) asm volatile("" : "+v"(acc[t][cb]));
+      const bool liveC = (wm >> kcur) & 1u;
+      const unsigned oobN = knext >= 0 ? 0u : S3_OOB;
+      if (liveC) {
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+          S3_EV(4 + 4 * itn);
+          // next item: (kcur, h + 1) or (knext, 0); nothing after the last one
+          const bool last = h + 1 == KH;
+          const unsigned wbase = __builtin_amdgcn_readfirstlane(
+              (((unsigned)(kb + (last ? (knext < 0 ? 0 : knext) : kcur)) * (unsigned)KH + (unsigned)(last ? 0 : h + 1)) *
+               (unsigned)(WP * 16)) + (unsigned)wave * 1024u);
+          const unsigned wlds = ldsW + (unsigned)(par ^ 1) * (unsigned)(WP * 16);
+          const unsigned wv = wlane | (last ? oobN : 0u);
+          const unsigned asoff = last ? 0u : (unsigned)(h + 1) * 128u;
+          s3_u32x4 a[RS][NS];
+#pragma unroll
+          for (int t = 0; t < RS; ++t)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) a[t][s] = (IRX_S4_ABL & 32) ? (s3_u32x4){faC[t][s], 1u, 2u, 3u} : *(lds_frag_ptr)(unsigned long long)faC[t][s];
+          const s3_u32x4* bw = reinterpret_cast<const s3_u32x4*>(sW + par * (WP * 16)) + lane;
+          // MFMA groups of GC column blocks: group g = (step g / NG, blocks GC (g % NG) ..); the B fragments of group g + 1 are
+          // requested before the MFMAs of group g (a ring of 2 x GC fragments), and the item's NA + WIW requests go out a few per
+          // group, in the shadow of the MFMA chain
+          constexpr int GC = NCB >= 2 ? 2 : 1, NG = NCB / GC, NGT = NS * NG;
+#ifndef IRX_S4_BD
+#define IRX_S4_BD 1
+#endif
+          constexpr int BD = (RS == 1) ? IRX_S4_BD : 1;   // groups of B fragments requested ahead of their MFMAs (LDS latency >> one group)
+          s3_u32x4 bq[BD + 1][GC];
+#pragma unroll
+          for (int g0 = 0; g0 < BD && g0 < NGT; ++g0)
+#pragma unroll
+            for (int c = 0; c < GC; ++c) bq[g0][c] = (IRX_S4_ABL & 8) ? (s3_u32x4){(unsigned)lane, 1u, 2u, 3u} : bw[((g0 / NG) * NCB + (g0 % NG) * GC + c) * 64];
+          // the rows are in registers before their buffer is handed to the next item's DMA
+          __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0)
+          __builtin_amdgcn_sched_barrier(0);
+          if (last) issue_rows(roN, npN, 0u); else issue_rows(roC, npC, asoff);
+          __builtin_amdgcn_sched_barrier(0);
+          S3_EV(5 + 4 * itn);
+#pragma unroll
+          for (int g = 0; g < NGT; ++g) {
+            const int sg = g / NG, cg = (g % NG) * GC;
+            if (g + BD < NGT) {
+              const int sn = (g + BD) / NG, cn = ((g + BD) % NG) * GC;
+#pragma unroll
+              for (int c = 0; c < GC; ++c) bq[(g + BD) % (BD + 1)][c] = (IRX_S4_ABL & 8) ? (s3_u32x4){(unsigned)lane, 1u, 2u, (unsigned)g} : bw[(sn * NCB + cn + c) * 64];
+            }
+            {
+              // the image instructions go out one per group, in the shadow of the MFMA chain
+              if (g < WIW && !(IRX_S4_ABL & 4)) s4_dma1(rs_w, wlds + (unsigned)g * (NW * 1024u), wv, wbase + (unsigned)g * (NW * 1024u));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < GC; ++c)
+#pragma unroll
+              for (int t = 0; t < RS; ++t) { if (!(IRX_S4_ABL & 2)) s4_mfma(acc[t][cg + c], a[t][sg], bq[g % (BD + 1)][c]); else acc[t][cg + c][0] += __uint_as_float(a[t][sg][0] ^ bq[g % (BD + 1)][c][0]); }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          S3_EV(6 + 4 * itn);
+          if (!(IRX_S4_ABL & 16)) { s3_wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+          S3_EV(7 + 4 * itn);
+#if IRX_S3_TRACE
+          ++itn;
+#endif
+          par ^= 1;
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+          S3_EV(4 + 4 * itn);
+          const bool last = h + 1 == KH;
+          const unsigned wbase = __builtin_amdgcn_readfirstlane(
+              (((unsigned)(kb + (last ? (knext < 0 ? 0 : knext) : kcur)) * (unsigned)KH + (unsigned)(last ? 0 : h + 1)) *
+               (unsigned)(WP * 16)) + (unsigned)wave * 1024u);
+          const unsigned wlds = ldsW + (unsigned)(par ^ 1) * (unsigned)(WP * 16);
+          const unsigned wv = wlane | (last ? oobN : 0u);
+          S3_EV(5 + 4 * itn);
+#pragma unroll
+          for (int i = 0; i < WIW; ++i) if (!(IRX_S4_ABL & 4)) s4_dma1(rs_w, wlds + (unsigned)i * (NW * 1024u), wv, wbase + (unsigned)i * (NW * 1024u));
+          if (last) issue_rows(roN, npN, 0u);         // (compile-time) the rows of the next offset; this offset has none
+          S3_EV(6 + 4 * itn);
+          if (!(IRX_S4_ABL & 16)) { s3_wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+          S3_EV(7 + 4 * itn);
+#if IRX_S3_TRACE
+          ++itn;
+#endif
+          par ^= 1;
+        }
+      }
+      kcur = knext;
+#pragma unroll
+      for (int jj = 0; jj < NA; ++jj) { roC[jj] = roN[jj]; roN[jj] = S3_OOB; }
+#pragma unroll
+      for (int t = 0; t < RS; ++t)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) faC[t][s] = faN[t][s];
+#pragma unroll
+      for (int t = 0; t < RS; ++t) { npC[t] = npN[t]; npN[t] = 0; }
+      knext = pop();
+      if (knext >= 0) rowoffs(knext, roN, faN, npN);
+    }
+  }
+
+  S3_EV(250);
+#if IRX_S3_TRACE
+  if (trc && lane == 0) trc[253] = (unsigned long long)itn;
+#endif
+  // ---- epilogue (as k_spconv3): one 32 x 32 block at a time through the wave's own LDS region ----
+  __syncthreads();
+  float* so = reinterpret_cast<float*>(smem) + wave * 32 * LDO;
+  const int col = lane & 31, r4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int t = 0; t < RS; ++t)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) so[((reg & 3) + 8 * (reg >> 2) + r4) * LDO + col] = acc[t][cb][reg];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int f = lane + 64 * it;
+        const int row = f >> 3, cc = (f & 7) * 4;
+        const int gr = q0 + wave * WR + 32 * t + row;
+        if (gr < n_out) {
+          float4 o = *reinterpret_cast<const float4*>(&so[row * LDO + cc]);
+          const size_t off = (size_t)gr * COUT + cb * 32 + cc;
+          if (accumulate) {
+            const float4 e = irx_ld4(y, off, y_bf);
+            o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+          }
+          irx_st4(y, off, y_bf, o);
+        }
+      }
+    }
+  S3_EV(251);
 }
 
 // ---- weight image: [K][NS][NCB][64 lanes][8 bf16]; lane l of fragment (s, cb) holds W[k][c = chan(s, l >> 5, j)][n = 32 cb + (l & 31)]
@@ -404,11 +947,11 @@ int irx_permute_w3_multi_launch(const IrxPermuteJobs& jobs, int trans_w, hipStre
 
 template <int CIN, int NW, int KH>
 static void launch3(int cout, dim3 grid, hipStream_t st, const unsigned short* x, const uint4* wimg, const int32_t* nbr, int ld,
-                    int n_out, int K, int flip_k, float* y, int kps, int acc, int ldx, int y_bf) {
-  if (cout == 128) k_spconv3<CIN, 128, NW, KH><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+                    int n_out, int K, int flip_k, float* y, int kps, int acc, int ldx, int y_bf, int xt, int sp) {
+  if (cout == 128) k_spconv3<CIN, 128, NW, KH><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, xt, sp);
   else if constexpr (KH == 1) {
-    if (cout == 64) k_spconv3<CIN, 64, NW, 1><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
-    else if constexpr (CIN >= 64) k_spconv3<CIN, 32, NW, 1><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf);
+    if (cout == 64) k_spconv3<CIN, 64, NW, 1><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, xt, sp);
+    else if constexpr (CIN >= 64) k_spconv3<CIN, 32, NW, 1><<<grid, 64 * NW, 0, st>>>(x, wimg, nbr, ld, n_out, K, flip_k, y, kps, acc, ldx, y_bf, xt, sp);
   }
 }
 
@@ -423,12 +966,38 @@ int irx_spconv3_launch(const float* x, const float* wimg, const int32_t* nbr, in
   // rows per workgroup of the instantiation launched below: 32 rows per wave; Cin = 32 always runs 4 waves (IRX_S3_NW=8 only has
   // 64- / 128-channel instantiations — the grid must follow the launch, not the knob: ADVICE r4)
   const int tile = (s3_nw() == 8 && cin != 32) ? 256 : 128;
-  const dim3 grid(irx_cdiv(n_out, tile), splits);
+  const int tiles = irx_cdiv(n_out, tile);
+  // XCD-contiguous tile ranges (k_spconv3's work-unit comment) from "spconv3_xcd_min" tiles on; below that a level's rows fit
+  // every L2 anyway
+  const long xmin = irx_knob(IRX_KNOB_SPCONV3_XCD_MIN);
+  const int xt = (xmin > 0 && tiles >= xmin) ? irx_cdiv(tiles, 8) : 0;
+  const dim3 grid = xt ? dim3(8 * xt * splits) : dim3(tiles, splits);
   const int kps = irx_cdiv(K, splits);
   const unsigned short* xb = reinterpret_cast<const unsigned short*>(x);
   const uint4* wi = reinterpret_cast<const uint4*>(wimg);
+  // fourth generation (k_spconv4: all-LDS-DMA, row-shaped gathers) for 64 / 128 input channels; "spconv4" = 0: k_spconv3
+  // policy ("spconv4"): 1 = the 128 -> 128 layers only (measured, kernel alone, B = 16 pyramid: 69-73 vs 79 us on the 81 k-row
+  // level, 28.0 vs 31.0 on 20 k rows, 19.8 vs 20.0 on 4.6 k; the 64-channel and 128 -> 64 shapes are SLOWER than k_spconv3:
+  // 90 vs 75 us and 48 vs 39 us — a 128-byte row is one instruction either way and the image is small), 2 = those layers with
+  // two row sets per wave (dev: 87 us), 3 = every 64 / 128-input-channel shape (dev)
+  const long s4 = irx_knob(IRX_KNOB_SPCONV4);
+  if (s4 != 0 && (cin == 64 || cin == 128) && s3_nw() == 4 && (s4 == 3 || (cin == 128 && cout == 128))) {
+    irx_bracket_begin(st);
+#define S4_GO(CIN_, COUT_) do {                                                                                                      \
+      if (rs2) k_spconv4<CIN_, COUT_, 2, 2><<<grid, 128, 0, st>>>(xb, wi, nbr, ld, n_out, K, flip_k, y, kps, accumulate, ldx, y_bf, xt, splits); \
+      else k_spconv4<CIN_, COUT_, 4, 1><<<grid, 256, 0, st>>>(xb, wi, nbr, ld, n_out, K, flip_k, y, kps, accumulate, ldx, y_bf, xt, splits);  \
+    } while (0)
+    // "spconv4" = 2: two waves of 64 rows (two row sets: every B fragment read feeds two MFMAs); 1: four waves of 32 rows
+    const bool rs2 = irx_knob(IRX_KNOB_SPCONV4) == 2 && cout >= 64;
+    if (cin == 128) { if (cout == 128) S4_GO(128, 128); else if (cout == 64) S4_GO(128, 64); else k_spconv4<128, 32, 4, 1><<<grid, 256, 0, st>>>(xb, wi, nbr, ld, n_out, K, flip_k, y, kps, accumulate, ldx, y_bf, xt, splits); }
+    else { if (cout == 128) S4_GO(64, 128); else if (cout == 64) S4_GO(64, 64); else k_spconv4<64, 32, 4, 1><<<grid, 256, 0, st>>>(xb, wi, nbr, ld, n_out, K, flip_k, y, kps, accumulate, ldx, y_bf, xt, splits); }
+#undef S4_GO
+    irx_bracket_end(st);
+    IRX_CHECK_LAUNCH("irx_spconv_fwd(v4)");
+    return IRX_OK;
+  }
   irx_bracket_begin(st);
-#define S3_GO(CIN_, NW_, KH_) launch3<CIN_, NW_, KH_>(cout, grid, st, xb, wi, nbr, ld, n_out, K, flip_k, y, kps, accumulate, ldx, y_bf)
+#define S3_GO(CIN_, NW_, KH_) launch3<CIN_, NW_, KH_>(cout, grid, st, xb, wi, nbr, ld, n_out, K, flip_k, y, kps, accumulate, ldx, y_bf, xt, splits)
   // 128 -> 128: the reduction in two half-items (three resident workgroups per CU); dev knob IRX_S3_KH=1: whole offsets
   static const int kh_env = getenv("IRX_S3_KH") ? atoi(getenv("IRX_S3_KH")) : 2;
   if (s3_nw() == 8) {

@@ -598,7 +598,8 @@ def test_conv_bf16_storage_operator_third_generation(lib, clouds, cin, cout, ks,
     SAME bf16 values: forward and data-gradient (flipped offsets / transposed weights for stride 1, the transposed child
     table for stride 2), fp32 and bf16 outputs, gradient accumulation (the level sizes of the fixture take the offset-split path). Only the fp32
     summation order differs: 1e-5 relative for fp32 outputs; bf16 outputs are the fp32 result rounded once (the bar is one
-    bf16 ulp of the value). The second-generation kernel (knob spconv3 = 0) must agree with it to the same bar."""
+    bf16 ulp of the value). The second-generation kernel (knob spconv3 = 0) and the fourth (k_spconv4, the default for the
+    128 -> 128 layers; forced onto every shape it is built for here) must agree with it to the same bar."""
     import instancerefer_amd as irx
     import oracle.torchsparse.nn.functional as OF
     from instancerefer_amd.sparse import functional as F_
@@ -636,8 +637,11 @@ def test_conv_bf16_storage_operator_third_generation(lib, clouds, cin, cout, ks,
     res = {}
     irx.set_compute_dtype("bf16")
     try:
-        for gen in (3, 2):
-            _lib.set_knob("spconv3", 1 if gen == 3 else 0)
+        # 3 / 2: k_spconv3 / k_spconv2; 4: k_spconv4 on every shape it has (knob spconv4 = 3: LDS-DMA, compacted row-shaped
+        # gathers; 32-input-channel shapes stay on k_spconv3), 42: its two-row-sets-per-wave form (128 -> 128 only)
+        for gen in (3, 4, 42, 2):
+            _lib.set_knob("spconv3", 0 if gen == 2 else 1)
+            _lib.set_knob("spconv4", {3: 0, 4: 3, 42: 2, 2: 0}[gen])
             yf = F_.spconv_gather_gemm_t(xb, wd, tbl, ld, n_out, K, cin, cout, 0, 0)
             yb = F_.spconv_gather_gemm_t(xb, wd, tbl, ld, n_out, K, cin, cout, 0, 0, y_dtype=torch.bfloat16)
             ya = F_.spconv_gather_gemm_t(xb, wd, tbl, ld, n_out, K, cin, cout, 0, 0, accumulate_into=y0.cuda().bfloat16())
@@ -645,6 +649,7 @@ def test_conv_bf16_storage_operator_third_generation(lib, clouds, cin, cout, ks,
             res[gen] = [v.float().cpu() for v in (yf, yb, ya, dx)]
     finally:
         _lib.set_knob("spconv3", 1)
+        _lib.set_knob("spconv4", 1)
         irx.set_compute_dtype("fp32")
     exp = yo.detach()
     ulp = 2.0 ** -8
@@ -655,6 +660,7 @@ def test_conv_bf16_storage_operator_third_generation(lib, clouds, cin, cout, ks,
         assert ((ya - ea).abs() <= ulp * ea.abs() + 2e-5).all(), ("accumulate", gen)
         assert (dx - dxo).abs().max().item() <= 1e-5 * max(dxo.abs().max().item(), 1.0), ("dgrad", gen)
     assert (res[3][0] - res[2][0]).abs().max().item() <= 2e-5 * max(exp.abs().max().item(), 1.0)
+    assert (res[4][0] - res[3][0]).abs().max().item() <= 2e-5 * max(exp.abs().max().item(), 1.0)
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride", [(128, 128, 3, 1), (64, 64, 3, 1), (64, 128, 2, 2), (128, 64, 3, 1), (32, 64, 2, 2)])

@@ -44,11 +44,21 @@ def timed(fn):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / REPS * 1e3
+    tot = e0.elapsed_time(e1) / REPS * 1e3
+    # the conv kernel alone (events recorded by the library right around it: no weight-image / split-reduce launches)
+    ks = []
+    for _ in range(min(REPS, 10)):
+        b0, b1 = F_._bracket()
+        fn()
+        torch.cuda.synchronize()
+        ks.append(b0.elapsed_time(b1) * 1e3)
+    ks.sort()
+    timed.kernel_us = ks[len(ks) // 2]
+    return tot
 
 
 def case(name, tbl, ld, n_in, n_out, K, cin, cout, flip, trans):
-    if ONLY and not any(t in name for t in ONLY.split(',')):
+    if ONLY and not any(t in '%s %d->%d' % (name, cin, cout) for t in ONLY.split(',')):
         return
     g = torch.Generator(device=dev).manual_seed(n_out + K + cin)
     x = torch.randn(n_in, cin, device=dev, generator=g).bfloat16()
@@ -70,11 +80,11 @@ def case(name, tbl, ld, n_in, n_out, K, cin, cout, flip, trans):
             ya = F_.spconv_gather_gemm_t(x, w, tbl, ld, n_out, K, cin, cout, flip, trans, accumulate_into=y0.clone())
             ea = float((ya.double() - (y0.double() + r).bfloat16().double()).abs().max() / r.abs().max())
             err = max(err, ea / 4)   # (bf16 rounding of the sum: one ulp of slack)
-        res[v3] = (us, err)
+        res[v3] = (us, err, timed.kernel_us)
     algo = 2 * (m * cin + n_out * cout + K * cin * cout) + 8 * m
-    print('%-22s n_out %7d K %2d %3d->%3d M %8d | v2 %7.1f us (err %.1e) | v3 %7.1f us (err %.1e) | x%.2f | v3 %.0f GB/s algo, %.0f TFLOP/s useful'
-          % (name, n_out, K, cin, cout, m, res[0][0], res[0][1], res[1][0], res[1][1], res[0][0] / res[1][0],
-             algo / res[1][0] / 1e3, 2.0 * m * cin * cout / res[1][0] / 1e6))
+    print('%-22s n_out %7d K %2d %3d->%3d M %8d | v2 %7.1f us (err %.1e) | v3 %7.1f us (err %.1e) | x%.2f | kernel only v2 %6.1f v3 %6.1f us | v3 %.0f GB/s algo (kernel), %.0f TFLOP/s useful'
+          % (name, n_out, K, cin, cout, m, res[0][0], res[0][1], res[1][0], res[1][1], res[0][0] / res[1][0], res[0][2], res[1][2],
+             algo / res[1][2] / 1e3, 2.0 * m * cin * cout / res[1][2] / 1e6))
 
 
 lv = st.level()

@@ -12,5 +12,5 @@ for f in *.hip; do
 done
 for spec in "$@"; do tag=${spec%%:*}; fl=${spec#*:}; hipcc $FL $fl -c irx_spconv3.hip -o $O/s3_$tag.obj & done
 wait
-for spec in "$@"; do tag=${spec%%:*}; hipcc --offload-arch=gfx950 -shared -fPIC $(ls $O/*.hip.o) $O/s3_$tag.obj -o ../../tools/micro/libirx_s3_$tag.so; done
-ls -la ../../tools/micro/libirx_s3_*.so
+for spec in "$@"; do tag=${spec%%:*}; hipcc --offload-arch=gfx950 -shared -fPIC $(ls $O/*.hip.o) $O/s3_$tag.obj -o ../../tools/devlib/libirx_s3_$tag.so; done
+ls -la ../../tools/devlib/libirx_s3_*.so
