@@ -408,6 +408,14 @@ int irx_encoder_submit(int lane, int backward, const int64_t* desc, const double
                        float* dc_scratch, float* dx0, void* workspace, size_t workspace_bytes, void* stream);
 int irx_encoder_wait(int lane);
 
+/* Orders the backward passes of TWO encoders of one training step (reference: models/instancerefer.py:38-53 runs the scene and the
+ * candidate encoder one after the other; here their passes run on two streams).  Applies to the NEXT irx_encoder_backward /
+ * irx_encoder_submit(backward) of the calling thread.  role 1 (recorder): an event is recorded on that pass's stream where its
+ * levels of fewer than `rows` rows are done (at its end if it has no larger level); role 2 (waiter): that pass's stream waits
+ * for the event before its first level of `rows` or more rows.  `token` pairs the two calls of a step (ascending from step to
+ * step).  A waiter whose recorder has not been issued within 1.5 ms goes on without the gate.  role 0 clears. */
+int irx_encoder_gate_next(int role, long long rows, unsigned long long token);
+
 
 /* ---- segmented reductions ------------------------------------------------------------- */
 

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "irx_encoder_backward_sync": (_I, [_P, _P, _I, _P, _P, _P, _Z, _P, _P, _P, _P, _P]),
     "irx_encoder_submit": (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _Z, _P]),
     "irx_encoder_wait": (_I, [_I]),
+    "irx_encoder_gate_next": (_I, [_I, ctypes.c_longlong, ctypes.c_ulonglong]),
     "irx_segment_max": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "irx_segment_max_backward": (_I, [_P, _P, _I, _I, _P, _P]),
     "irx_segment_mean": (_I, [_P, _I, _I, _I, _P, _P]),

@@ -7,6 +7,9 @@
 // C-ABI calls); the caller owns every buffer (one activation / gradient arena) and the workspace.
 #include "irx_common.h"
 #include "../../include/irx.h"
+#include <atomic>
+#include <chrono>
+#include <mutex>
 
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -96,6 +99,50 @@ int encoder_forward_impl(const int64_t* desc, const double* fdesc, int n_layers,
 int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers, float* dc_scratch, float* dx0, void* workspace,
                           size_t workspace_bytes, void* stream, const EncSync& sync);
 }  // namespace
+
+// ---- backward gate between two encoder passes of one training step (irx_encoder_gate_next, include/irx.h) ----
+// Two encoders' backward passes run on two streams.  Each walks its pyramid from the smallest level up: first a chain of ~100
+// short, latency-bound kernels, then a few long ones that fill every CU.  Left alone, the pass that reaches its long kernels
+// first starves the other's short chain (a short kernel only gets CUs when a long kernel's workgroups retire, all at once, every
+// 30-90 us): the candidate encoder's small levels took 2.6 ms beside the scene encoder's large ones against 0.5 ms alone
+// (profiles/r05_timeline_bf16.txt).  The gate orders them: the RECORDER marks the point where its levels below `rows` are done,
+// the WAITER does not start its levels of `rows` or more before that point.
+struct EncGate { int role = 0; int64_t rows = 0; uint64_t token = 0; };   // role 1 = recorder, 2 = waiter
+static thread_local EncGate g_gate_next;
+static std::atomic<uint64_t> g_gate_recorded{0};
+static hipEvent_t g_gate_ev[2] = {nullptr, nullptr};
+static std::mutex g_gate_mu;
+static hipEvent_t gate_event(uint64_t token) {
+  std::lock_guard<std::mutex> lk(g_gate_mu);
+  hipEvent_t& e = g_gate_ev[token & 1];
+  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+  return e;
+}
+extern "C" int irx_encoder_gate_next(int role, long long rows, unsigned long long token) {
+  IRX_REQUIRE(role >= 0 && role <= 2, "irx_encoder_gate_next: role %d", role);
+  g_gate_next.role = role;
+  g_gate_next.rows = rows;
+  g_gate_next.token = token;
+  return IRX_OK;
+}
+// at the head of backward layer `n_out` rows (or behind the last layer: n_out < 0); true once the gate has fired
+static bool gate_step(const EncGate& g, bool fired, int64_t n_out, void* stream) {
+  if (!g.role || fired || (n_out >= 0 && n_out < g.rows)) return fired;
+  hipEvent_t e = gate_event(g.token);
+  if (!e) return true;
+  if (g.role == 1) {
+    if (hipEventRecord(e, (hipStream_t)stream) == hipSuccess) g_gate_recorded.store(g.token, std::memory_order_release);
+  } else if (n_out >= 0) {
+    // the recorder's mark must be ENQUEUED before this wait is (a wait on an event without a pending record is a no-op); it is
+    // issued by another thread at about the same time: poll briefly, go on without the gate if it does not show up
+    const auto t0 = std::chrono::steady_clock::now();
+    while (g_gate_recorded.load(std::memory_order_acquire) < g.token &&
+           std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500))
+      __builtin_ia32_pause();
+    if (g_gate_recorded.load(std::memory_order_acquire) == g.token) (void)hipStreamWaitEvent((hipStream_t)stream, e, 0);
+  }
+  return true;
+}
 
 extern "C" int irx_encoder_forward(const int64_t* desc, const double* fdesc, int n_layers, void* workspace,
                                    size_t workspace_bytes, void* stream) {
@@ -275,8 +322,12 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
   IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_backward: bf16 storage needs a bf16 compute mode in IRX_ENC_MODE");
   IRX_REQUIRE(!st || !dx0, "irx_encoder_backward: the input gradient is not available with bf16 storage");
   IrxDySlabs pending;                        // gy of the layer about to be processed, still as its producer's offset-split slabs
+  const EncGate gate = g_gate_next;          // (set for this call by irx_encoder_gate_next on this thread, or by the lane)
+  g_gate_next = EncGate();
+  bool gate_fired = false;
   for (int i = n_layers - 1; i >= 0; --i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
+    gate_fired = gate_step(gate, gate_fired, L.n_out, stream);
     const IrxDySlabs dys = pending;
     pending = IrxDySlabs();
     float* dres = nullptr;
@@ -364,6 +415,7 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
       if (rc) return rc;
     }
   }
+  gate_step(gate, gate_fired, -1, stream);   // a recorder without a level of `rows` or more marks the end of its pass
   return IRX_OK;
 }
 }  // namespace
@@ -394,6 +446,7 @@ struct EncJob {
   void* ws;
   size_t wsb;
   void* stream;
+  EncGate gate;
 };
 struct EncLane {
   std::mutex mu;
@@ -429,6 +482,7 @@ void lane_main(EncLane* L) {
       L->queued.fetch_sub(1, std::memory_order_release);
     }
     int rc = (int)hipSetDevice(j.device);
+    g_gate_next = j.gate;
     if (rc == 0)
       rc = j.backward ? irx_encoder_backward(j.desc.data(), j.fdesc.data(), j.n, j.dc, j.dx0, j.ws, j.wsb, j.stream)
                       : irx_encoder_forward(j.desc.data(), j.fdesc.data(), j.n, j.ws, j.wsb, j.stream);
@@ -460,6 +514,8 @@ extern "C" int irx_encoder_submit(int lane, int backward, const int64_t* desc, c
   j.ws = workspace;
   j.wsb = workspace_bytes;
   j.stream = stream;
+  j.gate = backward ? g_gate_next : EncGate();
+  if (backward) g_gate_next = EncGate();
   EncLane* L = lane_of(lane);
   {
     std::lock_guard<std::mutex> lk(L->mu);

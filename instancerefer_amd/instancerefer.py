@@ -22,6 +22,10 @@ _PREP_PLANS = _os.environ.get('IRX_PREP_PLANS', '0') == '1'
 # (GPU-paced). Training mode on a HIP device only; IRX_LANG_THREAD=0 issues it inline.
 _LANG_THREAD = _os.environ.get('IRX_LANG_THREAD', '1') == '1'
 _STREAMS_ENV = _os.environ.get('IRX_STREAMS')                     # dev A/B switch: '0' / '1' overrides the policy in _streams_ok
+_g = _os.environ.get('IRX_BWD_GATE_ROWS', '2000').split(',')       # "rows" or "recorder rows,waiter rows"; 0: no gate between the encoders' backward passes
+_BWD_GATE_ROWS = int(_g[0])
+_BWD_GATE_WAIT_ROWS = int(_g[-1])
+_BWD_GATE = _BWD_GATE_ROWS > 0
 _STREAMS = _STREAMS_ENV != '0'                                   # three-stream training forward (_forward_streams); 0: round-4 layout
 _PREBUILD_BWD = _os.environ.get('IRX_PREBUILD_BWD', '0') == '1'   # backward-only tables built behind the scene head: measured neutral (3004-3013 vs 2920-2998 scenes/s), off
 _REL_THREAD = _os.environ.get('IRX_REL_THREAD', '0') == '1'      # dev: the relation head on that thread too (behind the language module)
@@ -246,6 +250,13 @@ class InstanceRefer(nn.Module):
         main = torch.cuda.current_stream()
         dev = data_dict['lang_feat'].device
         side = self._encoder_stream(dev)
+        # backward gate (irx_encoder_gate_next): the scene encoder's large levels start behind the candidate encoder's small ones
+        if _BWD_GATE and _BWD_GATE_ROWS > 0:
+            tok = self.__dict__['_gate_token'] = self.__dict__.get('_gate_token', 0) + 1
+            self.scene.net._irx_bwd_gate = (2, _BWD_GATE_WAIT_ROWS, tok)
+            self.attribute.net._irx_bwd_gate = (1, _BWD_GATE_ROWS, tok)
+        else:
+            self.scene.net._irx_bwd_gate = self.attribute.net._irx_bwd_gate = None
         lstream = self._aux_stream(dev)
         side.wait_stream(main)                               # inputs and the optimizer's parameter update are complete
         lstream.wait_stream(main)
@@ -320,6 +331,9 @@ class InstanceRefer(nn.Module):
         data_dict = self.prepare(data_dict)
         if self._streams_ok(data_dict):
             return self._forward_streams(data_dict)
+        for m in (getattr(self, 'scene', None), getattr(self, 'attribute', None)):
+            if m is not None and hasattr(m, 'net'):
+                m.net._irx_bwd_gate = None                   # (the gate belongs to the multi-stream layout)
         side = None
         lang_join = None
         if _LANG_THREAD and self.training and data_dict['lang_feat'].is_cuda:

@@ -446,6 +446,7 @@ class EncoderFn(torch.autograd.Function):
         ctx.lane, ctx.sync = st.lane, st.sync
         ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = st.layers, st.desc, st.fdesc, st.extra
         ctx.store, ctx.prof, ctx.sink = st.store, st.prof, st.sink
+        ctx.gate = getattr(encoder, '_irx_bwd_gate', None)   # (role, rows, token): irx_encoder_gate_next, set per step by the model
         ctx.save_for_backward(*st.saved)
         return st.out.view_as(st.out) if isinstance(layers, Launched) else st.out
 
@@ -525,6 +526,8 @@ class EncoderFn(torch.autograd.Function):
         if ctx.lane is not None and slots is not None and not need_dx0:
             # nothing autograd will touch depends on this pass: a library thread issues it; the optimizer waits for the
             # lane before it records the delivery event (FlatAdam.gather_grads)
+            if ctx.gate is not None:
+                lib.irx_encoder_gate_next(*ctx.gate)
             rc = lib.irx_encoder_submit(ctx.lane, 1, desc.ctypes.data, fdesc.ctypes.data, nl, gbase + dc_off, None,
                                         ws.data_ptr(), nbytes, _lib.stream_ptr())
             if rc:
@@ -533,6 +536,8 @@ class EncoderFn(torch.autograd.Function):
             owner.sink_delivered(key, sparams, lane=ctx.lane)
             return _returns(ctx, None, None)
         lane_wait(ctx.lane)                                  # same-stream order with the (possibly queued) forward
+        if ctx.gate is not None:
+            lib.irx_encoder_gate_next(*ctx.gate)
         rc = lib.irx_encoder_backward(desc.ctypes.data, fdesc.ctypes.data, nl, gbase + dc_off,
                                       dfeats.data_ptr() if need_dx0 else None, ws.data_ptr(), nbytes,
                                       _lib.stream_ptr())
