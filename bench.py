@@ -1008,7 +1008,7 @@ def traffic_for(roof, pmc, bf16):
     key = roof["kernel"].replace(",", ", ")
     if key.startswith(("k_spconv2<", "k_wgrad_pairs<")):           # template flags: <..., bf16 operands, bf16 storage>
         key = key[:-1] + (", true, true>" if bf16 else ", false, false>")
-    hit = [k for k in pmc if k == key or k.startswith(key[:-1] + ",")]     # (k_spconv3<cin, cout, waves, K parts>)
+    hit = [k for k in pmc if k == key or k.startswith(key[:-1] + ",")]     # (k_spconv3<cin, cout, waves, K parts>, k_spconv4<cin, cout, waves, row sets>)
     if hit:
         roof["traffic"] = pmc[hit[0]]
         roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py on this box (2 steps, serial "
@@ -1251,14 +1251,21 @@ def summarise_roofline(recs, bf16=False):
         from instancerefer_amd import _lib
         v3 = bool(_lib.get_knob("spconv3"))
         w3 = bool(_lib.get_knob("wgrad3"))
+        v4 = int(_lib.get_knob("spconv4"))
     except Exception:
         v3 = w3 = False
+        v4 = 0
 
     def klass(kind, cin, cout, e=4.0):
         if kind in ("fwd", "dgrad"):
             if cin in (32, 64, 128) and cout in (32, 64, 128):
                 # a bf16 INPUT (bf16 storage inside the executor) runs on the third-generation kernel (csrc/irx_spconv3.hip)
-                return ("k_spconv3<%d,%d>" if (bf16 and e == 2.0 and v3 and cin * cout >= 2048) else "k_spconv2<%d,%d>") % (cin, cout)
+                # ... the 128 -> 128 layers on the fourth (k_spconv4: LDS-DMA, row-shaped gathers; knob spconv4 = 3: every 64- /
+                # 128-input-channel shape)
+                if bf16 and e == 2.0 and v3 and cin * cout >= 2048:
+                    g4 = v4 and cin in (64, 128) and (v4 == 3 or (cin == 128 and cout == 128))
+                    return ("k_spconv4<%d,%d>" if g4 else "k_spconv3<%d,%d>") % (cin, cout)
+                return "k_spconv2<%d,%d>" % (cin, cout)
             if 128 < cin <= 136 and cout == 32 and kind == "fwd":
                 return "wide stem fwd (k_stem_fwd + k_spconv2<128,32>)"
             return "k_stem_fwd" if (cin <= 8 and cout == 32) else "k_spconv_fwd(generic)"
@@ -1288,7 +1295,7 @@ def summarise_roofline(recs, bf16=False):
         a["flops"] += flops
         a["bytes"] += byts
         a["launches"] += 1
-        a["peak_tf"] = peak_tf = PEAK_BF16_TFLOPS if (bf16 and kl.startswith(("k_spconv2<", "k_spconv3<", "k_wgrad_pairs<", "k_wgrad3<"))) else PEAK_F32_TFLOPS
+        a["peak_tf"] = peak_tf = PEAK_BF16_TFLOPS if (bf16 and kl.startswith(("k_spconv2<", "k_spconv3<", "k_spconv4<", "k_wgrad_pairs<", "k_wgrad3<"))) else PEAK_F32_TFLOPS
         b_ms = max(byts / (PEAK_HBM_GBS * 1e9), flops / (peak_tf * 1e12)) * 1e3
         a["bound_ms"] += b_ms
         tot["ms"] += ms
