@@ -728,13 +728,14 @@ def _three_steps(dev, dtype="fp32", no_dropout=False):
     return model, resident, opt, losses
 
 
-@pytest.mark.parametrize("knob", ["lang_thread", "scene_defer", "streams", "streams_inline_lang"])
+@pytest.mark.parametrize("knob", ["lang_thread", "scene_defer", "streams", "streams_inline_lang", "bwd_gate"])
 def test_helper_thread_and_deferred_scene_node_change_nothing(lib, monkeypatch, knob):
     """(1) The language module issued by the helper thread vs inline (IRX_LANG_THREAD=0): same kernels on the same stream.
     (2) The scene encoder's autograd node created at the head of SceneModule.forward (its pass issued earlier:
     encoder_fn.Launched) vs created at issue time: only the ORDER in which the backward reaches the encoders changes.
     (3) The three-stream forward (InstanceRefer._forward_streams: scene encoder + scene head | language + relation | candidate
     encoder + attribute head + scores) vs the one-stream layout, with the language module on the helper thread or inline.
+    (4) The backward gate of the three-stream layout on vs off.
     Bit-identical losses and parameters after 3 training steps either way."""
     from instancerefer_amd import instancerefer as IR, scene_module as SM
     dev = torch.device("cuda")
@@ -744,11 +745,17 @@ def test_helper_thread_and_deferred_scene_node_change_nothing(lib, monkeypatch, 
             monkeypatch.setattr(IR, "_LANG_THREAD", on)
         elif knob == "scene_defer":
             monkeypatch.setattr(SM, "_DEFER", on)
+        elif knob == "bwd_gate":
+            # (4) the backward gate between the two encoder passes (irx_encoder_gate_next: the scene encoder's backward waits,
+            # on its stream, for the head of the candidate encoder's): an ordering of launches, nothing else
+            monkeypatch.setattr(IR, "_STREAMS", True)
+            monkeypatch.setattr(IR, "_STREAMS_ENV", "1")
+            monkeypatch.setattr(IR, "_BWD_GATE", on)
         else:
             monkeypatch.setattr(IR, "_STREAMS", on)
             monkeypatch.setattr(IR, "_STREAMS_ENV", "1" if on else "0")     # (the policy alone keeps fp32 on one stream pair)
             monkeypatch.setattr(IR, "_LANG_THREAD", knob == "streams")
-        _, _, opt, losses = _three_steps(dev, no_dropout=knob.startswith("streams"))
+        _, _, opt, losses = _three_steps(dev, no_dropout=knob.startswith("streams") or knob == "bwd_gate")
         out[on] = (losses, opt.flat_p.clone())
     assert out[True][0] == out[False][0], (out[True][0], out[False][0])
     assert torch.equal(out[True][1], out[False][1])
