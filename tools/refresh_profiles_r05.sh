@@ -19,7 +19,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pb /tmp/pe
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o rb -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-alt-dtype --no-e2e --profile-steps 0 > /tmp/pb.log 2>&1
 cp $(find /tmp/pb -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$O/kernel_stats_bf16.csv
-python $GRAFT_REPO_ROOT/tools/stats_groups.py $GRAFT_REPO_ROOT/$O/kernel_stats_bf16.csv 15 > $GRAFT_REPO_ROOT/$O/kernel_groups_bf16.txt
+python $GRAFT_REPO_ROOT/tools/stats_groups.py $GRAFT_REPO_ROOT/$O/kernel_stats_bf16.csv 45 > $GRAFT_REPO_ROOT/$O/kernel_groups_bf16.txt
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe -o re -- python $GRAFT_REPO_ROOT/bench.py --dtype f32 --steps 10 --warmup 5 --no-cpu-baseline --no-alt-dtype --no-e2e --profile-steps 0 > /tmp/pe.log 2>&1
 cp $(find /tmp/pe -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$O/kernel_stats_f32.csv
 cd $GRAFT_REPO_ROOT

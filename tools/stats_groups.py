@@ -3,7 +3,7 @@
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
-groups = [("conv fwd/dgrad (k_spconv*)", r"k_spconv[23]?<|k_updgrad"), ("conv wgrad (k_wgrad*, k_spconv2_wgrad)", r"k_wgrad3|k_wgrad_pairs|k_spconv2_wgrad|k_spconv_wgrad"),
+groups = [("conv fwd/dgrad (k_spconv*)", r"k_spconv[234]?<|k_updgrad"), ("conv wgrad (k_wgrad*, k_spconv2_wgrad)", r"k_wgrad3|k_wgrad_pairs|k_spconv2_wgrad|k_spconv_wgrad"),
           ("split reduces (k_wgrad_reduce, k_pairs_reduce)", r"k_wgrad_reduce|k_pairs_reduce"), ("stem", r"k_stem"),
           ("BatchNorm (k_bn_*)", r"k_bn_"), ("weight images (k_permute*)", r"k_permute"),
           ("kernel maps / hash / pyramid (k_kmap, k_voxel, k_fill, k_ds, k_down, k_pairs_count/write, k_tile)", r"k_kmap|k_voxel|k_fill_|k_ds_|k_down_|k_pairs_count|k_pairs_write|k_tile|k_hash|k_keys|k_coords|k_quantize|k_batch_off|k_bev"),
