@@ -40,6 +40,10 @@ def setter(sw):
             name, val = name.split("=")[0], int(name.split("=")[1])
         return lambda on: _lib.set_knob(name, val if on else 0)
     mod = importlib.import_module(kind)
+    if "=" in name:                                   # module:ATTR=a|b  -> integer a when off, b when on
+        name, vals = name.split("=")
+        a_, b_ = (int(v) for v in vals.split("|"))
+        return lambda on: setattr(mod, name, b_ if on else a_)
     return lambda on: setattr(mod, name, bool(on))
 
 
