@@ -34,7 +34,9 @@ import time
 # language, input preparation); with more than one rank RCCL adds streams of its own, and a stream that shares a queue with another
 # runs behind it — round 5 measured a HALVED step when a fifth stream appeared. 8 queues measured neutral at N = 1 (2 984 vs 2 999
 # scenes/s). Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (ranks that SHARE one GPU — the IRX_BENCH_SHARE_GPU test rig — must not: two processes x 8 hardware queues on one device
+# oversubscribe its queue slots and every launch then waits for a queue switch: 31.8 s per step measured, 3.5 s with 4)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2" if os.environ.get("IRX_BENCH_SHARE_GPU") == "1" else "8")
 
 import numpy as np
 import torch

@@ -15,6 +15,15 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _few_hardware_queues_per_rank(monkeypatch):
+    """The ranks of these tests SHARE cuda:0. The package asks the HIP runtime for 8 hardware queues per process (one rank per GPU
+    in production); several processes x 8 on one device oversubscribe its queue slots and every launch waits for a queue switch
+    (bench.py --gpus 2 on one GPU: 31.8 s per step with 8, 1.2 s with 4, 20 ms with 2). The spawned ranks read this at start-up."""
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+
+
 KW = dict(num_points=5000, num_instances=5, points_per_instance=160)
 
 
