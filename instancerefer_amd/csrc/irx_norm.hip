@@ -14,8 +14,12 @@ static inline int bn_rows(int n, int c) {
   if (forced > 0) return forced;
   int rows = 65536 / (c < 32 ? 32 : c);
   if (rows > 2048) rows = 2048;
-  while (rows > 256 && n / rows < 128) rows >>= 1;
-  if (rows < 256) rows = 256;
+  // at least 64 rows per statistics workgroup (256 until round 5's second session: the passes that fold the offset-split slabs of a
+  // small level read S x 4 bytes per element from 36 workgroups — k_bn_partial1_slabs 32.6 -> 25.1 us, k_bn_partial_slabs 17.5 ->
+  // 11.8 us average at B = 16, 2.05 -> 1.90 ms of BatchNorm kernel time per step; tools/micro/bn_rows_stats.sh).  IRX_BN_ROWS_MIN: dev knob
+  static const int floor_ = getenv("IRX_BN_ROWS_MIN") ? atoi(getenv("IRX_BN_ROWS_MIN")) : 64;
+  while (rows > floor_ && n / rows < 128) rows >>= 1;
+  if (rows < floor_) rows = floor_;
   return rows;
 }
 
