@@ -70,14 +70,21 @@ __global__ __launch_bounds__(256) void k_cosine_rows_bwd_b(const float* __restri
     const int c = c0 + lane;
     float acc = 0.f;
     const float y = (c < d) ? br[c] : 0.f;
-    for (int i = 0; i < n; ++i) {
-      if ((idx ? idx[i] : (int64_t)i) != j) continue;    // wave-uniform
-      const float na = norms[2 * i], nb = norms[2 * i + 1];
-      const float ca = fmaxf(na, eps), cb = fmaxf(nb, eps);
-      const float g = dscore[i], s = score[i];
-      const float ka = g / (ca * cb);
-      const float kb = (nb > eps) ? g * s / (nb * nb) : 0.f;
-      if (c < d) acc += ka * a[(size_t)i * d + c] - kb * y;
+    // the rows of this target 64 at a time: one idx read per lane, then only the matching rows, in ascending i (the order of the
+    // one-row-at-a-time walk: bit-identical) — that walk was n dependent global reads per wave (14-26 us for ~100 rows)
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int ii = i0 + lane;
+      unsigned long long hit = __ballot(ii < n && (idx ? idx[ii] : (int64_t)ii) == (int64_t)j);
+      while (hit) {
+        const int i = i0 + __builtin_ctzll(hit);
+        hit &= hit - 1;
+        const float na = norms[2 * i], nb = norms[2 * i + 1];
+        const float ca = fmaxf(na, eps), cb = fmaxf(nb, eps);
+        const float g = dscore[i], s = score[i];
+        const float ka = g / (ca * cb);
+        const float kb = (nb > eps) ? g * s / (nb * nb) : 0.f;
+        if (c < d) acc += ka * a[(size_t)i * d + c] - kb * y;
+      }
     }
     if (c < d) db[(size_t)j * d + c] = acc;
   }

@@ -14,7 +14,19 @@ __global__ void k_segment_max(const float* __restrict__ x, const int32_t* __rest
   const int beg = offsets[seg], end = offsets[seg + 1];
   float best = 0.f;
   int arg = -1;
-  for (int r = beg; r < end; ++r) {
+  int r = beg;
+  for (; r + 8 <= end; r += 8) {     // eight rows' loads in flight, compared in row order (a load per compare was ~35 dependent round trips)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(r + u) * c + ch];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (arg < 0 || v[u] > best) {
+        best = v[u];
+        arg = r + u;
+      }
+  }
+  for (; r < end; ++r) {
     const float v = x[(size_t)r * c + ch];
     if (arg < 0 || v > best) {  // first maximum wins (torch.max / scatter_max tie rule)
       best = v;
