@@ -258,6 +258,38 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float* __restrict__ 
   }
 }
 
+// Many partial blocks, few elements (the stem's weight gradient: 1024 partial blocks of 27 x 7 x 32 = 6048 floats): k_wgrad_reduce gives
+// every element ONE thread that walks all S partials — 24 workgroups, 128 dependent load batches each, 47 us at the very end of the
+// scene encoder's backward.  Here a workgroup owns 32 elements x 8 slices of the partial blocks (slice t: blocks t, t + 8, ...), the
+// slices are folded through LDS in slice order: 189 workgroups, 16 batches each.  A different (fixed) summation order than
+// k_wgrad_reduce's, used from 64 partial blocks on only — the offset-split slabs (S <= 9), whose order the BatchNorm slab passes
+// reproduce, stay on k_wgrad_reduce.
+__global__ __launch_bounds__(256) void k_wgrad_reduce_wide(const float* __restrict__ part, int S, size_t elems, float* __restrict__ dw) {
+  __shared__ float sl[8][32];
+  const int e = threadIdx.x & 31, t = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + e;
+  float s = 0.f;
+  if (i < elems) {
+    int j = t;
+    for (; j + 56 < S; j += 64) {                 // eight of this slice's blocks per trip
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(j + 8 * u) * elems + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; j < S; j += 8) s += part[(size_t)j * elems + i];
+  }
+  sl[t][e] = s;
+  __syncthreads();
+  if (t == 0 && i < elems) {
+    float r = sl[0][e];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) r += sl[u][e];
+    dw[i] = r;
+  }
+}
+
 // out_bf: dw is a bf16 tensor (conv output of the executor's bf16 storage mode; the slabs are always fp32)
 __global__ void k_wgrad_reduce(const float* __restrict__ part, int S, size_t elems,
                                float* __restrict__ dw, int accumulate, int out_bf) {
@@ -593,7 +625,10 @@ int irx_spconv_wgrad_impl(const float* x, const float* dy, const int32_t* nbr, i
     const int blocks = irx_stem_wgrad_blocks(n_out);
     int rc = irx_stem_wgrad_launch(x, dy, nbr, ld, n_out, cin, blocks, (float*)workspace, S(stream), 0, dy_bf);
     if (rc) return rc;
-    k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>((const float*)workspace, blocks, elems, dw);
+    if (blocks >= 64)
+      k_wgrad_reduce_wide<<<irx_cdiv((long long)elems, 32), 256, 0, S(stream)>>>((const float*)workspace, blocks, elems, dw);
+    else
+      k_wgrad_reduce<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>((const float*)workspace, blocks, elems, dw);
     IRX_CHECK_LAUNCH("irx_spconv_wgrad(stem reduce)");
     return IRX_OK;
   }
@@ -626,7 +661,8 @@ int irx_spconv_wgrad_impl(const float* x, const float* dy, const int32_t* nbr, i
     }
     rc = irx_stem_wgrad_launch(x + WS_MAIN, dy, nbr, ld, n_out, ct, blocks, part_t, S(stream), cin, dy_bf);
     if (rc) return rc;
-    k_wgrad_reduce<<<irx_cdiv((long long)et, 256), 256, 0, S(stream)>>>(part_t, blocks, et, sum_t);
+    if (blocks >= 64) k_wgrad_reduce_wide<<<irx_cdiv((long long)et, 32), 256, 0, S(stream)>>>(part_t, blocks, et, sum_t);
+    else k_wgrad_reduce<<<irx_cdiv((long long)et, 256), 256, 0, S(stream)>>>(part_t, blocks, et, sum_t);
     IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem tail reduce)");
     k_merge_w<<<irx_cdiv((long long)elems, 256), 256, 0, S(stream)>>>(sum_m, sum_t, K, cin, WS_MAIN, cout, dw);
     IRX_CHECK_LAUNCH("irx_spconv_wgrad(wide stem merge)");

@@ -327,7 +327,8 @@ int irx_stem_fwd_launch(const float* x, const float* w, const int32_t* nbr, int 
 
 int irx_stem_wgrad_blocks(int n_out) {
   int b = irx_cdiv(n_out, 256);          // >= 4 chunks of 64 rows per workgroup
-  if (b > 1024) b = 1024;
+  static const int cap = getenv("IRX_STEM_WGRAD_BLOCKS") ? atoi(getenv("IRX_STEM_WGRAD_BLOCKS")) : 512;   // (1024: the same kernel time, a reduce twice as long; 256: k_stem_wgrad 81 -> 109 us) dev knob
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return b;
 }
