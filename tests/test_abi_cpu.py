@@ -42,7 +42,7 @@ def test_host_only_entry_points(lib):
     assert lib.irx_version() == 1
     assert lib.irx_hash_capacity(1000) == 2048 and lib.irx_hash_capacity(0) == 64
     assert lib.irx_hash_capacity(1 << 20) == 1 << 21
-    assert lib.irx_bn_workspace_bytes(1000, 128) == 4 * 2 * 128 * 4
+    assert lib.irx_bn_workspace_bytes(1000, 128) == 16 * 2 * 128 * 4      # 64 rows per statistics workgroup (256 until round 5)
     assert lib.irx_downsample_workspace_bytes(5000) >= 3 * 4
     small = lib.irx_spconv_wgrad_workspace_bytes(100, 27, 128, 128)
     assert lib.irx_spconv_wgrad_workspace_bytes(5000, 27, 7, 32) == 20 * 27 * 7 * 32 * 4   # stem path: per-workgroup partials
