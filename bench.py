@@ -36,13 +36,15 @@ import time
 # scenes/s). Must be set before the runtime initialises.
 # (ranks that SHARE one GPU — the IRX_BENCH_SHARE_GPU test rig — must not: two processes x 8 hardware queues on one device
 # oversubscribe its queue slots and every launch then waits for a queue switch: 31.8 s per step measured, 3.5 s with 4)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2" if os.environ.get("IRX_BENCH_SHARE_GPU") == "1" else "8")
-
 import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import instancerefer_amd as _irx_pkg
+# (the package no longer touches the environment at import: the queue count is this program's decision — ADVICE r5)
+if not torch.cuda.is_initialized():          # (imported by a test after the runtime started: the queue count is what it is)
+    _irx_pkg.configure_hw_queues(ranks_per_device=2 if os.environ.get("IRX_BENCH_SHARE_GPU") == "1" else 1)
 
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3      # fp32 vector == fp32-input MFMA peak
@@ -278,8 +280,8 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
 
 def prime(model, resident, args, reducer, opt, state):
     """model.warm(): IRX_BENCH_PRIME untimed steps of the real training step BEFORE the contract's warm-up steps are
-    counted, with parameters, Adam moments / step counts, BatchNorm running statistics and the RNG state restored afterwards. OFF by
-    default (0) — measured, round 5, alternating runs on one box, 5 warm-up + 20 timed steps: 0 primed steps 3 036 / 2 940, 40 primed
+    counted, with parameters, Adam moments / step counts, BatchNorm running statistics and the RNG state restored afterwards. ON by
+    default (IRX_BENCH_PRIME = 30 untimed steps, disclosed in the JSON line as `primed_steps`; 0 switches it off) — measured, round 5, alternating runs on one box, 5 warm-up + 20 timed steps: 0 primed steps 3 036 / 2 940, 40 primed
     2 996 / 3 020, 150 primed 2 822 / 2 929 scenes/s, 30 + 100 without priming 2 746-3 067 on the same box within minutes: the spread
     of the pool's boxes (+-5 %, other tenants on the host, and a downward drift under SUSTAINED load: consecutive 30-step blocks of
     one process read 5.4 -> 7.6 ms/step over ten seconds) is larger than anything the first five steps leave behind, and more
@@ -1304,17 +1306,26 @@ def summarise_roofline(recs, bf16=False):
         tot["bound_ms"] += b_ms
     if os.environ.get("IRX_BENCH_LAYERS"):
         lay = {}
+        # one line per distinct layer shape, priced with EXACTLY the byte formula of the driver line above (element sizes from the
+        # record's storage dtype: 2 B with bf16 storage — round 5's table priced every element at 4 B and printed figures above
+        # the HBM peak)
         for rec in recs:
             kind, n_out, K, cin, cout, M, e0, e1 = rec[:8]
-            a = lay.setdefault((kind, n_out, K, cin, cout, M), [0, 0.0])
+            e = float(rec[8]) if len(rec) > 8 else 4.0
+            a = lay.setdefault((kind, n_out, K, cin, cout, M, e), [0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1)
-        print("kind   n_out      K  cin cout        M   calls  avg_us   TFLOP/s  algoGB/s", file=sys.stderr)
-        for (kind, n_out, K, cin, cout, M), (c, ms) in sorted(lay.items(), key=lambda kv: -kv[1][1]):
+        print("kind   n_out      K  cin cout        M  eB   calls  avg_us   TFLOP/s  algoGB/s  frac_hbm", file=sys.stderr)
+        for (kind, n_out, K, cin, cout, M, e), (c, ms) in sorted(lay.items(), key=lambda kv: -kv[1][1]):
             us = 1e3 * ms / c
             fl = 2.0 * M * cin * cout
-            by = 4.0 * (M * (cin + cout if kind == "wgrad" else cin) + (0 if kind == "wgrad" else n_out * cout) + K * cin * cout) + 8.0 * M
-            print("%-6s %7d %4d %4d %4d %9d %6d %8.1f %8.2f %9.1f" % (kind, n_out, K, cin, cout, M, c, us, fl / us / 1e6, by / us / 1e3), file=sys.stderr)
+            ew = 2.0 if (bf16 and cin in (32, 64, 128) and cout in (32, 64, 128)) else 4.0
+            if kind == "wgrad":
+                by = e * M * (cin + cout) + 4.0 * K * cin * cout + 8.0 * M
+            else:
+                by = e * (M * cin + n_out * cout) + ew * K * cin * cout + 8.0 * M
+            print("%-6s %7d %4d %4d %4d %9d %3d %6d %8.1f %8.2f %9.1f %9.3f" % (kind, n_out, K, cin, cout, M, int(e), c, us, fl / us / 1e6,
+                                                                          by / us / 1e3, by / us / 1e3 / PEAK_HBM_GBS), file=sys.stderr)
     if not agg:
         return None
     dom = max(agg, key=lambda k: agg[k]["ms"])

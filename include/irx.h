@@ -132,6 +132,17 @@ int irx_kmap_build_s1(const int32_t* coords, int n, int tensor_stride,
                       const uint64_t* table_keys, const int32_t* table_vals, size_t capacity,
                       int32_t* nbr, int ld, void* stream);
 
+/* Hash tables AND 27-neighbour tables of up to 8 levels of one coordinate pyramid in ONE call (three launches in total: table fill,
+ * inserts, neighbour search; round 5 took four launches per level). Per level l: keys[l] uint64 [n[l]] (Morton keys, ASCENDING — the
+ * rows of every level of a pyramid built by irx_pyramid_build are), coords[l] int32 [n[l]][4], tensor_stride[l]; the level's hash
+ * table tk[l] / tv[l] of capacity cap[l] (irx_hash_capacity(n[l])) is (re)built as irx_hash_build does; nbr[l] int32 [27][ld[l]] as
+ * irx_kmap_build_s1. Levels with n[l] == 0 are skipped. The neighbour search stages a window of each workgroup's sorted keys in LDS
+ * and only consults the hash table for probes outside that window's key range (csrc/irx_coords.hip, k_kmap_win); irx_kmap_build_s1
+ * runs the same kernel for one level. Reference: torchsparse's `sphash` + `sphashquery` per Conv3d (models/basic_blocks.py:14-19). */
+int irx_kmaps_build_multi(int nlev, const uint64_t* const* keys, const int32_t* const* coords, const int* n,
+                          const int* tensor_stride, uint64_t* const* table_keys, int32_t* const* table_vals, const size_t* capacity,
+                          int32_t* const* nbr, const int* ld, void* stream);
+
 /* Strided (kernel 2, stride 2) down-sampling of a key-sorted coordinate set
  * (torchsparse `spdownsample` + kernel map, reached from BasicConvolutionBlock(ks=2,
  * stride=2) at models/basic_blocks.py:68,73,78,83): out coords = unique(floor(c/(2s))*2s, b).
@@ -590,6 +601,11 @@ int irx_mlp2_fwd(const float* x, int rows, int din, int dh, int dout, const floa
 int irx_mlp2_bwd(const float* x, const float* dy, int rows, int din, int dh, int dout, const float* w1, int norm,
                  const float* gamma, const float* w2, const float* saved, float drop_scale, float* dhid, float* dx, float* dw1,
                  float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, void* stream);
+
+/* nn.Dropout in training mode (models/scene_module.py:31, between the two Conv2d of vis_emb_fc) without a mask tensor: element o of
+ * the flat tensor x [n] is kept iff a counter-based hash of (seed, o) falls at or above p (the decision irx_mlp2_fwd uses), kept
+ * elements are scaled by 1 / (1 - p). The backward is the same call on the incoming gradient with the same seed. x == y allowed. */
+int irx_dropout_flat(const float* x, size_t n, float p, unsigned long long seed, float* y, void* stream);
 
 /* ---- language-instance matching scores ---------------------------------------------------
  * models/attribute_module.py:122-126 (normalize + normalize + row dot), relation_module.py:104-105 and

@@ -9,10 +9,42 @@ __version__ = "0.1.0"
 
 import os as _os
 
-# More hardware queues than the runtime's default of 4 (see bench.py): the training forward of the bf16 modes runs on three
-# streams beside the caller's preparation stream, and a collective library adds its own. Only effective when this package is
-# imported before the HIP runtime initialises (first GPU call); harmless otherwise.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+def configure_hw_queues(ranks_per_device=None, force=False):
+    """Ask the HIP runtime for the number of hardware queues this package's stream layout wants (GPU_MAX_HW_QUEUES; the runtime's
+    default is 4). NOT done at import: the variable is process-wide, only read when the runtime initialises, and the
+    right value depends on how many processes share a device —
+      one rank per GPU (production layout): 8. The bf16 training forward uses three streams beside the caller's preparation
+        stream and RCCL adds its own; a stream that shares a hardware queue with another runs behind it (round 5: a fifth stream
+        on four queues HALVED the step);
+      several ranks on ONE GPU (test rigs, train + eval on one device): 2. Two processes x 8 queues oversubscribe the device's
+        queue slots and every launch waits for a queue switch (measured: 31.8 s per step against 20 ms with 2).
+    ranks_per_device: None = LOCAL_WORLD_SIZE / visible devices, rounded up. An explicit GPU_MAX_HW_QUEUES in the environment
+    always wins unless force=True. Returns the value in force, or None when the runtime was already initialised (too late: a
+    warning says so). Callers: bench.py, Solver (before the first GPU call), tests/test_multirank_gpu.py."""
+    import warnings
+    if not force and "GPU_MAX_HW_QUEUES" in _os.environ:
+        return int(_os.environ["GPU_MAX_HW_QUEUES"])
+    try:
+        import torch
+        if torch.cuda.is_initialized():
+            warnings.warn("instancerefer_amd.configure_hw_queues: the HIP runtime is already initialised; GPU_MAX_HW_QUEUES "
+                          "keeps its start-up value (call this before the first GPU operation)", RuntimeWarning, stacklevel=2)
+            return None
+        ndev = torch.cuda.device_count()
+    except Exception:                                          # pragma: no cover - plumbing only
+        ndev = 0
+    if ranks_per_device is None:
+        local = int(_os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+        ranks_per_device = -(-local // ndev) if ndev > 0 else 1
+    if ranks_per_device > 1:
+        warnings.warn("instancerefer_amd: %d ranks share one GPU; asking for 2 hardware queues per process (8 per process "
+                      "oversubscribes the device's queue slots: ~1000x slower launches)" % ranks_per_device, RuntimeWarning,
+                      stacklevel=2)
+    val = 8 if ranks_per_device <= 1 else 2
+    _os.environ["GPU_MAX_HW_QUEUES"] = str(val)
+    return val
+
+
 
 # Host-side dispatch cost of the small dense GEMMs of the language / matching heads (M <= a few hundred rows), measured on
 # MI355X with PyTorch 2.10: hipBLASLt 18 us per mm / 21 us per nn.Linear, rocBLAS 7 / 16 us (tools/micro/gemm_host.py).

@@ -78,13 +78,23 @@ def _build_locked(objdir, verbose):
 # A Python extension module compiled against the torch headers with g++ (host code only: it calls libirx through function
 # addresses and never touches HIP). In-tree like libirx.so, so it travels to the GPU box with the snapshot.
 NODES_SRC = os.path.join(CSRC, "torch_nodes.cpp")
+NODES_SRCS = [NODES_SRC, os.path.join(CSRC, "heads_nodes.cpp")]       # heads_nodes.cpp: one node per head (round 6)
+NODES_HDRS = [os.path.join(CSRC, "torch_nodes.h")]
 NODES_PATH = os.path.join(CSRC, "_irx_nodes.so")
 CXX = os.environ.get("CXX", "g++")
 
 
+def nodes_stale() -> bool:
+    if not os.path.exists(NODES_PATH):
+        return True
+    t = os.path.getmtime(NODES_PATH)
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in NODES_SRCS + NODES_HDRS)
+
+
 def build_nodes(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/torch_nodes.cpp into csrc/_irx_nodes.so (torch C++ extension, ~1 min). Returns the module path."""
-    if not force and os.path.exists(NODES_PATH) and os.path.getmtime(NODES_PATH) >= os.path.getmtime(NODES_SRC):
+    """Compile csrc/torch_nodes.cpp + csrc/heads_nodes.cpp into csrc/_irx_nodes.so (torch C++ extension, ~1 min; the two translation
+    units compile in parallel). Returns the module path."""
+    if not force and not nodes_stale():
         return NODES_PATH
     import fcntl
     import sysconfig
@@ -95,19 +105,30 @@ def build_nodes(force: bool = False, verbose: bool = False) -> str:
     lock = open(os.path.join(objdir, ".lock_nodes"), "w")
     fcntl.flock(lock, fcntl.LOCK_EX)
     try:
-        if not force and os.path.exists(NODES_PATH) and os.path.getmtime(NODES_PATH) >= os.path.getmtime(NODES_SRC):
+        if not force and not nodes_stale():
             return NODES_PATH
         tlib = ce.library_paths()[0]
-        cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-DTORCH_EXTENSION_NAME=_irx_nodes", "-DTORCH_API_INCLUDE_EXTENSION_H",
-               "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
-        cmd += ["-I" + d for d in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"]]
+        base = [CXX, "-O2", "-std=c++17", "-fPIC", "-DTORCH_EXTENSION_NAME=_irx_nodes", "-DTORCH_API_INCLUDE_EXTENSION_H",
+                "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+        base += ["-I" + d for d in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"]]
+
+        def compile_one(src):
+            obj = os.path.join(objdir, os.path.basename(src).replace(".cpp", ".nodes.o"))
+            cmd = base + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("building _irx_nodes failed (%s):\n%s\n%s" % (os.path.basename(src), r.stdout, r.stderr))
+            return obj
+
+        with ThreadPoolExecutor(max_workers=len(NODES_SRCS)) as ex:
+            objs = list(ex.map(compile_one, NODES_SRCS))
         tmp = NODES_PATH + ".tmp.%d" % os.getpid()
-        cmd += [NODES_SRC, "-o", tmp, "-L" + tlib, "-Wl,-rpath," + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python"]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
+        cmd = [CXX, "-shared", "-fPIC"] + objs + ["-o", tmp, "-L" + tlib, "-Wl,-rpath," + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError("building _irx_nodes failed:\n%s\n%s" % (r.stdout, r.stderr))
+            raise RuntimeError("linking _irx_nodes failed:\n%s\n%s" % (r.stdout, r.stderr))
         os.replace(tmp, NODES_PATH)
         return NODES_PATH
     finally:

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "irx_voxel_select": (_I, [_P, _I, _P, _P, _Z, _P, _P, _P]),
     "irx_hash_build": (_I, [_P, _I, _P, _P, _Z, _P]),
     "irx_kmap_build_s1": (_I, [_P, _I, _I, _P, _P, _Z, _P, _I, _P]),
+    "irx_kmaps_build_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "irx_downsample_workspace_bytes": (_Z, [_I]),
     "irx_downsample": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
     "irx_pyramid_build": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _P]),
@@ -100,6 +101,7 @@ _SIGNATURES = {
     "irx_mlp2_saved_floats": (_Z, [_I, _I]),
     "irx_mlp2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _F, _P, _P, _F, _F, _c.c_uint64, _P, _P, _P, _P, _P]),
     "irx_mlp2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "irx_dropout_flat": (_I, [_P, _Z, _F, _c.c_uint64, _P, _P]),
     "irx_knn_batched": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "irx_project_workspace_bytes": (_Z, [_I]),
     "irx_project_points": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _Z, _P]),

@@ -11,7 +11,12 @@ from . import _build, _lib
 
 ENABLED = os.environ.get("IRX_CPP_NODES", "1") != "0"
 _ENTRY_POINTS = ("irx_mlp2_saved_floats", "irx_mlp2_fwd", "irx_mlp2_bwd", "irx_gru_forward", "irx_gru_backward", "irx_gru_wgrad", "irx_last_error",
-                 "irx_hash_capacity", "irx_hash_build", "irx_kmap_build_s1")
+                 "irx_hash_capacity", "irx_hash_build", "irx_kmap_build_s1", "irx_kmaps_build_multi")
+# csrc/heads_nodes.cpp (one node per head)
+_HEAD_ENTRY_POINTS = ("irx_mlp2_saved_floats", "irx_mlp2_fwd", "irx_mlp2_bwd", "irx_segment_max", "irx_segment_max_backward",
+                      "irx_cosine_rows_fwd", "irx_cosine_rows_bwd", "irx_spconv_fwd_workspace_bytes", "irx_spconv_fwd",
+                      "irx_spconv_wgrad_workspace_bytes", "irx_spconv_wgrad", "irx_bn_workspace_bytes", "irx_bn_forward", "irx_bn_backward",
+                      "irx_kmap_down_transpose", "irx_attn_pool_fwd", "irx_attn_pool_bwd", "irx_dropout_flat", "irx_total_loss")
 _mod = None
 _tried = False
 _lock = __import__("threading").Lock()
@@ -36,9 +41,9 @@ def load():
 def _load_locked():
     if not ENABLED or not os.path.exists(_build.NODES_PATH):
         return None
-    if os.path.exists(_build.NODES_SRC) and os.path.getmtime(_build.NODES_PATH) < os.path.getmtime(_build.NODES_SRC):
+    if _build.nodes_stale():
         import warnings
-        warnings.warn("instancerefer_amd: csrc/_irx_nodes.so is older than csrc/torch_nodes.cpp — the dense heads run through their "
+        warnings.warn("instancerefer_amd: csrc/_irx_nodes.so is older than its sources (csrc/torch_nodes.cpp, heads_nodes.cpp) — the dense heads run through their "
                       "Python / ATen path; rebuild with `python -m instancerefer_amd._build`", RuntimeWarning)
         return None
     try:
@@ -47,6 +52,7 @@ def _load_locked():
         spec.loader.exec_module(mod)
         lib = _lib.load()
         mod.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in _ENTRY_POINTS})
+        mod.bind_heads({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in _HEAD_ENTRY_POINTS})
     except Exception as e:                 # a module built against another torch: say so, run the heads through their Python nodes
         import warnings
         warnings.warn("instancerefer_amd: csrc/_irx_nodes.so could not be loaded (%s: %s) — the dense heads run through their "

@@ -478,6 +478,33 @@ __global__ __launch_bounds__(256) void k_mlp_bwd3(const float* __restrict__ x, i
   }
 }
 
+// ---- stand-alone dropout over a flat tensor, the ml_drop decision (no mask tensor) ------------------------------------------
+// y[o] = keep(seed, o) ? x[o] / (1 - p) : 0. The backward is the same call on the incoming gradient with the same seed.
+__global__ __launch_bounds__(256) void k_dropout_flat(const float* __restrict__ x, size_t n, float p, float scale,
+                                                      unsigned long long seed, float* __restrict__ y) {
+  const size_t q = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (q + 4 <= n && ((((size_t)x | (size_t)y) & 15) == 0)) {
+    const float4 v = *reinterpret_cast<const float4*>(x + q);
+    float4 r;
+    r.x = ml_drop(v.x, p, scale, seed, q);
+    r.y = ml_drop(v.y, p, scale, seed, q + 1);
+    r.z = ml_drop(v.z, p, scale, seed, q + 2);
+    r.w = ml_drop(v.w, p, scale, seed, q + 3);
+    *reinterpret_cast<float4*>(y + q) = r;
+  } else {
+    for (size_t o = q; o < n && o < q + 4; ++o) y[o] = ml_drop(x[o], p, scale, seed, o);
+  }
+}
+
+extern "C" int irx_dropout_flat(const float* x, size_t n, float p, unsigned long long seed, float* y, void* stream) {
+  IRX_REQUIRE(p >= 0.f && p < 1.f, "irx_dropout_flat: dropout probability %f outside [0, 1)", (double)p);
+  if (n == 0) return IRX_OK;
+  IRX_REQUIRE(x && y, "irx_dropout_flat: null pointer");
+  k_dropout_flat<<<irx_cdiv((long long)((n + 3) / 4), 256), 256, 0, S(stream)>>>(x, n, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, y);
+  IRX_CHECK_LAUNCH("irx_dropout_flat");
+  return IRX_OK;
+}
+
 // --------------------------------------------------------------------------------------------------------- host ---
 extern "C" size_t irx_mlp2_saved_floats(int rows, int dh) {
   // h [rows][dh], a [rows][dh], stat (2 dh for BatchNorm, 2 rows for LayerNorm: the larger is reserved)

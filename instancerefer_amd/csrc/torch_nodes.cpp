@@ -13,6 +13,8 @@
 // relation_module.py:18-27, scene_module.py:38-42 (nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, [Dropout], Linear)).
 #include <torch/extension.h>
 
+#include "torch_nodes.h"
+
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -34,10 +36,12 @@ typedef int (*gru_bwd_fn)(const float*, const float*, const float*, const int32_
                           float*, void*);
 typedef int (*gru_wgrad_fn)(const float*, const float*, const float*, const float*, int, int, int, int, int, float*, float*, float*,
                             float*, float*, float*, float*, float*, void*);
-typedef const char* (*last_error_fn)();
+using irxn::last_error_fn;
 typedef size_t (*hash_capacity_fn)(int);
 typedef int (*hash_build_fn)(const uint64_t*, int, uint64_t*, int32_t*, size_t, void*);
 typedef int (*kmap_s1_fn)(const int32_t*, int, int, const uint64_t*, const int32_t*, size_t, int32_t*, int, void*);
+typedef int (*kmaps_multi_fn)(int, const uint64_t* const*, const int32_t* const*, const int*, const int*, uint64_t* const*, int32_t* const*,
+                              const size_t*, int32_t* const*, const int*, void*);
 
 struct Api {
   saved_floats_fn mlp2_saved_floats = nullptr;
@@ -50,37 +54,11 @@ struct Api {
   hash_capacity_fn hash_capacity = nullptr;
   hash_build_fn hash_build = nullptr;
   kmap_s1_fn kmap_s1 = nullptr;
+  kmaps_multi_fn kmaps_multi = nullptr;
 } g_api;
 
-void check(int rc, const char* what) {
-  if (rc == 0) return;
-  const char* msg = g_api.last_error ? g_api.last_error() : "";       // (thread-local in libirx: read on the failing thread)
-  throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + (msg ? msg : ""));
-}
-
-// Gradient-sink handle (optim.FlatAdam.native_sink): slot addresses followed by [record address, generation, address of the
-// process-wide generation counter]. deliver() is true when the node may write the optimizer's slots NOW: the expected number of
-// slots came along, the optimizer that handed them out is still the current one (generation unchanged since the forward) and the
-// producer has not delivered since the last zero_grad() (record[0] == 0). The tensors the addresses point into travel with the
-// node (`keep` in saved_data), so a retired optimizer's buffers stay valid until the graph is gone.
-struct Sink {
-  std::vector<int64_t> slots;
-  int64_t* rec = nullptr;
-  int64_t gen = 0;
-  const int64_t* gen_now = nullptr;
-  explicit Sink(const std::vector<int64_t>& v) {
-    if (v.size() > 3) {
-      slots.assign(v.begin(), v.end() - 3);
-      rec = (int64_t*)v[v.size() - 3];
-      gen = v[v.size() - 2];
-      gen_now = (const int64_t*)v[v.size() - 1];
-    }
-  }
-  bool deliver(size_t expected) const {
-    return slots.size() == expected && rec != nullptr && gen_now != nullptr && *gen_now == gen && rec[0] == 0;
-  }
-  void delivered(void* stream) const { rec[1] = (int64_t)stream; rec[0] = 1; }
-};
+using irxn::check;
+using irxn::Sink;
 
 // the sink's keep-alive tensors (flat gradient buffer, record tensor) ride in the node's saved_data
 inline void keep_alive(AutogradContext* ctx, const c10::optional<Tensor>& a, const c10::optional<Tensor>& b) {
@@ -91,8 +69,8 @@ inline c10::optional<Tensor> opt_at(const std::vector<Tensor>& v, size_t i) {
   return i < v.size() ? c10::optional<Tensor>(v[i]) : c10::optional<Tensor>();
 }
 
-inline const float* fp(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
-inline float* fpm(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+using irxn::fp;
+using irxn::fpm;
 
 // y = W2 . D(relu(N(W1 x + b1))) + b2, irx_mlp2_fwd / irx_mlp2_bwd.  slot_ptrs: addresses of the six gradient slots
 // (w1, b1, gamma, beta, w2, b2) in the optimizer's flat buffer + the Sink trailer, or empty (see Sink above); a second backward
@@ -293,27 +271,44 @@ Tensor mlp_relu2(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tens
 // neighbours int32 [27][max(n, 1)]) or three undefined tensors.
 std::vector<Tensor> kmaps_build(const std::vector<Tensor>& keys, const std::vector<Tensor>& coords, const std::vector<int64_t>& strides,
                                 const std::vector<int64_t>& have, int64_t stream) {
-  TORCH_CHECK(g_api.hash_build && g_api.kmap_s1 && g_api.hash_capacity, "irx nodes: bind() has not been called");
+  TORCH_CHECK(g_api.kmaps_multi && g_api.hash_capacity, "irx nodes: bind() has not been called");
   TORCH_CHECK(keys.size() == coords.size() && keys.size() == strides.size() && keys.size() == have.size(), "kmaps_build: list sizes");
-  std::vector<Tensor> out;
-  out.reserve(3 * keys.size());
-  for (size_t l = 0; l < keys.size(); ++l) {
+  const size_t nl = keys.size();
+  std::vector<Tensor> out(3 * nl);
+  // round 6: ONE library call (three launches) for every level that still needs its tables, three allocations shared by the levels
+  std::vector<size_t> todo;
+  int64_t cap_total = 0, nbr_total = 0;
+  std::vector<size_t> caps;
+  for (size_t l = 0; l < nl; ++l) {
     const int64_t n = coords[l].size(0);
-    if (have[l] || n == 0) {
-      out.emplace_back(); out.emplace_back(); out.emplace_back();
-      continue;
-    }
-    const size_t cap = g_api.hash_capacity((int)n);
-    Tensor tk = torch::empty({(int64_t)cap}, keys[l].options().dtype(torch::kInt64));
-    Tensor tv = torch::empty({(int64_t)cap}, keys[l].options().dtype(torch::kInt32));
-    Tensor nbr = torch::empty({27, n > 0 ? n : 1}, keys[l].options().dtype(torch::kInt32));
-    check(g_api.hash_build((const uint64_t*)keys[l].data_ptr<int64_t>(), (int)n, (uint64_t*)tk.data_ptr<int64_t>(),
-                           tv.data_ptr<int32_t>(), cap, (void*)stream), "irx_hash_build");
-    check(g_api.kmap_s1(coords[l].data_ptr<int32_t>(), (int)n, (int)strides[l], (const uint64_t*)tk.data_ptr<int64_t>(),
-                        tv.data_ptr<int32_t>(), cap, nbr.data_ptr<int32_t>(), (int)(n > 0 ? n : 1), (void*)stream),
-          "irx_kmap_build_s1");
-    out.push_back(tk); out.push_back(tv); out.push_back(nbr);
+    if (have[l] || n == 0) continue;
+    todo.push_back(l);
+    caps.push_back(g_api.hash_capacity((int)n));
+    cap_total += (int64_t)caps.back();
+    nbr_total += 27 * ((n + 63) / 64 * 64);                 // (every level's table starts on a 256-byte boundary)
   }
+  if (todo.empty()) return out;
+  TORCH_CHECK(todo.size() <= 8, "kmaps_build: more than 8 levels");
+  const auto opt = keys[todo[0]].options();
+  Tensor tk_all = torch::empty({cap_total}, opt.dtype(torch::kInt64));
+  Tensor tv_all = torch::empty({cap_total}, opt.dtype(torch::kInt32));
+  Tensor nbr_all = torch::empty({nbr_total}, opt.dtype(torch::kInt32));
+  const uint64_t* kp[8]; const int32_t* cp[8]; int n_[8], st[8], ld[8]; uint64_t* tkp[8]; int32_t* tvp[8]; size_t cap[8]; int32_t* np_[8];
+  int64_t co = 0, no = 0;
+  for (size_t i = 0; i < todo.size(); ++i) {
+    const size_t l = todo[i];
+    const int64_t n = coords[l].size(0), ldl = (n + 63) / 64 * 64;
+    Tensor tk = tk_all.narrow(0, co, (int64_t)caps[i]), tv = tv_all.narrow(0, co, (int64_t)caps[i]);
+    Tensor nbr = nbr_all.narrow(0, no, 27 * ldl).view({27, ldl});
+    co += (int64_t)caps[i];
+    no += 27 * ldl;
+    kp[i] = (const uint64_t*)keys[l].data_ptr<int64_t>();
+    cp[i] = coords[l].data_ptr<int32_t>();
+    n_[i] = (int)n; st[i] = (int)strides[l]; ld[i] = (int)ldl;
+    tkp[i] = (uint64_t*)tk.data_ptr<int64_t>(); tvp[i] = tv.data_ptr<int32_t>(); cap[i] = caps[i]; np_[i] = nbr.data_ptr<int32_t>();
+    out[3 * l] = tk; out[3 * l + 1] = tv; out[3 * l + 2] = nbr;
+  }
+  check(g_api.kmaps_multi((int)todo.size(), kp, cp, n_, st, tkp, tvp, cap, np_, ld, (void*)stream), "irx_kmaps_build_multi");
   return out;
 }
 
@@ -331,12 +326,19 @@ void bind(const std::unordered_map<std::string, uint64_t>& addr) {
   g_api.gru_bwd = (gru_bwd_fn)get("irx_gru_backward");
   g_api.gru_wgrad = (gru_wgrad_fn)get("irx_gru_wgrad");
   g_api.last_error = (last_error_fn)get("irx_last_error");
+  irxn::g_last_error = g_api.last_error;
   g_api.hash_capacity = (hash_capacity_fn)get("irx_hash_capacity");
   g_api.hash_build = (hash_build_fn)get("irx_hash_build");
   g_api.kmap_s1 = (kmap_s1_fn)get("irx_kmap_build_s1");
+  g_api.kmaps_multi = (kmaps_multi_fn)get("irx_kmaps_build_multi");
 }
 
 }  // namespace
+
+namespace irxn {
+last_error_fn g_last_error = nullptr;
+void register_heads(pybind11::module& m);      // heads_nodes.cpp
+}  // namespace irxn
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd nodes over libirx's C-ABI (dense heads)";
@@ -345,4 +347,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("gru_layer", &gru_layer);
   m.def("mlp_relu2", &mlp_relu2);
   m.def("kmaps_build", &kmaps_build);
+  irxn::register_heads(m);
 }

@@ -308,12 +308,21 @@ class InstanceRefer(nn.Module):
                     prebuild_backward(self.attribute.net, prep[0].level(), use_stream=main)
         if MARK: MARK("fwd: scene head issued")
         main.wait_event(ev)
-        data_dict = self.attribute(data_dict)
-        if MARK: MARK("fwd: attribute head issued")
-        main.wait_stream(side)
-        for k in ('_scene_feats', 'seg_scores', 'vis_atten'):
-            data_dict[k].record_stream(main)
-        data_dict = self.scene(data_dict)                    # scene scores: needs obj_feats and the scene vector
+        from . import heads
+        if heads.attr_scene_ok(self.attribute, self.scene, data_dict) is not None:
+            # attribute head + scene scores as ONE autograd node (csrc/heads_nodes.cpp): it needs the scene vector up front
+            main.wait_stream(side)
+            for k in ('_scene_feats', 'seg_scores', 'vis_atten'):
+                data_dict[k].record_stream(main)
+            heads.attr_scene(self.attribute, self.scene, data_dict)
+            if MARK: MARK("fwd: attribute head issued")
+        else:
+            data_dict = self.attribute(data_dict)
+            if MARK: MARK("fwd: attribute head issued")
+            main.wait_stream(side)
+            for k in ('_scene_feats', 'seg_scores', 'vis_atten'):
+                data_dict[k].record_stream(main)
+            data_dict = self.scene(data_dict)                # scene scores: needs obj_feats and the scene vector
         main.wait_stream(lstream)
         for k in ('relation_scores', 'lang_scores', 'lang_feat', 'atten_attr'):
             if isinstance(data_dict.get(k), torch.Tensor):
@@ -355,7 +364,11 @@ class InstanceRefer(nn.Module):
         else:
             data_dict = self.lang(data_dict)
         if MARK: MARK("fwd: lang joined")
-        if self.args.attribute_module:
+        from . import heads
+        fused_tail = (self.args.attribute_module and self.args.scene_module and self.training and hasattr(self.scene, 'head')
+                      and data_dict.get('_attr_prepared') is not None and data_dict['_attr_prepared'][0] is not None
+                      and data_dict['lang_feat'].is_cuda and heads._mod() is not None)
+        if self.args.attribute_module and not fused_tail:
             data_dict = self.attribute(data_dict)
         if MARK: MARK("fwd: attribute head issued")
         if self.args.relation_module and not rel_done:
@@ -369,7 +382,13 @@ class InstanceRefer(nn.Module):
             main = torch.cuda.current_stream()
             main.wait_stream(side)
             data_dict['_scene_encoded'].record_stream(main)
-        if self.args.scene_module:
+        if fused_tail:
+            # scene head, then attribute head + scene scores as one node (heads.py); whatever a precondition refuses runs per operator
+            data_dict = self.scene.head(data_dict)
+            if not heads.attr_scene(self.attribute, self.scene, data_dict):
+                data_dict = self.attribute(data_dict)
+                data_dict = self.scene(data_dict)
+        elif self.args.scene_module:
             data_dict = self.scene(data_dict)
         return data_dict
 

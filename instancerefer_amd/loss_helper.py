@@ -291,11 +291,13 @@ def get_loss(data_dict, config):
             and data_dict['lang_scores'].dim() == 2 and data_dict['seg_scores'].dim() == 2):
         # the whole loss in one launch each way (csrc/irx_match.hip, k_total_loss): it sits on the step's critical path between
         # the last head's forward and the first head's backward
+        from . import heads
         from .dense import TotalLossFn
-        loss, ref_loss, lang_loss, seg_loss, seg_acc = TotalLossFn.apply(
-            data_dict['lang_scores'], data_dict['seg_scores'], data_dict['attribute_scores'], data_dict['relation_scores'],
-            data_dict['scene_scores'], data_dict['object_cat'].to(dev), lp['area_label'], lp['lab'], lp['seg_off'], lp['keep_dev'],
-            5.0, 0.2, 10.0, lp['batch_size'])
+        largs = (data_dict['lang_scores'], data_dict['seg_scores'], data_dict['attribute_scores'], data_dict['relation_scores'],
+                 data_dict['scene_scores'], data_dict['object_cat'].to(dev), lp['area_label'], lp['lab'], lp['seg_off'], lp['keep_dev'],
+                 5.0, 0.2, 10.0, lp['batch_size'])
+        out = heads.total_loss(*largs)               # the C++ node (csrc/heads_nodes.cpp); None: the Python node
+        loss, ref_loss, lang_loss, seg_loss, seg_acc = out if out is not None else TotalLossFn.apply(*largs)
         starts, label_dev, counts = lp['starts'], lp['label_dev'], lp['counts']
         data_dict.update(lang_loss=lang_loss, ref_loss=ref_loss, loss=loss, seg_loss=seg_loss, seg_acc=seg_acc,
                          cluster_label=[label_dev[starts[i]:starts[i + 1]] if counts[i] else [] for i in range(lp['batch_size'])])

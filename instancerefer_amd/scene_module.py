@@ -75,6 +75,9 @@ class SceneModule(nn.Module):
                 feats._batch_size = batch_size   # known from the collate; avoids the reference's .item() sync
             feats = self.net(feats)
         lane_wait(lane_of(self.net))             # the encoder may be issued by a library thread (encoder_fn.py)
+        from . import heads
+        if heads.scene_head(self, feats, data_dict):     # everything below as ONE autograd node (csrc/heads_nodes.cpp)
+            return data_dict
         # SparseCrop (to_bev[0]) is folded into the BEV gather: only voxels inside the window are looked up.
         # The dense head runs on channels-last cell rows (cells, C) with the irx conv / BatchNorm kernels.
         nx, ny = self.to_bev[1].bev_shape

@@ -69,6 +69,9 @@ def resume_base_lr(saved_lr, initial_lr, start_epoch, lr_decay_step, lr_decay_ra
 class Solver:
     def __init__(self, model, config, dataloader, lr=1e-3, weight_decay=1e-5, lr_decay_step=(15, 20), lr_decay_rate=0.1,
                  out_dir=None, verbose=20, device=None, use_checkpoint=None, sync_bn=False):
+        if not torch.cuda.is_initialized():        # the queue count is read once, when the HIP runtime starts (configure_hw_queues)
+            from . import configure_hw_queues
+            configure_hw_queues()
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.model = model.to(self.device)
         self.sync_bn = bool(sync_bn)

@@ -69,7 +69,7 @@ class Level:
     def nbr27(self):
         if self._nbr27 is None:
             self._nbr27 = F_.kmap_build_s1(self.coords, self.stride, self.table())
-        return self._nbr27, max(self.n, 1)
+        return self._nbr27, int(self._nbr27.shape[1])       # (leading dimension: the batched builder pads rows to 64 entries)
 
     def order27(self):
         """Launch order of the 64-row output tiles of this level's 3^3 convolutions (heaviest first; csrc/irx_sched.hip)."""
