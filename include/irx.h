@@ -143,6 +143,20 @@ int irx_kmaps_build_multi(int nlev, const uint64_t* const* keys, const int32_t* 
                           const int* tensor_stride, uint64_t* const* table_keys, int32_t* const* table_vals, const size_t* capacity,
                           int32_t* const* nbr, const int* ld, void* stream);
 
+/* The 27-neighbour tables of EVERY level of a coordinate pyramid built by irx_pyramid_build, by octree descent: the coarsest level
+ * (index nlev - 1) is searched like irx_kmaps_build_multi does (its hash table tk_top / tv_top of capacity cap_top is built and used
+ * only when that level has more than 2048 rows; otherwise the three may be NULL / 0), every finer level l is derived from level l + 1:
+ * nbr_l[d][q] = child_l[(b + d) mod 2][ nbr_{l+1}[floor((b + d) / 2)][parent_l[q]] ] with b = the child position of row q inside its
+ * parent (koff_l[q] = x * 4 + y * 2 + z) — parent_l int32 [n[l]], koff_l uint8 [n[l]], child_l int32 [8][child_ld[l]] are exactly the
+ * arrays irx_pyramid_build / irx_downsample wrote for the map l -> l + 1. No hash table and no key arithmetic below the top: one launch
+ * per level, reads of rows that are neighbours in Morton order. n[l], tensor_stride[l], nbr[l] int32 [27][ld[l]] per level (finest
+ * first). Same tables as irx_kmap_build_s1 (tests/test_kmaps_gpu.py). Reference: torchsparse's kernel-map construction per
+ * Conv3d (models/basic_blocks.py:14-19). */
+int irx_kmaps_build_pyramid(int nlev, const int* n, const int* tensor_stride, const uint64_t* keys_top, const int32_t* coords_top,
+                            uint64_t* table_keys_top, int32_t* table_vals_top, size_t capacity_top, const int32_t* const* parent,
+                            const uint8_t* const* koff, const int32_t* const* child, const int* child_ld, int32_t* const* nbr,
+                            const int* ld, void* stream);
+
 /* Strided (kernel 2, stride 2) down-sampling of a key-sorted coordinate set
  * (torchsparse `spdownsample` + kernel map, reached from BasicConvolutionBlock(ks=2,
  * stride=2) at models/basic_blocks.py:68,73,78,83): out coords = unique(floor(c/(2s))*2s, b).

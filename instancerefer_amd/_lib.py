@@ -36,6 +36,7 @@ _SIGNATURES = {
     "irx_hash_build": (_I, [_P, _I, _P, _P, _Z, _P]),
     "irx_kmap_build_s1": (_I, [_P, _I, _I, _P, _P, _Z, _P, _I, _P]),
     "irx_kmaps_build_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "irx_kmaps_build_pyramid": (_I, [_I, _P, _P, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P]),
     "irx_downsample_workspace_bytes": (_Z, [_I]),
     "irx_downsample": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
     "irx_pyramid_build": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _P]),

@@ -79,12 +79,14 @@ class AttributeModule(nn.Module):
             data_dict['_attr_prepared'] = (pending.finish(), data_dict['_attr_prepared'][1])
         return data_dict
 
-    def encode(self, data_dict):
+    def encode(self, data_dict, defer=False):
         """Issue the candidate encoder now if the candidates are already known (prepare() ran: GT classes) — it needs
-        nothing from the language module. forward() picks the result up; identical to running it there."""
+        nothing from the language module. forward() picks the result up; identical to running it there.
+        defer=True: the pass is issued now, its autograd node is created when the caller attaches it (encoder_fn.Deferred) — the
+        backward reaches the encoder in the order of the attach."""
         prep = data_dict.get('_attr_prepared')
         if prep is not None and prep[0] is not None and '_attr_encoded' not in data_dict:
-            data_dict['_attr_encoded'] = self.net(prep[0])
+            data_dict['_attr_encoded'] = self.net(prep[0], defer=defer)
         return data_dict
 
     def forward(self, data_dict):
@@ -112,6 +114,8 @@ class AttributeModule(nn.Module):
         feats = data_dict.pop('_attr_encoded', None)
         if feats is None:
             feats = self.net(st)
+        elif hasattr(feats, 'attach'):
+            feats = feats.attach()
         lane_wait(lane_of(self.net))                      # the encoder may be issued by a library thread
         feats = self.pooling(feats)                       # (Nc, 128)
         data_dict['obj_feats'] = feats

@@ -139,9 +139,11 @@ __global__ void k_voxel_select(const uint64_t* __restrict__ keys, int n,
 
 // ---- 27-neighbour tables ("rule generation") of Morton-sorted levels, round 6 -------------------------------------------------
 // Rows are sorted by Morton key, so the 26 neighbours of a workgroup's 256 consecutive voxels almost always live a few hundred rows
-// away: the workgroup stages the keys of rows [q0 - 896, q0 + 256 + 896) in LDS (as 32-bit offsets from the window's first key:
-// 8 KB) and resolves every probe whose key falls inside the window's key range by a binary search there — definitive both ways
-// (present -> row, absent -> -1), 11 ds_read_b32 instead of a dependent random walk through an 8-12 MB hash table. Only probes
+// away: the workgroup stages the keys of rows [q0 - 896, q0 + 256 + 896) in an LDS hash table (key + window row per slot, 4096
+// slots: 40 KB) and resolves every probe whose key falls inside the window's key range there —
+// definitive both ways (present -> row, absent -> -1), ~2 ds_read_b64 instead of a dependent random walk through a 16-24 MB hash
+// table in HBM. (First form: a binary search over the sorted offsets, 11 ds_read_b32 per probe — 286 LDS reads per voxel made the
+// kernel LDS-bandwidth-bound at 225 us for the 845 k voxels of a B = 16 scene pyramid.) Only probes
 // outside the window's key range (measured on 50 k-point scenes: ~20 % of the probes, 2-5 % of the neighbours that exist) go to
 // the level's global hash table; a level of <= 2048 rows is its own window and never does. All 27 columns are written by the
 // thread that owns the row: coalesced 4-byte stores per column, no mirrored scatter, no pre-fill (round 5's k_kmap_s1 probed 13
@@ -203,8 +205,20 @@ __global__ __launch_bounds__(256) void k_insert_multi(KmLevels L) {
   }
 }
 
+// window hash in LDS: 4096 slots of (64-bit key, 16-bit window row); load factor <= 0.5
+#define KM_SLOTS 4096
+#define KM_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ uint32_t km_hash(uint64_t k) {
+  uint32_t d = (uint32_t)k ^ (uint32_t)(k >> 29) ^ (uint32_t)(k >> 47);
+  d ^= d >> 15; d *= 0x2C1B3C6Du; d ^= d >> 12; d *= 0x297A2D39u; d ^= d >> 15;
+  return d & (KM_SLOTS - 1);
+}
+
 __global__ __launch_bounds__(256) void k_kmap_win(KmLevels L) {
-  __shared__ uint32_t s_rel[KM_WIN];
+  __shared__ unsigned long long s_tab[KM_SLOTS];
+  __shared__ unsigned short s_idx[KM_SLOTS];
+  __shared__ int s_unsorted;
   int b = blockIdx.x;
   const int l = km_level_of(L, b);
   const int n = L.n[l], s = L.stride[l], ld = L.ld[l];
@@ -212,15 +226,19 @@ __global__ __launch_bounds__(256) void k_kmap_win(KmLevels L) {
   const int4* __restrict__ coords = L.coords[l];
   const int q0 = b * KM_T;
   int lo = q0 - KM_W, hi = q0 + KM_T + KM_W;
-  if (n <= KM_WIN) { lo = 0; hi = n; }      // a small level is its own window: every probe is definitive
+  if (n <= KM_WIN) { lo = 0; hi = n; }      // a small level is its own window: every probe is definitive, no global table involved
   if (lo < 0) lo = 0;
   if (hi > n) hi = n;
   const int cnt = hi - lo;
-  uint64_t klo;
-  if (keys) klo = keys[lo];
-  else { const int4 c = coords[lo]; klo = irx_make_key(c.x, c.y, c.z, c.w); }
-  __shared__ int s_unsorted;
+  uint64_t klo, khi;
+  if (keys) { klo = keys[lo]; khi = keys[hi - 1]; }
+  else {
+    int4 c = coords[lo]; klo = irx_make_key(c.x, c.y, c.z, c.w);
+    c = coords[hi - 1]; khi = irx_make_key(c.x, c.y, c.z, c.w);
+  }
   if (threadIdx.x == 0) s_unsorted = 0;
+#pragma unroll
+  for (int i = threadIdx.x; i < KM_SLOTS; i += 256) s_tab[i] = KM_EMPTY;
   __syncthreads();
   for (int i = threadIdx.x; i < cnt; i += 256) {
     uint64_t k, prev = 0;
@@ -232,20 +250,18 @@ __global__ __launch_bounds__(256) void k_kmap_win(KmLevels L) {
       k = irx_make_key(c.x, c.y, c.z, c.w);
       if (i > 0) { const int4 p = coords[lo + i - 1]; prev = irx_make_key(p.x, p.y, p.z, p.w); }
     }
-    // rows that are not strictly ascending in Morton order (a caller of the one-level entry that did not sort): the window search
-    // would be wrong, so the whole workgroup resolves its probes in the hash table, as round 5's kernel did for every probe
+    // rows that are not strictly ascending in Morton order (a caller of the one-level entry that did not sort): the window's key
+    // range would mean nothing, so the whole workgroup resolves its probes in the global hash table, as round 5's kernel did
     if (i > 0 && k <= prev) s_unsorted = 1;
-    const uint64_t d = k - klo;
-    s_rel[i] = d >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d;       // (saturated entries never match a probe)
+    uint32_t h = km_hash(k);
+    while (atomicCAS(&s_tab[h], KM_EMPTY, (unsigned long long)k) != KM_EMPTY) h = (h + 1) & (KM_SLOTS - 1);
+    s_idx[h] = (unsigned short)i;
   }
   __syncthreads();
   const int q = q0 + threadIdx.x;
   if (q >= n) return;
   const bool unsorted = s_unsorted != 0;
-  const uint32_t rel_last = s_rel[cnt - 1];
-  const bool open_lo = lo == 0 && !unsorted, open_hi = hi == n && !unsorted;
-  int top = 1;                                          // largest power of two <= cnt - 1 (at most cnt - 1 entries are < a probe)
-  while (top * 2 <= cnt - 1) top *= 2;
+  const bool open_lo = lo == 0, open_hi = hi == n;
   const uint64_t* __restrict__ tk = L.tk[l];
   const int32_t* __restrict__ tv = L.tv[l];
   const uint64_t mask = L.mask[l];
@@ -265,39 +281,90 @@ __global__ __launch_bounds__(256) void k_kmap_win(KmLevels L) {
     sz[d] = irx_spread3((uint32_t)(z + IRX_COORD_BIAS)) << 2;
   }
   const uint64_t kb = (uint64_t)(uint32_t)c.w << 48;
-#pragma unroll 1
-  for (int k = 0; k < 27; ++k) {
-    const int dx = k % 3, dy = (k / 3) % 3, dz = k / 9;               // x fastest (odd kernel)
-    int r;
-    if (k == 13) {
-      r = q;
-    } else if (!(okx[dx] && oky[dy] && okz[dz])) {
-      r = -1;
-    } else {
-      const uint64_t nk = kb | ((sx[dx] | sy[dy] | sz[dz]) & 0xFFFFFFFFFFFFull);
-      bool fallback = false;
-      r = -1;
-      if (unsorted) {
-        fallback = true;
-      } else if (nk < klo) {
-        fallback = !open_lo;
-      } else {
-        const uint64_t d64 = nk - klo;
-        if (d64 < 0xFFFFFFFFull && (uint32_t)d64 <= rel_last) {
-          const uint32_t d = (uint32_t)d64;
-          int pos = 0;                                                 // number of window keys < nk
-          for (int step = top; step > 0; step >>= 1) {
-            const int p = pos + step;
-            if (p < cnt && s_rel[p - 1] < d) pos = p;
+  // fully unrolled: 26 independent probe chains per thread (x fastest: odd kernel)
+#pragma unroll
+  for (int dz = 0; dz < 3; ++dz) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int k = dx + 3 * dy + 9 * dz;
+        int r = -1;
+        if (k == 13) {
+          r = q;
+        } else if (okx[dx] && oky[dy] && okz[dz]) {
+          const uint64_t nk = kb | ((sx[dx] | sy[dy] | sz[dz]) & 0xFFFFFFFFFFFFull);
+          // definitive in LDS: inside the window's key range, or beyond an end of the level that the window reaches
+          const bool inside = !unsorted && ((nk >= klo || open_lo) && (nk <= khi || open_hi));
+          if (inside) {
+            if (nk >= klo && nk <= khi) {
+              uint32_t h = km_hash(nk);
+              while (true) {
+                const unsigned long long e = s_tab[h];
+                if (e == nk) { r = lo + (int)s_idx[h]; break; }
+                if (e == KM_EMPTY) break;
+                h = (h + 1) & (KM_SLOTS - 1);
+              }
+            }
+          } else {
+            r = irx_hash_lookup(tk, tv, mask, nk);
           }
-          if (s_rel[pos] == d) r = lo + pos;
-        } else {
-          fallback = !(rel_last != 0xFFFFFFFFu && open_hi);
         }
+        nbr[(size_t)k * ld + q] = r;
       }
-      if (fallback) r = irx_hash_lookup(tk, tv, mask, nk);
     }
-    nbr[(size_t)k * ld + q] = r;
+  }
+}
+
+// ---- octree descent: a level's 27-neighbour table from the NEXT COARSER level's table (round 6) ----------------------------------
+// The pyramid irx_pyramid_build makes IS an octree: row q of level l has a parent row p at level l + 1 and a child slot koff
+// (x * 4 + y * 2 + z of its position inside the parent's 2 x 2 x 2 cell). The voxel at q + d (d in {-1, 0, 1}^3, in units of the
+// level's stride) lies in the parent cell P + D with D = floor((b + d) / 2) per axis (b = the child-position bit) at child position
+// (b + d) mod 2 — so nbr_l[d][q] = child_l[(b + d) mod 2][ nbr_{l+1}[D][p] ]: two dependent reads of tables indexed by rows that are
+// NEIGHBOURS IN MORTON ORDER (cache-resident), no hash table, no key arithmetic, and an absent parent neighbour answers all of its
+// (up to 8) children at once. Each voxel needs 8 entries of the parent's table (2 values of D per axis) and <= 26 child-table
+// reads; the coarsest level (a few thousand rows) comes from k_kmap_win. Measured against the windowed / hashed search at B = 16:
+// see DESIGN.md section 12.
+__global__ __launch_bounds__(256) void k_kmap_descend(const int32_t* __restrict__ parent, const uint8_t* __restrict__ koff, int n,
+                                                      const int32_t* __restrict__ nbrc, int ldc, const int32_t* __restrict__ child,
+                                                      int ldch, int32_t* __restrict__ nbr, int ld) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= n) return;
+  const int p = parent[q];
+  const int ko = koff[q];
+  const int bx = (ko >> 2) & 1, by = (ko >> 1) & 1, bz = ko & 1;
+  // the 8 parent-level cells this voxel's neighbourhood touches: per axis D in {b - 1, b}
+  int pn[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int Dx = bx - 1 + (a & 1), Dy = by - 1 + ((a >> 1) & 1), Dz = bz - 1 + ((a >> 2) & 1);
+    const int Dk = (Dx + 1) + 3 * (Dy + 1) + 9 * (Dz + 1);
+    pn[a] = (Dk == 13) ? p : nbrc[(size_t)Dk * ldc + p];
+  }
+#pragma unroll
+  for (int dz = -1; dz <= 1; ++dz) {
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int k = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+        int r;
+        if (k == 13) {
+          r = q;
+        } else {
+          const int tx = bx + dx, ty = by + dy, tz = bz + dz;                       // -1 .. 2
+          // index of the parent cell among the 8 fetched: a = D - (b - 1), D = floor(t / 2)
+          const int ax = ((tx + 2) >> 1) - bx, ay = ((ty + 2) >> 1) - by, az = ((tz + 2) >> 1) - bz;     // ((t + 2) >> 1) - 1 = floor(t / 2)
+          const int sel = ax | (ay << 1) | (az << 2);
+          int pp = pn[0];
+#pragma unroll
+          for (int a = 1; a < 8; ++a) pp = (sel == a) ? pn[a] : pp;
+          const int kc = ((tx & 1) << 2) | ((ty & 1) << 1) | (tz & 1);
+          r = pp >= 0 ? child[(size_t)kc * ldch + pp] : -1;
+        }
+        nbr[(size_t)k * ld + q] = r;
+      }
+    }
   }
 }
 
@@ -632,6 +699,46 @@ extern "C" int irx_kmaps_build_multi(int nlev, const uint64_t* const* keys, cons
   L.nlev = m;
   if (m == 0) return IRX_OK;
   return km_launch(L, true, stream);
+}
+
+extern "C" int irx_kmaps_build_pyramid(int nlev, const int* n, const int* tensor_stride, const uint64_t* keys_top,
+                                       const int32_t* coords_top, uint64_t* tk_top, int32_t* tv_top, size_t cap_top,
+                                       const int32_t* const* parent, const uint8_t* const* koff, const int32_t* const* child,
+                                       const int* child_ld, int32_t* const* nbr, const int* ld, void* stream) {
+  IRX_REQUIRE(nlev >= 1 && nlev <= KM_MAXLEV, "irx_kmaps_build_pyramid: %d levels (1 .. %d)", nlev, KM_MAXLEV);
+  IRX_REQUIRE(n && tensor_stride && nbr && ld, "irx_kmaps_build_pyramid: null argument array");
+  IRX_REQUIRE(nlev == 1 || (parent && koff && child && child_ld), "irx_kmaps_build_pyramid: null map arrays");
+  for (int l = 0; l < nlev; ++l) {
+    IRX_REQUIRE(n[l] >= 0 && ld[l] >= n[l] && (n[l] == 0 || nbr[l]), "irx_kmaps_build_pyramid: bad n / ld / table of level %d", l);
+    IRX_REQUIRE(l == 0 || n[l] <= n[l - 1], "irx_kmaps_build_pyramid: level %d has more rows than the finer level", l);
+  }
+  const int top = nlev - 1;
+  if (n[top] > 0) {
+    IRX_REQUIRE(coords_top, "irx_kmaps_build_pyramid: null coordinates of the coarsest level");
+    KmLevels L;
+    memset(&L, 0, sizeof(L));
+    L.nlev = 1;
+    L.n[0] = n[top]; L.stride[0] = tensor_stride[top]; L.ld[0] = ld[top];
+    L.keys[0] = keys_top; L.coords[0] = (const int4*)coords_top;
+    L.nbr[0] = nbr[top];
+    const bool need_table = n[top] > KM_WIN;           // a level of <= KM_WIN rows is its own window: no hash table involved
+    if (need_table) {
+      int rc = check_table("irx_kmaps_build_pyramid", tk_top, tv_top, cap_top, n[top]);
+      if (rc) return rc;
+      L.tk[0] = tk_top; L.tv[0] = tv_top; L.mask[0] = (uint64_t)cap_top - 1;
+    }
+    int rc = km_launch(L, need_table, stream);
+    if (rc) return rc;
+  }
+  for (int l = top - 1; l >= 0; --l) {
+    if (n[l] == 0) continue;
+    IRX_REQUIRE(parent[l] && koff[l] && child[l] && child_ld[l] >= n[l + 1] && n[l + 1] > 0,
+                "irx_kmaps_build_pyramid: bad down-sampling map of level %d", l);
+    k_kmap_descend<<<irx_cdiv(n[l], 256), 256, 0, S(stream)>>>(parent[l], koff[l], n[l], nbr[l + 1], ld[l + 1], child[l], child_ld[l],
+                                                               nbr[l], ld[l]);
+    IRX_CHECK_LAUNCH("irx_kmaps_build_pyramid(descend)");
+  }
+  return IRX_OK;
 }
 
 extern "C" size_t irx_downsample_workspace_bytes(int n) {

@@ -15,6 +15,8 @@
 
 #include "torch_nodes.h"
 
+#include <ATen/SequenceNumber.h>
+
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -43,6 +45,9 @@ typedef int (*kmap_s1_fn)(const int32_t*, int, int, const uint64_t*, const int32
 typedef int (*kmaps_multi_fn)(int, const uint64_t* const*, const int32_t* const*, const int*, const int*, uint64_t* const*, int32_t* const*,
                               const size_t*, int32_t* const*, const int*, void*);
 
+typedef int (*kmaps_pyramid_fn)(int, const int*, const int*, const uint64_t*, const int32_t*, uint64_t*, int32_t*, size_t, const int32_t* const*,
+                                const uint8_t* const*, const int32_t* const*, const int*, int32_t* const*, const int*, void*);
+
 struct Api {
   saved_floats_fn mlp2_saved_floats = nullptr;
   mlp2_fwd_fn mlp2_fwd = nullptr;
@@ -55,6 +60,7 @@ struct Api {
   hash_build_fn hash_build = nullptr;
   kmap_s1_fn kmap_s1 = nullptr;
   kmaps_multi_fn kmaps_multi = nullptr;
+  kmaps_pyramid_fn kmaps_pyramid = nullptr;
 } g_api;
 
 using irxn::check;
@@ -312,6 +318,68 @@ std::vector<Tensor> kmaps_build(const std::vector<Tensor>& keys, const std::vect
   return out;
 }
 
+// The same tables by OCTREE DESCENT (irx_kmaps_build_pyramid, round 6): `parents`, `koffs`, `children` are the down-sampling maps of
+// level l -> l + 1 (irx_pyramid_build's arrays; one entry per level but the last). Only the coarsest level is searched (and gets a hash
+// table, when it has more than 2048 rows); every finer level is two cached table reads per neighbour. -> per level (table keys, table
+// values, neighbours) with undefined table tensors where none was built.
+std::vector<Tensor> kmaps_build_pyramid(const std::vector<Tensor>& keys, const std::vector<Tensor>& coords, const std::vector<int64_t>& strides,
+                                        const std::vector<Tensor>& parents, const std::vector<Tensor>& koffs, const std::vector<Tensor>& children,
+                                        const std::vector<int64_t>& child_lds, int64_t stream) {
+  TORCH_CHECK(g_api.kmaps_pyramid && g_api.hash_capacity, "irx nodes: bind() has not been called");
+  const size_t nl = keys.size();
+  TORCH_CHECK(nl >= 1 && nl <= 8 && coords.size() == nl && strides.size() == nl && parents.size() + 1 == nl && koffs.size() + 1 == nl &&
+              children.size() + 1 == nl && child_lds.size() + 1 == nl, "kmaps_build_pyramid: list sizes");
+  std::vector<Tensor> out(3 * nl);
+  int64_t nbr_total = 0;
+  int n_[8], st[8], ld[8], cld[8];
+  for (size_t l = 0; l < nl; ++l) {
+    const int64_t n = coords[l].size(0), ldl = (n + 63) / 64 * 64;
+    n_[l] = (int)n; st[l] = (int)strides[l]; ld[l] = (int)(ldl > 0 ? ldl : 64);
+    nbr_total += 27 * (int64_t)ld[l];
+  }
+  const auto opt = keys[0].options();
+  Tensor nbr_all = torch::empty({nbr_total}, opt.dtype(torch::kInt32));
+  int32_t* np_[8];
+  const int32_t* pp[8]; const uint8_t* kp[8]; const int32_t* cp[8];
+  int64_t no = 0;
+  for (size_t l = 0; l < nl; ++l) {
+    Tensor nbr = nbr_all.narrow(0, no, 27 * (int64_t)ld[l]).view({27, (int64_t)ld[l]});
+    no += 27 * (int64_t)ld[l];
+    np_[l] = nbr.data_ptr<int32_t>();
+    out[3 * l + 2] = nbr;
+    if (l + 1 < nl) {
+      pp[l] = parents[l].data_ptr<int32_t>(); kp[l] = koffs[l].data_ptr<uint8_t>(); cp[l] = children[l].data_ptr<int32_t>();
+      cld[l] = (int)child_lds[l];
+    }
+  }
+  const size_t top = nl - 1;
+  Tensor tk, tv;
+  size_t cap = 0;
+  if (n_[top] > 2048) {
+    cap = g_api.hash_capacity(n_[top]);
+    tk = torch::empty({(int64_t)cap}, opt.dtype(torch::kInt64));
+    tv = torch::empty({(int64_t)cap}, opt.dtype(torch::kInt32));
+    out[3 * top] = tk; out[3 * top + 1] = tv;
+  }
+  check(g_api.kmaps_pyramid((int)nl, n_, st, (const uint64_t*)keys[top].data_ptr<int64_t>(), coords[top].data_ptr<int32_t>(),
+                            tk.defined() ? (uint64_t*)tk.data_ptr<int64_t>() : nullptr, tv.defined() ? tv.data_ptr<int32_t>() : nullptr, cap,
+                            pp, kp, cp, cld, np_, ld, (void*)stream),
+        "irx_kmaps_build_pyramid");
+  return out;
+}
+
+// The autograd engine runs ready nodes in descending order of their sequence number, and that number comes from a THREAD-LOCAL counter
+// (at::sequence_number). InstanceRefer builds part of its graph on a helper thread (language module, relation head): with one node per
+// head the training thread creates ~10 nodes per step and the helper ~40, so after a few steps the helper's nodes outrank every node
+// of the training thread and the engine issues the language / relation backward (~0.5 ms of host time, off the critical path) BEFORE
+// the two encoders' backward passes (measured, round 6: fp32 8.49 -> 9.43 ms per step). The training thread therefore advances its own
+// counter by `n` at the head of every forward: its nodes stay ahead of the helper's, in creation order among themselves.
+int64_t bump_sequence(int64_t n) {
+  uint64_t v = 0;
+  for (int64_t i = 0; i < n; ++i) v = at::sequence_number::get_and_increment();
+  return (int64_t)v;
+}
+
 // addresses of the C-ABI entry points, taken from the library instance _lib.py loaded
 void bind(const std::unordered_map<std::string, uint64_t>& addr) {
   auto get = [&](const char* name) -> uint64_t {
@@ -331,6 +399,7 @@ void bind(const std::unordered_map<std::string, uint64_t>& addr) {
   g_api.hash_build = (hash_build_fn)get("irx_hash_build");
   g_api.kmap_s1 = (kmap_s1_fn)get("irx_kmap_build_s1");
   g_api.kmaps_multi = (kmaps_multi_fn)get("irx_kmaps_build_multi");
+  g_api.kmaps_pyramid = (kmaps_pyramid_fn)get("irx_kmaps_build_pyramid");
 }
 
 }  // namespace
@@ -347,5 +416,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("gru_layer", &gru_layer);
   m.def("mlp_relu2", &mlp_relu2);
   m.def("kmaps_build", &kmaps_build);
+  m.def("bump_sequence", &bump_sequence);
+  m.def("kmaps_build_pyramid", &kmaps_build_pyramid);
   irxn::register_heads(m);
 }

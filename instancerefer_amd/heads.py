@@ -186,6 +186,8 @@ def attr_scene(am, sm, data_dict):
     feats = data_dict.pop('_attr_encoded', None)
     if feats is None:
         feats = am.net(st)
+    elif hasattr(feats, 'attach'):
+        feats = feats.attach()
     lane_wait(lane_of(am.net))                      # the encoder may be issued by a library thread
     x = feats.canonical()
     lv = x.level()

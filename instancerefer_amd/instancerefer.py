@@ -29,6 +29,8 @@ _BWD_GATE = _BWD_GATE_ROWS > 0
 _STREAMS = _STREAMS_ENV != '0'                                   # three-stream training forward (_forward_streams); 0: round-4 layout
 _PREBUILD_BWD = _os.environ.get('IRX_PREBUILD_BWD', '0') == '1'   # backward-only tables built behind the scene head: measured neutral (3004-3013 vs 2920-2998 scenes/s), off
 _REL_THREAD = _os.environ.get('IRX_REL_THREAD', '0') == '1'      # dev: the relation head on that thread too (behind the language module)
+_BWD_ORDER = _os.environ.get('IRX_BWD_ORDER', 'cs')              # see InstanceRefer._attach_encoders
+_SEQ_BUMP = int(_os.environ.get('IRX_SEQ_BUMP', '256'))          # 0: leave the autograd sequence numbers alone (dev A/B)
 MARK = None        # dev: bench.py's timeline mode installs a callable(name) here (phase marks inside forward)
 _ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
 
@@ -257,6 +259,8 @@ class InstanceRefer(nn.Module):
             self.attribute.net._irx_bwd_gate = (1, _BWD_GATE_ROWS, tok)
         else:
             self.scene.net._irx_bwd_gate = self.attribute.net._irx_bwd_gate = None
+        if _SEQ_BUMP:
+            self._bump_sequence()
         lstream = self._aux_stream(dev)
         side.wait_stream(main)                               # inputs and the optimizer's parameter update are complete
         lstream.wait_stream(main)
@@ -270,7 +274,7 @@ class InstanceRefer(nn.Module):
             with torch.cuda.stream(side):
                 data_dict = self.scene.encode(data_dict)
             if MARK: MARK("fwd: scene encoder issued")
-            data_dict = self.attribute.encode(data_dict)
+            data_dict = self.attribute.encode(data_dict, defer=True)
         except BaseException:
             if lang_join is not None:                        # never leave a result behind for the next forward to pick up
                 try:
@@ -294,6 +298,7 @@ class InstanceRefer(nn.Module):
         pooled.record_stream(side)
         # scene head on the encoder's stream (its launches were issued by a library thread: wait for that first)
         lane_wait(lane_of(self.scene.net))
+        self._attach_encoders(data_dict)                     # both encoder nodes: created before the heads', replayed right behind them
         with torch.cuda.stream(side):
             side.wait_event(ev)
             data_dict = self.scene.head(data_dict)
@@ -329,6 +334,26 @@ class InstanceRefer(nn.Module):
                 data_dict[k].record_stream(main)
         return data_dict
 
+    def _attach_encoders(self, data_dict):
+        """Create the two encoders' autograd nodes NOW (both passes were issued earlier as encoder_fn.Deferred): the engine runs ready
+        nodes in reverse creation order, so whatever is created after this point (the heads, the loss) is replayed first and the
+        encoders' backward passes follow at once — ahead of the relation head and the language module. IRX_BWD_ORDER: which encoder's
+        backward is issued first ('cs': candidates, then scene — the scene pass's large levels wait for the candidates' small ones
+        anyway (backward gate); 'sc': scene first)."""
+        names = ('_scene_encoded', '_attr_encoded') if _BWD_ORDER == 'cs' else ('_attr_encoded', '_scene_encoded')
+        for k in names:                                      # (created first = replayed last)
+            e = data_dict.get(k)
+            if e is not None and hasattr(e, 'attach'):
+                data_dict[k] = e.attach()
+
+    @staticmethod
+    def _bump_sequence():
+        """Keep this thread's autograd sequence numbers ahead of the helper thread's (csrc/torch_nodes.cpp: bump_sequence)."""
+        from . import _nodes
+        mod = _nodes.load()
+        if mod is not None and hasattr(mod, 'bump_sequence'):
+            mod.bump_sequence(_SEQ_BUMP)
+
     def _aux_stream(self, device):
         cache = self.__dict__.setdefault('_enc_streams', {})
         st = cache.get((str(device), 'lang'))
@@ -345,6 +370,8 @@ class InstanceRefer(nn.Module):
                 m.net._irx_bwd_gate = None                   # (the gate belongs to the multi-stream layout)
         side = None
         lang_join = None
+        if _SEQ_BUMP and self.training and data_dict['lang_feat'].is_cuda:
+            self._bump_sequence()
         if _LANG_THREAD and self.training and data_dict['lang_feat'].is_cuda:
             lang_join = self._lang_async(data_dict)
         try:
@@ -370,6 +397,10 @@ class InstanceRefer(nn.Module):
                       and data_dict['lang_feat'].is_cuda and heads._mod() is not None)
         if self.args.attribute_module and not fused_tail:
             data_dict = self.attribute(data_dict)
+        elif fused_tail:
+            # the candidate encoder is issued HERE, where the per-operator attribute head issues it (beside the scene encoder, not
+            # behind it: fp32 B = 16 measured 8.45 -> 10.16 ms per step when it waited for the scene head)
+            data_dict = self.attribute.encode(data_dict, defer=True)
         if MARK: MARK("fwd: attribute head issued")
         if self.args.relation_module and not rel_done:
             data_dict = self.relation(data_dict)
@@ -384,6 +415,7 @@ class InstanceRefer(nn.Module):
             data_dict['_scene_encoded'].record_stream(main)
         if fused_tail:
             # scene head, then attribute head + scene scores as one node (heads.py); whatever a precondition refuses runs per operator
+            self._attach_encoders(data_dict)
             data_dict = self.scene.head(data_dict)
             if not heads.attr_scene(self.attribute, self.scene, data_dict):
                 data_dict = self.attribute(data_dict)
@@ -415,7 +447,7 @@ class InstanceRefer(nn.Module):
         if self.args.attribute_module and hasattr(self.attribute, 'encode') and self._attr_early():
             # candidates already chosen (prepare()): their encoder does not need the language features either, and its
             # launches are issued by a library thread while this one goes on with the language module (see _attr_early)
-            data_dict = self.attribute.encode(data_dict)
+            data_dict = self.attribute.encode(data_dict, defer=True)
         return data_dict, side
 
     @staticmethod

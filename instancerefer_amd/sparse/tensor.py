@@ -39,6 +39,10 @@ class DownMap:
         return self._child_t, max(self.parent.shape[0], 1)
 
 
+import os as _os
+KMAP_DESCENT = _os.environ.get("IRX_KMAP_DESCENT", "1") != "0"      # dev / test switch: 0 = every level by window search + hash table
+
+
 class Level:
     """One tensor stride of a coordinate pyramid: coords in ascending Morton-key order + cached maps
     (torchsparse caches `coord_maps` / `kernel_maps` on the tensor; here they live on the level and are
@@ -176,6 +180,19 @@ class Level:
         if all(have):
             return
         from .. import _lib
+        if KMAP_DESCENT and not any(have) and len(lvs) > 1 and hasattr(mod, "kmaps_build_pyramid") and all(lv.n > 0 for lv in lvs):
+            # octree descent (irx_kmaps_build_pyramid): only the coarsest level is searched, every finer level is derived from the
+            # next coarser one through the down-sampling maps — no hash tables below the top
+            dms = [lv._down for lv in lvs[:-1]]
+            out = mod.kmaps_build_pyramid([lv.keys for lv in lvs], [lv.coords for lv in lvs], [lv.stride for lv in lvs],
+                                          [d.parent for d in dms], [d.koff for d in dms], [d.child for d in dms], [d.ld for d in dms],
+                                          _lib.stream_ptr())
+            for i, lv in enumerate(lvs):
+                tk, tv, nbr = out[3 * i:3 * i + 3]
+                if tk is not None and lv._table is None:
+                    lv._table = (tk, tv, int(tk.shape[0]))
+                lv._nbr27 = nbr
+            return
         out = mod.kmaps_build([lv.keys for lv in lvs], [lv.coords for lv in lvs], [lv.stride for lv in lvs], have, _lib.stream_ptr())
         for i, lv in enumerate(lvs):
             if not have[i]:

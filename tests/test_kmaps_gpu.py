@@ -40,11 +40,15 @@ def _levels(st):
     return out
 
 
+@pytest.mark.parametrize("builder", ["descent", "window"])
 @pytest.mark.parametrize("variant", ["corner", "centred"])
-def test_multi_level_tables_equal_sorted_search(lib, variant):
-    """every level of a 6-scene pyramid through ONE irx_kmaps_build_multi call (Level.build_kmaps); 'centred' scenes straddle the
-    coordinate origin, where biased Morton keys jump by 2^47 inside a window (the 32-bit window offsets saturate there)"""
+def test_multi_level_tables_equal_sorted_search(lib, variant, builder, monkeypatch):
+    """every level of a 6-scene pyramid through ONE native call (Level.build_kmaps): by octree descent from the coarsest level
+    (irx_kmaps_build_pyramid, the default) and by window search + hash table at every level (irx_kmaps_build_multi); 'centred' scenes
+    straddle the coordinate origin, where biased Morton keys jump by 2^47 inside a window (the 32-bit window offsets saturate there)"""
     from instancerefer_amd import synthetic as S
+    from instancerefer_amd.sparse import tensor as T
+    monkeypatch.setattr(T, "KMAP_DESCENT", builder == "descent")
     dev = torch.device("cuda")
     dd = S.to_device(S.make_batch(6, seed=11, num_points=30000, num_instances=6, num_candidates=3, points_per_instance=256,
                                   variant=variant), dev)

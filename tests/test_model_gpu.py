@@ -153,8 +153,9 @@ def test_model_with_the_fused_head_mlps_matches_reference(lib, monkeypatch, back
     """dense.mlp2 routes the seven head MLPs through irx_mlp2_fwd / _bwd — as C++ autograd nodes (csrc/torch_nodes.cpp, the
     default when built), as the Python autograd.Function, or not at all (the ATen modules): the same 1e-4 forward bar against
     the reference's output (tests/golden/model.npz) and the same gradient-norm bar on every path."""
-    from instancerefer_amd import dense
+    from instancerefer_amd import dense, heads
     from instancerefer_amd.loss_helper import DatasetConfig, get_loss
+    monkeypatch.setattr(heads, "FUSED", False)          # the per-operator heads (one node per head: tests/test_heads_gpu.py)
     monkeypatch.setattr(dense, "FUSED_MLP2", backend != "aten")
     monkeypatch.setattr(dense, "MLP2_BACKEND", backend)
     gold = np.load(os.path.join(G, "model.npz"))
