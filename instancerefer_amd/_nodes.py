@@ -11,7 +11,8 @@ from . import _build, _lib
 
 ENABLED = os.environ.get("IRX_CPP_NODES", "1") != "0"
 _ENTRY_POINTS = ("irx_mlp2_saved_floats", "irx_mlp2_fwd", "irx_mlp2_bwd", "irx_gru_forward", "irx_gru_backward", "irx_gru_wgrad", "irx_last_error",
-                 "irx_hash_capacity", "irx_hash_build", "irx_kmap_build_s1", "irx_kmaps_build_multi", "irx_kmaps_build_pyramid")
+                 "irx_hash_capacity", "irx_hash_build", "irx_kmap_build_s1", "irx_kmaps_build_multi", "irx_kmaps_build_pyramid",
+                 "irx_pairs_workspace_bytes", "irx_pairs_build_multi", "irx_kmap_down_transpose")
 # csrc/heads_nodes.cpp (one node per head)
 _HEAD_ENTRY_POINTS = ("irx_mlp2_saved_floats", "irx_mlp2_fwd", "irx_mlp2_bwd", "irx_segment_max", "irx_segment_max_backward",
                       "irx_cosine_rows_fwd", "irx_cosine_rows_bwd", "irx_spconv_fwd_workspace_bytes", "irx_spconv_fwd",

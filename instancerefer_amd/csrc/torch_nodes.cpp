@@ -48,6 +48,11 @@ typedef int (*kmaps_multi_fn)(int, const uint64_t* const*, const int32_t* const*
 typedef int (*kmaps_pyramid_fn)(int, const int*, const int*, const uint64_t*, const int32_t*, uint64_t*, int32_t*, size_t, const int32_t* const*,
                                 const uint8_t* const*, const int32_t* const*, const int*, int32_t* const*, const int*, void*);
 
+typedef size_t (*pairs_ws_fn)(int, int);
+typedef int (*pairs_multi_fn)(int, const int32_t* const*, const int*, const int*, const int*, int32_t* const*, int32_t* const*, const int*,
+                              int32_t* const*, void*, size_t, void*);
+typedef int (*down_transpose_fn)(const int32_t*, const uint8_t*, int, int32_t*, int, void*);
+
 struct Api {
   saved_floats_fn mlp2_saved_floats = nullptr;
   mlp2_fwd_fn mlp2_fwd = nullptr;
@@ -61,6 +66,9 @@ struct Api {
   kmap_s1_fn kmap_s1 = nullptr;
   kmaps_multi_fn kmaps_multi = nullptr;
   kmaps_pyramid_fn kmaps_pyramid = nullptr;
+  pairs_ws_fn pairs_ws = nullptr;
+  pairs_multi_fn pairs_multi = nullptr;
+  down_transpose_fn down_transpose = nullptr;
 } g_api;
 
 using irxn::check;
@@ -368,6 +376,58 @@ std::vector<Tensor> kmaps_build_pyramid(const std::vector<Tensor>& keys, const s
   return out;
 }
 
+// The tables only the encoders' BACKWARD passes read — compacted pair lists of the given neighbour / child tables (irx_pairs_build_multi:
+// two launches for all of them) and the transposed child maps of the down-sampling layers (irx_kmap_down_transpose, one launch each) —
+// in one call, so that the preparation stage builds them beside the kernel maps instead of the autograd engine's thread at the head
+// of each encoder's backward (sparse/encoder_fn.py _backward_tables: ~0.1 ms of interpreter time per encoder, on the step's critical
+// path). tbls[t] int32 [K[t]][ld[t]] with n_out[t] valid columns -> per table (in_list [K][ldp], out_list [K][ldp], counts [K]) as
+// sparse/functional.py pairs_build_multi lays them out; parents / koffs [n] -> per map the (8, max(n, 1)) transposed table.
+std::vector<Tensor> backward_tables(const std::vector<Tensor>& tbls, const std::vector<int64_t>& lds, const std::vector<int64_t>& n_outs,
+                                    const std::vector<int64_t>& Ks, const std::vector<Tensor>& parents, const std::vector<Tensor>& koffs,
+                                    int64_t stream) {
+  TORCH_CHECK(g_api.pairs_multi && g_api.pairs_ws && g_api.down_transpose, "irx nodes: bind() has not been called");
+  const size_t nt = tbls.size(), nm = parents.size();
+  TORCH_CHECK(lds.size() == nt && n_outs.size() == nt && Ks.size() == nt && koffs.size() == nm && nt <= 16, "backward_tables: list sizes");
+  std::vector<Tensor> out;
+  out.reserve(3 * nt + nm);
+  if (nt > 0) {
+    const auto opt = tbls[0].options().dtype(torch::kInt32);
+    int64_t total = 0, ktotal = 0;
+    size_t wsb = 0;
+    std::vector<int64_t> ldp(nt), sz(nt);
+    for (size_t t = 0; t < nt; ++t) {
+      ldp[t] = n_outs[t] > 0 ? n_outs[t] : 1;
+      sz[t] = Ks[t] * ldp[t];
+      total += 2 * sz[t];
+      ktotal += Ks[t];
+      wsb += g_api.pairs_ws((int)n_outs[t], (int)Ks[t]);
+    }
+    Tensor lists = torch::empty({total}, opt), counts = torch::empty({ktotal}, opt);
+    Tensor ws = torch::empty({(int64_t)(wsb > 4 ? wsb : 4)}, opt.dtype(torch::kUInt8));
+    const int32_t* tp[16]; int ld_[16], no_[16], k_[16], ldp_[16]; int32_t* il[16]; int32_t* ol[16]; int32_t* cn[16];
+    int64_t lo = 0, co = 0;
+    for (size_t t = 0; t < nt; ++t) {
+      Tensor a = lists.narrow(0, lo, sz[t]).view({Ks[t], ldp[t]}), b = lists.narrow(0, lo + sz[t], sz[t]).view({Ks[t], ldp[t]});
+      Tensor c = counts.narrow(0, co, Ks[t]);
+      lo += 2 * sz[t];
+      co += Ks[t];
+      tp[t] = tbls[t].data_ptr<int32_t>(); ld_[t] = (int)lds[t]; no_[t] = (int)n_outs[t]; k_[t] = (int)Ks[t]; ldp_[t] = (int)ldp[t];
+      il[t] = a.data_ptr<int32_t>(); ol[t] = b.data_ptr<int32_t>(); cn[t] = c.data_ptr<int32_t>();
+      out.push_back(a); out.push_back(b); out.push_back(c);
+    }
+    check(g_api.pairs_multi((int)nt, tp, ld_, no_, k_, il, ol, ldp_, cn, ws.data_ptr(), wsb, (void*)stream), "irx_pairs_build_multi");
+  }
+  for (size_t m = 0; m < nm; ++m) {
+    const int64_t n = parents[m].size(0), ld = n > 0 ? n : 1;
+    Tensor tbl = torch::empty({8, ld}, parents[m].options().dtype(torch::kInt32));
+    check(g_api.down_transpose(parents[m].data_ptr<int32_t>(), koffs[m].data_ptr<uint8_t>(), (int)n, tbl.data_ptr<int32_t>(), (int)ld,
+                               (void*)stream),
+          "irx_kmap_down_transpose");
+    out.push_back(tbl);
+  }
+  return out;
+}
+
 // The autograd engine runs ready nodes in descending order of their sequence number, and that number comes from a THREAD-LOCAL counter
 // (at::sequence_number). InstanceRefer builds part of its graph on a helper thread (language module, relation head): with one node per
 // head the training thread creates ~10 nodes per step and the helper ~40, so after a few steps the helper's nodes outrank every node
@@ -400,6 +460,9 @@ void bind(const std::unordered_map<std::string, uint64_t>& addr) {
   g_api.kmap_s1 = (kmap_s1_fn)get("irx_kmap_build_s1");
   g_api.kmaps_multi = (kmaps_multi_fn)get("irx_kmaps_build_multi");
   g_api.kmaps_pyramid = (kmaps_pyramid_fn)get("irx_kmaps_build_pyramid");
+  g_api.pairs_ws = (pairs_ws_fn)get("irx_pairs_workspace_bytes");
+  g_api.pairs_multi = (pairs_multi_fn)get("irx_pairs_build_multi");
+  g_api.down_transpose = (down_transpose_fn)get("irx_kmap_down_transpose");
 }
 
 }  // namespace
@@ -417,6 +480,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("mlp_relu2", &mlp_relu2);
   m.def("kmaps_build", &kmaps_build);
   m.def("bump_sequence", &bump_sequence);
+  m.def("backward_tables", &backward_tables);
   m.def("kmaps_build_pyramid", &kmaps_build_pyramid);
   irxn::register_heads(m);
 }

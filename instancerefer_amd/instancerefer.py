@@ -9,11 +9,11 @@ import torch.nn as nn
 
 _PKG = __name__.rsplit('.', 1)[0]
 import os as _os
-# Kernel maps + tile orders enqueued by prepare_finish() on the preparation stream instead of lazily at the head of the
-# encoders' streams: OFF by default. Measured (round 3, alternating runs on one box): the resident-input loop of bench.py gains
-# 0.5 % (9.27-9.30 vs 9.31-9.35 ms/step), the end-to-end loop (tools/e2e_train_bench.py, whose preparation stream also carries
-# the next batches' input pipeline) LOSES 5-15 % (1425-1560 vs 1665-1693 scenes/s). IRX_PREP_TABLES=1 enables it.
-_PREP_TABLES = _os.environ.get('IRX_PREP_TABLES', '0') == '1'
+# Kernel maps, tile orders and the backward-only tables enqueued by prepare_finish() on the preparation stream (two native calls per
+# pyramid) instead of lazily at the head of the encoders' streams / of their backward passes. Round 3 (ten k_kmap_s1 launches through
+# per-level Python builders) measured +0.5 % resident and -5..15 % end to end, and it stayed off; round 6 (octree-descent maps, one
+# call) measures bf16 4.287 -> 4.191, fp32 8.300 -> 8.189 ms per step: ON. IRX_PREP_TABLES=0 builds them lazily again.
+_PREP_TABLES = _os.environ.get('IRX_PREP_TABLES', '1') == '1'
 _PREP_PLANS = _os.environ.get('IRX_PREP_PLANS', '0') == '1'
 # The language module (word projection, GRU, attention pooling, classifier: ~0.6 ms of dispatch per step, independent of both
 # encoders) is issued by a helper THREAD on the same stream while this thread assembles and submits the encoders: ATen operators
@@ -29,7 +29,6 @@ _BWD_GATE = _BWD_GATE_ROWS > 0
 _STREAMS = _STREAMS_ENV != '0'                                   # three-stream training forward (_forward_streams); 0: round-4 layout
 _PREBUILD_BWD = _os.environ.get('IRX_PREBUILD_BWD', '0') == '1'   # backward-only tables built behind the scene head: measured neutral (3004-3013 vs 2920-2998 scenes/s), off
 _REL_THREAD = _os.environ.get('IRX_REL_THREAD', '0') == '1'      # dev: the relation head on that thread too (behind the language module)
-_BWD_ORDER = _os.environ.get('IRX_BWD_ORDER', 'cs')              # see InstanceRefer._attach_encoders
 _SEQ_BUMP = int(_os.environ.get('IRX_SEQ_BUMP', '256'))          # 0: leave the autograd sequence numbers alone (dev A/B)
 MARK = None        # dev: bench.py's timeline mode installs a callable(name) here (phase marks inside forward)
 _ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
@@ -144,13 +143,16 @@ class InstanceRefer(nn.Module):
         if '_attr_pending' in data_dict:
             data_dict = self.attribute.prepare_finish(data_dict)
         pending = data_dict.pop('_scene_pending', None)
+        c0 = getattr(getattr(self, 'attribute', None), 'input_feature_dim', 0)
+        wide = 128 < c0 <= 136                               # the wide stem's weight gradient runs over pair lists (encoder_fn._uses_pairs)
         if pending is not None:
             data_dict['lidar'].level().build_pyramid_finish(pending)
             if self.training and _PREP_TABLES:
-                data_dict['lidar'].level().build_tables()      # kernel maps + tile order on the preparation stream
+                # kernel maps, tile order and the backward-only tables (pair lists, transposed child maps) on the preparation stream
+                data_dict['lidar'].level().build_tables(backward=torch.is_grad_enabled(), pairs_level0=wide)
         prep = data_dict.get('_attr_prepared')
         if self.training and _PREP_TABLES and prep is not None and prep[0] is not None:
-            prep[0].level().build_tables()
+            prep[0].level().build_tables(backward=torch.is_grad_enabled(), pairs_level0=wide)
         if self.training and _PREP_PLANS and torch.is_grad_enabled():
             # dev (IRX_PREP_PLANS=1): the encoders' plans and level-only descriptors here instead of in the forward (this also
             # builds the kernel maps on the preparation stream, like IRX_PREP_TABLES)
@@ -298,7 +300,8 @@ class InstanceRefer(nn.Module):
         pooled.record_stream(side)
         # scene head on the encoder's stream (its launches were issued by a library thread: wait for that first)
         lane_wait(lane_of(self.scene.net))
-        self._attach_encoders(data_dict)                     # both encoder nodes: created before the heads', replayed right behind them
+        self._attach(data_dict, '_scene_encoded')            # (creation order = reverse backward order: see _attach)
+        self._attach(data_dict, '_attr_encoded')
         with torch.cuda.stream(side):
             side.wait_event(ev)
             data_dict = self.scene.head(data_dict)
@@ -334,17 +337,17 @@ class InstanceRefer(nn.Module):
                 data_dict[k].record_stream(main)
         return data_dict
 
-    def _attach_encoders(self, data_dict):
-        """Create the two encoders' autograd nodes NOW (both passes were issued earlier as encoder_fn.Deferred): the engine runs ready
-        nodes in reverse creation order, so whatever is created after this point (the heads, the loss) is replayed first and the
-        encoders' backward passes follow at once — ahead of the relation head and the language module. IRX_BWD_ORDER: which encoder's
-        backward is issued first ('cs': candidates, then scene — the scene pass's large levels wait for the candidates' small ones
-        anyway (backward gate); 'sc': scene first)."""
-        names = ('_scene_encoded', '_attr_encoded') if _BWD_ORDER == 'cs' else ('_attr_encoded', '_scene_encoded')
-        for k in names:                                      # (created first = replayed last)
-            e = data_dict.get(k)
-            if e is not None and hasattr(e, 'attach'):
-                data_dict[k] = e.attach()
+    @staticmethod
+    def _attach(data_dict, key):
+        """Create the autograd node of an encoder pass that was issued earlier (encoder_fn.Deferred) NOW. The engine runs ready nodes
+        in reverse creation order: scene encoder node, candidate encoder node, scene head, attribute / scene-score head, loss are
+        created in this order, so the backward issues loss -> attribute head -> scene head -> candidate encoder -> scene encoder and
+        only then the relation head and the language module (whose nodes come from the helper thread: _bump_sequence). Measured
+        (round 6, B = 16): with the candidate encoder AHEAD of the scene head the fp32 step loses 11 % (8.29 -> 9.25 ms: its kernels
+        take CUs from the scene head's chain, which gates the scene encoder — the long pole), bf16 is indifferent (4.28 / 4.30)."""
+        e = data_dict.get(key)
+        if e is not None and hasattr(e, 'attach'):
+            data_dict[key] = e.attach()
 
     @staticmethod
     def _bump_sequence():
@@ -415,7 +418,8 @@ class InstanceRefer(nn.Module):
             data_dict['_scene_encoded'].record_stream(main)
         if fused_tail:
             # scene head, then attribute head + scene scores as one node (heads.py); whatever a precondition refuses runs per operator
-            self._attach_encoders(data_dict)
+            self._attach(data_dict, '_scene_encoded')
+            self._attach(data_dict, '_attr_encoded')
             data_dict = self.scene.head(data_dict)
             if not heads.attr_scene(self.attribute, self.scene, data_dict):
                 data_dict = self.attribute(data_dict)

@@ -147,7 +147,7 @@ class Level:
                 lv = out
         return lv
 
-    def build_tables(self, order_min_rows=None):
+    def build_tables(self, order_min_rows=None, backward=False, pairs_level0=False):
         """Enqueue NOW, on the current stream, every table the encoder's convolutions will ask for: the 27-neighbour table
         of each level of the (already built) pyramid and the tile launch order of the levels whose 3^3 convolutions run on
         k_spconv2 with more than one round of tiles. Called by the input-preparation stage (its own stream, one step
@@ -155,6 +155,7 @@ class Level:
         from . import encoder_fn
         if order_min_rows is None:
             order_min_rows = encoder_fn.TILE_ORDER_MIN_ROWS if encoder_fn.TILE_ORDER else None
+        self.build_kmaps()                           # every level's table in one native call (no-op for the ones already built)
         lv, first = self, True
         while lv is not None:
             if lv.n > 0:
@@ -163,6 +164,45 @@ class Level:
                     lv.order27()                     # (level 0 hosts the stem convolution: no k_spconv2 layer)
             first = False
             lv = lv._down.out_level if lv._down is not None else None
+        if backward:
+            self.build_backward_tables(pairs_level0)
+
+    def build_backward_tables(self, pairs_level0=False):
+        """The tables only the encoders' backward passes read, for the whole (already built) pyramid in ONE native call
+        (csrc/torch_nodes.cpp backward_tables): pair lists of every stride-1 level's 27-neighbour table (level 0 only when its
+        convolution's weight gradient runs over pair lists: the wide stem) and of every down-sampling map's child table, plus the
+        transposed child maps. Needs the 27-neighbour tables (build_kmaps). No-op for what is already there."""
+        from .. import _lib, _nodes
+        mod = _nodes.load() if self.coords.is_cuda else None
+        if mod is None or not hasattr(mod, "backward_tables"):
+            return
+        lvs, lv = [], self
+        while lv is not None:
+            lvs.append(lv)
+            lv = lv._down.out_level if lv._down is not None else None
+        jobs, holders, maps = [], [], []
+        for i, lv in enumerate(lvs):
+            if lv.n == 0:
+                continue
+            if (i > 0 or pairs_level0) and lv._pairs27 is None and lv._nbr27 is not None:
+                tbl, ld = lv.nbr27()
+                jobs.append((tbl, ld, lv.n, 27))
+                holders.append((lv, "_pairs27"))
+            dm = lv._down
+            if dm is not None:
+                if dm._pairs is None:
+                    jobs.append((dm.child, dm.ld, dm.out_level.n, 8))
+                    holders.append((dm, "_pairs"))
+                if dm._child_t is None:
+                    maps.append(dm)
+        if not jobs and not maps:
+            return
+        out = mod.backward_tables([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], [j[3] for j in jobs],
+                                  [d.parent for d in maps], [d.koff for d in maps], _lib.stream_ptr())
+        for t, (holder, attr) in enumerate(holders):
+            setattr(holder, attr, (out[3 * t], out[3 * t + 1], out[3 * t + 2], max(jobs[t][2], 1)))
+        for m, dm in enumerate(maps):
+            dm._child_t = out[3 * len(jobs) + m]
 
     def build_kmaps(self):
         """Hash table + 27-neighbour table of EVERY level of the (already built) pyramid that does not have them yet, in one call
