@@ -439,7 +439,8 @@ def mlp2(seq, x):
         norm = 1 if nrm.training else 2
         rmean, rvar, momentum = nrm.running_mean, nrm.running_var, nrm.momentum
         if nrm.training:
-            nrm.num_batches_tracked += 1
+            from . import _counters
+            _counters.bump([nrm.num_batches_tracked])
     else:
         norm, rmean, rvar, momentum = 3, None, None, 0.0
     seed = _dropout_seed(x.device) if drop_p > 0 else 0

@@ -147,8 +147,8 @@ def scene_head(sm, feats, data_dict):
                                      [n_out0, n_in0, n_out1, n_in1], params, stats, f, [_i64(s_conv), _i64(s_lang)],
                                      _lib.stream_ptr(), list(slots), list(keep))
     if counters:
-        with torch.no_grad():
-            torch._foreach_add_(counters, 1)
+        from . import _counters
+        _counters.bump(counters)
     h, w = nx - k0 - k1 + 2, ny - k0 - k1 + 2
     data_dict['vis_atten'] = atten.reshape(batch_size, h, w)
     data_dict['seg_scores'] = seg
@@ -210,8 +210,8 @@ def attr_scene(am, sm, data_dict):
     obj, s_attr, s_scene = mod.attr_head(x.F, lv.offsets(), lv.batch_size, sd['cand_scene'], data_dict['lang_attr_feats'], scene_vec,
                                          params, stats, f, [_i64(s_fc1)], _lib.stream_ptr(), list(slots), list(keep))
     if counters:
-        with torch.no_grad():
-            torch._foreach_add_(counters, 1)
+        from . import _counters
+        _counters.bump(counters)
     data_dict['obj_feats'] = obj
     data_dict['attribute_scores'] = s_attr
     data_dict['scene_scores'] = s_scene

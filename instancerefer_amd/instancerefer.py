@@ -365,6 +365,19 @@ class InstanceRefer(nn.Module):
         return st
 
     def forward(self, data_dict):
+        """reference models/instancerefer.py:37-70; the train-mode BatchNorm batch counters of the whole pass are bumped in one
+        multi-tensor launch at its end (_counters.py)"""
+        from . import _counters
+        collect = self.training and data_dict['lang_feat'].is_cuda
+        if collect:
+            _counters.open_collector()
+        try:
+            return self._forward(data_dict)
+        finally:
+            if collect:
+                _counters.close()
+
+    def _forward(self, data_dict):
         data_dict = self.prepare(data_dict)
         if self._streams_ok(data_dict):
             return self._forward_streams(data_dict)

@@ -193,7 +193,11 @@ class Solver:
                 continue
             self.optimizer.zero_grad()
             data_dict = self._forward(data_dict)
-            data_dict["loss"].backward()
+            loss = data_dict["loss"]
+            one = self.__dict__.get("_unit_grad")     # (saves the ones_like allocation + fill launch of a bare backward() per step)
+            if one is None or one.device != loss.device or one.shape != loss.shape or one.dtype != loss.dtype:
+                one = self.__dict__["_unit_grad"] = torch.ones_like(loss)
+            loss.backward(gradient=one)
             self.optimizer.backward_step()
             self.global_iter += 1
             seen += data_dict["lang_scores"].shape[0]

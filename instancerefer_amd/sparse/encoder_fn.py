@@ -409,8 +409,8 @@ def launch(feats, encoder, layers, params, need_dx0=False):
         _lib.check(rc, "irx_encoder_forward")
     st.lane = lane
     if counters:
-        with torch.no_grad():
-            torch._foreach_add_(counters, 1)
+        from .. import _counters
+        _counters.bump(counters)             # (one launch per forward when InstanceRefer collects them: _counters.py)
     st.layers, st.desc, st.fdesc, st.extra = layers, desc, fdesc, (n_out, cout, poffs, ptotal)
     st.store, st.prof, st.need_dx0 = store, prof, bool(need_dx0)
     if TRACE is not None:

@@ -325,9 +325,14 @@ class SparseTensor:
         ts = [t for t in (self.F, self.C) if isinstance(t, torch.Tensor)]
         if self._level is not None:
             ts += self._level.tensors()
+        seen = set()
         for t in ts:
             if t.is_cuda:
-                t.record_stream(stream)
+                # (the levels of a pyramid are views of five shared allocations: one record per storage is what the allocator keeps)
+                key = t.untyped_storage().data_ptr()
+                if key not in seen:
+                    seen.add(key)
+                    t.record_stream(stream)
 
     def canonical(self):
         """Rows re-ordered to ascending Morton key (device tensors). No-op when already canonical.
