@@ -105,15 +105,15 @@ class DynamicEdgeConv(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(3 * F_in, F_out), nn.ReLU(), nn.Linear(F_out, F_out))
         self.weight = nn.Sequential(nn.Linear(3 + num_classes + num_classes, 64), nn.ReLU(), nn.Linear(64, F_in))
 
-    def forward(self, support_xyz, batch_index, filtered_index, features, support_offsets=None):
-        query_xyz = torch.index_select(support_xyz, 0, filtered_index)
-        query_batch = torch.index_select(batch_index, 0, filtered_index)
-        query_features = torch.index_select(features, 0, filtered_index)
-        if support_offsets is None:
-            nb = int(batch_index.max().item()) + 1 if batch_index.numel() else 0
-            counts = torch.bincount(batch_index, minlength=nb)
-            support_offsets = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
-        nbr = F_.knn_batched(support_xyz, support_offsets, query_xyz, query_batch.int(), self.k)  # (nq,k)
+    def forward(self, support_xyz, batch_index, filtered_index, features, support_offsets=None, nbr=None):
+        if nbr is None:                                  # (nbr: the kNN grid when the input preparation already built it)
+            query_xyz = torch.index_select(support_xyz, 0, filtered_index)
+            query_batch = torch.index_select(batch_index, 0, filtered_index)
+            if support_offsets is None:
+                nb = int(batch_index.max().item()) + 1 if batch_index.numel() else 0
+                counts = torch.bincount(batch_index, minlength=nb)
+                support_offsets = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
+            nbr = F_.knn_batched(support_xyz, support_offsets, query_xyz, query_batch.int(), self.k)  # (nq,k)
         if not self.fused_supported(features.shape[1]):
             return self.forward_unfused(support_xyz, filtered_index, features, nbr)
         return EdgeConvMaxFn.apply(features, support_xyz, filtered_index, nbr, self.num_classes,

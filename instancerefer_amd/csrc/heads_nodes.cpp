@@ -54,6 +54,15 @@ typedef int (*attn_fwd_fn)(const float*, const float*, int, int, int, float, flo
 typedef int (*attn_bwd_fn)(const float*, const float*, const float*, const float*, const float*, int, int, int, float, float*, float*,
                            void*);
 typedef int (*drop_fn)(const float*, size_t, float, unsigned long long, float*, void*);
+typedef size_t (*ec_ws_fn)(int, int, int, int, int, int);
+typedef int (*ec_fwd_fn)(const float*, const float*, const int64_t*, const int32_t*, int, int, int, int, int, int, const float* const*,
+                         float*, int32_t*, void*);
+typedef int (*ec_bwd_fn)(const float*, const float*, const int64_t*, const int32_t*, int, int, int, int, int, int, const float* const*,
+                         const float*, const int32_t*, float* const*, float*, void*, size_t, void*);
+typedef int (*lp_fwd_fn)(const float*, const float*, const int64_t*, int, int, int, int, const float* const*, const float* const*, float*,
+                         float*, float*, float*, void*);
+typedef int (*lp_bwd_fn)(const float*, const float*, const int64_t*, int, int, int, int, const float* const*, const float*, const float*,
+                         const float*, const float*, const float*, float*, float*, float*, float*, float*, void*);
 typedef int (*loss_fn)(const float*, const int64_t*, int, int, const float*, const int64_t*, int, const float*, const float*,
                        const float*, const float*, const int64_t*, const float*, int, float, float, float, int, float*, float*, float*,
                        float*, void*);
@@ -78,6 +87,11 @@ struct Api {
   attn_bwd_fn attn_bwd = nullptr;
   drop_fn dropout = nullptr;
   loss_fn total_loss = nullptr;
+  ec_ws_fn ec_ws = nullptr;
+  ec_fwd_fn ec_fwd = nullptr;
+  ec_bwd_fn ec_bwd = nullptr;
+  lp_fwd_fn lp_fwd = nullptr;
+  lp_bwd_fn lp_bwd = nullptr;
 } api;
 
 inline Tensor f32c(const Tensor& t) { return t.contiguous().to(torch::kFloat32); }
@@ -563,6 +577,178 @@ std::vector<Tensor> total_loss(const Tensor& lang_scores_in, const Tensor& seg_s
   return outs;
 }
 
+// =================================================================================================================================
+// RelationHeadNode (reference models/relation_module.py:84-107, basic_blocks.py:98-133)
+//   data input  : lang [B][256] (the language module's relation vector). Node features / positions / kNN grid are data (prepared).
+//   parameters  : lang_emb_fc (6), vis_emb_fc (6), gcn.weight.{0,2}.{weight,bias} (4), gcn.mlp.{0,2}.{weight,bias} (4)
+//   output      : relation_scores [Nc]
+// =================================================================================================================================
+struct RelationHeadNode : public HeadNode {
+  Tensor feats, pos, qidx, nbr, idx, arg, lang_h, vis_h, score, norms;
+  int nq = 0, k = 0, fin = 0, nc = 0, hid = 0, fout = 0, B = 0;
+  Mlp lang, vis;
+  float eps_cos = 1e-8f;
+
+  std::string name() const override { return "irx::RelationHeadNode"; }
+  void release_variables() override {
+    released = true;
+    feats = pos = qidx = nbr = idx = arg = lang_h = vis_h = score = norms = Tensor();
+    lang.reset(); vis.reset();
+  }
+
+  variable_list apply(variable_list&& grads) override {
+    guard();
+    at::NoGradGuard ng;
+    variable_list out(num_outputs());
+    PGrads pg;
+    pg.init(sink, params);
+    const Tensor ds = grads[0].defined() ? f32c(grads[0]) : at::zeros_like(score);
+    Tensor d_vis_h = at::empty_like(vis_h), d_lang_h = at::empty_like(lang_h);
+    check(api.cos_bwd(fp(vis_h), fp(lang_h), idx.data_ptr<int64_t>(), fp(score), fp(norms), fp(ds), nq, B, (int)vis_h.size(1), eps_cos,
+                      fpm(d_vis_h), fpm(d_lang_h), stream),
+          "irx_cosine_rows_bwd");
+    Tensor d_gcn = mlp_bwd(vis, params, d_vis_h, true, pg, stream);
+    const float* pp[8];
+    float* gp[8];
+    for (int i = 0; i < 8; ++i) { pp[i] = fp(params[12 + i]); gp[i] = pg.ptr[12 + i]; }
+    const size_t wsb = api.ec_ws(nq, k, fin, nc, hid, fout);
+    Tensor ws = bytes(wsb, feats);
+    check(api.ec_bwd(fp(feats), fp(pos), qidx.data_ptr<int64_t>(), nbr.data_ptr<int32_t>(), nq, k, fin, nc, hid, fout, pp, fp(d_gcn),
+                     arg.data_ptr<int32_t>(), gp, nullptr, ws.data_ptr(), wsb, stream),
+          "irx_edgeconv_max_bwd");
+    Tensor dlang = mlp_bwd(lang, params, d_lang_h, should_compute_output(0), pg, stream);
+    if (should_compute_output(0)) out[0] = dlang;
+    finish(pg, out);
+    return out;
+  }
+};
+
+std::vector<Tensor> relation_head(const Tensor& lang_in, const Tensor& feats, const Tensor& pos, const Tensor& qidx, const Tensor& nbr,
+                                  const Tensor& idx, int64_t nc, std::vector<Tensor> params, std::vector<Tensor> stats,
+                                  std::vector<double> f, std::vector<int64_t> seeds, int64_t stream_i, std::vector<int64_t> slot_ptrs,
+                                  std::vector<Tensor> keep) {
+  TORCH_CHECK(api.ec_fwd && api.cos_fwd && api.mlp2_fwd, "irx nodes: bind_heads() has not been called");
+  TORCH_CHECK(params.size() == 20 && stats.size() == 2 && f.size() == 6 && seeds.size() == 2, "relation_head: argument lists");
+  void* stream = (void*)stream_i;
+  auto node = std::shared_ptr<RelationHeadNode>(new RelationHeadNode(), torch::autograd::deleteNode);
+  RelationHeadNode& s = *node;
+  s.params = std::move(params);
+  s.stream = stream;
+  const bool rec = at::GradMode::is_enabled() && (lang_in.requires_grad() || s.params[0].requires_grad());
+  std::vector<Tensor> outs;
+  {
+    at::NoGradGuard ng;
+    const std::vector<Tensor>& P = s.params;
+    s.feats = f32c(feats); s.pos = f32c(pos); s.qidx = qidx.contiguous(); s.nbr = nbr.contiguous(); s.idx = idx;
+    TORCH_CHECK(s.qidx.scalar_type() == torch::kInt64 && s.nbr.scalar_type() == torch::kInt32 && idx.scalar_type() == torch::kInt64,
+                "relation_head: index tensors");
+    s.nq = (int)s.nbr.size(0); s.k = (int)s.nbr.size(1); s.fin = (int)s.feats.size(1); s.nc = (int)nc;
+    s.hid = (int)P[12].size(0); s.fout = (int)P[18].size(0); s.B = (int)lang_in.size(0);
+    s.lang.p0 = 0; s.lang.norm = 1; s.lang.rmean = stats[0]; s.lang.rvar = stats[1]; s.lang.eps = (float)f[0]; s.lang.momentum = (float)f[1];
+    s.lang.drop_p = (float)f[2]; s.lang.seed = (unsigned long long)seeds[0];
+    s.vis.p0 = 6; s.vis.norm = 3; s.vis.eps = (float)f[3]; s.vis.drop_p = (float)f[4]; s.vis.seed = (unsigned long long)seeds[1];
+    s.eps_cos = (float)f[5];
+    s.lang_h = mlp_fwd(s.lang, P, lang_in, stream);
+    Tensor gcn = at::empty({s.nq, s.fout}, s.feats.options());
+    s.arg = at::empty({s.nq, s.fout}, s.feats.options().dtype(torch::kInt32));
+    const float* pp[8];
+    for (int i = 0; i < 8; ++i) pp[i] = fp(P[12 + i]);
+    check(api.ec_fwd(fp(s.feats), fp(s.pos), s.qidx.data_ptr<int64_t>(), s.nbr.data_ptr<int32_t>(), s.nq, s.k, s.fin, s.nc, s.hid, s.fout, pp,
+                     fpm(gcn), s.arg.data_ptr<int32_t>(), stream),
+          "irx_edgeconv_max_fwd");
+    s.vis_h = mlp_fwd(s.vis, P, gcn, stream);
+    s.score = at::empty({s.nq}, s.feats.options());
+    s.norms = at::empty({s.nq > 0 ? s.nq : 1, 2}, s.feats.options());
+    check(api.cos_fwd(fp(s.vis_h), fp(s.lang_h), idx.data_ptr<int64_t>(), s.nq, (int)s.vis_h.size(1), s.eps_cos, fpm(s.score), fpm(s.norms),
+                      stream),
+          "irx_cosine_rows_fwd");
+    outs = {s.score.detach()};
+  }
+  if (rec) {
+    s.wire({lang_in}, slot_ptrs, keep);
+    torch::autograd::set_history(outs, node);
+  }
+  return outs;
+}
+
+// =================================================================================================================================
+// LangPoolNode: the language module's four attention heads (reference models/lang_module.py:61-83; irx_lang_pool_fwd / _bwd)
+//   data inputs : feats [B][T][O] (GRU output), embed [B][T][E] (projected words)
+//   parameters  : fc_a / fc_cls / fc_rel / fc_scene .{weight [1][O], bias [1]} (8)
+//   outputs     : att [B][T][4], pooled vectors attr / cls / rel / scene, each [B][E] contiguous (no select nodes behind them)
+// =================================================================================================================================
+struct LangPoolNode : public HeadNode {
+  Tensor feats, embed, length, att, prob, qsum;
+  int B = 0, T = 0, O = 0, E = 0;
+  std::string name() const override { return "irx::LangPoolNode"; }
+  void release_variables() override { released = true; feats = embed = length = att = prob = qsum = Tensor(); }
+  variable_list apply(variable_list&& grads) override {
+    guard();
+    at::NoGradGuard ng;
+    variable_list out(num_outputs());
+    PGrads pg;
+    pg.init(sink, params);
+    // d pooled [B][4][E] from the four vectors' gradients (a missing one is zero)
+    Tensor dpooled = at::zeros({B, 4, E}, feats.options());
+    for (int h = 0; h < 4; ++h)
+      if (grads[1 + h].defined()) dpooled.select(1, h).copy_(grads[1 + h]);
+    const Tensor datt = grads[0].defined() ? f32c(grads[0]) : Tensor();
+    Tensor dfeats = at::empty_like(feats), dembed = at::empty_like(embed);
+    Tensor dwb = at::empty({4 * (int64_t)O + 4}, feats.options()), part = at::empty({(int64_t)B * 4 * (O + 1)}, feats.options());
+    const float* wp[4];
+    for (int h = 0; h < 4; ++h) wp[h] = fp(params[2 * h]);
+    check(api.lp_bwd(fp(feats), fp(embed), length.data_ptr<int64_t>(), B, T, O, E, wp, fp(att), fp(prob), fp(qsum), fp(dpooled), fp(datt),
+                     fpm(dfeats), fpm(dembed), fpm(dwb), fpm(dwb) + 4 * (size_t)O, fpm(part), stream),
+          "irx_lang_pool_bwd");
+    for (int h = 0; h < 4; ++h) {
+      pg.view(2 * h).copy_(dwb.narrow(0, (int64_t)h * O, O).view({1, O}));
+      pg.view(2 * h + 1).copy_(dwb.narrow(0, 4 * (int64_t)O + h, 1));
+    }
+    if (should_compute_output(0)) out[0] = dfeats;
+    if (should_compute_output(1)) out[1] = dembed;
+    finish(pg, out);
+    return out;
+  }
+};
+
+std::vector<Tensor> lang_pool(const Tensor& feats_in, const Tensor& embed_in, const Tensor& length, std::vector<Tensor> params, int64_t stream_i,
+                              std::vector<int64_t> slot_ptrs, std::vector<Tensor> keep) {
+  TORCH_CHECK(api.lp_fwd && api.lp_bwd, "irx nodes: bind_heads() has not been called");
+  TORCH_CHECK(params.size() == 8, "lang_pool: four (weight, bias) pairs");
+  void* stream = (void*)stream_i;
+  auto node = std::shared_ptr<LangPoolNode>(new LangPoolNode(), torch::autograd::deleteNode);
+  LangPoolNode& s = *node;
+  s.params = std::move(params);
+  s.stream = stream;
+  const bool rec = at::GradMode::is_enabled() && (feats_in.requires_grad() || embed_in.requires_grad() || s.params[0].requires_grad());
+  std::vector<Tensor> outs;
+  {
+    at::NoGradGuard ng;
+    s.feats = f32c(feats_in); s.embed = f32c(embed_in);
+    s.length = length.contiguous().to(torch::kInt64);
+    s.B = (int)s.feats.size(0); s.T = (int)s.feats.size(1); s.O = (int)s.feats.size(2); s.E = (int)s.embed.size(2);
+    TORCH_CHECK(s.embed.size(0) == s.B && s.embed.size(1) == s.T, "lang_pool: feats / embed shapes");
+    const auto opt = s.feats.options();
+    s.att = at::empty({s.B, s.T, 4}, opt);
+    s.prob = at::empty({s.B, s.T, 4}, opt);
+    s.qsum = at::empty({s.B, 4}, opt);
+    Tensor pooled = at::empty({s.B, 4, s.E}, opt);
+    const float* wp[4];
+    const float* bp[4];
+    for (int h = 0; h < 4; ++h) { wp[h] = fp(s.params[2 * h]); bp[h] = fp(s.params[2 * h + 1]); }
+    check(api.lp_fwd(fp(s.feats), fp(s.embed), s.length.data_ptr<int64_t>(), s.B, s.T, s.O, s.E, wp, bp, fpm(s.att), fpm(s.prob), fpm(s.qsum),
+                     fpm(pooled), stream),
+          "irx_lang_pool_fwd");
+    outs = {s.att.detach()};
+    for (int h = 0; h < 4; ++h) outs.push_back(pooled.select(1, h).contiguous());     // four small copies instead of four select nodes
+  }
+  if (rec) {
+    s.wire({feats_in, embed_in}, slot_ptrs, keep);
+    torch::autograd::set_history(outs, node);
+  }
+  return outs;
+}
+
 void bind_heads(const std::unordered_map<std::string, uint64_t>& addr) {
   auto get = [&](const char* name) -> uint64_t {
     auto it = addr.find(name);
@@ -588,6 +774,11 @@ void bind_heads(const std::unordered_map<std::string, uint64_t>& addr) {
   api.attn_bwd = (attn_bwd_fn)get("irx_attn_pool_bwd");
   api.dropout = (drop_fn)get("irx_dropout_flat");
   api.total_loss = (loss_fn)get("irx_total_loss");
+  api.ec_ws = (ec_ws_fn)get("irx_edgeconv_workspace_bytes");
+  api.ec_fwd = (ec_fwd_fn)get("irx_edgeconv_max_fwd");
+  api.ec_bwd = (ec_bwd_fn)get("irx_edgeconv_max_bwd");
+  api.lp_fwd = (lp_fwd_fn)get("irx_lang_pool_fwd");
+  api.lp_bwd = (lp_bwd_fn)get("irx_lang_pool_bwd");
 }
 
 }  // namespace
@@ -597,6 +788,8 @@ void register_heads(pybind11::module& m) {
   m.def("scene_head", &scene_head);
   m.def("attr_head", &attr_head);
   m.def("total_loss", &total_loss);
+  m.def("relation_head", &relation_head);
+  m.def("lang_pool", &lang_pool);
 }
 
 }  // namespace irxn

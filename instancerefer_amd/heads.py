@@ -25,7 +25,7 @@ from . import _lib
 from .dense import _dropout_seed
 
 FUSED = os.environ.get("IRX_FUSED_HEADS", "1") != "0"
-CALLS = {"scene_head": 0, "attr_scene": 0, "total_loss": 0}          # how often each node was taken (tests assert the path)
+CALLS = {"scene_head": 0, "attr_scene": 0, "total_loss": 0, "relation_head": 0, "lang_pool": 0}          # how often each node was taken (tests assert the path)
 
 
 def _mod():
@@ -228,3 +228,57 @@ def total_loss(lang_scores, seg_scores, s1, s2, s3, lang_label, seg_label, lab, 
     CALLS["total_loss"] += 1
     return mod.total_loss(lang_scores, seg_scores, s1, s2, s3, lang_label, seg_label, lab, seg_off, keep, float(gamma), float(margin),
                           float(ref_weight), int(batch_size), _lib.stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------------------------ relation head
+def relation_head(rm, lang_feats, prep, data_dict):
+    """RelationModule.forward behind the prepared node features: language MLP -> edge convolution over the prepared kNN grid -> visual
+    MLP -> cosine score, as one node (reference models/relation_module.py:84-107). Fills relation_scores. -> True / False."""
+    mod = _mod()
+    if (mod is None or not hasattr(mod, "relation_head") or not (rm.training and torch.is_grad_enabled() and lang_feats.is_cuda)
+            or prep is None or len(prep) < 5 or lang_feats.shape[0] < 2):
+        return False
+    sel, sd, centres, feats, nbr = prep[:5]
+    gcn = rm.gcn
+    if not (_mlp_ok(rm.lang_emb_fc, "bn", True) and _mlp_ok(rm.vis_emb_fc, "ln", True) and gcn.fused_supported(feats.shape[1])
+            and feats.dtype == torch.float32 and nbr.shape[0] > 0):
+        return False
+    cache = rm.__dict__.get('_irx_head_params')
+    if cache is None:
+        params = _mlp_params(rm.lang_emb_fc) + _mlp_params(rm.vis_emb_fc)
+        params += [gcn.weight[0].weight, gcn.weight[0].bias, gcn.weight[2].weight, gcn.weight[2].bias,
+                   gcn.mlp[0].weight, gcn.mlp[0].bias, gcn.mlp[2].weight, gcn.mlp[2].bias]
+        bn = rm.lang_emb_fc[1]
+        cache = rm.__dict__['_irx_head_params'] = (params, [bn.running_mean, bn.running_var],
+                                                   [bn.num_batches_tracked] if bn.num_batches_tracked is not None else [])
+    params, stats, counters = cache
+    bn = rm.lang_emb_fc[1]
+    dev = lang_feats.device
+    p_lang, p_vis = _drop_p(rm.lang_emb_fc[3]), _drop_p(rm.vis_emb_fc[3])
+    s_lang = _dropout_seed(dev) if p_lang > 0 else 0          # (the per-operator path's order: language MLP, then visual MLP)
+    s_vis = _dropout_seed(dev) if p_vis > 0 else 0
+    f = [bn.eps, bn.momentum, p_lang, rm.vis_emb_fc[1].eps, p_vis, 1e-8]
+    slots, keep = _sink(("relation_head", id(rm)), params)
+    (scores,) = mod.relation_head(lang_feats, feats, centres, sd['query_in_support'], nbr, sd['cand_scene'], gcn.num_classes, params, stats,
+                                  f, [_i64(s_lang), _i64(s_vis)], _lib.stream_ptr(), list(slots), list(keep))
+    if counters:
+        from . import _counters
+        _counters.bump(counters)
+    data_dict['relation_scores'] = scores
+    CALLS["relation_head"] += 1
+    return True
+
+
+# ----------------------------------------------------------------------------------------- language module: attention pooling
+def lang_pool(lm, feats, embed, length):
+    """The four attention heads of the language module as one node whose pooled vectors come out as four contiguous tensors (no
+    select nodes behind them; reference models/lang_module.py:61-83). -> (att (B, T, 4), [attr, cls, rel, scene] each (B, E)) or None"""
+    mod = _mod()
+    if mod is None or not hasattr(mod, "lang_pool") or not (torch.is_grad_enabled() and feats.is_cuda):
+        return None
+    params = [lm.fc_a.weight, lm.fc_a.bias, lm.fc_cls.weight, lm.fc_cls.bias, lm.fc_rel.weight, lm.fc_rel.bias,
+              lm.fc_scene.weight, lm.fc_scene.bias]
+    slots, keep = _sink(("lang_pool", id(lm)), params)
+    out = mod.lang_pool(feats, embed, length, params, _lib.stream_ptr(), list(slots), list(keep))
+    CALLS["lang_pool"] += 1
+    return out[0], out[1:]

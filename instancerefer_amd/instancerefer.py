@@ -295,9 +295,9 @@ class InstanceRefer(nn.Module):
                 data_dict = self.relation(data_dict)
         ev = data_dict.pop('_lang_event')
         if MARK: MARK("fwd: lang joined")
-        pooled = data_dict['lang_attr_feats']                # the four language vectors are views of one tensor
-        pooled.record_stream(main)
-        pooled.record_stream(side)
+        for k in ('lang_attr_feats', 'lang_scene_feats'):    # (views of one tensor, or four tensors: heads.lang_pool)
+            data_dict[k].record_stream(main)
+            data_dict[k].record_stream(side)
         # scene head on the encoder's stream (its launches were issued by a library thread: wait for that first)
         lane_wait(lane_of(self.scene.net))
         self._attach(data_dict, '_scene_encoded')            # (creation order = reverse backward order: see _attach)

@@ -59,7 +59,17 @@ class LangModule(nn.Module):
         data_dict['lang_feat'] = feats
         t_max = feats.shape[1]
         if feats.is_cuda and _FUSED_POOL and embed.shape[1] >= t_max:
-            # the four heads in one launch each way (csrc/irx_match.hip, dense.LangPoolFn): order attr, cls, rel, scene
+            # the four heads in one launch each way (csrc/irx_match.hip): order attr, cls, rel, scene. As a C++ node whose pooled
+            # vectors are four separate tensors (heads.lang_pool) when the nodes module is there, else dense.LangPoolFn
+            from . import heads
+            got = heads.lang_pool(self, feats, embed[:, :t_max], length)
+            if got is not None:
+                att, vecs = got
+                data_dict['atten_attr'] = att[:, :, 0]
+                data_dict['atten_rel'] = att[:, :, 2]
+                data_dict['atten_scene'] = att[:, :, 3]
+                data_dict['lang_attr_feats'], data_dict['lang_cls_feats'], data_dict['lang_rel_feats'], data_dict['lang_scene_feats'] = vecs
+                return data_dict
             att, pooled = LangPoolFn.apply(feats, embed[:, :t_max], length, self.fc_a.weight, self.fc_a.bias, self.fc_cls.weight,
                                            self.fc_cls.bias, self.fc_rel.weight, self.fc_rel.bias, self.fc_scene.weight,
                                            self.fc_scene.bias)

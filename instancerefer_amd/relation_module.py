@@ -53,14 +53,18 @@ class RelationModule(nn.Module):
         mean = torch.cat([centres, mean[:, 3:]], 1)                         # xyz <- box centre
         onehot = nn.functional.one_hot(sd['support_class'], self.args.num_classes).to(mean.dtype)
         feats = torch.cat([mean, onehot], 1)                                # (S, C0 + num_classes)
-        return sel, sd, centres, feats
+        # the kNN grid of the edge convolution depends on the boxes only: built here (input preparation), not in the head
+        qis = sd['query_in_support']
+        nbr = F_.knn_batched(centres, sd['support_offsets'], torch.index_select(centres, 0, qis),
+                             torch.index_select(sd['support_seg'], 0, qis).int(), self.gcn.k)
+        return sel, sd, centres, feats, nbr
 
     def prepare(self, data_dict, cls_list):
         data_dict['_rel_prepared'] = (self.node_features(data_dict, cls_list),)
         return data_dict
 
     def forward(self, data_dict):
-        lang_feats = mlp2(self.lang_emb_fc, data_dict['lang_rel_feats'])     # (B, h_dim)
+        lang_feats_in = data_dict['lang_rel_feats']
         if '_rel_prepared' in data_dict:
             prep = data_dict.pop('_rel_prepared')[0]
         else:
@@ -71,11 +75,17 @@ class RelationModule(nn.Module):
                 cls_list = lang_cls_pred.tolist()
             prep = self.node_features(data_dict, cls_list)
         if prep is None:
-            data_dict['relation_scores'] = lang_feats.new_zeros((0,))
+            mlp2(self.lang_emb_fc, lang_feats_in)                            # (the reference runs the language MLP before it looks)
+            data_dict['relation_scores'] = lang_feats_in.new_zeros((0,))
             return data_dict
-        sel, sd, centres, feats = prep
+        from . import heads
+        if heads.relation_head(self, lang_feats_in, prep, data_dict):       # the whole head as ONE autograd node (csrc/heads_nodes.cpp)
+            return data_dict
+        lang_feats = mlp2(self.lang_emb_fc, lang_feats_in)                   # (B, h_dim)
+        sel, sd, centres, feats = prep[:4]
         # batch ids of the support rows are renumbered over the kept scenes (contiguous segments)
-        feats = self.gcn(centres, sd['support_seg'], sd['query_in_support'], feats, support_offsets=sd['support_offsets'])
+        feats = self.gcn(centres, sd['support_seg'], sd['query_in_support'], feats, support_offsets=sd['support_offsets'],
+                         nbr=prep[4] if len(prep) > 4 else None)
         feats = mlp2(self.vis_emb_fc, feats)
         data_dict['relation_scores'] = cosine_rows(feats, lang_feats, sd['cand_scene'])      # F.cosine_similarity, eps 1e-8
         return data_dict

@@ -53,9 +53,9 @@ def test_head_nodes_equal_the_per_operator_heads(lib, monkeypatch, streams):
     monkeypatch.setattr(IR, "_STREAMS", streams != "0")
     ma, mb = _model(False), _model(False)
     da, taken = _step(ma, True, monkeypatch)
-    assert taken == {"scene_head": 1, "attr_scene": 1, "total_loss": 1}, taken
+    assert taken == {"scene_head": 1, "attr_scene": 1, "total_loss": 1, "relation_head": 1, "lang_pool": 1}, taken
     db, taken = _step(mb, False, monkeypatch)
-    assert taken == {"scene_head": 0, "attr_scene": 0, "total_loss": 0}, taken
+    assert not any(taken.values()), taken
     for k in KEYS:
         assert torch.equal(da[k].detach(), db[k].detach()), (k, float((da[k].detach() - db[k].detach()).abs().max()))
     nb = dict(mb.named_parameters())
@@ -80,7 +80,7 @@ def test_head_nodes_deliver_into_the_optimizer_slots(lib, monkeypatch):
     da, taken = _step(ma, True, monkeypatch, opt)
     assert taken["scene_head"] == 1 and taken["attr_scene"] == 1
     prod, nparams = opt.native_delivered()
-    assert prod >= 2 and nparams >= 21 + 18
+    assert prod >= 4 and nparams >= 21 + 18 + 20 + 8          # scene head, attribute / scene-score head, relation head, language pooling
     db, _ = _step(mb, False, monkeypatch)
     assert torch.equal(da["loss"].detach(), db["loss"].detach())
     nb = dict(mb.named_parameters())
