@@ -391,6 +391,15 @@ enum {
                                      * whose table is TBL with flipped offsets) */
   IRX_ENC_PROF,                     /* 0, or a HOST pointer to 6 event handles (hipEvent_t): start / stop around this layer's
                                      * dominant forward, data-gradient and weight-gradient kernel (measurement aid, bench.py) */
+  IRX_ENC_DC2,                      /* row 0 only, backward only: 0, or a device pointer to a SECOND gradient scratch of the size of
+                                     * dc_scratch. The pass then issues every layer's weight gradient on a stream of its own (the
+                                     * library's, one per issuing thread) beside the BatchNorm-backward -> data-gradient chain of the next
+                                     * layers, the two scratches alternating from layer to layer; results are bit-identical (same kernels,
+                                     * same operands), everything is joined on the caller's stream before the call returns */
+  IRX_ENC_WSTREAM,                  /* row 0 only, with IRX_ENC_DC2: 0 = a stream the library creates per issuing thread, else the
+                                     * hipStream_t the weight gradients are issued on (a stream the caller already runs: every additional
+                                     * stream of a process risks sharing a hardware queue with a busy one — measured: two library streams
+                                     * beside the model's four HALVED the bf16 step) */
   IRX_ENC_NFIELDS
 };
 /* Launch order of the 64-row output tiles of a stride-1 convolution over table `nbr` (int32 [K][ld], the irx_kmap_build_s1

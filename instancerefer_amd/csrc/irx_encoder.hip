@@ -321,6 +321,29 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
   const int st = (int)desc[IRX_ENC_STORE];
   IRX_REQUIRE(!st || irx_conv_bf16(), "irx_encoder_backward: bf16 storage needs a bf16 compute mode in IRX_ENC_MODE");
   IRX_REQUIRE(!st || !dx0, "irx_encoder_backward: the input gradient is not available with bf16 storage");
+  // Weight gradients on a second stream (IRX_ENC_DC2, round 6). The chain of a backward pass is BatchNorm backward -> data gradient,
+  // layer after layer; a layer's weight gradient reads the same d c and the saved input but feeds nothing downstream, and on the
+  // large levels it is a third of the pass (profiles/r06_e_stepdump.txt: the scene encoder's last 0.6 ms run one kernel at a time, none
+  // of them above 0.4 of its HBM bound). With two d c scratches alternating by layer the weight gradient of layer i runs on the
+  // library's own stream while the chain goes on with layer i - 1; events order (a) wgrad(i) behind BN-backward(i), (b) BN-backward(i - 2)
+  // — which overwrites the scratch wgrad(i) reads — behind wgrad(i), (c) the caller's stream behind every wgrad at the end.
+  float* dc2 = (float*)desc[IRX_ENC_DC2];
+  const bool two = dc2 != nullptr && !sync.cb && n_layers <= 16;
+  hipStream_t sW = (hipStream_t)stream;
+  hipEvent_t* ev = nullptr;                  // [0..16): BN-backward(i) done, [16..32): wgrad(i) done
+  if (two) {
+    static thread_local hipStream_t t_stream = nullptr;
+    static thread_local hipEvent_t t_ev[32] = {nullptr};
+    if (!t_ev[0])
+      for (int e = 0; e < 32; ++e) IRX_CHECK_HIP(hipEventCreateWithFlags(&t_ev[e], hipEventDisableTiming), "irx_encoder_backward(event)");
+    sW = (hipStream_t)desc[IRX_ENC_WSTREAM];
+    if (!sW) {
+      if (!t_stream) IRX_CHECK_HIP(hipStreamCreateWithFlags(&t_stream, hipStreamNonBlocking), "irx_encoder_backward(stream)");
+      sW = t_stream;
+    }
+    ev = t_ev;
+  }
+  float* const dc_main = dc_scratch;
   IrxDySlabs pending;                        // gy of the layer about to be processed, still as its producer's offset-split slabs
   const EncGate gate = g_gate_next;          // (set for this call by irx_encoder_gate_next on this thread, or by the lane)
   g_gate_next = EncGate();
@@ -328,6 +351,12 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
   for (int i = n_layers - 1; i >= 0; --i) {
     const Layer L = unpack(desc + (size_t)i * IRX_ENC_NFIELDS, fdesc + (size_t)i * 2);
     gate_fired = gate_step(gate, gate_fired, L.n_out, stream);
+    if (two) {
+      dc_scratch = (i & 1) ? dc2 : dc_main;
+      // the weight gradient of layer i + 2 read this scratch: it must be done before BatchNorm backward overwrites it
+      if (i + 2 < n_layers) IRX_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ev[16 + i + 2], 0), "irx_encoder_backward(wait W)");
+    }
+    void* const wstream = two ? (void*)sW : stream;
     const IrxDySlabs dys = pending;
     pending = IrxDySlabs();
     float* dres = nullptr;
@@ -359,6 +388,10 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
                              3, nullptr, nullptr, 0.0, nullptr, mk_beta, dys);
     }
     if (rc) return rc;
+    if (two) {
+      IRX_CHECK_HIP(hipEventRecord(ev[i], (hipStream_t)stream), "irx_encoder_backward(record E)");
+      IRX_CHECK_HIP(hipStreamWaitEvent(sW, ev[i], 0), "irx_encoder_backward(wait E)");
+    }
     const long abl = irx_knob(IRX_KNOB_ABL);         // dev, timing only: what the chain costs without a kernel family
     if (L.prof) irx_profile_next_kernel(L.prof[4], L.prof[5]);
     if (abl & 1) {
@@ -366,7 +399,7 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
     } else if (pairs_path(L)) {
       IRX_REQUIRE(!st || i > 0, "irx_encoder_backward: bf16 storage expects a stem (Cin <= 8 or 129..136) as layer 0");
       rc = irx_spconv_wgrad_pairs_impl(L.x, dc_scratch, L.pair_in, L.pair_out, L.ld_pairs, L.pair_counts, L.n_out, L.K,
-                                       L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st, L.n_in);
+                                       L.cin, L.cout, L.dw, ws_w, r.wgrad, wstream, st, L.n_in);
     } else {
       IRX_REQUIRE(!st || i == 0, "irx_encoder_backward: layer %d (%d -> %d channels) has no bf16-storage weight-gradient path",
                   i, L.cin, L.cout);
@@ -374,9 +407,10 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
       if (L.pair_in && irx_wide_stem(L.K, L.cin, L.cout)) {   // the multiview stem: its 128 leading channels through the pair lists
         pl.in_list = L.pair_in; pl.out_list = L.pair_out; pl.counts = L.pair_counts; pl.ldp = L.ld_pairs;
       }
-      rc = irx_spconv_wgrad_impl(L.x, dc_scratch, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, L.dw, ws_w, r.wgrad, stream, st, pl);
+      rc = irx_spconv_wgrad_impl(L.x, dc_scratch, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, L.dw, ws_w, r.wgrad, wstream, st, pl);
     }
     if (rc) return rc;
+    if (two) IRX_CHECK_HIP(hipEventRecord(ev[16 + i], sW), "irx_encoder_backward(record W)");
     float* dx = (i > 0) ? (float*)desc[(size_t)(i - 1) * IRX_ENC_NFIELDS + IRX_ENC_GY] : dx0;
     if (dx && !(abl & 2)) {
       const int acc = (i > 0 && is_res_source[i - 1]) ? 1 : 0;
@@ -416,6 +450,9 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
     }
   }
   gate_step(gate, gate_fired, -1, stream);   // a recorder without a level of `rows` or more marks the end of its pass
+  if (two)                                   // join: everything this pass wrote is complete on the caller's stream
+    for (int i = 0; i < n_layers && i < 2; ++i)
+      IRX_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ev[16 + i], 0), "irx_encoder_backward(join)");
   return IRX_OK;
 }
 }  // namespace

@@ -29,6 +29,12 @@ _BWD_GATE = _BWD_GATE_ROWS > 0
 _STREAMS = _STREAMS_ENV != '0'                                   # three-stream training forward (_forward_streams); 0: round-4 layout
 _PREBUILD_BWD = _os.environ.get('IRX_PREBUILD_BWD', '0') == '1'   # backward-only tables built behind the scene head: measured neutral (3004-3013 vs 2920-2998 scenes/s), off
 _REL_THREAD = _os.environ.get('IRX_REL_THREAD', '0') == '1'      # dev: the relation head on that thread too (behind the language module)
+# The scene encoder's backward can issue its weight gradients on the language stream beside its BatchNorm-backward / data-gradient
+# chain (IRX_ENC_DC2 / IRX_ENC_WSTREAM, include/irx.h; bit-identical). Measured NEGATIVE at B = 16 bf16 (alternating runs on one box:
+# 4.350 / 4.349 ms per step with it, 4.217 / 4.249 without — the two kernel families contend for the same CUs and the chain, which is
+# the long pole, slows down); with two library-owned streams instead the step HALVED its speed (9.19 ms: a sixth / seventh stream
+# shares a hardware queue with a busy one). OFF; IRX_WGRAD_LANG=1 enables it.
+_WGRAD_LANG = _os.environ.get('IRX_WGRAD_LANG', '0') == '1'
 _SEQ_BUMP = int(_os.environ.get('IRX_SEQ_BUMP', '256'))          # 0: leave the autograd sequence numbers alone (dev A/B)
 MARK = None        # dev: bench.py's timeline mode installs a callable(name) here (phase marks inside forward)
 _ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
@@ -264,6 +270,10 @@ class InstanceRefer(nn.Module):
         if _SEQ_BUMP:
             self._bump_sequence()
         lstream = self._aux_stream(dev)
+        # the scene encoder's backward (the step's long pole) issues its weight gradients on the language stream, beside its own
+        # BatchNorm-backward / data-gradient chain (sparse/encoder_fn.py WGRAD_STREAM)
+        self.scene.net.__dict__['_irx_wgrad_stream'] = lstream.cuda_stream if _WGRAD_LANG else None
+        self.attribute.net.__dict__['_irx_wgrad_stream'] = None
         side.wait_stream(main)                               # inputs and the optimizer's parameter update are complete
         lstream.wait_stream(main)
         self.hand_over(data_dict, lstream)                   # prepared tensors (relation node features, index lists) used on `lang`
@@ -384,6 +394,7 @@ class InstanceRefer(nn.Module):
         for m in (getattr(self, 'scene', None), getattr(self, 'attribute', None)):
             if m is not None and hasattr(m, 'net'):
                 m.net._irx_bwd_gate = None                   # (the gate belongs to the multi-stream layout)
+                m.net.__dict__['_irx_wgrad_stream'] = None   # (... and so does the lent weight-gradient stream)
         side = None
         lang_join = None
         if _SEQ_BUMP and self.training and data_dict['lang_feat'].is_cuda:

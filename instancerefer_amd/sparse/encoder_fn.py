@@ -97,7 +97,7 @@ def _ws(nbytes, dev):
 # field order of the descriptor table: include/irx.h, enum IRX_ENC_* (tests/test_abi_cpu.py checks the two agree)
 ENC_FIELDS = ("K", "CIN", "COUT", "N_IN", "N_OUT", "RES", "TBL", "LD", "TBL_B", "LD_B", "FLIP_B", "PAIR_IN", "PAIR_OUT",
               "PAIR_COUNTS", "LD_PAIRS", "W", "GAMMA", "BETA", "RUNNING_MEAN", "RUNNING_VAR", "X", "C", "Y", "MEAN",
-              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "MODE", "ORDER", "PROF")
+              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "MODE", "ORDER", "PROF", "DC2", "WSTREAM")
 _E = {n: i for i, n in enumerate(ENC_FIELDS)}
 _NF = len(ENC_FIELDS)
 _ALIGN = 64                                           # float32 elements (256 B)
@@ -216,6 +216,11 @@ def lane_wait(lane):
 # than one round of workgroups on 256 CUs x 2); IRX_TILE_ORDER=0 switches it off (dev A/B; results are bit-identical).
 TILE_ORDER = os.environ.get("IRX_TILE_ORDER", "1") != "0"
 TILE_ORDER_MIN_ROWS = int(os.environ.get("IRX_TILE_ORDER_MIN_ROWS", str(512 * 64)))
+
+# The backward pass's weight gradients on a second stream beside the BatchNorm-backward / data-gradient chain (IRX_ENC_DC2 /
+# IRX_ENC_WSTREAM, include/irx.h; bit-identical) — for an encoder whose owner lends a stream (`_irx_wgrad_stream`: InstanceRefer's
+# three-stream forward lends the language stream to the scene encoder). IRX_WGRAD_STREAM=0 keeps the one-stream order.
+WGRAD_STREAM = os.environ.get("IRX_WGRAD_STREAM", "1") != "0"
 
 # Tests only (tests/test_bf16_gpu.py): a dict that receives the executor's arenas, so that every layer's stored tensors
 # (conv output c_i, layer output y_i, gradient in flight gy_i) can be compared one layer at a time; None = no tracing.
@@ -447,6 +452,7 @@ class EncoderFn(torch.autograd.Function):
         ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = st.layers, st.desc, st.fdesc, st.extra
         ctx.store, ctx.prof, ctx.sink = st.store, st.prof, st.sink
         ctx.gate = getattr(encoder, '_irx_bwd_gate', None)   # (role, rows, token): irx_encoder_gate_next, set per step by the model
+        ctx.wstream = getattr(encoder, '_irx_wgrad_stream', None)   # hipStream_t (int) lent for the backward's weight gradients, or None
         ctx.save_for_backward(*st.saved)
         return st.out.view_as(st.out) if isinstance(layers, Launched) else st.out
 
@@ -462,7 +468,9 @@ class EncoderFn(torch.autograd.Function):
         gsz = _up256(n_out * cout * (2 if store else 4))
         goffs = np.concatenate([[0], np.cumsum(gsz[:-1])])              # nl entries; the last one = start of dc
         dc_off = int(goffs[-1])
-        total = dc_off + int(gsz.max())
+        dc_size = int(gsz.max())
+        two = WGRAD_STREAM and ctx.sync is None and ctx.wstream is not None
+        total = dc_off + dc_size * (2 if two else 1)
         garena = torch.empty(total, dtype=torch.uint8, device=dev)
         slots = None
         if ctx.sink is not None:
@@ -499,6 +507,9 @@ class EncoderFn(torch.autograd.Function):
         desc[:, _E["DW"]:_E["DBETA"] + 1] = pptr
         desc[:-1, _E["GY"]] = gbase + goffs[:-1]
         desc[-1, _E["GY"]] = dout.data_ptr()
+        if two:                          # weight gradients on a second stream the model lends (irx.h IRX_ENC_DC2 / IRX_ENC_WSTREAM)
+            desc[0, _E["DC2"]] = gbase + dc_off + dc_size
+            desc[0, _E["WSTREAM"]] = int(ctx.wstream)
         dfeats = torch.empty((layers[0].n_in, layers[0].cin), dtype=_f32, device=dev) if need_dx0 else None
         fdesc = ctx.fdesc
         nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 1)
