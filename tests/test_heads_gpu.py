@@ -140,3 +140,23 @@ def test_dropout_flat_is_a_scaled_bernoulli_mask(lib):
     xc = x.clone()
     _lib.call("irx_dropout_flat", _lib.ptr(xc), 1000, 0.5, 42, _lib.ptr(ref), _lib.stream_ptr())
     assert torch.equal(y, ref)
+
+
+def test_encoder_backward_with_weight_gradients_on_a_lent_stream(lib, monkeypatch):
+    """IRX_ENC_DC2 / IRX_ENC_WSTREAM (include/irx.h): the scene encoder's backward issues its weight gradients on a second stream,
+    two gradient scratches alternating by layer — same kernels, same operands: every parameter gradient bit-identical to the
+    one-stream order (the option is off by default: measured slower, instancerefer.py _WGRAD_LANG)"""
+    from instancerefer_amd import instancerefer as IR
+    monkeypatch.setattr(IR, "_STREAMS_ENV", "1")
+    monkeypatch.setattr(IR, "_STREAMS", True)
+    grads = {}
+    for lent in (True, False):
+        monkeypatch.setattr(IR, "_WGRAD_LANG", lent)
+        m = _model(False)
+        dd, _ = _step(m, True, monkeypatch)
+        assert (m.scene.net.__dict__.get("_irx_wgrad_stream") is not None) == lent
+        grads[lent] = ({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, dd["loss"].detach().clone())
+    assert torch.equal(grads[True][1], grads[False][1])
+    assert grads[True][0].keys() == grads[False][0].keys() and len(grads[True][0]) > 150
+    for n, g in grads[True][0].items():
+        assert torch.equal(g, grads[False][0][n]), n
