@@ -275,11 +275,19 @@ def _model_runs(cfg, seed, c0, mode):
     finally:
         irx.set_compute_dtype("fp32")
     runs = {}
-    for name, m, a64 in (("emu", mode, False), ("emu64", mode, True)):
+    # "emu_alt": the fp32 emulation once more with another intra-op thread count, i.e. another (equally valid) partition of its
+    # fp32 sums — a second sample of the emulation's own reordering distance, so that the self-calibrated bars below do not hinge
+    # on which order one particular thread count happens to produce (round 6: the bars were calibrated at the box's 128-thread default)
+    nthreads = torch.get_num_threads()
+    for name, m, a64, nt in (("emu", mode, False, nthreads), ("emu64", mode, True, nthreads), ("emu_alt", mode, False, 3)):
         oracle = fresh(OracleModel)
-        with emulate.mode(m), emulate.acc64(a64):
-            od = get_loss(oracle(oracle_data_dict(S.make_batch(**dict(cfg)))), DatasetConfig())
-            od["loss"].backward()
+        torch.set_num_threads(nt)
+        try:
+            with emulate.mode(m), emulate.acc64(a64):
+                od = get_loss(oracle(oracle_data_dict(S.make_batch(**dict(cfg)))), DatasetConfig())
+                od["loss"].backward()
+        finally:
+            torch.set_num_threads(nthreads)
         runs[name] = (oracle, od)
     return (model, dd), runs
 
@@ -304,6 +312,16 @@ def check_model_against_emulation(model, dd, runs, tag):
         scale = max(1.0, float(exp.abs().max()))
         pe[k] = float((dd[k].detach().cpu() - exp).abs().max()) / scale
         ee[k] = float((runs["emu64"][1][k].detach() - exp).abs().max()) / scale
+        if "emu_alt" in runs:            # the larger of the pairwise distances between the three orderings of the emulation
+            alt = runs["emu_alt"][1][k].detach()
+            ee[k] = max(ee[k], float((alt - exp).abs().max()) / scale, float((alt - runs["emu64"][1][k].detach()).abs().max()) / scale)
+    # The matching loss is a max-margin functional of x = 5 (s_attr + s_rel + s_scene): |d ref_loss| <= 2 * 5 * (sum of the three
+    # scores' perturbations) (log-sum-exp and the positive term are 1-Lipschitz in max|dx| each). One fp32-vs-float64 run can land
+    # its own ref_loss closer than that by luck (round 6, stress configuration: 1e-4 while the scores moved 1.6e-3), so the scalars
+    # derived from the scores take the propagated distance when it is larger — never more than the largest distance of any tensor.
+    prop = min(10.0 * (ee["attribute_scores"] + ee["relation_scores"] + ee["scene_scores"]), max(ee.values()))
+    ee["ref_loss"] = max(ee["ref_loss"], prop)
+    ee["loss"] = max(ee["loss"], prop)
     bar = 2.0 * max(ee.values()) + 2e-5
     print("%s: HIP-emu %s | emu-emu64 %s | pooled bar %.1e" % (tag, {k: "%.0e" % v for k, v in pe.items()},
           {k: "%.0e" % v for k, v in ee.items()}, bar))
