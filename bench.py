@@ -1049,7 +1049,7 @@ def end_to_end(args):
 def measure_support_kernels(model, resident, args, reps=20):
     """The HBM-bound sparse kernels BESIDE the convolutions (north_star: "rocprof-reported HBM GB/s (sparse path)"; SURVEY 8(d)
     gives their algorithmic bytes): BatchNorm (+ shortcut) + ReLU forward / backward of every encoder layer, the 3^3 kernel
-    maps (hash build + 27-neighbour table) of every level, the Morton sort of the scene tensor and the candidate voxeliser,
+    maps (27-neighbour tables, octree descent) of every level, the Morton sort of the scene tensor and the candidate voxeliser,
     each timed ALONE with HIP events on the current stream on tensors of exactly this batch's sizes, through the same C-ABI
     entry points the step uses. -> {name: {calls_per_step, us_per_step, algo_mb_per_step, algo_gbs, frac_of_bound}} + totals.
     Algorithmic bytes (e = 2 bf16 storage / 4 fp32): BatchNorm forward 3 e N C (statistics read, apply read + write; + e N C for a
@@ -1096,6 +1096,7 @@ def measure_support_kernels(model, resident, args, reps=20):
         encoders.append((model.attribute.net, prep[0].level()))
     P = lambda t: t.data_ptr() if t is not None else None
     s = _lib.stream_ptr()
+    kmap_bytes = [0.0]
     for enc, lv0 in encoders:
         layers = encoder_fn.build_plan(enc, lv0)
         nl = len(layers)
@@ -1131,10 +1132,23 @@ def measure_support_kernels(model, resident, args, reps=20):
             if not L.down and id(lv) not in seen_levels and lv.n > 0:
                 seen_levels.add(id(lv))
                 tbl, _ = lv.nbr27()
-                m = int((tbl[:27, :lv.n] >= 0).sum().item())
-                keys, coords, stride = lv.keys, lv.coords, lv.stride
-                tk = timed(lambda: F_.kmap_build_s1(coords, stride, F_.hash_build(keys)))
-                add("kernel map 3^3 (k_fill_table + k_voxel_insert + k_kmap_s1)", tk, lv.n * 27 * 8.0 + 8.0 * m + 16.0 * lv.n)
+                kmap_bytes[0] += lv.n * 27 * 8.0 + 8.0 * int((tbl[:27, :lv.n] >= 0).sum().item()) + 16.0 * lv.n
+        # the 3^3 kernel maps of the whole pyramid the way the step builds them (round 6): ONE native call per pyramid — the coarsest
+        # level by window search (k_kmap_win; + its hash table when it has more than 2048 rows), every finer level by octree descent
+        # (k_kmap_descend). Same algorithmic bytes as rounds 4-5 priced (N K 8 probe bytes + 8 M pair bytes + 16 N).
+        lvs, lv = [], lv0
+        while lv is not None:
+            lvs.append(lv)
+            lv = lv._down.out_level if lv._down is not None else None
+        from instancerefer_amd import _nodes
+        mod = _nodes.load()
+        if mod is not None and hasattr(mod, "kmaps_build_pyramid") and len(lvs) > 1 and all(l.n > 0 for l in lvs):
+            dms = [l._down for l in lvs[:-1]]
+            ka = ([l.keys for l in lvs], [l.coords for l in lvs], [l.stride for l in lvs], [d.parent for d in dms], [d.koff for d in dms],
+                  [d.child for d in dms], [d.ld for d in dms], s)
+            tk = timed(lambda: mod.kmaps_build_pyramid(*ka))
+            add("kernel map 3^3, all levels of a pyramid in one call (k_kmap_win + %d x k_kmap_descend)" % (len(lvs) - 1), tk, kmap_bytes[0])
+        kmap_bytes[0] = 0.0
     # Morton sort of the scene tensor (SparseTensor.canonical: key encode, radix sort, decode, feature gather)
     if "lidar_F" in resident:
         Fr, Cr, Bn = resident["lidar_F"], resident["lidar_C"], resident["B"]
