@@ -35,6 +35,9 @@ _REL_THREAD = _os.environ.get('IRX_REL_THREAD', '0') == '1'      # dev: the rela
 # the long pole, slows down); with two library-owned streams instead the step HALVED its speed (9.19 ms: a sixth / seventh stream
 # shares a hardware queue with a busy one). OFF; IRX_WGRAD_LANG=1 enables it.
 _WGRAD_LANG = _os.environ.get('IRX_WGRAD_LANG', '0') == '1'
+# creation order of the two encoders' nodes = reverse order of their backward passes: 'sc' (default) issues the candidate encoder's
+# backward first, then the scene encoder's; 'cs' the other way round (dev A/B)
+_ATTACH_ORDER = ('_attr_encoded', '_scene_encoded') if _os.environ.get('IRX_ATTACH_ORDER', 'sc') == 'cs' else ('_scene_encoded', '_attr_encoded')
 _SEQ_BUMP = int(_os.environ.get('IRX_SEQ_BUMP', '256'))          # 0: leave the autograd sequence numbers alone (dev A/B)
 MARK = None        # dev: bench.py's timeline mode installs a callable(name) here (phase marks inside forward)
 _ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
@@ -310,8 +313,8 @@ class InstanceRefer(nn.Module):
             data_dict[k].record_stream(side)
         # scene head on the encoder's stream (its launches were issued by a library thread: wait for that first)
         lane_wait(lane_of(self.scene.net))
-        self._attach(data_dict, '_scene_encoded')            # (creation order = reverse backward order: see _attach)
-        self._attach(data_dict, '_attr_encoded')
+        for k in _ATTACH_ORDER:                              # (creation order = reverse backward order: see _attach)
+            self._attach(data_dict, k)
         with torch.cuda.stream(side):
             side.wait_event(ev)
             data_dict = self.scene.head(data_dict)
@@ -442,8 +445,8 @@ class InstanceRefer(nn.Module):
             data_dict['_scene_encoded'].record_stream(main)
         if fused_tail:
             # scene head, then attribute head + scene scores as one node (heads.py); whatever a precondition refuses runs per operator
-            self._attach(data_dict, '_scene_encoded')
-            self._attach(data_dict, '_attr_encoded')
+            for k in _ATTACH_ORDER:
+                self._attach(data_dict, k)
             data_dict = self.scene.head(data_dict)
             if not heads.attr_scene(self.attribute, self.scene, data_dict):
                 data_dict = self.attribute(data_dict)
