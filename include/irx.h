@@ -402,6 +402,10 @@ enum {
                                      * beside the model's four HALVED the bf16 step) */
   IRX_ENC_NFIELDS
 };
+/* Stream `to` continues behind everything enqueued on stream `from` so far (event record + wait; the library owns the events).
+ * For callers that issue independent halves of one operator on two streams — plumbing, no reference counterpart. */
+int irx_stream_fork(void* from, void* to);
+
 /* Launch order of the 64-row output tiles of a stride-1 convolution over table `nbr` (int32 [K][ld], the irx_kmap_build_s1
  * table): order[i] = i-th tile to start, heaviest cost class first (cost = per active offset a fixed part + one part per
  * 16-pair group), ties in tile order; deterministic. Pure scheduling aid for irx_encoder_forward / _backward (IRX_ENC_ORDER):

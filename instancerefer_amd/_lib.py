@@ -102,6 +102,7 @@ _SIGNATURES = {
     "irx_mlp2_saved_floats": (_Z, [_I, _I]),
     "irx_mlp2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _F, _P, _P, _F, _F, _c.c_uint64, _P, _P, _P, _P, _P]),
     "irx_mlp2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "irx_stream_fork": (_I, [_P, _P]),
     "irx_dropout_flat": (_I, [_P, _Z, _F, _c.c_uint64, _P, _P]),
     "irx_knn_batched": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "irx_project_workspace_bytes": (_Z, [_I]),

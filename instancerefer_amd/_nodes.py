@@ -17,7 +17,7 @@ _ENTRY_POINTS = ("irx_mlp2_saved_floats", "irx_mlp2_fwd", "irx_mlp2_bwd", "irx_g
 _HEAD_ENTRY_POINTS = ("irx_mlp2_saved_floats", "irx_mlp2_fwd", "irx_mlp2_bwd", "irx_segment_max", "irx_segment_max_backward",
                       "irx_cosine_rows_fwd", "irx_cosine_rows_bwd", "irx_spconv_fwd_workspace_bytes", "irx_spconv_fwd",
                       "irx_spconv_wgrad_workspace_bytes", "irx_spconv_wgrad", "irx_bn_workspace_bytes", "irx_bn_forward", "irx_bn_backward",
-                      "irx_kmap_down_transpose", "irx_attn_pool_fwd", "irx_attn_pool_bwd", "irx_dropout_flat", "irx_total_loss", "irx_edgeconv_workspace_bytes",
+                      "irx_kmap_down_transpose", "irx_attn_pool_fwd", "irx_attn_pool_bwd", "irx_dropout_flat", "irx_stream_fork", "irx_total_loss", "irx_edgeconv_workspace_bytes",
                       "irx_edgeconv_max_fwd", "irx_edgeconv_max_bwd", "irx_lang_pool_fwd", "irx_lang_pool_bwd")
 _mod = None
 _tried = False

@@ -90,8 +90,9 @@ class AttributeModule(nn.Module):
         return data_dict
 
     def forward(self, data_dict):
-        lang_feats = data_dict['lang_attr_feats']
-        lang_feats = mlp2(self.lang_emb_fc, lang_feats)                       # (B, h_dim)
+        lang_feats = data_dict.pop('_attr_lang_h', None)                      # already through lang_emb_fc (heads.PreLang) ...
+        if lang_feats is None:
+            lang_feats = mlp2(self.lang_emb_fc, data_dict['lang_attr_feats'])  # ... or here: (B, h_dim)
 
         if '_attr_prepared' in data_dict:
             st, sel = data_dict.pop('_attr_prepared')

@@ -19,6 +19,9 @@
 #include <torch/csrc/autograd/function.h>
 #include <torch/csrc/autograd/functions/utils.h>
 
+#include <c10/core/Stream.h>
+#include <c10/core/StreamGuard.h>
+
 #include <cmath>
 #include <unordered_map>
 
@@ -53,6 +56,7 @@ typedef int (*kdt_fn)(const int32_t*, const uint8_t*, int, int32_t*, int, void*)
 typedef int (*attn_fwd_fn)(const float*, const float*, int, int, int, float, float*, float*, void*);
 typedef int (*attn_bwd_fn)(const float*, const float*, const float*, const float*, const float*, int, int, int, float, float*, float*,
                            void*);
+typedef int (*fork_fn)(void*, void*);
 typedef int (*drop_fn)(const float*, size_t, float, unsigned long long, float*, void*);
 typedef size_t (*ec_ws_fn)(int, int, int, int, int, int);
 typedef int (*ec_fwd_fn)(const float*, const float*, const int64_t*, const int32_t*, int, int, int, int, int, int, const float* const*,
@@ -86,6 +90,7 @@ struct Api {
   attn_fwd_fn attn_fwd = nullptr;
   attn_bwd_fn attn_bwd = nullptr;
   drop_fn dropout = nullptr;
+  fork_fn fork = nullptr;
   loss_fn total_loss = nullptr;
   ec_ws_fn ec_ws = nullptr;
   ec_fwd_fn ec_fwd = nullptr;
@@ -175,7 +180,8 @@ struct Mlp {
   size_t p0 = 0;                 // index of w1 in the node's parameter list: (w1, b1, gamma, beta, w2, b2)
   Tensor rmean, rvar;            // BatchNorm1d running statistics (undefined: LayerNorm)
   int norm = 3;
-  float eps = 1e-5f, momentum = 0.f, drop_p = 0.f;
+  float eps = 1e-5f, momentum = 0.f;
+  double drop_p = 0.0;           // (double: the backward's 1 / (1 - p) is evaluated as dense.py / MLP2Node evaluate it, bit for bit)
   unsigned long long seed = 0;
   Tensor x, saved;               // kept for the backward
   int rows = 0, din = 0, dh = 0, dout = 0;
@@ -190,7 +196,7 @@ Tensor mlp_fwd(Mlp& m, const std::vector<Tensor>& P, const Tensor& x_in, void* s
   Tensor y = at::empty({m.rows, m.dout}, m.x.options());
   m.saved = at::empty({(int64_t)api.mlp2_saved_floats(m.rows, m.dh)}, m.x.options());
   check(api.mlp2_fwd(fp(m.x), m.rows, m.din, m.dh, m.dout, fp(w1), fp(b1), m.norm, fp(gamma), fp(beta), m.eps, fpm(m.rmean),
-                     fpm(m.rvar), m.momentum, m.drop_p, m.seed, fp(w2), fp(b2), fpm(m.saved), fpm(y), stream),
+                     fpm(m.rvar), m.momentum, (float)m.drop_p, m.seed, fp(w2), fp(b2), fpm(m.saved), fpm(y), stream),
         "irx_mlp2_fwd");
   return y;
 }
@@ -202,7 +208,7 @@ Tensor mlp_bwd(const Mlp& m, const std::vector<Tensor>& P, const Tensor& dy, boo
   float* dx_ptr = want_dx ? base + (size_t)m.rows * m.dh : nullptr;
   float* const* gp = pg.ptr.data() + m.p0;
   check(api.mlp2_bwd(fp(m.x), fp(dy), m.rows, m.din, m.dh, m.dout, fp(w1), m.norm, fp(gamma), fp(w2), fp(m.saved),
-                     m.drop_p > 0 ? 1.f / (1.f - m.drop_p) : 1.f, base, dx_ptr, gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], stream),
+                     m.drop_p > 0 ? (float)(1.0 / (1.0 - m.drop_p)) : 1.f, base, dx_ptr, gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], stream),
         "irx_mlp2_bwd");
   return want_dx ? scratch.narrow(0, (int64_t)m.rows * m.dh, (int64_t)m.rows * m.din).view({m.rows, m.din}) : Tensor();
 }
@@ -280,27 +286,44 @@ Tensor conv2d_fwd(Conv2dRows& c, const std::vector<Tensor>& P, const Tensor& x, 
   return y;
 }
 
-Tensor conv2d_bwd(const Conv2dRows& c, const std::vector<Tensor>& P, const Tensor& dy, const PGrads& pg, void* stream) {
+// data gradient only (the chain the encoder's backward waits for) ...
+Tensor conv2d_dgrad(const Conv2dRows& c, const Tensor& dy, void* stream) {
+  return conv_rows(dy, c.wk, c.bwd_tbl, c.n_in, c.n_in, 0, 1, stream);
+}
+// ... and the parameter gradients (bias: column sums; weight: pair-free weight gradient, permuted back to the Conv2d layout) — ATen
+// operators here run on the thread's CURRENT stream: the caller sets it to `stream` when that is not the node's own
+void conv2d_wgrad(const Conv2dRows& c, const std::vector<Tensor>& P, const Tensor& dy, const PGrads& pg, void* stream) {
   const Tensor& w = P[c.p0];
   const int64_t cout = w.size(0), cin = w.size(1);
   const int K = c.ks * c.ks;
   Tensor db = pg.view(c.p0 + 1);
   const std::vector<int64_t> dim0{0};
   at::sum_out(db, dy, dim0);
-  Tensor dx = conv_rows(dy, c.wk, c.bwd_tbl, c.n_in, c.n_in, 0, 1, stream);
   Tensor dwk = at::empty({K, cin, cout}, dy.options());
   wgrad_rows(c.x, dy, c.fwd_tbl, c.n_out, c.n_out, K, fpm(dwk), stream);
   Tensor dw = pg.view(c.p0);
   dw.copy_(dwk.view({(int64_t)c.ks, (int64_t)c.ks, cin, cout}).permute({3, 2, 0, 1}));
-  return dx;
 }
+
+// a second stream lent by the caller (torch.cuda.Stream: handle + the c10 triple), or none
+struct AuxStream {
+  void* ptr = nullptr;
+  int64_t id = 0, device_index = 0, device_type = 0;
+  bool on() const { return ptr != nullptr; }
+  c10::Stream c10s() const { return c10::Stream::unpack3(id, (c10::DeviceIndex)device_index, (c10::DeviceType)device_type); }
+};
 
 // =================================================================================================================================
 // SceneHeadNode
-//   data inputs : feats [n][128] (the BEV encoder's output rows), lang [B][256] (the language module's scene vector)
+//   data inputs : feats [n][128] (the BEV encoder's output rows), lang: the language module's scene vector [B][256] — or, with
+//                 pre_lang, that vector already through lang_emb_fc ([B][128]; the MLP then runs as a node of its own on the language
+//                 stream, off this head's chain)
 //   parameters  : to_bev.1.kernel, to_bev.2.{weight,bias}, vis_emb_fc.0.{weight,bias}, vis_emb_fc.1.{weight,bias},
-//                 vis_emb_fc.4.{weight,bias}, lang_emb_fc (6), cls (6)
+//                 vis_emb_fc.4.{weight,bias}, [lang_emb_fc (6) unless pre_lang], cls (6)
 //   outputs     : vis_atten [B][n_vis], seg_scores [B][9], scene vector [B][128]
+// Backward: the data-gradient chain (classifier -> attention -> Conv2d -> Dropout -> BatchNorm -> Conv2d -> BatchNorm -> BEV rows) is
+// what the scene encoder's backward — the step's long pole — waits for; the weight / bias gradients feed nothing downstream. With a
+// lent second stream (aux) they are issued there, behind an event on the chain, and the chain is 21 launches instead of 35.
 // =================================================================================================================================
 struct SceneHeadNode : public HeadNode {
   Tensor feats, bev_tbl, cell, zbin;
@@ -308,6 +331,8 @@ struct SceneHeadNode : public HeadNode {
   BnRows bn0, bn1;
   Conv2dRows cv0, cv1;
   Mlp lang, cls;
+  bool pre_lang = false;
+  AuxStream aux;
   float drop_p = 0.f;
   unsigned long long drop_seed = 0;
   Tensor rows4, lang_h, atten, scene_vec;
@@ -335,40 +360,71 @@ struct SceneHeadNode : public HeadNode {
     check(api.attn_bwd(fp(rows4), fp(lang_h), fp(atten), fp(d_vec), fp(datten), B, n_vis, d, 1.f / std::sqrt((float)d), fpm(dfeats),
                        fpm(dlang_h), stream),
           "irx_attn_pool_bwd");
-    Tensor g = conv2d_bwd(cv1, params, dfeats, pg, stream);
-    if (drop_p > 0.f) check(api.dropout(fp(g), (size_t)g.numel(), drop_p, drop_seed, fpm(g), stream), "irx_dropout_flat");
-    g = bn_bwd(bn1, params, g, pg, stream);
-    g = conv2d_bwd(cv0, params, g, pg, stream);
-    g = bn_bwd(bn0, params, g, pg, stream);
-    // BEV rows: data gradient through the transposed cell table, weight gradient through the forward table
+    // ---- the chain ----
+    Tensor g1 = conv2d_dgrad(cv1, dfeats, stream);
+    if (drop_p > 0.f) check(api.dropout(fp(g1), (size_t)g1.numel(), drop_p, drop_seed, fpm(g1), stream), "irx_dropout_flat");
+    Tensor g2 = bn_bwd(bn1, params, g1, pg, stream);
+    Tensor g3 = conv2d_dgrad(cv0, g2, stream);
+    Tensor g4 = bn_bwd(bn0, params, g3, pg, stream);
     const Tensor& kernel = params[0];
     const int K = (int)kernel.size(0), n = (int)feats.size(0), ld_b = n > 0 ? n : 1;
     if (should_compute_output(0)) {
       Tensor tbl_b = at::empty({8, ld_b}, bev_tbl.options());
       check(api.kdt(cell.data_ptr<int32_t>(), zbin.data_ptr<uint8_t>(), n, tbl_b.data_ptr<int32_t>(), ld_b, stream),
             "irx_kmap_down_transpose");
-      out[0] = conv_rows(g, kernel, tbl_b, ld_b, n, 0, 1, stream);
+      out[0] = conv_rows(g4, kernel, tbl_b, ld_b, n, 0, 1, stream);
     }
-    wgrad_rows(feats, g, bev_tbl, ncell, ncell, K, pg.ptr[0], stream);
-    Tensor dlang = mlp_bwd(lang, params, dlang_h, should_compute_output(1), pg, stream);
-    if (should_compute_output(1)) out[1] = dlang;
-    finish(pg, out);
+    // the language MLP (unless it is a node of its own): its output gradient leaves this node, so it stays on the node's stream
+    if (!pre_lang) {
+      Tensor dlang = mlp_bwd(lang, params, dlang_h, should_compute_output(1), pg, stream);
+      if (should_compute_output(1)) out[1] = dlang;
+    } else if (should_compute_output(1)) {
+      out[1] = dlang_h;
+    }
+    // ---- parameter gradients that feed nothing downstream ----
+    void* ws = stream;
+    if (aux.on() && aux.ptr != stream) {
+      check(api.fork(stream, aux.ptr), "irx_stream_fork");
+      ws = aux.ptr;
+      const c10::Stream cs = aux.c10s();
+      for (const Tensor* t : {&dfeats, &g2, &g4, &cv1.x, &cv0.x, &feats, &cv1.fwd_tbl, &cv0.fwd_tbl, &bev_tbl})
+        if (t->defined()) t->record_stream(cs);
+      c10::StreamGuard sg(cs);                       // (ATen operators of conv2d_wgrad and their allocations follow the current stream)
+      conv2d_wgrad(cv1, params, dfeats, pg, ws);
+      conv2d_wgrad(cv0, params, g2, pg, ws);
+      wgrad_rows(feats, g4, bev_tbl, ncell, ncell, K, pg.ptr[0], ws);
+    } else {
+      conv2d_wgrad(cv1, params, dfeats, pg, ws);
+      conv2d_wgrad(cv0, params, g2, pg, ws);
+      wgrad_rows(feats, g4, bev_tbl, ncell, ncell, K, pg.ptr[0], ws);
+    }
+    if (pg.deliver) {
+      // every slot is complete on `ws`: the chain's BatchNorm / MLP gradients were enqueued on the node's stream ahead of the fork
+      sink.delivered(ws);
+    } else {
+      if (ws != stream) check(api.fork(ws, stream), "irx_stream_fork");      // autograd reads the gradients on the node's stream
+      finish(pg, out);
+    }
     return out;
   }
 };
 
-std::vector<Tensor> scene_head(const Tensor& feats_in, const Tensor& lang_in, const Tensor& bev_tbl, const Tensor& cell, const Tensor& zbin,
-                               int64_t ncell, int64_t B, std::vector<Tensor> grid, std::vector<int64_t> grid_n, std::vector<Tensor> params,
-                               std::vector<Tensor> stats, std::vector<double> f, std::vector<int64_t> seeds, int64_t stream_i,
-                               std::vector<int64_t> slot_ptrs, std::vector<Tensor> keep) {
+std::vector<Tensor> scene_head(const Tensor& feats_in, const Tensor& lang_in, bool pre_lang, const Tensor& bev_tbl, const Tensor& cell,
+                               const Tensor& zbin, int64_t ncell, int64_t B, std::vector<Tensor> grid, std::vector<int64_t> grid_n,
+                               std::vector<Tensor> params, std::vector<Tensor> stats, std::vector<double> f, std::vector<int64_t> seeds,
+                               int64_t stream_i, std::vector<int64_t> aux_stream, std::vector<int64_t> slot_ptrs, std::vector<Tensor> keep) {
   TORCH_CHECK(api.conv_fwd && api.bn_fwd && api.mlp2_fwd && api.attn_fwd, "irx nodes: bind_heads() has not been called");
-  TORCH_CHECK(params.size() == 21 && stats.size() == 6 && f.size() == 9 && seeds.size() == 2 && grid.size() == 4 && grid_n.size() == 4,
-              "scene_head: argument lists");
+  TORCH_CHECK(params.size() == (pre_lang ? 15u : 21u) && stats.size() == 6 && f.size() == 9 && seeds.size() == 2 && grid.size() == 4 &&
+              grid_n.size() == 4 && (aux_stream.empty() || aux_stream.size() == 4), "scene_head: argument lists");
   void* stream = (void*)stream_i;
   auto node = std::shared_ptr<SceneHeadNode>(new SceneHeadNode(), torch::autograd::deleteNode);
   SceneHeadNode& s = *node;
   s.params = std::move(params);
   s.stream = stream;
+  s.pre_lang = pre_lang;
+  if (aux_stream.size() == 4) {
+    s.aux.ptr = (void*)aux_stream[0]; s.aux.id = aux_stream[1]; s.aux.device_index = aux_stream[2]; s.aux.device_type = aux_stream[3];
+  }
   const bool rec = at::GradMode::is_enabled() && (feats_in.requires_grad() || lang_in.requires_grad() || s.params[0].requires_grad());
   std::vector<Tensor> outs;
   {
@@ -383,8 +439,9 @@ std::vector<Tensor> scene_head(const Tensor& feats_in, const Tensor& lang_in, co
     s.cv1.p0 = 7; s.cv1.fwd_tbl = grid[2]; s.cv1.bwd_tbl = grid[3]; s.cv1.n_out = (int)grid_n[2]; s.cv1.n_in = (int)grid_n[3];
     s.cv0.ks = (int)P[3].size(2); s.cv1.ks = (int)P[7].size(2);
     s.drop_p = (float)f[4]; s.drop_seed = (unsigned long long)seeds[0];
-    s.lang.p0 = 9; s.lang.norm = 3; s.lang.eps = (float)f[5]; s.lang.drop_p = (float)f[6]; s.lang.seed = (unsigned long long)seeds[1];
-    s.cls.p0 = 15; s.cls.norm = 1; s.cls.rmean = stats[4]; s.cls.rvar = stats[5]; s.cls.eps = (float)f[7]; s.cls.momentum = (float)f[8];
+    s.lang.p0 = 9; s.lang.norm = 3; s.lang.eps = (float)f[5]; s.lang.drop_p = f[6]; s.lang.seed = (unsigned long long)seeds[1];
+    s.cls.p0 = pre_lang ? 9 : 15; s.cls.norm = 1; s.cls.rmean = stats[4]; s.cls.rvar = stats[5]; s.cls.eps = (float)f[7];
+    s.cls.momentum = (float)f[8];
     Tensor rows = conv_rows(s.feats, P[0], bev_tbl, s.ncell, s.ncell, 0, 0, stream);          // (B * nx * ny, 128)
     rows = bn_fwd(s.bn0, P, rows, stream);
     rows = conv2d_fwd(s.cv0, P, rows, stream);
@@ -398,7 +455,8 @@ std::vector<Tensor> scene_head(const Tensor& feats_in, const Tensor& lang_in, co
     TORCH_CHECK(s.rows4.size(0) % B == 0, "scene_head: rows do not divide by the batch size");
     s.n_vis = (int)(s.rows4.size(0) / B);
     const int d = (int)s.rows4.size(1);
-    s.lang_h = mlp_fwd(s.lang, P, lang_in, stream);
+    s.lang_h = pre_lang ? f32c(lang_in) : mlp_fwd(s.lang, P, lang_in, stream);
+    TORCH_CHECK(s.lang_h.size(0) == B && s.lang_h.size(1) == d, "scene_head: language vector shape");
     s.atten = at::empty({B, s.n_vis}, s.rows4.options());
     s.scene_vec = at::empty({B, d}, s.rows4.options());
     check(api.attn_fwd(fp(s.rows4), fp(s.lang_h), s.B, s.n_vis, d, 1.f / std::sqrt((float)d), fpm(s.atten), fpm(s.scene_vec), stream),
@@ -415,20 +473,24 @@ std::vector<Tensor> scene_head(const Tensor& feats_in, const Tensor& lang_in, co
 
 // =================================================================================================================================
 // AttrHeadNode
-//   data inputs : feats [n][128] (the candidate encoder's output rows), lang [B][256] (attribute vector), scene vector [B][128]
-//   parameters  : attribute.lang_emb_fc (6), attribute.vis_emb_fc (6), scene.vis_emb_fc1 (6)
-//   outputs     : obj_feats [Nc][128], attribute_scores [Nc], scene_scores [Nc]
+//   data inputs : feats [n][128] (the candidate encoder's output rows), lang: the attribute vector [B][256] (or, with pre_lang, already
+//                 through attribute.lang_emb_fc)
+//   parameters  : [attribute.lang_emb_fc (6) unless pre_lang], attribute.vis_emb_fc (6), scene.vis_emb_fc1 (6)
+//   outputs     : obj_feats [Nc][128], attribute_scores [Nc], obj_h [Nc][128] = vis_emb_fc1(obj_feats) — the candidate side of the
+//                 scene scores, which a CosineNode takes against the scene vector once the scene head has produced it (so that
+//                 everything here runs beside the scene head, forward and backward)
 // =================================================================================================================================
 struct AttrHeadNode : public HeadNode {
-  Tensor offsets, idx, arg, pooled, lang_h, vis_h, obj_h, scene_vec, score_a, norms_a, score_s, norms_s;
+  Tensor offsets, idx, arg, pooled, lang_h, vis_h, score_a, norms_a;
   int n_rows = 0, nc = 0, B = 0;
   Mlp lang, vis, fc1;
-  float eps_a = 1e-12f, eps_s = 1e-8f;
+  bool pre_lang = false;
+  float eps_a = 1e-12f;
 
   std::string name() const override { return "irx::AttrHeadNode"; }
   void release_variables() override {
     released = true;
-    offsets = idx = arg = pooled = lang_h = vis_h = obj_h = scene_vec = score_a = norms_a = score_s = norms_s = Tensor();
+    offsets = idx = arg = pooled = lang_h = vis_h = score_a = norms_a = Tensor();
     lang.reset(); vis.reset(); fc1.reset();
   }
 
@@ -438,19 +500,14 @@ struct AttrHeadNode : public HeadNode {
     variable_list out(num_outputs());
     PGrads pg;
     pg.init(sink, params);
-    const int64_t* ip = idx.data_ptr<int64_t>();
-    // scene scores -> candidate-side MLP (the later node of the forward: first in the engine's order)
-    const Tensor d_ss = grads[2].defined() ? f32c(grads[2]) : at::zeros_like(score_s);
-    Tensor d_obj_h = at::empty_like(obj_h), d_vec = at::empty_like(scene_vec);
-    check(api.cos_bwd(fp(obj_h), fp(scene_vec), ip, fp(score_s), fp(norms_s), fp(d_ss), nc, B, (int)obj_h.size(1), eps_s, fpm(d_obj_h),
-                      fpm(d_vec), stream),
-          "irx_cosine_rows_bwd");
+    // candidate-side MLP of the scene scores (the later operator of the forward: first in the engine's order)
+    const Tensor d_obj_h = grads[2].defined() ? f32c(grads[2]) : at::zeros({nc, fc1.dout}, pooled.options());
     Tensor d_pool = mlp_bwd(fc1, params, d_obj_h, true, pg, stream);
     // attribute scores -> visual MLP
     const Tensor d_as = grads[1].defined() ? f32c(grads[1]) : at::zeros_like(score_a);
     Tensor d_vis_h = at::empty_like(vis_h), d_lang_h = at::empty_like(lang_h);
-    check(api.cos_bwd(fp(vis_h), fp(lang_h), ip, fp(score_a), fp(norms_a), fp(d_as), nc, B, (int)vis_h.size(1), eps_a, fpm(d_vis_h),
-                      fpm(d_lang_h), stream),
+    check(api.cos_bwd(fp(vis_h), fp(lang_h), idx.data_ptr<int64_t>(), fp(score_a), fp(norms_a), fp(d_as), nc, B, (int)vis_h.size(1), eps_a,
+                      fpm(d_vis_h), fpm(d_lang_h), stream),
           "irx_cosine_rows_bwd");
     d_pool = d_pool + mlp_bwd(vis, params, d_vis_h, true, pg, stream);
     if (grads[0].defined()) d_pool = d_pool + f32c(grads[0]);
@@ -459,26 +516,29 @@ struct AttrHeadNode : public HeadNode {
       check(api.segmax_bwd(fp(d_pool), arg.data_ptr<int32_t>(), nc, (int)pooled.size(1), fpm(dx), stream), "irx_segment_max_backward");
       out[0] = dx;
     }
-    Tensor dlang = mlp_bwd(lang, params, d_lang_h, should_compute_output(1), pg, stream);
-    if (should_compute_output(1)) out[1] = dlang;
-    if (should_compute_output(2)) out[2] = d_vec;
+    if (!pre_lang) {
+      Tensor dlang = mlp_bwd(lang, params, d_lang_h, should_compute_output(1), pg, stream);
+      if (should_compute_output(1)) out[1] = dlang;
+    } else if (should_compute_output(1)) {
+      out[1] = d_lang_h;
+    }
     finish(pg, out);
     return out;
   }
 };
 
 std::vector<Tensor> attr_head(const Tensor& feats_in, const Tensor& offsets, int64_t nseg, const Tensor& idx, const Tensor& lang_in,
-                              const Tensor& scene_vec_in, std::vector<Tensor> params, std::vector<Tensor> stats, std::vector<double> f,
+                              bool pre_lang, std::vector<Tensor> params, std::vector<Tensor> stats, std::vector<double> f,
                               std::vector<int64_t> seeds, int64_t stream_i, std::vector<int64_t> slot_ptrs, std::vector<Tensor> keep) {
   TORCH_CHECK(api.segmax && api.cos_fwd && api.mlp2_fwd, "irx nodes: bind_heads() has not been called");
-  TORCH_CHECK(params.size() == 18 && stats.size() == 2 && f.size() == 7 && seeds.size() == 1, "attr_head: argument lists");
+  TORCH_CHECK(params.size() == (pre_lang ? 12u : 18u) && stats.size() == 2 && f.size() == 6 && seeds.size() == 1, "attr_head: argument lists");
   void* stream = (void*)stream_i;
   auto node = std::shared_ptr<AttrHeadNode>(new AttrHeadNode(), torch::autograd::deleteNode);
   AttrHeadNode& s = *node;
   s.params = std::move(params);
   s.stream = stream;
-  const bool rec = at::GradMode::is_enabled() &&
-                   (feats_in.requires_grad() || lang_in.requires_grad() || scene_vec_in.requires_grad() || s.params[0].requires_grad());
+  s.pre_lang = pre_lang;
+  const bool rec = at::GradMode::is_enabled() && (feats_in.requires_grad() || lang_in.requires_grad() || s.params[0].requires_grad());
   std::vector<Tensor> outs;
   {
     at::NoGradGuard ng;
@@ -488,34 +548,85 @@ std::vector<Tensor> attr_head(const Tensor& feats_in, const Tensor& offsets, int
     s.n_rows = (int)x.size(0); s.nc = (int)nseg; s.B = (int)lang_in.size(0);
     s.offsets = offsets; s.idx = idx;
     TORCH_CHECK(idx.size(0) == nseg && idx.scalar_type() == torch::kInt64 && offsets.scalar_type() == torch::kInt32, "attr_head: index tensors");
+    const size_t o = pre_lang ? 0 : 6;
     s.lang.p0 = 0; s.lang.norm = 1; s.lang.rmean = stats[0]; s.lang.rvar = stats[1]; s.lang.eps = (float)f[0]; s.lang.momentum = (float)f[1];
-    s.vis.p0 = 6; s.vis.norm = 3; s.vis.eps = (float)f[2];
-    s.fc1.p0 = 12; s.fc1.norm = 3; s.fc1.eps = (float)f[3]; s.fc1.drop_p = (float)f[4]; s.fc1.seed = (unsigned long long)seeds[0];
-    s.eps_a = (float)f[5]; s.eps_s = (float)f[6];
-    s.lang_h = mlp_fwd(s.lang, P, lang_in, stream);
+    s.vis.p0 = o; s.vis.norm = 3; s.vis.eps = (float)f[2];
+    s.fc1.p0 = o + 6; s.fc1.norm = 3; s.fc1.eps = (float)f[3]; s.fc1.drop_p = f[4]; s.fc1.seed = (unsigned long long)seeds[0];
+    s.eps_a = (float)f[5];
+    s.lang_h = pre_lang ? f32c(lang_in) : mlp_fwd(s.lang, P, lang_in, stream);
     s.pooled = at::empty({nseg, c}, x.options());
     s.arg = at::empty({nseg, c}, x.options().dtype(torch::kInt32));
     check(api.segmax(fp(x), offsets.data_ptr<int32_t>(), s.nc, c, fpm(s.pooled), s.arg.data_ptr<int32_t>(), stream), "irx_segment_max");
     s.vis_h = mlp_fwd(s.vis, P, s.pooled, stream);
+    TORCH_CHECK(s.lang_h.size(1) == s.vis_h.size(1), "attr_head: language vector width");
     s.score_a = at::empty({nseg}, x.options());
     s.norms_a = at::empty({nseg > 0 ? nseg : 1, 2}, x.options());
     check(api.cos_fwd(fp(s.vis_h), fp(s.lang_h), idx.data_ptr<int64_t>(), s.nc, (int)s.vis_h.size(1), s.eps_a, fpm(s.score_a), fpm(s.norms_a),
                       stream),
           "irx_cosine_rows_fwd");
-    s.scene_vec = f32c(scene_vec_in);
-    s.obj_h = mlp_fwd(s.fc1, P, s.pooled, stream);
-    s.score_s = at::empty({nseg}, x.options());
-    s.norms_s = at::empty({nseg > 0 ? nseg : 1, 2}, x.options());
-    check(api.cos_fwd(fp(s.obj_h), fp(s.scene_vec), idx.data_ptr<int64_t>(), s.nc, (int)s.obj_h.size(1), s.eps_s, fpm(s.score_s),
-                      fpm(s.norms_s), stream),
-          "irx_cosine_rows_fwd");
-    outs = {s.pooled.detach(), s.score_a.detach(), s.score_s.detach()};
+    Tensor obj_h = mlp_fwd(s.fc1, P, s.pooled, stream);
+    outs = {s.pooled.detach(), s.score_a.detach(), obj_h};
   }
   if (rec) {
-    s.wire({feats_in, lang_in, scene_vec_in}, slot_ptrs, keep);
+    s.wire({feats_in, lang_in}, slot_ptrs, keep);
     torch::autograd::set_history(outs, node);
   }
   return outs;
+}
+
+// =================================================================================================================================
+// CosineNode: score[i] = cos(a_i, b_{idx[i]}) (irx_cosine_rows_fwd / _bwd; reference models/scene_module.py:104-106,
+// relation_module.py:104-105, attribute_module.py:122-126). data inputs a [n][d], b [m][d]; no parameters.
+// =================================================================================================================================
+struct CosineNode : public HeadNode {
+  Tensor a, b, idx, score, norms;
+  float eps = 1e-8f;
+  std::string name() const override { return "irx::CosineNode"; }
+  void release_variables() override { released = true; a = b = idx = score = norms = Tensor(); }
+  variable_list apply(variable_list&& grads) override {
+    guard();
+    at::NoGradGuard ng;
+    variable_list out(num_outputs());
+    if (!grads[0].defined()) return out;
+    const Tensor ds = f32c(grads[0]);
+    const bool wa = should_compute_output(0), wb = should_compute_output(1);
+    Tensor da = wa ? at::empty_like(a) : Tensor(), db = wb ? at::empty_like(b) : Tensor();
+    check(api.cos_bwd(fp(a), fp(b), idx.defined() ? idx.data_ptr<int64_t>() : nullptr, fp(score), fp(norms), fp(ds), (int)a.size(0),
+                      (int)b.size(0), (int)a.size(1), eps, fpm(da), fpm(db), stream),
+          "irx_cosine_rows_bwd");
+    if (wa) out[0] = da;
+    if (wb) out[1] = db;
+    return out;
+  }
+};
+
+Tensor cosine_rows(const Tensor& a_in, const Tensor& b_in, const c10::optional<Tensor>& idx, double eps, int64_t stream_i) {
+  TORCH_CHECK(api.cos_fwd && api.cos_bwd, "irx nodes: bind_heads() has not been called");
+  auto node = std::shared_ptr<CosineNode>(new CosineNode(), torch::autograd::deleteNode);
+  CosineNode& s = *node;
+  s.stream = (void*)stream_i;
+  const bool rec = at::GradMode::is_enabled() && (a_in.requires_grad() || b_in.requires_grad());
+  Tensor out;
+  {
+    at::NoGradGuard ng;
+    s.a = f32c(a_in); s.b = f32c(b_in);
+    if (idx.has_value() && idx->defined()) s.idx = idx->contiguous();
+    s.eps = (float)eps;
+    const int64_t n = s.a.size(0);
+    TORCH_CHECK(s.a.size(1) == s.b.size(1) && (!s.idx.defined() || (s.idx.size(0) == n && s.idx.scalar_type() == torch::kInt64)),
+                "cosine_rows: shapes");
+    s.score = at::empty({n}, s.a.options());
+    s.norms = at::empty({n > 0 ? n : 1, 2}, s.a.options());
+    check(api.cos_fwd(fp(s.a), fp(s.b), s.idx.defined() ? s.idx.data_ptr<int64_t>() : nullptr, (int)n, (int)s.a.size(1), s.eps, fpm(s.score),
+                      fpm(s.norms), s.stream),
+          "irx_cosine_rows_fwd");
+    out = s.score.detach();
+  }
+  if (rec) {
+    s.wire({a_in, b_in}, {}, {});
+    torch::autograd::set_history(out, node);
+  }
+  return out;
 }
 
 // =================================================================================================================================
@@ -645,8 +756,8 @@ std::vector<Tensor> relation_head(const Tensor& lang_in, const Tensor& feats, co
     s.nq = (int)s.nbr.size(0); s.k = (int)s.nbr.size(1); s.fin = (int)s.feats.size(1); s.nc = (int)nc;
     s.hid = (int)P[12].size(0); s.fout = (int)P[18].size(0); s.B = (int)lang_in.size(0);
     s.lang.p0 = 0; s.lang.norm = 1; s.lang.rmean = stats[0]; s.lang.rvar = stats[1]; s.lang.eps = (float)f[0]; s.lang.momentum = (float)f[1];
-    s.lang.drop_p = (float)f[2]; s.lang.seed = (unsigned long long)seeds[0];
-    s.vis.p0 = 6; s.vis.norm = 3; s.vis.eps = (float)f[3]; s.vis.drop_p = (float)f[4]; s.vis.seed = (unsigned long long)seeds[1];
+    s.lang.drop_p = f[2]; s.lang.seed = (unsigned long long)seeds[0];
+    s.vis.p0 = 6; s.vis.norm = 3; s.vis.eps = (float)f[3]; s.vis.drop_p = f[4]; s.vis.seed = (unsigned long long)seeds[1];
     s.eps_cos = (float)f[5];
     s.lang_h = mlp_fwd(s.lang, P, lang_in, stream);
     Tensor gcn = at::empty({s.nq, s.fout}, s.feats.options());
@@ -773,6 +884,7 @@ void bind_heads(const std::unordered_map<std::string, uint64_t>& addr) {
   api.attn_fwd = (attn_fwd_fn)get("irx_attn_pool_fwd");
   api.attn_bwd = (attn_bwd_fn)get("irx_attn_pool_bwd");
   api.dropout = (drop_fn)get("irx_dropout_flat");
+  api.fork = (fork_fn)get("irx_stream_fork");
   api.total_loss = (loss_fn)get("irx_total_loss");
   api.ec_ws = (ec_ws_fn)get("irx_edgeconv_workspace_bytes");
   api.ec_fwd = (ec_fwd_fn)get("irx_edgeconv_max_fwd");
@@ -787,6 +899,7 @@ void register_heads(pybind11::module& m) {
   m.def("bind_heads", &bind_heads);
   m.def("scene_head", &scene_head);
   m.def("attr_head", &attr_head);
+  m.def("cosine_rows", &cosine_rows);
   m.def("total_loss", &total_loss);
   m.def("relation_head", &relation_head);
   m.def("lang_pool", &lang_pool);

@@ -568,6 +568,20 @@ extern "C" int irx_encoder_submit(int lane, int backward, const int64_t* desc, c
   return IRX_OK;
 }
 
+// `to` continues behind everything enqueued on `from` so far (an event from a small per-thread ring is recorded on `from`
+// and waited for on `to`): lets a caller that issues one operator's independent halves on two streams order them without owning
+// HIP events (csrc/heads_nodes.cpp: the scene head's weight gradients beside its data-gradient chain).
+extern "C" int irx_stream_fork(void* from, void* to) {
+  IRX_REQUIRE(from != to, "irx_stream_fork: the two streams are the same");
+  static thread_local hipEvent_t ring[16] = {nullptr};
+  static thread_local unsigned next = 0;
+  hipEvent_t& e = ring[next++ & 15];
+  if (!e) IRX_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), "irx_stream_fork(event)");
+  IRX_CHECK_HIP(hipEventRecord(e, (hipStream_t)from), "irx_stream_fork(record)");
+  IRX_CHECK_HIP(hipStreamWaitEvent((hipStream_t)to, e, 0), "irx_stream_fork(wait)");
+  return IRX_OK;
+}
+
 extern "C" int irx_encoder_wait(int lane) {
   IRX_REQUIRE(lane >= 0 && lane < kLanes, "irx_encoder_wait: lane %d outside [0, %d)", lane, kLanes);
   EncLane* L = lane_of(lane);

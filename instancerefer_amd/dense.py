@@ -412,7 +412,7 @@ def _dropout_seed(device):
     return (gen.initial_seed() * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03 + 1) & 0xFFFFFFFFFFFFFFFF
 
 
-def mlp2(seq, x):
+def mlp2(seq, x, seed=None):
     """Apply a head MLP `seq` = nn.Sequential(Linear, BatchNorm1d | LayerNorm, ReLU, [Dropout], Linear) to (rows, C) device rows
     through the fused operator; anything else (host tensors, another layout, sync-BatchNorm over more than one rank, a
     single row in training) goes through the module itself. Same parameters, buffers and state-dict keys either way."""
@@ -443,7 +443,8 @@ def mlp2(seq, x):
             _counters.bump([nrm.num_batches_tracked])
     else:
         norm, rmean, rvar, momentum = 3, None, None, 0.0
-    seed = _dropout_seed(x.device) if drop_p > 0 else 0
+    if seed is None or drop_p <= 0:                      # (seed: a caller that draws its seeds up front, heads.draw_seeds)
+        seed = _dropout_seed(x.device) if drop_p > 0 else 0
     if backend != "py":
         # C++ node: the optimizer's slot addresses (gradient sink) are looked up once per MLP and travel as integers
         slots, keep = (), ()

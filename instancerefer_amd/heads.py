@@ -25,6 +25,8 @@ from . import _lib
 from .dense import _dropout_seed
 
 FUSED = os.environ.get("IRX_FUSED_HEADS", "1") != "0"
+AUX_WGRAD = os.environ.get("IRX_HEAD_AUX", "1") != "0"       # the scene head's weight gradients on a lent second stream (dev A/B; bit-identical)
+PRE_LANG = os.environ.get("IRX_PRE_LANG", "1") != "0"        # the heads' language-side MLPs as nodes of their own behind the language module
 CALLS = {"scene_head": 0, "attr_scene": 0, "total_loss": 0, "relation_head": 0, "lang_pool": 0}          # how often each node was taken (tests assert the path)
 
 
@@ -87,6 +89,55 @@ def _drop_p(m):
     return float(m.p) if m.training else 0.0
 
 
+# ----------------------------------------------------------------------------------------------------- per-forward seeds
+SEED_NAMES = ("rel_lang", "rel_vis", "scene_conv", "scene_lang", "fc1")
+
+
+def draw_seeds(data_dict, device):
+    """Every dropout seed of the fused heads for ONE forward, drawn on the calling (training) thread in a fixed order — the heads run
+    on three streams and two threads, and seeds drawn where they are used would depend on which thread reaches the generator first
+    (ADVICE r5). Stored as data_dict['_seeds']; a head that finds none draws its own."""
+    data_dict['_seeds'] = {n: _dropout_seed(device) for n in SEED_NAMES}
+
+
+def _seed(data_dict, name, device, p):
+    if p <= 0:
+        return 0
+    seeds = data_dict.get('_seeds')
+    return seeds[name] if seeds is not None else _dropout_seed(device)
+
+
+# ------------------------------------------------------------------- the heads' language-side MLPs, ahead of the heads
+def pre_lang_ok(model, data_dict):
+    """The scene head's and the attribute head's lang_emb_fc depend on the language module only: run as nodes of their own right
+    behind it (on the language stream, by the helper thread) they leave both heads' chains — 2 launches forward and 2-3 backward per
+    head that sat between an encoder and its backward. Only when both fused heads will run (training, the reference's layout)."""
+    if not PRE_LANG or _mod() is None or not (model.training and torch.is_grad_enabled()):
+        return False
+    a = model.args
+    if not (a.attribute_module and a.scene_module and hasattr(model.scene, 'head')):
+        return False
+    lang = data_dict['lang_feat']
+    prep = data_dict.get('_attr_prepared')
+    return (lang.is_cuda and lang.shape[0] >= 2 and prep is not None and prep[0] is not None
+            and _mlp_ok(model.scene.lang_emb_fc, "ln", True) and _mlp_ok(model.attribute.lang_emb_fc, "bn", False))
+
+
+class PreLang:
+    """callable(data_dict) -> data_dict with '_scene_lang_h' / '_attr_lang_h' (dense.mlp2: one C++ node each)"""
+
+    def __init__(self, model):
+        self.scene_fc, self.attr_fc = model.scene.lang_emb_fc, model.attribute.lang_emb_fc
+
+    def __call__(self, data_dict):
+        from .dense import mlp2
+        dev = data_dict['lang_scene_feats'].device
+        data_dict['_scene_lang_h'] = mlp2(self.scene_fc, data_dict['lang_scene_feats'],
+                                          seed=_seed(data_dict, "scene_lang", dev, _drop_p(self.scene_fc[3])))
+        data_dict['_attr_lang_h'] = mlp2(self.attr_fc, data_dict['lang_attr_feats'])
+        return data_dict
+
+
 # ---------------------------------------------------------------------------------------------------------------- scene head
 def scene_head_ok(sm, feats, lang_feats):
     mod = _mod()
@@ -111,6 +162,7 @@ def scene_head(sm, feats, data_dict):
     mod = scene_head_ok(sm, feats, lang_feats)
     if mod is None:
         return False
+    pre = data_dict.pop('_scene_lang_h', None)       # lang_emb_fc already applied (PreLang), or None: the node runs it
     from .basic_blocks import _grid_tables
     batch_size = data_dict['point_min'].shape[0]
     x = feats.canonical()
@@ -129,23 +181,25 @@ def scene_head(sm, feats, data_dict):
     cache = sm.__dict__.get('_irx_head_params')
     if cache is None:
         bn0, bn1, cls = sm.to_bev[2], ve[1], sm.cls
-        params = [bev.kernel, bn0.weight, bn0.bias, ve[0].weight, ve[0].bias, bn1.weight, bn1.bias, ve[4].weight, ve[4].bias]
-        params += _mlp_params(sm.lang_emb_fc) + _mlp_params(cls)
+        base = [bev.kernel, bn0.weight, bn0.bias, ve[0].weight, ve[0].bias, bn1.weight, bn1.bias, ve[4].weight, ve[4].bias]
         stats = [bn0.running_mean, bn0.running_var, bn1.running_mean, bn1.running_var, cls[1].running_mean, cls[1].running_var]
         counters = [b.num_batches_tracked for b in (bn0, bn1, cls[1]) if b.num_batches_tracked is not None]
-        cache = sm.__dict__['_irx_head_params'] = (params, stats, counters)
-    params, stats, counters = cache
+        cache = sm.__dict__['_irx_head_params'] = (base + _mlp_params(sm.lang_emb_fc) + _mlp_params(cls), base + _mlp_params(cls),
+                                                   stats, counters)
+    params = cache[1] if pre is not None else cache[0]
+    stats, counters = cache[2], cache[3]
     bn0, bn1 = sm.to_bev[2], ve[1]
-    p_conv, p_lang = _drop_p(ve[3]), _drop_p(sm.lang_emb_fc[3])
+    p_conv, p_lang = _drop_p(ve[3]), (0.0 if pre is not None else _drop_p(sm.lang_emb_fc[3]))
     dev = x.F.device
-    # seeds in the per-operator path's order: the dropout between the two Conv2d first, then the language MLP's
-    s_conv = _dropout_seed(dev) if p_conv > 0 else 0
-    s_lang = _dropout_seed(dev) if p_lang > 0 else 0
+    s_conv = _seed(data_dict, "scene_conv", dev, p_conv)
+    s_lang = _seed(data_dict, "scene_lang", dev, p_lang)
     f = [bn0.eps, bn0.momentum, bn1.eps, bn1.momentum, p_conv, sm.lang_emb_fc[1].eps, p_lang, sm.cls[1].eps, sm.cls[1].momentum]
-    slots, keep = _sink(("scene_head", id(sm)), params)
-    atten, seg, vec = mod.scene_head(x.F, lang_feats, tbl, cell, zbin, ncell, batch_size, [f0, b0, f1, b1],
-                                     [n_out0, n_in0, n_out1, n_in1], params, stats, f, [_i64(s_conv), _i64(s_lang)],
-                                     _lib.stream_ptr(), list(slots), list(keep))
+    slots, keep = _sink(("scene_head", id(sm), pre is not None), params)
+    aux = data_dict.get('_aux_stream')               # a second stream for the backward's weight gradients (InstanceRefer lends one)
+    aux = [aux.cuda_stream, aux.stream_id, aux.device_index, aux.device_type] if (aux is not None and AUX_WGRAD) else []
+    atten, seg, vec = mod.scene_head(x.F, pre if pre is not None else lang_feats, pre is not None, tbl, cell, zbin, ncell, batch_size,
+                                     [f0, b0, f1, b1], [n_out0, n_in0, n_out1, n_in1], params, stats, f, [_i64(s_conv), _i64(s_lang)],
+                                     _lib.stream_ptr(), aux, list(slots), list(keep))
     if counters:
         from . import _counters
         _counters.bump(counters)
@@ -158,12 +212,12 @@ def scene_head(sm, feats, data_dict):
 
 
 # ------------------------------------------------------------------------------------------- attribute head + scene scores
-def attr_scene_ok(am, sm, data_dict):
+def attr_head_ok(am, sm, data_dict):
     mod = _mod()
-    if mod is None or not (am.training and sm.training and torch.is_grad_enabled()):
+    if mod is None or not hasattr(mod, "cosine_rows") or not (am.training and sm.training and torch.is_grad_enabled()):
         return None
     prep = data_dict.get('_attr_prepared')
-    if prep is None or prep[0] is None or '_scene_feats' not in data_dict:
+    if prep is None or prep[0] is None:
         return None
     lang = data_dict['lang_attr_feats']
     ok = (lang.is_cuda and lang.shape[0] >= 2 and _mlp_ok(am.lang_emb_fc, "bn", False) and _mlp_ok(am.vis_emb_fc, "ln", False)
@@ -171,11 +225,12 @@ def attr_scene_ok(am, sm, data_dict):
     return mod if ok else None
 
 
-def attr_scene(am, sm, data_dict):
-    """AttributeModule.forward followed by SceneModule.forward's candidate scores, as one node: fills num_filtered_objs,
-    pred_obb_batch, obj_feats, attribute_scores, scene_scores, _sel_dev. Needs the prepared candidates (InstanceRefer.prepare) and
-    the scene vector (SceneModule.head). -> True, or False when the per-operator path has to run."""
-    mod = attr_scene_ok(am, sm, data_dict)
+def attr_head(am, sm, data_dict):
+    """AttributeModule.forward plus the candidate side of SceneModule.forward's scores (vis_emb_fc1) as one node: fills
+    num_filtered_objs, pred_obb_batch, obj_feats, attribute_scores, _sel_dev and '_obj_h' (what scene_scores() takes against the scene
+    vector). Needs the prepared candidates (InstanceRefer.prepare) but NOT the scene head: it runs beside it, forward and backward.
+    -> True, or False when the per-operator path has to run."""
+    mod = attr_head_ok(am, sm, data_dict)
     if mod is None:
         return False
     from .data import selection_on_device, upload_instances
@@ -194,29 +249,40 @@ def attr_scene(am, sm, data_dict):
     dev = x.F.device
     sd = selection_on_device(sel, upload_instances(data_dict), dev)
     data_dict['_sel_dev'] = sd
+    pre = data_dict.pop('_attr_lang_h', None)
     cache = am.__dict__.get('_irx_head_params')
-    if cache is None or cache[3] is not sm:
-        params = _mlp_params(am.lang_emb_fc) + _mlp_params(am.vis_emb_fc) + _mlp_params(sm.vis_emb_fc1)
+    if cache is None or cache[4] is not sm:
+        tail = _mlp_params(am.vis_emb_fc) + _mlp_params(sm.vis_emb_fc1)
         bn = am.lang_emb_fc[1]
-        cache = am.__dict__['_irx_head_params'] = (params, [bn.running_mean, bn.running_var],
+        cache = am.__dict__['_irx_head_params'] = (_mlp_params(am.lang_emb_fc) + tail, tail, [bn.running_mean, bn.running_var],
                                                    [bn.num_batches_tracked] if bn.num_batches_tracked is not None else [], sm)
-    params, stats, counters, _ = cache
+    params = cache[1] if pre is not None else cache[0]
+    stats, counters = cache[2], ([] if pre is not None else cache[3])
     bn = am.lang_emb_fc[1]
     p_fc1 = _drop_p(sm.vis_emb_fc1[3])
-    s_fc1 = _dropout_seed(dev) if p_fc1 > 0 else 0
-    f = [bn.eps, bn.momentum, am.vis_emb_fc[1].eps, sm.vis_emb_fc1[1].eps, p_fc1, 1e-12, 1e-8]
-    slots, keep = _sink(("attr_scene", id(am)), params)
-    scene_vec = data_dict.pop('_scene_feats')
-    obj, s_attr, s_scene = mod.attr_head(x.F, lv.offsets(), lv.batch_size, sd['cand_scene'], data_dict['lang_attr_feats'], scene_vec,
-                                         params, stats, f, [_i64(s_fc1)], _lib.stream_ptr(), list(slots), list(keep))
+    s_fc1 = _seed(data_dict, "fc1", dev, p_fc1)
+    f = [bn.eps, bn.momentum, am.vis_emb_fc[1].eps, sm.vis_emb_fc1[1].eps, p_fc1, 1e-12]
+    slots, keep = _sink(("attr_head", id(am), pre is not None), params)
+    obj, s_attr, obj_h = mod.attr_head(x.F, lv.offsets(), lv.batch_size, sd['cand_scene'], pre if pre is not None else data_dict['lang_attr_feats'],
+                                       pre is not None, params, stats, f, [_i64(s_fc1)], _lib.stream_ptr(), list(slots), list(keep))
     if counters:
         from . import _counters
         _counters.bump(counters)
     data_dict['obj_feats'] = obj
     data_dict['attribute_scores'] = s_attr
-    data_dict['scene_scores'] = s_scene
+    data_dict['_obj_h'] = obj_h
     CALLS["attr_scene"] += 1
     return True
+
+
+def scene_scores(data_dict):
+    """cosine of every candidate's vis_emb_fc1 vector ('_obj_h', attr_head) against its scene's vector ('_scene_feats', scene head):
+    SceneModule.forward's score (reference models/scene_module.py:104-106) as a C++ node."""
+    mod = _mod()
+    obj_h = data_dict.pop('_obj_h')
+    vec = data_dict.pop('_scene_feats')
+    data_dict['scene_scores'] = mod.cosine_rows(obj_h, vec, data_dict['_sel_dev']['cand_scene'], 1e-8, _lib.stream_ptr())
+    return data_dict
 
 
 # ---------------------------------------------------------------------------------------------------------------------- loss
@@ -255,8 +321,8 @@ def relation_head(rm, lang_feats, prep, data_dict):
     bn = rm.lang_emb_fc[1]
     dev = lang_feats.device
     p_lang, p_vis = _drop_p(rm.lang_emb_fc[3]), _drop_p(rm.vis_emb_fc[3])
-    s_lang = _dropout_seed(dev) if p_lang > 0 else 0          # (the per-operator path's order: language MLP, then visual MLP)
-    s_vis = _dropout_seed(dev) if p_vis > 0 else 0
+    s_lang = _seed(data_dict, "rel_lang", dev, p_lang)
+    s_vis = _seed(data_dict, "rel_vis", dev, p_vis)
     f = [bn.eps, bn.momentum, p_lang, rm.vis_emb_fc[1].eps, p_vis, 1e-8]
     slots, keep = _sink(("relation_head", id(rm)), params)
     (scores,) = mod.relation_head(lang_feats, feats, centres, sd['query_in_support'], nbr, sd['cand_scene'], gcn.num_classes, params, stats,

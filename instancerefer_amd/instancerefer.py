@@ -38,6 +38,9 @@ _WGRAD_LANG = _os.environ.get('IRX_WGRAD_LANG', '0') == '1'
 # creation order of the two encoders' nodes = reverse order of their backward passes: 'sc' (default) issues the candidate encoder's
 # backward first, then the scene encoder's; 'cs' the other way round (dev A/B)
 _ATTACH_ORDER = ('_attr_encoded', '_scene_encoded') if _os.environ.get('IRX_ATTACH_ORDER', 'sc') == 'cs' else ('_scene_encoded', '_attr_encoded')
+# Measured (round 6, B = 16 bf16, one box, alternating runs): attr_first + gate 3.829 ms per step, attr_first without the gate 4.242,
+# scene_first without the gate 4.142, scene_first + gate 5.200 (the scene pass, issued first, polls for the candidate pass's mark)
+_HEAD_ORDER = _os.environ.get('IRX_HEAD_ORDER', 'attr_first')      # see _forward_streams (dev A/B)
 _SEQ_BUMP = int(_os.environ.get('IRX_SEQ_BUMP', '256'))          # 0: leave the autograd sequence numbers alone (dev A/B)
 MARK = None        # dev: bench.py's timeline mode installs a callable(name) here (phase marks inside forward)
 _ATTR_EARLY = _os.environ.get('IRX_ATTR_EARLY')   # dev A/B switch: '0' / '1' overrides the policy in forward()
@@ -74,8 +77,8 @@ class _LangWorker:
                     for i, m in enumerate(mods):
                         if m is not None:
                             dd = m(dd)
-                        if i == 0 and dd.get('_lang_event') is not None:
-                            dd['_lang_event'].record(stream)             # the language features are complete on `stream`
+                        if i == 1 and dd.get('_lang_event') is not None:
+                            dd['_lang_event'].record(stream)             # language features (+ the heads' language MLPs) complete
                 q_out.put((seq, dd))
             except BaseException as e:              # surfaced by the training thread at join time
                 q_out.put((seq, e))
@@ -211,7 +214,9 @@ class InstanceRefer(nn.Module):
         rel = bool(rel and self.args.relation_module and '_rel_prepared' in data_dict)
         orig = dict(data_dict)                          # what was there when the job was posted
         sub = dict(orig)                                # the worker adds / replaces keys in its own shallow copy
-        seq = w.post((self.lang, self.relation if rel else None), sub, stream)
+        from . import heads
+        pre = heads.PreLang(self) if heads.pre_lang_ok(self, data_dict) else None     # the heads' language-side MLPs (heads.py)
+        seq = w.post((self.lang, pre, self.relation if rel else None), sub, stream)    # (the worker records _lang_event behind slot 1)
 
         def join():
             out = w.take(seq)
@@ -272,11 +277,14 @@ class InstanceRefer(nn.Module):
             self.scene.net._irx_bwd_gate = self.attribute.net._irx_bwd_gate = None
         if _SEQ_BUMP:
             self._bump_sequence()
+        from . import heads
+        heads.draw_seeds(data_dict, dev)                     # every dropout seed of the fused heads, in a fixed order, on this thread
         lstream = self._aux_stream(dev)
-        # the scene encoder's backward (the step's long pole) issues its weight gradients on the language stream, beside its own
-        # BatchNorm-backward / data-gradient chain (sparse/encoder_fn.py WGRAD_STREAM)
+        # the scene encoder's backward (the step's long pole) can issue its weight gradients on the language stream, beside its own
+        # BatchNorm-backward / data-gradient chain (sparse/encoder_fn.py WGRAD_STREAM; measured negative, off)
         self.scene.net.__dict__['_irx_wgrad_stream'] = lstream.cuda_stream if _WGRAD_LANG else None
         self.attribute.net.__dict__['_irx_wgrad_stream'] = None
+        data_dict['_aux_stream'] = lstream                   # lent to the scene head's backward for its weight gradients (heads.py)
         side.wait_stream(main)                               # inputs and the optimizer's parameter update are complete
         lstream.wait_stream(main)
         self.hand_over(data_dict, lstream)                   # prepared tensors (relation node features, index lists) used on `lang`
@@ -304,17 +312,32 @@ class InstanceRefer(nn.Module):
         else:
             with torch.cuda.stream(lstream):
                 data_dict = self.lang(data_dict)
+                if heads.pre_lang_ok(self, data_dict):
+                    data_dict = heads.PreLang(self)(data_dict)
                 data_dict['_lang_event'].record(lstream)
                 data_dict = self.relation(data_dict)
         ev = data_dict.pop('_lang_event')
         if MARK: MARK("fwd: lang joined")
-        for k in ('lang_attr_feats', 'lang_scene_feats'):    # (views of one tensor, or four tensors: heads.lang_pool)
-            data_dict[k].record_stream(main)
-            data_dict[k].record_stream(side)
+        for k in ('lang_attr_feats', 'lang_scene_feats', '_attr_lang_h', '_scene_lang_h'):   # produced on the language stream
+            if isinstance(data_dict.get(k), torch.Tensor):
+                data_dict[k].record_stream(main)
+                data_dict[k].record_stream(side)
         # scene head on the encoder's stream (its launches were issued by a library thread: wait for that first)
         lane_wait(lane_of(self.scene.net))
-        for k in _ATTACH_ORDER:                              # (creation order = reverse backward order: see _attach)
-            self._attach(data_dict, k)
+        split = heads.attr_head_ok(self.attribute, self.scene, data_dict) is not None
+        main.wait_event(ev)
+        # Creation order of the nodes = reverse order of the backward (see _attach). _HEAD_ORDER 'scene_first': candidate encoder node,
+        # attribute head, scene encoder node, scene head, scene scores, loss -> backward: loss, scene scores, scene head, SCENE ENCODER,
+        # attribute head, candidate encoder. 'attr_first': scene encoder node, candidate encoder node, scene head, attribute head,
+        # scene scores -> backward: ..., attribute head, scene head, candidate encoder, scene encoder.
+        if split and _HEAD_ORDER == 'scene_first':
+            self._attach(data_dict, '_attr_encoded')
+            heads.attr_head(self.attribute, self.scene, data_dict)
+            if MARK: MARK("fwd: attribute head issued")
+            self._attach(data_dict, '_scene_encoded')
+        else:
+            for k in _ATTACH_ORDER:
+                self._attach(data_dict, k)
         with torch.cuda.stream(side):
             side.wait_event(ev)
             data_dict = self.scene.head(data_dict)
@@ -328,26 +351,24 @@ class InstanceRefer(nn.Module):
                     side.wait_stream(main)                   # the candidate levels' kernel maps were built on the main stream
                     prebuild_backward(self.attribute.net, prep[0].level(), use_stream=main)
         if MARK: MARK("fwd: scene head issued")
-        main.wait_event(ev)
-        from . import heads
-        if heads.attr_scene_ok(self.attribute, self.scene, data_dict) is not None:
-            # attribute head + scene scores as ONE autograd node (csrc/heads_nodes.cpp): it needs the scene vector up front
-            main.wait_stream(side)
-            for k in ('_scene_feats', 'seg_scores', 'vis_atten'):
-                data_dict[k].record_stream(main)
-            heads.attr_scene(self.attribute, self.scene, data_dict)
+        if split and _HEAD_ORDER != 'scene_first':
+            heads.attr_head(self.attribute, self.scene, data_dict)       # beside the scene head: it does not need the scene vector
             if MARK: MARK("fwd: attribute head issued")
-        else:
+        if not split:
             data_dict = self.attribute(data_dict)
             if MARK: MARK("fwd: attribute head issued")
-            main.wait_stream(side)
-            for k in ('_scene_feats', 'seg_scores', 'vis_atten'):
-                data_dict[k].record_stream(main)
+        main.wait_stream(side)
+        for k in ('_scene_feats', 'seg_scores', 'vis_atten'):
+            data_dict[k].record_stream(main)
+        if split:
+            data_dict = heads.scene_scores(data_dict)        # cosine(vis_emb_fc1(obj_feats), scene vector): needs both heads
+        else:
             data_dict = self.scene(data_dict)                # scene scores: needs obj_feats and the scene vector
         main.wait_stream(lstream)
         for k in ('relation_scores', 'lang_scores', 'lang_feat', 'atten_attr'):
             if isinstance(data_dict.get(k), torch.Tensor):
                 data_dict[k].record_stream(main)
+        data_dict.pop('_aux_stream', None)
         return data_dict
 
     @staticmethod
@@ -402,6 +423,9 @@ class InstanceRefer(nn.Module):
         lang_join = None
         if _SEQ_BUMP and self.training and data_dict['lang_feat'].is_cuda:
             self._bump_sequence()
+        if self.training and data_dict['lang_feat'].is_cuda:
+            from . import heads as _h
+            _h.draw_seeds(data_dict, data_dict['lang_feat'].device)
         if _LANG_THREAD and self.training and data_dict['lang_feat'].is_cuda:
             lang_join = self._lang_async(data_dict)
         try:
@@ -448,7 +472,9 @@ class InstanceRefer(nn.Module):
             for k in _ATTACH_ORDER:
                 self._attach(data_dict, k)
             data_dict = self.scene.head(data_dict)
-            if not heads.attr_scene(self.attribute, self.scene, data_dict):
+            if heads.attr_head(self.attribute, self.scene, data_dict):
+                data_dict = heads.scene_scores(data_dict)
+            else:
                 data_dict = self.attribute(data_dict)
                 data_dict = self.scene(data_dict)
         elif self.args.scene_module:

@@ -89,7 +89,8 @@ class SceneModule(nn.Module):
         rows = conv2d_rows(self.vis_emb_fc[4], rows, batch_size, nx - 2, ny - 2)  # -> (B*11*21, D)
         h, w = nx - 4, ny - 4
         feats = rows.view(batch_size, h * w, self.h_dim)                        # (B, n_vis, D)
-        lang_feats = mlp2(self.lang_emb_fc, lang_feats)
+        pre = data_dict.pop('_scene_lang_h', None)                              # already through lang_emb_fc (heads.PreLang)
+        lang_feats = pre if pre is not None else mlp2(self.lang_emb_fc, lang_feats)
         if feats.is_cuda and _FUSED_ATTN and feats.shape[2] <= 256:
             atten, scene_feats = AttentionPoolFn.apply(feats, lang_feats)     # one launch each way (csrc/irx_match.hip)
         else:

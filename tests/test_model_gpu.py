@@ -513,7 +513,8 @@ def test_gradient_sink_equals_autograd_accumulation(lib):
     # C++ producers: round 5 = 7 head MLPs + 2 GRU layers; with one node per head (heads.py) = scene head + attribute/scene-score head
     # + the relation head's 2 MLPs + 2 GRU layers
     # ... then the relation head as one node (its 2 MLPs inside) and the language attention pooling: 4 head nodes + 2 GRU layers
-    expect = 0 if (_nodes.load() is None or dense.FUSED_MLP2 is False) else (6 if heads._mod() is not None else 9)
+    # ... and the two heads' language-side MLPs as nodes of their own (heads.PreLang): 4 head nodes + 2 MLPs + 2 GRU layers
+    expect = 0 if (_nodes.load() is None or dense.FUSED_MLP2 is False) else (8 if heads._mod() is not None else 9)
     assert out["sink"][3] == expect and out["autograd"][3] == 0, out["sink"][3]
     assert out["sink"][0] == out["autograd"][0], (out["sink"][0], out["autograd"][0])
     assert torch.equal(out["sink"][1], out["autograd"][1])
