@@ -326,7 +326,7 @@ struct AuxStream {
 // lent second stream (aux) they are issued there, behind an event on the chain, and the chain is 21 launches instead of 35.
 // =================================================================================================================================
 struct SceneHeadNode : public HeadNode {
-  Tensor feats, bev_tbl, cell, zbin;
+  Tensor feats, bev_tbl, bev_tbl_t;             // bev_tbl_t: the transposed table (8, max(n, 1)) of the data gradient
   int ncell = 0, B = 0, n_vis = 0;
   BnRows bn0, bn1;
   Conv2dRows cv0, cv1;
@@ -340,7 +340,7 @@ struct SceneHeadNode : public HeadNode {
   std::string name() const override { return "irx::SceneHeadNode"; }
   void release_variables() override {
     released = true;
-    feats = bev_tbl = cell = zbin = rows4 = lang_h = atten = scene_vec = Tensor();
+    feats = bev_tbl = bev_tbl_t = rows4 = lang_h = atten = scene_vec = Tensor();
     bn0.reset(); bn1.reset(); cv0.reset(); cv1.reset(); lang.reset(); cls.reset();
   }
 
@@ -369,10 +369,8 @@ struct SceneHeadNode : public HeadNode {
     const Tensor& kernel = params[0];
     const int K = (int)kernel.size(0), n = (int)feats.size(0), ld_b = n > 0 ? n : 1;
     if (should_compute_output(0)) {
-      Tensor tbl_b = at::empty({8, ld_b}, bev_tbl.options());
-      check(api.kdt(cell.data_ptr<int32_t>(), zbin.data_ptr<uint8_t>(), n, tbl_b.data_ptr<int32_t>(), ld_b, stream),
-            "irx_kmap_down_transpose");
-      out[0] = conv_rows(g4, kernel, tbl_b, ld_b, n, 0, 1, stream);
+      TORCH_CHECK(bev_tbl_t.size(0) == 8 && bev_tbl_t.size(1) == ld_b, "scene head: transposed BEV table shape");
+      out[0] = conv_rows(g4, kernel, bev_tbl_t, ld_b, n, 0, 1, stream);
     }
     // the language MLP (unless it is a node of its own): its output gradient leaves this node, so it stays on the node's stream
     if (!pre_lang) {
@@ -409,8 +407,8 @@ struct SceneHeadNode : public HeadNode {
   }
 };
 
-std::vector<Tensor> scene_head(const Tensor& feats_in, const Tensor& lang_in, bool pre_lang, const Tensor& bev_tbl, const Tensor& cell,
-                               const Tensor& zbin, int64_t ncell, int64_t B, std::vector<Tensor> grid, std::vector<int64_t> grid_n,
+std::vector<Tensor> scene_head(const Tensor& feats_in, const Tensor& lang_in, bool pre_lang, const Tensor& bev_tbl, const Tensor& bev_tbl_t,
+                               int64_t ncell, int64_t B, std::vector<Tensor> grid, std::vector<int64_t> grid_n,
                                std::vector<Tensor> params, std::vector<Tensor> stats, std::vector<double> f, std::vector<int64_t> seeds,
                                int64_t stream_i, std::vector<int64_t> aux_stream, std::vector<int64_t> slot_ptrs, std::vector<Tensor> keep) {
   TORCH_CHECK(api.conv_fwd && api.bn_fwd && api.mlp2_fwd && api.attn_fwd, "irx nodes: bind_heads() has not been called");
@@ -431,7 +429,7 @@ std::vector<Tensor> scene_head(const Tensor& feats_in, const Tensor& lang_in, bo
     at::NoGradGuard ng;
     const std::vector<Tensor>& P = s.params;
     s.feats = f32c(feats_in);
-    s.bev_tbl = bev_tbl; s.cell = cell; s.zbin = zbin;
+    s.bev_tbl = bev_tbl; s.bev_tbl_t = bev_tbl_t;
     s.ncell = (int)ncell; s.B = (int)B;
     s.bn0.p0 = 1; s.bn0.rmean = stats[0]; s.bn0.rvar = stats[1]; s.bn0.eps = (float)f[0]; s.bn0.momentum = (float)f[1];
     s.cv0.p0 = 3; s.cv0.fwd_tbl = grid[0]; s.cv0.bwd_tbl = grid[1]; s.cv0.n_out = (int)grid_n[0]; s.cv0.n_in = (int)grid_n[1];

@@ -171,6 +171,7 @@ def scene_head(sm, feats, data_dict):
     nx, ny = bev.bev_shape
     nz = bev.n_kernels
     tbl, cell, zbin = lv.bev(nx, ny, nz)
+    tbl_t = lv.bev_t(nx, ny, nz)                     # (both usually built by the preparation stage already)
     ncell = lv.batch_size * nx * ny
     if lv.batch_size != batch_size or x.F.shape[0] == 0:
         return False
@@ -197,7 +198,7 @@ def scene_head(sm, feats, data_dict):
     slots, keep = _sink(("scene_head", id(sm), pre is not None), params)
     aux = data_dict.get('_aux_stream')               # a second stream for the backward's weight gradients (InstanceRefer lends one)
     aux = [aux.cuda_stream, aux.stream_id, aux.device_index, aux.device_type] if (aux is not None and AUX_WGRAD) else []
-    atten, seg, vec = mod.scene_head(x.F, pre if pre is not None else lang_feats, pre is not None, tbl, cell, zbin, ncell, batch_size,
+    atten, seg, vec = mod.scene_head(x.F, pre if pre is not None else lang_feats, pre is not None, tbl, tbl_t, ncell, batch_size,
                                      [f0, b0, f1, b1], [n_out0, n_in0, n_out1, n_in1], params, stats, f, [_i64(s_conv), _i64(s_lang)],
                                      _lib.stream_ptr(), aux, list(slots), list(keep))
     if counters:

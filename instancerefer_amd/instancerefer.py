@@ -40,6 +40,7 @@ _WGRAD_LANG = _os.environ.get('IRX_WGRAD_LANG', '0') == '1'
 _ATTACH_ORDER = ('_attr_encoded', '_scene_encoded') if _os.environ.get('IRX_ATTACH_ORDER', 'sc') == 'cs' else ('_scene_encoded', '_attr_encoded')
 # Measured (round 6, B = 16 bf16, one box, alternating runs): attr_first + gate 3.829 ms per step, attr_first without the gate 4.242,
 # scene_first without the gate 4.142, scene_first + gate 5.200 (the scene pass, issued first, polls for the candidate pass's mark)
+_PREP_BEV = _os.environ.get('IRX_PREP_BEV', '1') == '1'           # dev A/B: the scene head's BEV tables built by the preparation stage
 _HEAD_ORDER = _os.environ.get('IRX_HEAD_ORDER', 'attr_first')      # see _forward_streams (dev A/B)
 _SEQ_BUMP = int(_os.environ.get('IRX_SEQ_BUMP', '256'))          # 0: leave the autograd sequence numbers alone (dev A/B)
 MARK = None        # dev: bench.py's timeline mode installs a callable(name) here (phase marks inside forward)
@@ -162,6 +163,14 @@ class InstanceRefer(nn.Module):
             if self.training and _PREP_TABLES:
                 # kernel maps, tile order and the backward-only tables (pair lists, transposed child maps) on the preparation stream
                 data_dict['lidar'].level().build_tables(backward=torch.is_grad_enabled(), pairs_level0=wide)
+            if self.training and _PREP_TABLES and _PREP_BEV and hasattr(getattr(self, 'scene', None), 'to_bev'):
+                # the dense-BEV gather tables of the scene head (forward table + its transpose for the data gradient): coordinate-only
+                lv = data_dict['lidar'].level()
+                while lv._down is not None:
+                    lv = lv._down.out_level
+                bev = self.scene.to_bev[1]
+                if lv.n > 0 and hasattr(bev, 'bev_shape'):
+                    lv.bev_t(bev.bev_shape[0], bev.bev_shape[1], bev.n_kernels)
         prep = data_dict.get('_attr_prepared')
         if self.training and _PREP_TABLES and prep is not None and prep[0] is not None:
             prep[0].level().build_tables(backward=torch.is_grad_enabled(), pairs_level0=wide)

@@ -252,6 +252,15 @@ class Level:
             self._bev[key] = F_.bev_table(self.coords, self.stride, self.batch_size, nx, ny, nz, self.table())
         return self._bev[key]
 
+    def bev_t(self, nx, ny, nz):
+        """The transposed BEV table (8, max(n, 1)) the data gradient of ToDenseBEVConvolution gathers through; cached, so that the
+        preparation stage can build it with the forward table (InstanceRefer.prepare_finish) instead of the head's backward chain."""
+        key = ("t", nx, ny, nz)
+        if key not in self._bev:
+            _, cell, zbin = self.bev(nx, ny, nz)
+            self._bev[key] = (F_.kmap_down_transpose(cell, zbin),)
+        return self._bev[key][0]
+
 
 class SparseTensor:
     def __init__(self, feats, coords, stride=1, batch_size=None, _level=None):
