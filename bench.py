@@ -118,6 +118,7 @@ def build_model(args_ns, workload, device):
 
 
 _SPIN_US = float(os.environ.get("IRX_BENCH_SPIN_US", "0"))
+_PREP_WORKER_ALL = os.environ.get("IRX_BENCH_PREP_WORKER", "launch") == "all"
 _MARKS = None          # dev (IRX_BENCH_TIMELINE=1): list receiving (name, event on the main stream, host clock) per step
 
 
@@ -265,7 +266,9 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
         w = state.get("worker")
         if w is None:
             w = state["worker"] = _Worker(torch.cuda.current_device())
-        w.post(lambda: prepare_next(model, resident, state, phase="launch"))
+        # IRX_BENCH_PREP_WORKER=all (dev A/B): the worker also FINISHES the preparation (waits for the level sizes, builds the kernel
+        # maps / tables) inside the backward window instead of the training thread doing that behind the optimizer
+        w.post(lambda: prepare_next(model, resident, state, phase="all" if _PREP_WORKER_ALL else "launch"))
     _mark("loss issued")
     # (an explicit unit gradient: loss.backward() alone allocates and fills a ones_like(loss) per step — ~0.1 ms of host time and a
     #  launch at the head of the backward; same arithmetic)
@@ -278,7 +281,7 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
         state["worker"].wait()
     opt.backward_step()          # one cat -> one all-reduce (N > 1) -> one fused Adam launch
     _mark("optimizer issued")
-    if state is not None and state.get("pipeline") and not state.get("threaded", True):
+    if state is not None and state.get("pipeline") and not state.get("threaded", True) and not (at_bwd and _PREP_WORKER_ALL):
         prepare_next(model, resident, state, phase="finish")   # level sizes arrived during the step: no wait
     return loss
 

@@ -6,6 +6,10 @@
 // descriptor table and launches the same kernels in the same order (results are bit-identical to the per-layer
 // C-ABI calls); the caller owns every buffer (one activation / gradient arena) and the workspace.
 #include "irx_common.h"
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
 #include "../../include/irx.h"
 #include <atomic>
 #include <chrono>
@@ -107,6 +111,16 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
 // 30-90 us): the candidate encoder's small levels took 2.6 ms beside the scene encoder's large ones against 0.5 ms alone
 // (profiles/r05_timeline_bf16.txt).  The gate orders them: the RECORDER marks the point where its levels below `rows` are done,
 // the WAITER does not start its levels of `rows` or more before that point.
+// a polite spin (the x86 pause intrinsic is not portable host code)
+static inline void irx_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#else
+  std::this_thread::yield();
+#endif
+}
 struct EncGate { int role = 0; int64_t rows = 0; uint64_t token = 0; };   // role 1 = recorder, 2 = waiter
 static thread_local EncGate g_gate_next;
 static std::atomic<uint64_t> g_gate_recorded{0};
@@ -138,7 +152,7 @@ static bool gate_step(const EncGate& g, bool fired, int64_t n_out, void* stream)
     const auto t0 = std::chrono::steady_clock::now();
     while (g_gate_recorded.load(std::memory_order_acquire) < g.token &&
            std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500))
-      __builtin_ia32_pause();
+      irx_cpu_relax();
     if (g_gate_recorded.load(std::memory_order_acquire) == g.token) (void)hipStreamWaitEvent((hipStream_t)stream, e, 0);
   }
   return true;
@@ -511,7 +525,7 @@ void lane_main(EncLane* L) {
       const auto t0 = std::chrono::steady_clock::now();
       while (L->queued.load(std::memory_order_acquire) == 0 &&
              std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(poll_us))
-        __builtin_ia32_pause();
+        irx_cpu_relax();
       std::unique_lock<std::mutex> lk(L->mu);
       L->cv_job.wait(lk, [&] { return !L->q.empty(); });
       j = std::move(L->q.front());
@@ -589,7 +603,7 @@ extern "C" int irx_encoder_wait(int lane) {
     const auto t0 = std::chrono::steady_clock::now();   // the pass is usually done or nearly done: poll briefly first
     while (L->pending.load(std::memory_order_acquire) != 0 &&
            std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2))
-      __builtin_ia32_pause();
+      irx_cpu_relax();
   }
   std::unique_lock<std::mutex> lk(L->mu);
   L->cv_done.wait(lk, [&] { return L->pending.load(std::memory_order_acquire) == 0; });

@@ -402,13 +402,17 @@ def mlp_relu2(seq, x):
     return y.view(*lead, lin2.out_features)
 
 
+_SEED_LOCK = __import__('threading').Lock()
+
+
 def _dropout_seed(device):
     """A 64-bit key for one dropout call, drawn host-side from the device's default generator: (seed, Philox offset), and the
     offset is advanced like a real dropout kernel would — so torch.manual_seed() reproduces the masks, two calls never share
     one, and no GPU work or sync is involved."""
     gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
-    off = gen.get_offset()
-    gen.set_offset(off + 4)
+    with _SEED_LOCK:                                   # (the helper thread draws too: read-modify-write of the offset, ADVICE r5)
+        off = gen.get_offset()
+        gen.set_offset(off + 4)
     return (gen.initial_seed() * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03 + 1) & 0xFFFFFFFFFFFFFFFF
 
 

@@ -41,6 +41,7 @@ _ATTACH_ORDER = ('_attr_encoded', '_scene_encoded') if _os.environ.get('IRX_ATTA
 # Measured (round 6, B = 16 bf16, one box, alternating runs): attr_first + gate 3.829 ms per step, attr_first without the gate 4.242,
 # scene_first without the gate 4.142, scene_first + gate 5.200 (the scene pass, issued first, polls for the candidate pass's mark)
 _PREP_BEV = _os.environ.get('IRX_PREP_BEV', '1') == '1'           # dev A/B: the scene head's BEV tables built by the preparation stage
+_GATE_TOKEN, _GATE_LOCK = [0], __import__('threading').Lock()
 _HEAD_ORDER = _os.environ.get('IRX_HEAD_ORDER', 'attr_first')      # see _forward_streams (dev A/B)
 _SEQ_BUMP = int(_os.environ.get('IRX_SEQ_BUMP', '256'))          # 0: leave the autograd sequence numbers alone (dev A/B)
 MARK = None        # dev: bench.py's timeline mode installs a callable(name) here (phase marks inside forward)
@@ -279,7 +280,11 @@ class InstanceRefer(nn.Module):
         side = self._encoder_stream(dev)
         # backward gate (irx_encoder_gate_next): the scene encoder's large levels start behind the candidate encoder's small ones
         if _BWD_GATE and _BWD_GATE_ROWS > 0:
-            tok = self.__dict__['_gate_token'] = self.__dict__.get('_gate_token', 0) + 1
+            # a process-wide, monotonic token (per-model counters restarting at 1 let a second model's first waiter see the
+            # first model's mark as its own and skip the gate)
+            with _GATE_LOCK:
+                _GATE_TOKEN[0] += 1
+                tok = _GATE_TOKEN[0]
             self.scene.net._irx_bwd_gate = (2, _BWD_GATE_WAIT_ROWS, tok)
             self.attribute.net._irx_bwd_gate = (1, _BWD_GATE_ROWS, tok)
         else:

@@ -52,11 +52,12 @@ def broadcast_buffers(module, src=0):
                 off += b.numel()
 
 
-# Generation of the native gradient sink: one process-wide counter that lives as long as the module (C++ nodes hold its
-# ADDRESS). Every FlatAdam construction bumps it; a node captures (generation, address) at forward time and delivers into the
-# optimizer's slots at backward time only if the counter still has that value — a node whose optimizer was replaced between its
-# forward and its backward returns ordinary gradient tensors instead of writing into a retired buffer.
-_SINK_GEN = np.zeros(1, dtype=np.int64)
+# Liveness of an optimizer's native gradient sink: a cell in the optimizer's own record tensor (row 256), 1 while this optimizer owns
+# its parameters' slots, 0 once another FlatAdam re-homed them. C++ nodes capture the cell's address at forward time (the record tensor
+# travels with the node, so the address stays valid) and deliver into the slots at backward time only while it still reads 1 — a node
+# whose optimizer was replaced between its forward and its backward returns ordinary gradient tensors. (Round 5 used ONE process-wide
+# generation counter: constructing a second optimizer — another model, a bench leg, a test — silently switched the first one's nodes
+# to the slow path for the rest of the run: ADVICE r5.)
 _SINK_LOCK = __import__("threading").Lock()
 
 
@@ -98,16 +99,19 @@ class FlatAdam:
         # parameters: no AccumulateGrad node, no .grad tensor, no copy at gather time for ~half of the parameters.
         self._index = {id(p): i for i, p in enumerate(self.params)}
         for p, slot in zip(self.params, self._slots):
+            prev = getattr(p, "_irx_sink", None)
+            if prev is not None and prev[0] is not self:
+                prev[0]._native_rec[256, 0] = 0              # that optimizer's slots are no longer this parameter's home: retire its sink
             p._irx_sink = (self, slot)
         # ... and the C++ autograd nodes (csrc/torch_nodes.cpp): they get the slot ADDRESSES at forward time and raise one host
         # flag per producer when their backward wrote them (no interpreter on that path); gather_grads() folds the flags in
         # one record per producer: [delivered flag, HIP stream the backward ran on]; a torch tensor so that the nodes can keep it
         # (and flat_g) alive for as long as their graph exists
-        self._native_rec_t = torch.zeros((256, 2), dtype=torch.int64)
+        self._native_rec_t = torch.zeros((257, 2), dtype=torch.int64)          # rows 0..255: producers; row 256: the liveness cell
         self._native_rec = self._native_rec_t.numpy()
         with _SINK_LOCK:
-            _SINK_GEN[0] += 1
-            self._gen = int(_SINK_GEN[0])
+            self._native_rec[256, 0] = 1
+            self._gen = 1
         self._native = {}               # producer key -> (record index, parameter indices, (slot addresses + record), keep-alive)
         self._direct = set()            # parameter indices whose slot already holds this step's gradient
         self._direct_groups = set()     # producer keys that delivered since the last zero_grad()
@@ -195,10 +199,10 @@ class FlatAdam:
                     except KeyError:
                         return None
                     j = len(self._native)
-                    if j >= self._native_rec.shape[0]:
+                    if j >= 256:
                         return None
                     vec = [self._slots[i].data_ptr() for i in idx] + [self._native_rec.ctypes.data + 16 * j, self._gen,
-                                                                      _SINK_GEN.ctypes.data]
+                                                                      self._native_rec.ctypes.data + 16 * 256]
                     ent = (j, idx, vec, [self.flat_g, self._native_rec_t])
                     self._native[key] = ent
         return ent[2], ent[3]

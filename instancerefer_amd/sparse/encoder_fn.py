@@ -571,7 +571,9 @@ class _Hidden:
 def apply_encoder(feats, encoder, layers, params):
     """EncoderFn.apply in its compact form when the parameters' gradients can go to an optimizer's sink (optim.FlatAdam re-homed
     them), else with every parameter as an input."""
-    if getattr(params[0], "_irx_sink", None) is not None and not feats.requires_grad:
+    # (ADVICE r5: the compact form's only autograd input is params[0] — a frozen stem kernel, or any frozen parameter, would leave
+    #  the whole encoder without a node or some parameters without a gradient path: every parameter must require grad)
+    if getattr(params[0], "_irx_sink", None) is not None and not feats.requires_grad and all(p.requires_grad for p in params):
         return EncoderFn.apply(feats, encoder, layers, params[0], _Hidden(params))
     return EncoderFn.apply(feats, encoder, layers, *params)
 

@@ -160,3 +160,21 @@ def test_encoder_backward_with_weight_gradients_on_a_lent_stream(lib, monkeypatc
     assert grads[True][0].keys() == grads[False][0].keys() and len(grads[True][0]) > 150
     for n, g in grads[True][0].items():
         assert torch.equal(g, grads[False][0][n]), n
+
+
+def test_two_optimizers_keep_their_native_sinks(lib, monkeypatch):
+    """the sink's liveness is the optimizer's own (a cell of its record tensor), not a process-wide generation — a second
+    model + optimizer in the process must not switch the first one's C++ nodes to the ordinary-gradient path; re-homing the SAME
+    parameters in a new optimizer retires the old one's sink."""
+    from instancerefer_amd.optim import FlatAdam
+    ma, mb = _model(False), _model(False)
+    oa = FlatAdam(ma.parameters(), lr=1e-3, weight_decay=0.0, world_size=1, module=ma)
+    ob = FlatAdam(mb.parameters(), lr=1e-3, weight_decay=0.0, world_size=1, module=mb)      # constructed AFTER oa
+    _step(ma, True, monkeypatch, oa)
+    _step(mb, True, monkeypatch, ob)
+    pa, pb = oa.native_delivered(), ob.native_delivered()
+    assert pa[0] >= 4 and pb[0] >= 4 and pa == pb, (pa, pb)
+    oc = FlatAdam(ma.parameters(), lr=1e-3, weight_decay=0.0, world_size=1, module=ma)      # takes ma's parameters over
+    assert oa._native_rec[256, 0] == 0 and oc._native_rec[256, 0] == 1 and ob._native_rec[256, 0] == 1
+    _step(ma, True, monkeypatch, oc)
+    assert oc.native_delivered()[0] >= 4
