@@ -307,6 +307,9 @@ def prime(model, resident, args, reducer, opt, state):
     snap = (opt.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), list(opt.steps), [b.clone() for b in bufs],
             torch.cuda.get_rng_state(), torch.get_rng_state())
     t0, done = time.perf_counter(), 0
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        n, min_s = max(n, 200 if min_s > 0 else n), 0.0     # every rank must run the SAME number of steps (collectives inside): a fixed count
     while done < n or (time.perf_counter() - t0 < min_s and done < 400):
         step_fn(model, resident, args.workload, reducer, opt, state)
         done += 1
