@@ -400,6 +400,10 @@ enum {
                                      * hipStream_t the weight gradients are issued on (a stream the caller already runs: every additional
                                      * stream of a process risks sharing a hardware queue with a busy one — measured: two library streams
                                      * beside the model's four HALVED the bf16 step) */
+  IRX_ENC_WROWS,                    /* row 0 only, with IRX_ENC_DC2: 0 = every layer's weight gradient goes to the second stream, else only
+                                     * those of layers with fewer than this many output rows (the latency-bound small levels, where the
+                                     * GPU idles between the chain's short kernels; on the large levels two saturating kernel families
+                                     * only take CUs from each other) */
   IRX_ENC_NFIELDS
 };
 /* Stream `to` continues behind everything enqueued on stream `from` so far (event record + wait; the library owns the events).

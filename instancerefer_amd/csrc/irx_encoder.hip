@@ -358,6 +358,7 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
     ev = t_ev;
   }
   float* const dc_main = dc_scratch;
+  const int64_t wrows = two ? desc[IRX_ENC_WROWS] : 0;
   IrxDySlabs pending;                        // gy of the layer about to be processed, still as its producer's offset-split slabs
   const EncGate gate = g_gate_next;          // (set for this call by irx_encoder_gate_next on this thread, or by the lane)
   g_gate_next = EncGate();
@@ -370,7 +371,8 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
       // the weight gradient of layer i + 2 read this scratch: it must be done before BatchNorm backward overwrites it
       if (i + 2 < n_layers) IRX_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ev[16 + i + 2], 0), "irx_encoder_backward(wait W)");
     }
-    void* const wstream = two ? (void*)sW : stream;
+    const bool lent = two && (wrows <= 0 || L.n_out < wrows);       // this layer's weight gradient on the second stream?
+    void* const wstream = lent ? (void*)sW : stream;
     const IrxDySlabs dys = pending;
     pending = IrxDySlabs();
     float* dres = nullptr;
@@ -402,7 +404,7 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
                              3, nullptr, nullptr, 0.0, nullptr, mk_beta, dys);
     }
     if (rc) return rc;
-    if (two) {
+    if (lent) {
       IRX_CHECK_HIP(hipEventRecord(ev[i], (hipStream_t)stream), "irx_encoder_backward(record E)");
       IRX_CHECK_HIP(hipStreamWaitEvent(sW, ev[i], 0), "irx_encoder_backward(wait E)");
     }
@@ -424,7 +426,7 @@ int encoder_backward_impl(const int64_t* desc, const double* fdesc, int n_layers
       rc = irx_spconv_wgrad_impl(L.x, dc_scratch, L.tbl, L.ld, L.n_out, L.K, L.cin, L.cout, L.dw, ws_w, r.wgrad, wstream, st, pl);
     }
     if (rc) return rc;
-    if (two) IRX_CHECK_HIP(hipEventRecord(ev[16 + i], sW), "irx_encoder_backward(record W)");
+    if (two) IRX_CHECK_HIP(hipEventRecord(ev[16 + i], (hipStream_t)wstream), "irx_encoder_backward(record W)");
     float* dx = (i > 0) ? (float*)desc[(size_t)(i - 1) * IRX_ENC_NFIELDS + IRX_ENC_GY] : dx0;
     if (dx && !(abl & 2)) {
       const int acc = (i > 0 && is_res_source[i - 1]) ? 1 : 0;

@@ -34,7 +34,7 @@ _REL_THREAD = _os.environ.get('IRX_REL_THREAD', '0') == '1'      # dev: the rela
 # 4.350 / 4.349 ms per step with it, 4.217 / 4.249 without — the two kernel families contend for the same CUs and the chain, which is
 # the long pole, slows down); with two library-owned streams instead the step HALVED its speed (9.19 ms: a sixth / seventh stream
 # shares a hardware queue with a busy one). OFF; IRX_WGRAD_LANG=1 enables it.
-_WGRAD_LANG = _os.environ.get('IRX_WGRAD_LANG', '0') == '1'
+_WGRAD_LANG = int(_os.environ.get('IRX_WGRAD_LANG', '0'))          # 1: the scene encoder's; 2: both encoders'
 # creation order of the two encoders' nodes = reverse order of their backward passes: 'sc' (default) issues the candidate encoder's
 # backward first, then the scene encoder's; 'cs' the other way round (dev A/B)
 _ATTACH_ORDER = ('_attr_encoded', '_scene_encoded') if _os.environ.get('IRX_ATTACH_ORDER', 'sc') == 'cs' else ('_scene_encoded', '_attr_encoded')
@@ -297,7 +297,7 @@ class InstanceRefer(nn.Module):
         # the scene encoder's backward (the step's long pole) can issue its weight gradients on the language stream, beside its own
         # BatchNorm-backward / data-gradient chain (sparse/encoder_fn.py WGRAD_STREAM; measured negative, off)
         self.scene.net.__dict__['_irx_wgrad_stream'] = lstream.cuda_stream if _WGRAD_LANG else None
-        self.attribute.net.__dict__['_irx_wgrad_stream'] = None
+        self.attribute.net.__dict__['_irx_wgrad_stream'] = lstream.cuda_stream if _WGRAD_LANG == 2 else None
         data_dict['_aux_stream'] = lstream                   # lent to the scene head's backward for its weight gradients (heads.py)
         side.wait_stream(main)                               # inputs and the optimizer's parameter update are complete
         lstream.wait_stream(main)

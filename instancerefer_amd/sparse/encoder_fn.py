@@ -97,7 +97,7 @@ def _ws(nbytes, dev):
 # field order of the descriptor table: include/irx.h, enum IRX_ENC_* (tests/test_abi_cpu.py checks the two agree)
 ENC_FIELDS = ("K", "CIN", "COUT", "N_IN", "N_OUT", "RES", "TBL", "LD", "TBL_B", "LD_B", "FLIP_B", "PAIR_IN", "PAIR_OUT",
               "PAIR_COUNTS", "LD_PAIRS", "W", "GAMMA", "BETA", "RUNNING_MEAN", "RUNNING_VAR", "X", "C", "Y", "MEAN",
-              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "MODE", "ORDER", "PROF", "DC2", "WSTREAM")
+              "INVSTD", "DW", "DGAMMA", "DBETA", "GY", "STORE", "MODE", "ORDER", "PROF", "DC2", "WSTREAM", "WROWS")
 _E = {n: i for i, n in enumerate(ENC_FIELDS)}
 _NF = len(ENC_FIELDS)
 _ALIGN = 64                                           # float32 elements (256 B)
@@ -221,6 +221,7 @@ TILE_ORDER_MIN_ROWS = int(os.environ.get("IRX_TILE_ORDER_MIN_ROWS", str(512 * 64
 # IRX_ENC_WSTREAM, include/irx.h; bit-identical) — for an encoder whose owner lends a stream (`_irx_wgrad_stream`: InstanceRefer's
 # three-stream forward lends the language stream to the scene encoder). IRX_WGRAD_STREAM=0 keeps the one-stream order.
 WGRAD_STREAM = os.environ.get("IRX_WGRAD_STREAM", "1") != "0"
+WGRAD_STREAM_ROWS = int(os.environ.get("IRX_WGRAD_STREAM_ROWS", "30000"))    # only layers with fewer output rows (0: all): IRX_ENC_WROWS
 
 # Tests only (tests/test_bf16_gpu.py): a dict that receives the executor's arenas, so that every layer's stored tensors
 # (conv output c_i, layer output y_i, gradient in flight gy_i) can be compared one layer at a time; None = no tracing.
@@ -510,6 +511,7 @@ class EncoderFn(torch.autograd.Function):
         if two:                          # weight gradients on a second stream the model lends (irx.h IRX_ENC_DC2 / IRX_ENC_WSTREAM)
             desc[0, _E["DC2"]] = gbase + dc_off + dc_size
             desc[0, _E["WSTREAM"]] = int(ctx.wstream)
+            desc[0, _E["WROWS"]] = WGRAD_STREAM_ROWS
         dfeats = torch.empty((layers[0].n_in, layers[0].cin), dtype=_f32, device=dev) if need_dx0 else None
         fdesc = ctx.fdesc
         nbytes = lib.irx_encoder_workspace_bytes(desc.ctypes.data, fdesc.ctypes.data, nl, 1)
