@@ -118,6 +118,8 @@ def build_model(args_ns, workload, device):
 
 
 _SPIN_US = float(os.environ.get("IRX_BENCH_SPIN_US", "0"))
+_SPIKES = [] if os.environ.get("IRX_BENCH_SPIKES") == "1" else None   # dev: host clock at the phase boundaries of every step
+_SPIKE_MARKS = []
 _PREP_WORKER_ALL = os.environ.get("IRX_BENCH_PREP_WORKER", "launch") == "all"
 _MARKS = None          # dev (IRX_BENCH_TIMELINE=1): list receiving (name, event on the main stream, host clock) per step
 
@@ -231,9 +233,16 @@ def take_prepared(model, state):
 def step_fn(model, resident, workload, reducer, opt, state=None):
     """One training step on the resident batch. Returns the loss tensor (no host sync)."""
     from instancerefer_amd.loss_helper import DatasetConfig, get_loss, compute_lang_classification_loss
+    _sp = [time.perf_counter()] if _SPIKES is not None else None
+    if _SPIKES is not None:
+        from instancerefer_amd import instancerefer as _IR
+        _fm = []
+        _IR.MARK = lambda name, _fm=_fm: _fm.append((name, time.perf_counter()))
+        _SPIKE_MARKS.append(_fm)
     dd = take_prepared(model, state) if state is not None else None
     if dd is None:
         dd = fresh_batch(resident)
+    if _sp is not None: _sp.append(time.perf_counter())
     at_bwd = state is not None and state.get("pipeline") and state.get("at_backward")
     if state is not None and state.get("pipeline") and not at_bwd:
         # batch N+1: threaded -> the whole preparation runs beside this step; inline -> only its launch phase now
@@ -247,6 +256,7 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
         while time.perf_counter() < t_end:
             pass
     dd = model(dd)
+    if _sp is not None: _sp.append(time.perf_counter())
     _mark("forward issued")
     if workload in ("full", "stress"):
         loss = get_loss(dd, step_fn.cfg)["loss"]
@@ -270,6 +280,7 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
         # maps / tables) inside the backward window instead of the training thread doing that behind the optimizer
         w.post(lambda: prepare_next(model, resident, state, phase="all" if _PREP_WORKER_ALL else "launch"))
     _mark("loss issued")
+    if _sp is not None: _sp.append(time.perf_counter())
     # (an explicit unit gradient: loss.backward() alone allocates and fills a ones_like(loss) per step — ~0.1 ms of host time and a
     #  launch at the head of the backward; same arithmetic)
     one = step_fn.__dict__.get("_one")
@@ -277,12 +288,18 @@ def step_fn(model, resident, workload, reducer, opt, state=None):
         one = step_fn.__dict__["_one"] = torch.ones_like(loss)
     loss.backward(gradient=one)
     _mark("backward returned")
+    if _sp is not None: _sp.append(time.perf_counter())
     if at_bwd:
         state["worker"].wait()
+    if _sp is not None: _sp.append(time.perf_counter())
     opt.backward_step()          # one cat -> one all-reduce (N > 1) -> one fused Adam launch
+    if _sp is not None: _sp.append(time.perf_counter())
     _mark("optimizer issued")
     if state is not None and state.get("pipeline") and not state.get("threaded", True) and not (at_bwd and _PREP_WORKER_ALL):
         prepare_next(model, resident, state, phase="finish")   # level sizes arrived during the step: no wait
+    if _sp is not None:
+        _sp.append(time.perf_counter())
+        _SPIKES.append(_sp)
     return loss
 
 
@@ -789,10 +806,14 @@ def main():
     if os.environ.get("IRX_BENCH_SWITCH_US"):          # dev A/B: GIL hand-over interval (default 5000 us)
         sys.setswitchinterval(float(os.environ["IRX_BENCH_SWITCH_US"]) * 1e-6)
     import gc
-    if os.environ.get("IRX_BENCH_GC", "freeze") == "freeze":
+    # (round 6: the 6-10 ms pauses on every ~30th step that IRX_BENCH_SPIKES=1 showed were generation-2 collections of a reference
+    #  cycle per coordinate pyramid — level -> cached encoder plan -> level, ~200 objects and ~120 device tensors per step — fixed in
+    #  sparse/encoder_fn.Plan; freeze / off / default now time the same, tools/micro/gc_cycles.py counts what a step leaves behind)
+    gc_mode = os.environ.get("IRX_BENCH_GC", "freeze")
+    if gc_mode == "freeze":
         gc.collect()
         gc.freeze()
-    elif os.environ.get("IRX_BENCH_GC") == "off":
+    elif gc_mode == "off":
         gc.collect()
         gc.disable()
     barrier()
@@ -823,6 +844,19 @@ def main():
         d = [1e3 * (b - a) for a, b in zip(_STEP_T[:-1], _STEP_T[1:])]
         sys.stderr.write("step times (ms, host clock at step start; warm-up %d then timed): %s\n" % (args.warmup, " ".join("%.1f" % v for v in d)))
     log("timed region done: %.1f ms/step" % (1000.0 * dt / args.steps))
+    if _SPIKES is not None and rank == 0:
+        names = ("take_prepared", "forward", "get_loss", "backward", "worker wait", "optimizer", "prepare finish")
+        rows = _SPIKES[-args.steps:]
+        tot = [1e3 * (r[-1] - r[0]) for r in rows]
+        med = sorted(tot)[len(tot) // 2]
+        sys.stderr.write("host phases (ms) of the timed steps: median step %.2f; steps over 2x the median:\n" % med)
+        for i, r in enumerate(rows):
+            if tot[i] > 2 * med:
+                sys.stderr.write("  step %3d %6.1f ms: %s\n" % (i, tot[i], "  ".join("%s %.1f" % (n, 1e3 * (b - a)) for n, a, b in zip(names, r[:-1], r[1:]))))
+                fm = _SPIKE_MARKS[len(_SPIKE_MARKS) - len(rows) + i]
+                sys.stderr.write("        forward marks: %s\n" % "  ".join("%s +%.1f" % (n.replace("fwd: ", ""), 1e3 * (t - r[1])) for n, t in fm))
+        sums = [sum(1e3 * (r[j + 1] - r[j]) for r in rows) / len(rows) for j in range(len(names))]
+        sys.stderr.write("  mean per phase: %s\n" % "  ".join("%s %.2f" % (n, v) for n, v in zip(names, sums)))
 
     if rank == 0 and os.environ.get("IRX_BENCH_CPROFILE") == "1":     # dev: host profile of the real pipelined loop
         import cProfile, io, pstats
@@ -854,7 +888,7 @@ def main():
         try:
             for _ in range(max(20, min(args.warmup, 40))):        # (a dtype switch re-sizes every arena: its own settling time)
                 step_fn(model, resident, args.workload, reducer, opt, state)
-            if os.environ.get("IRX_BENCH_GC", "freeze") == "freeze":
+            if gc_mode == "freeze":
                 gc.collect()                           # the plans / arenas of the new mode join the permanent generation too
                 gc.freeze()
             barrier()

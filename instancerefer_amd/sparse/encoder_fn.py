@@ -10,6 +10,7 @@ results); Python only fills the table and allocates three arenas.
 Layer list (index: conv, residual source): 0 stem | per stage s: 3s+1 down (2^3/2), 3s+2 res-a, 3s+3 res-b (+ out of 3s+1).
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -53,8 +54,12 @@ def _skeleton(encoder):
 class Plan(list):
     """The layers of one encoder pass + what only depends on the coordinate levels (`pre`: descriptor columns, arena layout,
     workspace size per storage mode). Cached on the pass's finest level, so the preparation stage can build it ahead of the
-    forward (prebuild) — the forward half of the bf16 step is host-paced, DESIGN.md section 5."""
-    __slots__ = ("pre",)
+    forward (prebuild) — the forward half of the bf16 step is host-paced, DESIGN.md section 5.
+    The plan lives in that level's __dict__, so it must not own the level: its layers see the finest level through a weak
+    proxy and `root` is a weak reference (level -> plan -> level would be a reference cycle per batch, i.e. ~200 objects and
+    ~120 device tensors per step that only the cyclic collector frees — measured round 6: a 6-10 ms generation-2 pause every
+    ~30 steps of the benchmark loop). Whoever runs the plan holds the level: launch() pins it on the Launched pass / the node."""
+    __slots__ = ("pre", "root")
 
 
 def build_plan(encoder, level0):
@@ -66,8 +71,9 @@ def build_plan(encoder, level0):
         return plan
     layers = Plan()
     layers.pre = {}
+    layers.root = weakref.ref(level0)
     level0.build_kmaps()                # every level's kernel map in one native call (no-op for the ones already built)
-    lv = level0
+    lv = weakref.proxy(level0)
     for conv, bn, down, res in _skeleton(encoder):
         L = _Layer()
         L.conv, L.bn, L.lv_in, L.down, L.res = conv, bn, lv, down, res
@@ -362,7 +368,7 @@ class Launched:
     first in the forward (it is the long pole) — as an ordinary node it would then be the LAST one the backward reaches, after
     every head and the candidate encoder (measured, round 5: its backward started 1.0 ms after the candidate encoder's, the side
     stream idle meanwhile). Created at the head of SceneModule.forward instead, it is replayed right behind the scene head."""
-    __slots__ = ("layers", "desc", "fdesc", "extra", "store", "prof", "lane", "sync", "sink", "saved", "out", "need_dx0")
+    __slots__ = ("layers", "desc", "fdesc", "extra", "store", "prof", "lane", "sync", "sink", "saved", "out", "need_dx0", "level0")
 
 
 def launch(feats, encoder, layers, params, need_dx0=False):
@@ -419,6 +425,9 @@ def launch(feats, encoder, layers, params, need_dx0=False):
         _counters.bump(counters)             # (one launch per forward when InstanceRefer collects them: _counters.py)
     st.layers, st.desc, st.fdesc, st.extra = layers, desc, fdesc, (n_out, cout, poffs, ptotal)
     st.store, st.prof, st.need_dx0 = store, prof, bool(need_dx0)
+    st.level0 = layers.root()            # the plan only holds its finest level weakly (Plan): the pass and its node own it
+    if st.level0 is None:
+        raise RuntimeError("encoder pass launched over a coordinate pyramid that no longer exists")
     if TRACE is not None:
         TRACE["fwd"] = dict(layers=layers, arena=arena, stats=stats, x0=x0, start=start, cb=cb, n_out=n_out, cout=cout,
                             store=store)
@@ -451,7 +460,7 @@ class EncoderFn(torch.autograd.Function):
             raise RuntimeError("encoder pass was launched without an input gradient (bf16 storage) but its features require one")
         ctx.lane, ctx.sync = st.lane, st.sync
         ctx.layers, ctx.desc, ctx.fdesc, ctx.extra = st.layers, st.desc, st.fdesc, st.extra
-        ctx.store, ctx.prof, ctx.sink = st.store, st.prof, st.sink
+        ctx.store, ctx.prof, ctx.sink, ctx.level0 = st.store, st.prof, st.sink, st.level0
         ctx.gate = getattr(encoder, '_irx_bwd_gate', None)   # (role, rows, token): irx_encoder_gate_next, set per step by the model
         ctx.wstream = getattr(encoder, '_irx_wgrad_stream', None)   # hipStream_t (int) lent for the backward's weight gradients, or None
         ctx.save_for_backward(*st.saved)

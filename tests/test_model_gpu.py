@@ -827,3 +827,40 @@ def test_helper_thread_lifecycle(lib, monkeypatch):
     assert wr() is None
     th.join(timeout=5.0)
     assert not th.is_alive()
+
+
+def test_a_training_step_leaves_nothing_for_the_cyclic_collector(lib):
+    """Reference counting alone frees a step: the coordinate pyramid, its tables, the encoder plans cached on it and the autograd graph.
+    (Round 6: level -> cached plan -> level was a cycle per pyramid — ~200 objects and ~120 device tensors per step that stayed until a
+    generation-2 collection, a 6-10 ms pause every ~30 steps of a training loop. encoder_fn.Plan holds its finest level weakly.)"""
+    import gc
+    from instancerefer_amd.loss_helper import DatasetConfig, get_loss
+    from instancerefer_amd import synthetic as S
+    model, _ = _build("train")
+    cfg = DatasetConfig()
+
+    def step():
+        dd = S.to_device(S.make_batch(**dict(GOLDEN_CFG)), torch.device("cuda"))
+        get_loss(model(dd), cfg)["loss"].backward()
+        model.zero_grad(set_to_none=True)
+
+    step()
+    torch.cuda.synchronize()
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        gc.collect()
+        gc.set_debug(0)
+        kinds = sorted({type(o).__name__ for o in gc.garbage})
+        tensors = sum(isinstance(o, torch.Tensor) for o in gc.garbage)
+        levels = [o for o in gc.garbage if type(o).__name__ in ("Level", "DownMap", "Plan", "_Layer")]
+        del gc.garbage[:]
+    finally:
+        if was:
+            gc.enable()
+    assert tensors == 0 and not levels, "a step left %d tensors / %d pyramid objects to the cyclic collector (%s)" % (tensors, len(levels), kinds)
