@@ -1219,10 +1219,12 @@ def measure_support_kernels(model, resident, args, reps=20):
         npts = len(prep[1]["cand"]) * ppi
 
         def vox():
+            # what the step's preparation stage enqueues (no host sync: the voxel count and the level sizes travel to pinned memory and
+            # are read by prepare_finish() a step later); rounds 4-5 timed launch + finish back to back, i.e. a host round trip per call
             d2 = fresh_batch(resident)
-            model.attribute.prepare_finish(model.attribute.prepare_launch(d2, cls_list))
+            model.attribute.prepare_launch(d2, cls_list)
         tv = timed(vox)
-        add("candidate voxeliser + pyramid (k_quantize, k_voxel_insert / _select, k_rs_*, k_ds_*; includes one host sync)", tv,
+        add("candidate voxeliser + pyramid (k_quantize, k_voxel_insert / _select, k_rs_*, k_ds_*; sync-free launch)", tv,
             npts * (24 + 4.0 * c0) + nvox * (16 + 4.0 * c0) + 16.0 * npts)
     tot_us = tot_b = 0.0
     res = {}

@@ -5,7 +5,7 @@
 // voxels by Morton code, so the sort IS the row order every later kernel relies on.
 //
 // 8-bit digits, three launches per pass:
-//   k_rs_count   : workgroup = RS_TILE consecutive elements, wave w owns the w-th quarter of them; per 64-element chunk the
+//   k_rs_count   : workgroup = 4 x per_wave consecutive elements, wave w owns the w-th quarter of them; per 64-element chunk the
 //                  lanes holding the same digit find each other with 8 ballots (one per digit bit) and the lowest lane of
 //                  each peer group adds the group size to the wave's LDS counter -> counts[bin][4 * block + wave]
 //   k_rs_rowscan : one workgroup per digit value: exclusive scan of its row of the table + the bin total (the scatter
@@ -17,8 +17,21 @@
 
 #define RS_BITS 8
 #define RS_BINS 256
-#define RS_PER_WAVE 1024                 // elements per wave
-#define RS_TILE (4 * RS_PER_WAVE)        // elements per workgroup (256 threads)
+// elements per wave (a workgroup of 4 waves sorts 4 x this many consecutive elements). Round 6: sized from n instead of 1024 — at
+// 1024 the scene's 490 k keys were 120 workgroups on 256 CUs, one 4-wave workgroup per CU walking 16 chunks in sequence
+// (IRX_SORT_PER_WAVE: dev A/B, a multiple of 64)
+static int rs_per_wave(int n) {
+  static const int forced = [] {
+    const char* e = getenv("IRX_SORT_PER_WAVE");
+    int x = e ? atoi(e) : 0;
+    return x > 0 ? (x < 64 ? 64 : (x + 63) / 64 * 64) : 0;
+  }();
+  if (forced) return forced;
+  // 120-400 workgroups: fewer leave CUs idle, more make the 256 x (4 x workgroups) digit table the larger stream. Measured (us per
+  // 7-pass sort, tools/micro/sort_bench.py) at 1024 / 512 / 256 / 128 / 64 elements per wave: 61 k keys 218 / 147 / 113 / 99 / 103,
+  // 489 k keys 240 / 182 / 194 / 253 / 484, 800 k keys 262 / 236 / 294 / 496 / 733
+  return n <= 150000 ? 128 : (n <= 300000 ? 256 : 512);
+}
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
@@ -40,15 +53,15 @@ __device__ __forceinline__ uint64_t rs_key(const uint64_t* __restrict__ keys, in
 }
 
 __global__ __launch_bounds__(256) void k_rs_count(const uint64_t* __restrict__ keys, int n, const int32_t* __restrict__ n_dev,
-                                                  uint64_t pad, int shift, int nslots, int32_t* __restrict__ counts) {
+                                                  uint64_t pad, int shift, int nslots, int32_t* __restrict__ counts, int per_wave) {
   __shared__ int hist[4][RS_BINS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 4 * RS_BINS; i += 256) (&hist[0][0])[i] = 0;
   __syncthreads();
   const int n_real = n_dev ? (*n_dev < n ? (*n_dev < 0 ? 0 : *n_dev) : n) : n;
-  const int base = blockIdx.x * RS_TILE + wave * RS_PER_WAVE;
+  const int base = (blockIdx.x * 4 + wave) * per_wave;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int c = 0; c < RS_PER_WAVE; c += 64) {
+  for (int c = 0; c < per_wave; c += 64) {
     const int i = base + c + lane;
     const bool valid = i < n;
     const unsigned digit = valid ? (unsigned)((rs_key(keys, i, n_real, pad) >> shift) & (RS_BINS - 1)) : 0u;
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const uint64_t* __restrict__
                                                     int n, const int32_t* __restrict__ n_dev, uint64_t pad, int shift,
                                                     int nslots, const int32_t* __restrict__ offsets,
                                                     const int32_t* __restrict__ totals,
-                                                    uint64_t* __restrict__ keys_out, int32_t* __restrict__ idx_out) {
+                                                    uint64_t* __restrict__ keys_out, int32_t* __restrict__ idx_out, int per_wave) {
   __shared__ int base_s[4][RS_BINS];
   __shared__ int bin_base[RS_BINS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,9 +134,9 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const uint64_t* __restrict__
   }
   __syncthreads();
   const int n_real = n_dev ? (*n_dev < n ? (*n_dev < 0 ? 0 : *n_dev) : n) : n;
-  const int base = blockIdx.x * RS_TILE + wave * RS_PER_WAVE;
+  const int base = (blockIdx.x * 4 + wave) * per_wave;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int c = 0; c < RS_PER_WAVE; c += 64) {
+  for (int c = 0; c < per_wave; c += 64) {
     const int i = base + c + lane;
     const bool valid = i < n;
     const uint64_t key = valid ? rs_key(keys, i, n_real, pad) : 0ull;
@@ -146,7 +159,7 @@ static inline int rs_passes(int begin_bit, int end_bit) { return (end_bit - begi
 
 extern "C" size_t irx_sort_workspace_bytes(int n) {
   if (n <= 0) return 256;
-  const size_t nslots = 4 * (size_t)irx_cdiv(n, RS_TILE);
+  const size_t nslots = 4 * (size_t)irx_cdiv(n, 4 * rs_per_wave(n));
   size_t b = RS_BINS * nslots * sizeof(int32_t);       // digit counts / offsets
   b = (b + 255) & ~(size_t)255;
   b += 1024;                                           // bin totals
@@ -165,7 +178,8 @@ extern "C" int irx_sort_pairs_u64(const uint64_t* keys, int n, const int32_t* n_
   IRX_REQUIRE(keys && keys_out && order_out && keys != keys_out, "irx_sort_pairs_u64: null or aliased pointer");
   IRX_REQUIRE(workspace && workspace_bytes >= irx_sort_workspace_bytes(n), "irx_sort_pairs_u64: workspace %zu < %zu",
               workspace_bytes, irx_sort_workspace_bytes(n));
-  const int nblk = irx_cdiv(n, RS_TILE), nslots = 4 * nblk;
+  const int pw = rs_per_wave(n);
+  const int nblk = irx_cdiv(n, 4 * pw), nslots = 4 * nblk;
   char* p = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   int32_t* counts = (int32_t*)p;
   p += ((size_t)RS_BINS * nslots * sizeof(int32_t) + 255) & ~(size_t)255;
@@ -185,9 +199,9 @@ extern "C" int irx_sort_pairs_u64(const uint64_t* keys, int n, const int32_t* n_
     const int shift = begin_bit + ps * RS_BITS;
     // after the first pass the padding has been materialised into the key buffer: no device count needed any more
     const int32_t* nd = (ps == 0) ? n_dev : nullptr;
-    k_rs_count<<<nblk, 256, 0, S(stream)>>>(kin, n, nd, pad, shift, nslots, counts);
+    k_rs_count<<<nblk, 256, 0, S(stream)>>>(kin, n, nd, pad, shift, nslots, counts, pw);
     k_rs_rowscan<<<RS_BINS, 1024, 0, S(stream)>>>(counts, nslots, totals);
-    k_rs_scatter<<<nblk, 256, 0, S(stream)>>>(kin, iin, n, nd, pad, shift, nslots, counts, totals, ko, io);
+    k_rs_scatter<<<nblk, 256, 0, S(stream)>>>(kin, iin, n, nd, pad, shift, nslots, counts, totals, ko, io, pw);
     kin = ko;
     iin = io;
   }

@@ -65,6 +65,10 @@ WORKER = None
 if os.environ.get("IRX_E2E_WORKER", "1") != "0":
     import bench as _bench
     WORKER = _bench._Worker(torch.cuda.current_device())
+PROF = None
+if os.environ.get("IRX_E2E_CPROFILE") == "1" and WORKER is None:       # dev: host profile of stage_launch (IRX_E2E_WORKER=0)
+    import cProfile
+    PROF = cProfile.Profile()
 RESIDENT = None      # second leg: the sampled batch of the last end-to-end step, reused as a resident input
 
 
@@ -102,7 +106,12 @@ def loop(cur, n_warm, n_steps):
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(main)
         if WORKER is None:
-            launched = stage_launch(step)
+            if PROF is not None and step >= n_warm and RESIDENT is None:
+                PROF.enable()
+                launched = stage_launch(step)
+                PROF.disable()
+            else:
+                launched = stage_launch(step)
         opt.zero_grad()
         out = get_loss(model(cur), cfg)
         if WORKER is not None:
@@ -145,6 +154,14 @@ with torch.cuda.stream(side):
     RESIDENT = finish(pend)
 torch.cuda.synchronize()
 dt_res, _, _ = loop(cur, max(5, a.warmup // 3), a.steps)
+if PROF is not None:
+    import io, pstats
+    buf = io.StringIO()
+    pstats.Stats(PROF, stream=buf).sort_stats("tottime").print_stats(45)
+    sys.stderr.write("stage_launch over %d steps:\n%s\n" % (a.steps, buf.getvalue()))
+    buf = io.StringIO()
+    pstats.Stats(PROF, stream=buf).sort_stats("cumulative").print_stats(40)
+    sys.stderr.write(buf.getvalue())
 if os.environ.get("IRX_E2E_TIMES") and TIMES[2]:
     sys.stderr.write("worker: stage_launch %.3f ms/step, training thread waited %.3f ms/step\n" % (1e3 * TIMES[0] / TIMES[2], 1e3 * TIMES[1] / TIMES[2]))
 if a.json:
