@@ -358,3 +358,50 @@ def test_bench_launcher_helpers_and_sort_key_widths():
     for bs in (1, 2, 16, 17, 64, 1000):
         assert ((bs - 1) << 48 | ((1 << 48) - 1)) < (1 << morton_bits(bs))
         assert (bs << 48) < (1 << morton_bits(bs, True))
+
+
+def test_encoder_plan_cached_on_a_level_does_not_keep_the_level_alive():
+    """sparse/encoder_fn.build_plan caches the plan in the finest level's __dict__; the plan reaches that level only through weak
+    references (round 6: level -> plan -> level was a cycle per pyramid that only the cyclic collector freed: kernel maps and pair lists of
+    every training step stayed allocated until a generation-2 collection). Coordinate levels stubbed: no GPU."""
+    import gc
+    import weakref
+    from instancerefer_amd.basic_blocks import SparseConvEncoder
+    from instancerefer_amd.sparse import encoder_fn
+
+    class FakeDown:
+        def __init__(self, out):
+            self.out_level, self.child, self.ld = out, torch.zeros((8, 4), dtype=torch.int32), 4
+
+    class FakeLevel:
+        def __init__(self, n, depth):
+            self.n = n
+            self._next = FakeLevel(max(n // 2, 1), depth - 1) if depth else None
+            self.payload = torch.zeros(16)
+
+        def build_kmaps(self):
+            pass
+
+        def down(self):
+            return FakeDown(self._next)
+
+        def nbr27(self):
+            return torch.zeros((27, 4), dtype=torch.int32), 4
+
+    enc = SparseConvEncoder(7)
+    lv0 = FakeLevel(64, 4)
+    plan = encoder_fn.build_plan(enc, lv0)
+    assert len(plan) == 13 and encoder_fn.build_plan(enc, lv0) is plan          # cached on the level
+    assert plan.root() is lv0 and plan[0].lv_in.n == 64 and plan[1].lv_in.n == 64 and plan[2].lv_in.n == 32
+    alive = weakref.ref(lv0)
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        del lv0
+        assert alive() is None, "the cached plan keeps its level alive (reference cycle)"
+        assert plan.root() is None
+        with pytest.raises(ReferenceError):
+            plan[0].lv_in.n
+    finally:
+        if was:
+            gc.enable()
