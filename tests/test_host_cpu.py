@@ -405,3 +405,42 @@ def test_encoder_plan_cached_on_a_level_does_not_keep_the_level_alive():
     finally:
         if was:
             gc.enable()
+
+
+def test_configure_hw_queues_is_explicit_and_respects_the_environment(monkeypatch):
+    """importing the package no longer sets GPU_MAX_HW_QUEUES; configure_hw_queues() picks 8 for one rank per device
+    and 2 (with a warning) when ranks share one, and an explicit value in the environment wins unless force=True."""
+    import importlib
+    import warnings
+    import instancerefer_amd as irx
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    importlib.reload(irx)
+    assert "GPU_MAX_HW_QUEUES" not in os.environ, "import must not touch the process environment"
+    assert irx.configure_hw_queues(ranks_per_device=1) == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "3")
+    assert irx.configure_hw_queues(ranks_per_device=1) == 3 and os.environ["GPU_MAX_HW_QUEUES"] == "3"      # the caller's value stays
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert irx.configure_hw_queues(ranks_per_device=4, force=True) == 2
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "2" and any("share one GPU" in str(x.message) for x in w)
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert irx.configure_hw_queues() == 8                      # no device here: one rank per device is assumed
+
+
+def test_batchnorm_counter_collector_applies_every_increment_once():
+    """_counters: num_batches_tracked increments handed in between open_collector() and close() are applied by close() in one call —
+    each exactly once, duplicates included (a layer that ran twice counts twice, like nn.BatchNorm); without a collector at once."""
+    from instancerefer_amd import _counters
+    a, b = torch.zeros((), dtype=torch.int64), torch.full((), 5, dtype=torch.int64)
+    _counters.bump([a, None])
+    assert int(a) == 1
+    _counters.open_collector()
+    _counters.bump([a, b])
+    _counters.bump([b])
+    assert int(a) == 1 and int(b) == 5                         # nothing applied yet
+    _counters.close()
+    assert int(a) == 2 and int(b) == 7
+    _counters.close()                                          # closing twice is a no-op
+    _counters.bump([a])
+    assert int(a) == 3
