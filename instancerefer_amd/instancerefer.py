@@ -139,7 +139,11 @@ class InstanceRefer(nn.Module):
             data_dict = self.attribute.prepare_launch(data_dict, cls_list)
             if self.args.relation_module and hasattr(self.relation, 'prepare'):
                 data_dict = self.relation.prepare(data_dict, cls_list)
-        if self.args.scene_module and 'lidar' in data_dict:
+        if self.args.scene_module and 'lidar' in data_dict and hasattr(data_dict['lidar'], 'pyramid') and hasattr(data_dict['lidar'], 'finish'):
+            # a sparse.utils.VoxelizePending (scene_input with IRX_INPUT_VOXELIZE_LAUNCH=1): voxeliser + pyramid already enqueued,
+            # sync-free; prepare_finish() collects the tensor
+            data_dict['_scene_vox_pending'] = data_dict['lidar']
+        elif self.args.scene_module and 'lidar' in data_dict:
             lidar = data_dict['lidar']
             if lidar._batch_size is None and 'point_min' in data_dict:
                 lidar._batch_size = data_dict['point_min'].shape[0]
@@ -157,10 +161,15 @@ class InstanceRefer(nn.Module):
         if '_attr_pending' in data_dict:
             data_dict = self.attribute.prepare_finish(data_dict)
         pending = data_dict.pop('_scene_pending', None)
+        vox = data_dict.pop('_scene_vox_pending', None)
+        if vox is not None:
+            data_dict['lidar'] = vox.finish()                # canonical, pyramid built (the one wait for voxel count + level sizes)
+            pending = (None, None)
         c0 = getattr(getattr(self, 'attribute', None), 'input_feature_dim', 0)
         wide = 128 < c0 <= 136                               # the wide stem's weight gradient runs over pair lists (encoder_fn._uses_pairs)
         if pending is not None:
-            data_dict['lidar'].level().build_pyramid_finish(pending)
+            if pending[0] is not None:
+                data_dict['lidar'].level().build_pyramid_finish(pending)
             if self.training and _PREP_TABLES:
                 # kernel maps, tile order and the backward-only tables (pair lists, transposed child maps) on the preparation stream
                 data_dict['lidar'].level().build_tables(backward=torch.is_grad_enabled(), pairs_level0=wide)

@@ -26,6 +26,8 @@ from .data import InstancePack, idx_tensor
 MEAN_COLOR_RGB = np.array([109.8, 97.2, 83.8])     # lib/dataset.py:22
 MAX_NUM_OBJ = 128                                  # lib/dataset.py:21
 NUM_INSTANCE_POINTS = 1024                         # lib/dataset.py:224
+import os as _os
+_VOXELIZE_LAUNCH = _os.environ.get("IRX_INPUT_VOXELIZE_LAUNCH", "0") == "1"     # dev switch, see PendingBatch._assemble
 
 
 class ClassTables:
@@ -279,13 +281,18 @@ class PendingBatch:
         return self._assemble(data_dict, back[:S * 7].reshape(S, 7).copy(), back[S * 7:].reshape(B, 6).copy())
 
     def _assemble(self, data_dict, obbs, ext):
-        from .sparse.utils import voxelize
+        from .sparse.utils import voxelize, voxelize_launch
         B = len(self.draws)
         dd = {} if data_dict is None else data_dict
         n, c = self.clouds.shape[1], self.clouds.shape[2]
         flat = self.clouds.view(B * n, c)
         batch = torch.arange(B, device=self.device, dtype=torch.int32).repeat_interleave(n)
-        dd["lidar"] = voxelize(flat[:, :3].contiguous(), flat, batch, [self.voxel_size] * 3, B)
+        if _VOXELIZE_LAUNCH:
+            # dev (IRX_INPUT_VOXELIZE_LAUNCH=1): the scene voxeliser without its host sync — a sparse.utils.VoxelizePending that
+            # InstanceRefer.prepare_launch / prepare_finish turn into the canonical tensor when the level sizes have arrived
+            dd["lidar"] = voxelize_launch(flat[:, :3].contiguous(), flat, batch, [self.voxel_size] * 3, B, 4)
+        else:
+            dd["lidar"] = voxelize(flat[:, :3].contiguous(), flat, batch, [self.voxel_size] * 3, B)
         classes, scene_of, start = [], [], [0]
         for i, d in enumerate(self.draws):
             classes += d.classes

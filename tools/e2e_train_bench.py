@@ -65,6 +65,7 @@ WORKER = None
 if os.environ.get("IRX_E2E_WORKER", "1") != "0":
     import bench as _bench
     WORKER = _bench._Worker(torch.cuda.current_device())
+POST_EARLY = os.environ.get("IRX_E2E_POST") == "early"     # dev A/B: the worker's job posted at the head of the step (whole step as its window)
 PROF = None
 if os.environ.get("IRX_E2E_CPROFILE") == "1" and WORKER is None:       # dev: host profile of stage_launch (IRX_E2E_WORKER=0)
     import cProfile
@@ -112,14 +113,19 @@ def loop(cur, n_warm, n_steps):
                 PROF.disable()
             else:
                 launched = stage_launch(step)
+        box = {}
+        if WORKER is not None and POST_EARLY:
+            def job():
+                t_ = time.perf_counter()
+                box["dd"] = stage_launch(step)
+                TIMES[0] += time.perf_counter() - t_
+            WORKER.post(job)
         opt.zero_grad()
         out = get_loss(model(cur), cfg)
-        if WORKER is not None:
+        if WORKER is not None and not POST_EARLY:
             # the next batches' host work (box labels, augmentation draws, ~40 small launches) on a helper thread while this
             # thread sits in the autograd engine's C++ loop (GIL released): in the host-paced bf16 mode that Python was 1.5 ms
             # of a 6.4 ms step on the training thread (round 5: end to end / resident 0.73)
-            box = {}
-
             def job():
                 t_ = time.perf_counter()
                 box["dd"] = stage_launch(step)
