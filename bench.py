@@ -794,7 +794,10 @@ def main():
         state["at_backward"] = False
     from instancerefer_amd.loss_helper import prepare_labels
     state["labels"] = lambda dd: prepare_labels(dd, step_fn.cfg, device) if "_attr_prepared" in dd else None
-    primed = prime(model, resident, args, reducer, opt, state) if world == 1 else 0
+    # (N > 1 with a GPU per rank: primed too — a fixed 200 steps on every rank, see prime() — so that the per-N values of a scaling run
+    #  are taken in the same state as the N = 1 one: a fresh box starts in a low-power state and its first second reads 10-20 % low.
+    #  The shared-GPU test rig is not primed: its steps are 10x longer and it measures logic, not speed)
+    primed = prime(model, resident, args, reducer, opt, state) if (world == 1 or not share) else 0
     for i in range(args.warmup):
         step_fn(model, resident, args.workload, reducer, opt, state)
         if i == 0:
